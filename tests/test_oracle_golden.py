@@ -1,0 +1,184 @@
+"""CPU: the oracle (oracle/p2c_oracle.c + oracle/ref_torch.py) against the golden vectors that
+oracle/make_golden.py produced by running the upstream reference.  This is what pins the oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cref, ref_torch as R
+from tests.conftest import load_golden, same_up_to_sign
+
+t = torch.from_numpy
+
+
+@pytest.mark.parametrize("tag", ["uniform", "sa2", "grid"])
+def test_fps_bit_exact(tag):
+    g = load_golden("g1_fps_" + tag)
+    out = cref.fps(g["xyz"], g["start"], int(g["npoint"]))
+    assert np.array_equal(out, g["idx"])
+    out_t = R.farthest_point_sample(t(g["xyz"]), int(g["npoint"]), t(g["start"]), geom="torch").numpy()
+    assert np.array_equal(out_t, g["idx"])
+
+
+@pytest.mark.parametrize("tag", ["sparse", "dense", "r04", "grid"])
+def test_ball_query_bit_exact(tag):
+    g = load_golden("g2_ball_" + tag)
+    d = cref.square_distance(g["new_xyz"], g["xyz"])
+    assert np.array_equal(d, g["sqrdist"]), "square_distance rounding order differs from the reference"
+    gi = cref.ball_query(float(g["radius"]), int(g["nsample"]), g["xyz"], g["new_xyz"])
+    assert np.array_equal(gi, g["group_idx"])
+    if tag == "sparse":
+        assert (gi[:, :, -1] == gi[:, :, 0]).any(), "padding path not exercised"
+    if tag == "dense":
+        assert (gi[:, :, -1] != gi[:, :, 0]).mean() > 0.5, "truncation path not exercised"
+
+
+@pytest.mark.parametrize("tag", ["fp1", "fp2", "grid"])
+def test_three_nn_bit_exact(tag):
+    g = load_golden("g3_3nn_" + tag)
+    d, i = cref.three_nn(g["xyz1"], g["xyz2"])
+    assert np.array_equal(d, g["dist"])
+    if tag == "grid":
+        # exact distance ties: torch.sort (stable=False, pointnet_util.py:302) orders tied entries in an
+        # implementation-defined way; ours is lowest-index-first.  Indices must agree wherever the
+        # neighbour's distance is unique among the candidates.
+        full = cref.square_distance(g["xyz1"], g["xyz2"])
+        assert np.array_equal(np.take_along_axis(full, i, 2), g["dist"])
+        uniq = (full[:, :, None, :] == g["dist"][:, :, :, None]).sum(-1) == 1
+        assert uniq.any() and np.array_equal(i[uniq], g["idx"][uniq])
+    else:
+        assert np.array_equal(i, g["idx"])
+
+
+def test_lsa_matches_scipy():
+    from scipy.optimize import linear_sum_assignment
+    rng = np.random.default_rng(0)
+    for it in range(3000):
+        nr = int(rng.integers(1, 9))
+        c = rng.random((nr, 8)).astype(np.float32)
+        if it % 3 == 1:
+            c[:, rng.random(8) < 0.5] = 0
+        if it % 3 == 2:
+            c = (rng.integers(0, 3, (nr, 8)) / 2).astype(np.float32)
+        assert np.array_equal(linear_sum_assignment(-c)[1], cref.lsa_max(c))
+
+
+def _sd_checks(sd, g, which):
+    keys = [str(k) for k in g["keys"]]
+    assert keys == list(sd.keys())
+    ck = np.stack([[v.double().sum().item(), v.double().abs().sum().item(), (v.double() ** 2).sum().item()]
+                   for v in sd.values()])
+    np.testing.assert_allclose(ck, g[which], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("geom", ["c", "torch"])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_backbone_forward_backward(mode, geom):
+    g = load_golden("g5_backbone_" + mode)
+    sd = R.make_state_dict(output_sizes=(3, 16), seed=int(g["seed"]))
+    _sd_checks(sd, g, "init_ck")          # same seed -> same init as the reference module
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    x = t(g["pcs"]).requires_grad_(True)
+    outs = R.backbone_forward(sd, x, [t(g["start1"]), t(g["start2"])], None, training=(mode == "train"),
+                              momentum=float(g["momentum"]), geom=geom)
+    X, W_raw = outs
+    np.testing.assert_allclose(X.detach().numpy(), g["X"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(W_raw.detach().numpy(), g["W_raw"], rtol=1e-4, atol=1e-5)
+    loss = (X * X).mean() + (W_raw.softmax(-1)[..., 0]).mean() + (W_raw * W_raw).mean() * 0.1
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5)
+    loss.backward()
+    if geom == "torch":
+        # d(loss)/d(xyz) also flows through the 3-NN interpolation weights (pointnet_util.py:301-307);
+        # only the literal torch geometry keeps that graph.  No trainer asks for input gradients.
+        np.testing.assert_allclose(x.grad.numpy(), g["grad_x"], rtol=1e-3, atol=1e-6)
+    for k in g:
+        if k.startswith("grad:"):
+            np.testing.assert_allclose(params[k[5:]].grad.numpy().reshape(g[k].shape), g[k], rtol=2e-3, atol=2e-6)
+        if k.startswith("after:"):
+            np.testing.assert_allclose(sd[k[6:]].detach().numpy(), g[k], rtol=1e-4, atol=1e-6)
+
+
+def _soft_inputs(g):
+    W_raw = t(g["W_raw"]).requires_grad_(True)
+    X = t(g["X"]).requires_grad_(True)
+    W2 = torch.softmax(W_raw, 2)
+    return W_raw, X, W2[:, :, 0::2] + W2[:, :, 1::2]
+
+
+def test_losses():
+    g = load_golden("g6_losses")
+    W_raw, X, W = _soft_inputs(g)
+    seg, bb, nrm = t(g["seg"]), t(g["bb"]), t(g["normals"])
+    total, nl, ml, match, mask = R.compute_all_losses(W, seg, X, nrm, 1.0, 1.0)
+    assert np.array_equal(match.numpy(), g["match"]) and np.array_equal(mask.numpy(), g["mask"])
+    np.testing.assert_allclose([total.item(), nl.item(), ml.item()], [g["total"], g["normal_loss"], g["miou_loss"]], rtol=1e-6)
+    bbl = R.bb_loss(W, W_raw, match, mask, bb, 8)
+    np.testing.assert_allclose(bbl.item(), g["bb_loss"], rtol=1e-6)
+    (total + bbl).backward()
+    np.testing.assert_allclose(W_raw.grad.numpy(), g["grad_W_raw"], rtol=1e-4, atol=1e-9)
+    np.testing.assert_allclose(X.grad.numpy(), g["grad_X"], rtol=1e-4, atol=1e-9)
+    hard = R.hard_W_encoding(W.detach(), to_null_mask=True)
+    hm, hmask = R.hungarian_matching(hard, seg)
+    assert np.array_equal(hm.numpy(), g["hardW_match"]) and np.array_equal(hmask.numpy(), g["hardW_mask"])
+    np.testing.assert_allclose(R.compute_segmentation_iou(hard, seg, hm, hmask.float()).numpy(), g["seg_iou"], rtol=1e-6)
+    np.testing.assert_allclose(R.compute_normal_difference(X.detach(), nrm, in_radians=False).numpy(), g["normal_diff_deg"], rtol=1e-5)
+    assert np.array_equal(R.get_mask_gt(seg, 8).numpy(), g["mask_gt"])
+    # restated JV solver == scipy on the reference's own cost matrices
+    for b in range(W.shape[0]):
+        n_gt = int(seg[b].max()) + 1
+        oh = torch.eye(n_gt + 1)[seg[b]]
+        inter = oh.t() @ W[b].detach()
+        iou = (inter / (oh.sum(0).unsqueeze(1) + W[b].detach().sum(0).unsqueeze(0) - inter).clamp(min=1e-10))[:n_gt]
+        assert np.array_equal(cref.lsa_max(iou.numpy()), g["match"][b, :n_gt])
+
+
+@pytest.mark.parametrize("wtag", ["hard", "soft"])
+@pytest.mark.parametrize("norm", [0, 1])
+@pytest.mark.parametrize("literal", [False, True])
+def test_extrusion_axis(wtag, norm, literal):
+    g = load_golden("g7_axis")
+    X = t(g["X"]).requires_grad_(True)
+    wb = t(g["Wb_" + wtag]).requires_grad_(True)
+    wc = t(g["Wc_" + wtag]).requires_grad_(True)
+    seg, bb, gt = t(g["seg"]), t(g["bb"]), t(g["gt_axes"])
+    E = R.estimate_extrusion_axis(X, wb, wc, bb, seg, normalize=bool(norm), literal=literal)
+    tag = "%s_%d" % (wtag, norm)
+    m = g["mask_gt"]
+    assert (same_up_to_sign(E.detach().numpy(), g["E_" + tag])[m] > 1 - 1e-6).all()
+    lo = R.reduce_mean_masked_instance(R.compute_normal_loss(E, gt, collapse=False), t(m)).mean()
+    np.testing.assert_allclose(lo.item(), g["loss_" + tag], rtol=1e-4, atol=1e-6)
+    lo.backward()
+    for name, v in (("gX_", X), ("gWb_", wb), ("gWc_", wc)):
+        ref = g[name + tag]
+        np.testing.assert_allclose(v.grad.numpy(), ref, rtol=5e-3, atol=2e-5 * max(1.0, np.abs(ref).max()))
+    deg = R.compute_normal_difference(E.detach(), gt, in_radians=False, collapse=False).numpy()
+    np.testing.assert_allclose(deg[m], g["deg_" + tag][m], rtol=1e-3, atol=2e-2)
+
+
+def test_centers_extents():
+    g = load_golden("g8_centers_extents")
+    c = R.estimate_extrusion_centers(t(g["W"]), t(g["pcs"]))
+    np.testing.assert_allclose(c.numpy(), g["centers_pred"], rtol=1e-5, atol=1e-7)
+    rk = {tuple(k): t(r) for k, r in zip(g["rand_keys"].tolist(), g["rand_idx"])}
+    ext, found = R.get_extrusion_extents(t(g["pcs"]), t(g["seg"]), t(g["bb"]), t(g["axes"]), t(g["centers"]), rk)
+    assert np.array_equal(found.numpy(), g["found"])
+    np.testing.assert_allclose(ext.numpy(), g["extents"], rtol=1e-5, atol=1e-6)
+
+
+def test_train_step_forward_losses():
+    """G9: forward + the three losses of one training step (the parameter deltas are checked on the
+    product side in tests/test_train_step.py)."""
+    g = load_golden("g9_train_step")
+    sd = R.make_state_dict(output_sizes=(3, 16), seed=int(g["seed"]))
+    dmask = np.unpackbits(g["dropout_mask_bcn"])[: 2 * 128 * 1024].reshape(2, 128, 1024).astype(np.float32)
+    outs = R.backbone_forward(sd, t(g["pcs"]), [t(g["start1"]), t(g["start2"])], t(dmask).transpose(1, 2),
+                              training=True, momentum=0.5, geom="c")
+    X = F.normalize(outs[0], p=2, dim=2, eps=1e-12)
+    W2 = torch.softmax(outs[1], 2)
+    W = W2[:, :, 0::2] + W2[:, :, 1::2]
+    total, nl, ml, match, mask = R.compute_all_losses(W, t(g["seg"]), X, t(g["normals"]), 1.0, 1.0)
+    bbl = R.bb_loss(W, outs[1], match, mask, t(g["bb"]), 8)
+    assert np.array_equal(match.numpy(), g["match"])
+    assert np.array_equal(W.argmax(-1).numpy(), g["label"])
+    np.testing.assert_allclose([(total + bbl).item(), nl.item(), ml.item(), bbl.item()],
+                               [g["total"], g["normal_loss"], g["miou_loss"], g["bb_loss"]], rtol=2e-5)

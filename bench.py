@@ -1,0 +1,138 @@
+"""Point2Cyl hot-path bench: training-step points/sec at N=8192 (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N --steps K --warmup W]       (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = backbone forward + (seg, normal, base/barrel) losses + backward + Adam on one synthetic batch of
+B=32 clouds x 8192 points per GPU, already resident in HBM.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch_size", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--num_point", type=int, default=8192)
+    ap.add_argument("--K", type=int, default=8)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_batch", type=int, default=2)
+    ap.add_argument("--full_losses", action="store_true", help="configs[2]: + --pred_extrusion --pred_center")
+    args = ap.parse_args()
+
+    from point2cyl_amd import ddp, ops, step, synth
+    from point2cyl_amd.backbone import backbone
+    import torch.distributed as dist
+
+    rank, world, local = ddp.init_from_env()
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("bench: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    B, N, K = args.batch_size, args.num_point, args.K
+    fl = step.StepFlags(K=K, pred_extrusion=args.full_losses, pred_center=args.full_losses)
+    pcs, normals, seg, bb, _, _, axes, _, centers = synth.make_batch(B, N, K, seed=1234 + 1000 * rank)
+    batch = tuple(x.to(dev) for x in (pcs, normals, seg, bb, axes, centers))
+
+    torch.manual_seed(0)
+    model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
+    ddp.broadcast_module(model)
+    step.update_momentum(model, step.get_batch_norm_decay(0, B, 200000))
+    sync = ddp.FlatGradSync(model.parameters(), world)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+
+    def one_step():
+        out = step.compute_losses(model, *batch, fl)
+        sync.zero()
+        out["total"].backward()
+        sync.allreduce()
+        opt.step()
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    ops.PROFILE.reset(enabled=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.PROFILE.enabled = False
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    loss = float(out["total"])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms = dt / args.steps * 1e3
+    value = world * B * N * args.steps / dt
+    prof = ops.PROFILE.summary()           # per kernel family: launches, total ms (HIP events on the launch stream), flops, bytes
+    dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
+    roofline = None
+    if dom[0] is not None:
+        d = dom[1]
+        if d["flops"] > 0:
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                            launches_per_step=d["launches"] / args.steps, avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
+                            share_of_step=round(d["ms"] / (ms * args.steps), 3))
+        else:
+            ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=dom[0], achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None,
+                            launches_per_step=d["launches"] / args.steps, avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
+                            share_of_step=round(d["ms"] / (ms * args.steps), 3))
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_step
+        cb = args.cpu_batch
+        sample = tuple(x[:cb].contiguous() for x in (pcs, normals, seg, bb))
+        pps, sec, thr = ref_step.time_cpu_baseline(sample, steps=1, threads=os.cpu_count())
+        cpu = dict(value=round(pps, 1), unit="points/s", cores=thr, kind="port",
+                   sample="1 full training step (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
+                          "points (same generator as the GPU batch), %.1f s" % (cb, N, sec))
+    line = dict(metric="training-step points/sec (BxN) at N=8192", value=round(value, 1), unit="points/s", n_gpus=world,
+                steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
+                vs_baseline=None, dtype="f32", data="synthetic",
+                config=dict(workload="configs[%d]: B=%d clouds/GPU x N=%d points, K=%d, %s, random-init backbone, synthetic "
+                                     "extrusion-cylinder clouds; step = fwd + losses + bwd + Adam" %
+                                     (2 if args.full_losses else 1, B, N, K,
+                                      "full loss set" if args.full_losses else "pred_seg+pred_normal+pred_bb"),
+                            batch_per_gpu=B, global_batch=B * world, num_point=N, parallelism="dp%d" % world, loss=round(loss, 5)),
+                roofline=roofline, cpu_baseline=cpu,
+                kernels={k: dict(ms_per_step=round(v["ms"] / args.steps, 3), launches_per_step=v["launches"] / args.steps)
+                         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])})
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

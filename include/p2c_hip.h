@@ -1,0 +1,194 @@
+/*
+ * p2c_hip.h -- C ABI of libp2c_hip.so: the MI355X (gfx950) kernels behind Point2Cyl's hot path.
+ *
+ * The upstream reference (mikacuy/point2cyl) is pure Python on PyTorch: it has no FFI, no custom op and
+ * no plugin ABI.  Its "interface" for this path is a set of Python functions / nn.Modules; each entry
+ * point below replaces the stock-torch op sequence inside one of them (file:line cited per function).
+ * INTEGRATION.md shows the ctypes stub a maintainer of the reference would add to call these.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP, gfx950) unless the name ends in _host;
+ *   - all float tensors are fp32, row-major, POINT-MAJOR: a feature map is [rows, channels] with an
+ *     explicit leading dimension (ld*, in elements) so that column slices of a wider matrix can be passed;
+ *   - index tensors are int32 on the device (the Python boundary converts to int64 where the reference
+ *     returns int64);
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, nothing synchronises, nothing
+ *     allocates; buffers are caller-owned; workspace sizes are given by the *_ws_bytes helpers;
+ *   - return value: 0 on success, a negative P2C_E* code on bad arguments, or the positive hipError_t of
+ *     a failed launch.
+ */
+#ifndef P2C_HIP_H
+#define P2C_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define P2C_OK 0
+#define P2C_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
+#define P2C_EALIGN (-2)   /* leading dimension or pointer not aligned as required */
+
+int p2c_abi_version(void);            /* bumps when a signature changes */
+const char *p2c_build_arch(void);     /* "gfx950" */
+
+/* ---------------------------------------------------------------------------------------------
+ * Geometry (integer outputs: bit-exact with the reference's CPU path)
+ * ------------------------------------------------------------------------------------------- */
+
+/* farthest_point_sample, models/pointnet_util.py:63-84.
+ * xyz [B,N,3]; start [B] int64 = the reference's torch.randint(0,N,(B,)) draw (:75), made by the caller on
+ * the CPU generator exactly like the reference; idx_out [B,npoint]; new_xyz_out [B,npoint,3] (optional,
+ * = index_points(xyz, idx), :127).  N <= 16384. */
+int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start, int npoint, int32_t *idx_out,
+                float *new_xyz_out, void *stream);
+
+/* query_ball_point (+ square_distance), models/pointnet_util.py:87-107, :19-40.
+ * radius2 = (float)(radius**2).  idx_out [B,S,nsample]: first nsample in-ball indices ascending, padded
+ * with the first.  nsample <= 64. */
+int p2c_ball_query_f32(const float *xyz, const float *new_xyz, int B, int N, int S, float radius2, int nsample,
+                       int32_t *idx_out, void *stream);
+
+/* 3-NN + inverse-distance weights, models/pointnet_util.py:301-307.
+ * xyz1 [B,N,3] dense, xyz2 [B,S,3] sparse (S>=3) -> idx_out [B,N,3], weight_out [B,N,3]
+ * (w = 1/(d+1e-8), normalised); dist_out [B,N,3] optional (the 3 smallest squared distances, ascending;
+ * ties broken towards the lower index). */
+int p2c_three_nn_f32(const float *xyz1, const float *xyz2, int B, int N, int S, int32_t *idx_out, float *weight_out,
+                     float *dist_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Grouping / interpolation (gathers; backward = scatter-add)
+ * ------------------------------------------------------------------------------------------- */
+
+/* sample_and_group's gather + centring + concat, models/pointnet_util.py:128-139.
+ * out row (b,s,j) = [xyz[b,idx]-new_xyz[b,s] (3) | feats[b,idx,:D] | 0-pad up to ldo], ldo % 4 == 0.
+ * feats may be NULL (D=0).  ldf = leading dimension of feats rows. */
+int p2c_group_gather_f32(const float *xyz, const float *feats, int ldf, const float *new_xyz, const int32_t *idx, int B,
+                         int N, int S, int nsample, int D, float *out, int ldo, void *stream);
+/* backward of the feature part: dfeats[b,idx[b,s,j],:] += dout[(b,s,j), 3:3+D]   (dfeats pre-zeroed) */
+int p2c_group_gather_bwd_f32(const float *dout, int ldo, const int32_t *idx, int B, int N, int S, int nsample, int D,
+                             float *dfeats, int ldf, void *stream);
+
+/* weighted 3-NN interpolation, models/pointnet_util.py:308.
+ * out[b,n,:C] = sum_j w[b,n,j] * feats[b, idx[b,n,j], :C] */
+int p2c_three_interp_f32(const float *feats, int ldf, const int32_t *idx, const float *weight, int B, int N, int S, int C,
+                         float *out, int ldo, void *stream);
+int p2c_three_interp_bwd_f32(const float *dout, int ldo, const int32_t *idx, const float *weight, int B, int N, int S,
+                             int C, float *dfeats, int ldf, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Shared per-point MLP: 1x1 conv (+ train-mode BatchNorm + ReLU) as fp32 MFMA GEMMs
+ * (models/pointnet_util.py:201-205, :317-319; models/pointnet_extrusion.py:58-65)
+ *
+ * A layer is  Y = act_in(X) . W^T + bias,  with the PREVIOUS layer's BatchNorm+ReLU folded into the load
+ * of X (act_in) so post-activation tensors are never written to HBM:
+ *   in_mode 0: act_in(x) = x
+ *   in_mode 1: act_in(x) = relu(in_scale[k]*x + in_shift[k])
+ *   in_mode 2: act_in(x) = relu(in_scale[k]*x + in_shift[k]) * drop_mask[m,k] * drop_scale   (F.dropout, :60)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Forward.  X [M,K] (ldx), W [N,K] row-major (ldw) = the conv weight (Co,Ci,1[,1]) as stored in the
+ * reference's state_dict, bias [N] (may be NULL), Y [M,N] (ldy).  If stat_partials != NULL the kernel also
+ * writes per-row-tile partial sums: stat_partials[tile][0][n] = sum_m y, [tile][1][n] = sum_m y*y with
+ * tile = m / P2C_STAT_TILE_M; size from p2c_linear_stat_tiles(M). */
+#define P2C_STAT_TILE_M 128
+int p2c_linear_stat_tiles(int M);
+int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
+                       int K, int in_mode, const float *in_scale, const float *in_shift, const uint8_t *drop_mask,
+                       int ldmask, float drop_scale, float *stat_partials, void *stream);
+
+/* BatchNorm batch statistics -> affine.  training != 0: mean/var from the partials (biased var for the
+ * normalisation, unbiased for running_var, torch semantics), running stats updated in place with
+ * `momentum`; training == 0: affine from the running stats.  The partial sums are taken BEFORE the bias
+ * add (better conditioned); `bias` (may be NULL) is added back to the mean here.  Outputs scale[c] = gamma*invstd,
+ * shift[c] = beta - mean*scale, and mean / invstd (saved for backward). */
+int p2c_bn_finalize_f32(const float *stat_partials, int n_tiles, int C, long long count, const float *bias,
+                        const float *gamma, const float *beta, float eps, float momentum, int training,
+                        float *running_mean, float *running_var, float *scale, float *shift, float *mean,
+                        float *invstd, void *stream);
+
+/* Z = relu(scale*Y + shift), materialised (only where a consumer needs the post-activation tensor) */
+int p2c_bn_relu_apply_f32(const float *Y, int ldy, const float *scale, const float *shift, int M, int C, float *Z, int ldz,
+                          void *stream);
+
+/* max over the nsample axis of relu(bn(Y)) (models/pointnet_util.py:205): Y [G*ns, C] -> out [G,C],
+ * arg [G,C] (row offset j of the winner, first on ties). */
+int p2c_maxpool_bnrelu_f32(const float *Y, int ldy, const float *scale, const float *shift, int G, int ns, int C, float *out,
+                           int ldo, int32_t *arg, void *stream);
+/* dZ [G*ns, C] (dense, zero except the winners) from dOut [G,C] */
+int p2c_maxpool_bwd_f32(const float *dout, int ldo, const int32_t *arg, int G, int ns, int C, float *dZ, int ldz, void *stream);
+
+/* Backward of relu(bn(Y)) in training mode, step 1: per-channel sums over rows of
+ *   g = dZ * [scale*Y+shift > 0],   s1 = sum g,   s2 = sum g * (Y-mean)*invstd
+ * then step 2 (finalize): dgamma = s2, dbeta = s1 and the coefficients that let a GEMM rebuild
+ *   dY = gs*g + q*Y + p      (gs = gamma*invstd, q = -gs*invstd*s2/M, p = -gs*s1/M - q*mean)
+ * coef_out [5,C] = {scale, shift, gs, q, p}.  ws: p2c_bn_bwd_ws_bytes(M,C) bytes. */
+size_t p2c_bn_bwd_ws_bytes(int M, int C);
+int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float *Y, int ldy, const float *scale, const float *shift,
+                              const float *mean, const float *invstd, const float *gamma, int M, int C, float *dgamma,
+                              float *dbeta, float *coef_out, void *ws, void *stream);
+
+/* grad_mode 0: dY = G (the tensor passed as dZ is already dY; Yfwd/coef unused)
+ * grad_mode 1: dY = gs*(dZ*[scale*Yfwd+shift>0]) + q*Yfwd + p   with coef [5,Co] from the stats call above */
+
+/* dX[m,ci] = sum_co dY[m,co] * W[co,ci]   (optionally multiplied by out_mask[m,ci]*out_mask_scale: the
+ * dropout in front of the layer).  dX [M,K] (lddx). */
+int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
+                            const float *W, int ldw, float *dX, int lddx, int M, int N, int K, const uint8_t *out_mask,
+                            int ldmask, float out_mask_scale, void *stream);
+
+/* dW[co,ci] += sum_m dY[m,co] * act_in(X)[m,ci];  dbias[co] += sum_m dY[m,co] (dbias may be NULL).
+ * dW / dbias must be zero-initialised by the caller (the kernel splits the row range over workgroups and
+ * accumulates with fp32 atomics). */
+int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
+                              const float *X, int ldx, int in_mode, const float *in_scale, const float *in_shift,
+                              const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW, int lddw, float *dbias,
+                              int M, int N, int K, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Extrusion-cylinder fitting  (data_utils.py:99-177, :253-266, :1650-1730; eval.py:409-436)
+ * ------------------------------------------------------------------------------------------- */
+
+/* estimate_extrusion_axis: per (b,k) the 3x3 matrices  BtB = sum_n wb^2 x x^T, CtC = sum_n wc^2 x x^T,
+ * M = BtB/sb^2 - CtC/sc^2 (sb = sc = 1 unless normalize: sqrt(#gt barrel/base points of segment k)+1,
+ * data_utils.py:133-160), then the eigenvector of the smallest (signed) eigenvalue of M (:170-171).
+ * X [B,N,3] normals, Wb/Wc [B,N,K]; bb_gt / inst_gt [B,N] int64 only when normalize != 0.
+ * axis_out [B,K,3] (sign convention: largest-magnitude component positive);
+ * eig_out [B,K,12] = {lambda0..2 ascending, v1 (3), v2 (3), 1/sb^2, 1/sc^2, sign} saved for backward (may be NULL).
+ * K <= 16. */
+int p2c_extrusion_axis_f32(const float *X, const float *Wb, const float *Wc, const int64_t *bb_gt, const int64_t *inst_gt,
+                           int normalize, int B, int N, int K, float *axis_out, float *eig_out, void *stream);
+/* backward: d axis [B,K,3] -> dX [B,N,3], dWb, dWc [B,N,K] */
+int p2c_extrusion_axis_bwd_f32(const float *daxis, const float *axis, const float *eig, const float *X, const float *Wb,
+                               const float *Wc, int B, int N, int K, float *dX, float *dWb, float *dWc, void *stream);
+
+/* estimate_extrusion_centers: c[b,k,:] = (1/N) sum_n W[b,n,k] * P[b,n,:]    (data_utils.py:253-266) */
+int p2c_extrusion_centers_f32(const float *W, const float *P, int B, int N, int K, float *centers_out, void *stream);
+int p2c_extrusion_centers_bwd_f32(const float *dcenters, const float *P, int B, int N, int K, float *dW, void *stream);
+
+/* hard per-segment centroids (eval.py:409-436): mean of points whose label == k; found[b,k] = count > 1 */
+int p2c_segment_centroids_f32(const float *P, const int64_t *label, int B, int N, int K, float *centroids_out,
+                              float *found_out, void *stream);
+
+/* get_extrusion_extents (data_utils.py:1650-1730): min/max of (p - c).a over the sampled barrel points.
+ * rand_idx [B,K,S] int64 = the reference's torch.randint(0, n_barrel(b,k), (S,)) draws (:1696) made by the
+ * caller (ignored where the segment is not found).  extents_out [K,B,2], found_out [B,K].
+ * ws: p2c_extents_ws_bytes(B,K) bytes. */
+size_t p2c_extents_ws_bytes(int B, int K);
+int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, const int64_t *bb, const float *axes, const float *centers,
+                              const int64_t *rand_idx, int B, int N, int K, int S, float *extents_out, float *found_out,
+                              void *ws, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Hungarian matching on the device (losses.py:22-52; scipy.optimize.linear_sum_assignment restated)
+ * W [B,N,K] soft or hard segmentation, I_gt [B,N] int64 (may contain -1).  match_out [B,K] int64,
+ * mask_out [B,K] uint8.  K <= 15. */
+int p2c_hungarian_f32(const float *W, const int64_t *I_gt, int B, int N, int K, int64_t *match_out, uint8_t *mask_out,
+                      void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* P2C_HIP_H */

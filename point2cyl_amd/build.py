@@ -1,0 +1,63 @@
+"""Build libp2c_hip.so (gfx950 only) in-tree with hipcc.  No GPU is needed to compile.
+
+    python -m point2cyl_amd.build [--force]
+
+The shared object lands next to this file so that it travels with a snapshot of the repo; it is
+git-ignored (sources only in history).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "libp2c_hip.so")
+SOURCES = ["geom.hip", "gather.hip", "gemm.hip", "bn.hip", "fit.hip", "assign.hip", "loss.hip"]
+# -ffp-contract=off: geom.hip reproduces the reference's rounding order (explicit fmaf only)
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    deps = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "p2c_hip.h")]
+    objs, dirty = [], False
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        if not os.path.exists(s):
+            continue
+        o = os.path.join(OBJ, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            cmd = [_hipcc()] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+            dirty = True
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            sys.stderr.write(out.decode())
+            raise RuntimeError("hipcc failed on %s" % src)
+    if dirty or not os.path.exists(LIB):
+        cmd = [_hipcc(), "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,243 @@
+// bn.hip -- the small kernels around the GEMMs: BatchNorm statistics -> affine, the materialised
+// relu(bn(.)) where a consumer needs it, max-pool over the neighbour axis (fwd/bwd), and the
+// per-channel reductions of the ReLU+BatchNorm backward.  All HBM-bound streaming / reductions; lanes
+// run along the (contiguous) channel axis so every wave access is a coalesced row segment.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm finalize.  partials[tile][0][C] = sum(acc), [tile][1][C] = sum(acc^2) with acc = y - bias
+// (the GEMM epilogue accumulates before the bias add; var is bias-free, mean gets the bias back here).
+// Block = 64 channels x 16 tile-lanes, fp64 accumulation.  torch semantics: biased variance normalises,
+// unbiased variance feeds running_var; running = (1-momentum)*running + momentum*batch.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) bn_finalize_kernel(const float *__restrict__ partials, int n_tiles, int C, long long count,
+                                                           const float *__restrict__ bias, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, float eps, float momentum, int training,
+                                                           float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                           float *__restrict__ scale, float *__restrict__ shift,
+                                                           float *__restrict__ mean_out, float *__restrict__ invstd_out)
+{
+    __shared__ double red[2][16][64];
+    const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (training && c < C) {
+        for (int t = ty; t < n_tiles; t += 16) {
+            s1 += (double)partials[(size_t)t * 2 * C + c];
+            s2 += (double)partials[(size_t)t * 2 * C + C + c];
+        }
+    }
+    red[0][ty][cx] = s1;
+    red[1][ty][cx] = s2;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    float mean, invstd;
+    if (training) {
+        s1 = 0.0; s2 = 0.0;
+        for (int t = 0; t < 16; ++t) { s1 += red[0][t][cx]; s2 += red[1][t][cx]; }
+        const double m0 = s1 / (double)count;
+        double var = s2 / (double)count - m0 * m0;
+        if (var < 0.0) var = 0.0;
+        const double m = m0 + (bias ? (double)bias[c] : 0.0);
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = count > 1 ? var * (double)count / (double)(count - 1) : var;
+            running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+            running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.0f / sqrtf(running_var[c] + eps);
+    }
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (mean_out) mean_out[c] = mean;
+    if (invstd_out) invstd_out[c] = invstd;
+}
+
+extern "C" int p2c_bn_finalize_f32(const float *stat_partials, int n_tiles, int C, long long count, const float *bias,
+                                   const float *gamma, const float *beta, float eps, float momentum, int training,
+                                   float *running_mean, float *running_var, float *scale, float *shift, float *mean,
+                                   float *invstd, void *stream)
+{
+    if (C <= 0 || !gamma || !beta || !scale || !shift) return P2C_EINVAL;
+    if (training && (!stat_partials || n_tiles <= 0 || count <= 0)) return P2C_EINVAL;
+    if (!training && (!running_mean || !running_var)) return P2C_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, stat_partials, n_tiles, C, count, bias,
+                       gamma, beta, eps, momentum, training, running_mean, running_var, scale, shift, mean, invstd);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Z = relu(scale*Y + shift)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) bn_relu_apply_kernel(const float *__restrict__ Y, int ldy, const float *__restrict__ scale,
+                                                            const float *__restrict__ shift, long long M, int C, float *__restrict__ Z,
+                                                            int ldz)
+{
+    const long long total = M * C;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / C;
+        const int c = (int)(e - r * C);
+        Z[r * ldz + c] = fmaxf(scale[c] * Y[r * ldy + c] + shift[c], 0.f);
+    }
+}
+
+extern "C" int p2c_bn_relu_apply_f32(const float *Y, int ldy, const float *scale, const float *shift, int M, int C, float *Z, int ldz,
+                                     void *stream)
+{
+    if (!Y || !scale || !shift || !Z || M <= 0 || C <= 0) return P2C_EINVAL;
+    const int blocks = (int)min((long long)p2c_cdiv((long long)M * C, 256), 8192LL);
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, Y, ldy, scale, shift, (long long)M, C, Z, ldz);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// max over the neighbour axis of relu(bn(Y)) (pointnet_util.py:205).  One thread per (group, channel).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) maxpool_bnrelu_kernel(const float *__restrict__ Y, int ldy, const float *__restrict__ scale,
+                                                             const float *__restrict__ shift, int G, int ns, int C,
+                                                             float *__restrict__ out, int ldo, int32_t *__restrict__ arg)
+{
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    const int g = blockIdx.x;
+    if (c >= C) return;
+    const float sc = scale[c], sh = shift[c];
+    const float *y = Y + (size_t)g * ns * ldy + c;
+    float best = -INFINITY;
+    int bj = 0;
+#pragma unroll 8
+    for (int j = 0; j < ns; ++j) {
+        const float z = fmaxf(sc * y[(size_t)j * ldy] + sh, 0.f);
+        if (z > best) { best = z; bj = j; }
+    }
+    out[(size_t)g * ldo + c] = best;
+    arg[(size_t)g * C + c] = bj;
+}
+
+extern "C" int p2c_maxpool_bnrelu_f32(const float *Y, int ldy, const float *scale, const float *shift, int G, int ns, int C, float *out,
+                                      int ldo, int32_t *arg, void *stream)
+{
+    if (!Y || !scale || !shift || !out || !arg || G <= 0 || ns <= 0 || C <= 0) return P2C_EINVAL;
+    const int bx = C >= 256 ? 256 : ((C + 63) & ~63);
+    hipLaunchKernelGGL(maxpool_bnrelu_kernel, dim3(G, p2c_cdiv(C, bx)), dim3(bx), 0, (hipStream_t)stream, Y, ldy, scale, shift, G, ns, C, out,
+                       ldo, arg);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+__global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float *__restrict__ dout, int ldo, const int32_t *__restrict__ arg, int G,
+                                                          int ns, int C, float *__restrict__ dZ, int ldz)
+{
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    const int g = blockIdx.x;
+    if (c >= C) return;
+    const float gv = dout[(size_t)g * ldo + c];
+    const int a = arg[(size_t)g * C + c];
+    float *d = dZ + (size_t)g * ns * ldz + c;
+#pragma unroll 8
+    for (int j = 0; j < ns; ++j) d[(size_t)j * ldz] = (j == a) ? gv : 0.f;
+}
+
+extern "C" int p2c_maxpool_bwd_f32(const float *dout, int ldo, const int32_t *arg, int G, int ns, int C, float *dZ, int ldz, void *stream)
+{
+    if (!dout || !arg || !dZ || G <= 0 || ns <= 0 || C <= 0) return P2C_EINVAL;
+    const int bx = C >= 256 ? 256 : ((C + 63) & ~63);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(G, p2c_cdiv(C, bx)), dim3(bx), 0, (hipStream_t)stream, dout, ldo, arg, G, ns, C, dZ, ldz);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ReLU + train-mode BatchNorm backward, reduction part.
+//   g = dZ * [scale*Y+shift > 0];  s1[c] = sum_m g;  s2[c] = sum_m g * (Y-mean)*invstd
+// pass 1: block = 64 channels x 4 row-lanes over a chunk of BWD_ROWS rows -> ws[chunk][2][C]
+// pass 2: fp64 sum over chunks; dgamma = s2, dbeta = s1; coef = {scale, shift, gs, q, p} with
+//         gs = gamma*invstd, q = -gs*invstd*s2/M, p = -gs*s1/M - q*mean   (so dY = gs*g + q*Y + p)
+// ------------------------------------------------------------------------------------------------
+#define BWD_ROWS 512
+
+__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float *__restrict__ dZ, int lddz, const float *__restrict__ Y, int ldy,
+                                                             const float *__restrict__ scale, const float *__restrict__ shift,
+                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                             long long M, int C, float *__restrict__ ws)
+{
+    __shared__ float red[2][4][64];
+    const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cx;
+    const long long r0 = (long long)blockIdx.x * BWD_ROWS;
+    const long long r1 = min(M, r0 + BWD_ROWS);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+#pragma unroll 4
+        for (long long r = r0 + ty; r < r1; r += 4) {
+            const float y = Y[r * ldy + c];
+            const float g = (sc * y + sh > 0.f) ? dZ[r * lddz + c] : 0.f;
+            s1 += g;
+            s2 += g * ((y - mu) * is);
+        }
+    }
+    red[0][ty][cx] = s1;
+    red[1][ty][cx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float *o = ws + (size_t)blockIdx.x * 2 * C;
+        o[c] = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+        o[C + c] = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+    }
+}
+
+__global__ void __launch_bounds__(1024) bn_bwd_finalize_kernel(const float *__restrict__ ws, int n_chunks, int C, long long M,
+                                                               const float *__restrict__ scale, const float *__restrict__ shift,
+                                                               const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                               const float *__restrict__ gamma, float *__restrict__ dgamma,
+                                                               float *__restrict__ dbeta, float *__restrict__ coef)
+{
+    __shared__ double red[2][16][64];
+    const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int t = ty; t < n_chunks; t += 16) {
+            s1 += (double)ws[(size_t)t * 2 * C + c];
+            s2 += (double)ws[(size_t)t * 2 * C + C + c];
+        }
+    red[0][ty][cx] = s1;
+    red[1][ty][cx] = s2;
+    __syncthreads();
+    if (ty != 0 || c >= C) return;
+    s1 = 0.0; s2 = 0.0;
+    for (int t = 0; t < 16; ++t) { s1 += red[0][t][cx]; s2 += red[1][t][cx]; }
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+    const double is = (double)invstd[c], gs = (double)gamma[c] * is;
+    const double q = -gs * is * s2 / (double)M;
+    const double p = -gs * s1 / (double)M - q * (double)mean[c];
+    coef[c] = scale[c];
+    coef[C + c] = shift[c];
+    coef[2 * C + c] = (float)gs;
+    coef[3 * C + c] = (float)q;
+    coef[4 * C + c] = (float)p;
+}
+
+extern "C" size_t p2c_bn_bwd_ws_bytes(int M, int C) { return (size_t)p2c_cdiv(M, BWD_ROWS) * 2 * (size_t)C * sizeof(float); }
+
+extern "C" int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float *Y, int ldy, const float *scale, const float *shift,
+                                         const float *mean, const float *invstd, const float *gamma, int M, int C, float *dgamma,
+                                         float *dbeta, float *coef_out, void *ws, void *stream)
+{
+    if (!dZ || !Y || !scale || !shift || !mean || !invstd || !gamma || !coef_out || !ws || M <= 0 || C <= 0) return P2C_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = p2c_cdiv(M, BWD_ROWS);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dZ, lddz, Y, ldy, scale, shift, mean, invstd,
+                       (long long)M, C, (float *)ws);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(1024), 0, s, (const float *)ws, chunks, C, (long long)M, scale, shift,
+                       mean, invstd, gamma, dgamma, dbeta, coef_out);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

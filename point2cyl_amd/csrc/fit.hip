@@ -1,0 +1,383 @@
+// fit.hip -- differentiable extrusion-cylinder fitting on gfx950.
+//
+// estimate_extrusion_axis (data_utils.py:99-177) in the reference materialises two N x N diagonal
+// matrices per segment and runs LAPACK syev per 3x3.  Here: ONE streaming pass over (X, Wb, Wc) per cloud
+// accumulates, for every segment k, the 6+6 unique entries of B^T B = sum wb^2 x x^T and
+// C^T C = sum wc^2 x x^T (76 B/point of HBM traffic, nothing else), followed in the same kernel by a
+// cyclic-Jacobi eigen-solve in fp64 registers that returns the eigenvector of the smallest signed
+// eigenvalue of B^T B/sb^2 - C^T C/sc^2 (the reference's v[:,:,0] of an ascending symeig).
+// Thread (g,k) of the 1024-thread workgroup owns segment k and the point slice g, g+G, g+2G, ... so a wave
+// reads whole 32-byte weight rows and every lane is busy for any K.
+#include "common.h"
+
+#define FIT_THREADS 1024
+#define FIT_MAXK 16
+
+// cyclic Jacobi for a symmetric 3x3 (fp64).  a = {a00,a01,a02,a11,a12,a22}; out: lam[3] ascending, v[3][3]
+// (v[j] = j-th eigenvector).  Zero matrix -> identity eigenvectors (LAPACK's answer too).
+__device__ void p2c_eigh3(const double a_in[6], double lam[3], double v[3][3])
+{
+    double A[3][3] = {{a_in[0], a_in[1], a_in[2]}, {a_in[1], a_in[3], a_in[4]}, {a_in[2], a_in[4], a_in[5]}};
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
+        if (off <= 1e-18 * diag || off == 0.0) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int r = 0; r < 3; ++r) {   // A <- A J
+                    const double arp = A[r][p], arq = A[r][q];
+                    A[r][p] = c * arp - s * arq;
+                    A[r][q] = s * arp + c * arq;
+                }
+                for (int r = 0; r < 3; ++r) {   // A <- J^T A
+                    const double apr = A[p][r], aqr = A[q][r];
+                    A[p][r] = c * apr - s * aqr;
+                    A[q][r] = s * apr + c * aqr;
+                }
+                for (int r = 0; r < 3; ++r) {
+                    const double vrp = V[r][p], vrq = V[r][q];
+                    V[r][p] = c * vrp - s * vrq;
+                    V[r][q] = s * vrp + c * vrq;
+                }
+            }
+    }
+    int o[3] = {0, 1, 2};
+    double d[3] = {A[0][0], A[1][1], A[2][2]};
+    // stable ascending sort of 3
+    if (d[o[1]] < d[o[0]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
+    if (d[o[2]] < d[o[1]]) { int t = o[1]; o[1] = o[2]; o[2] = t; }
+    if (d[o[1]] < d[o[0]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
+    for (int j = 0; j < 3; ++j) {
+        lam[j] = d[o[j]];
+        for (int r = 0; r < 3; ++r) v[j][r] = V[r][o[j]];
+    }
+}
+
+__global__ void __launch_bounds__(FIT_THREADS) axis_kernel(const float *__restrict__ X, const float *__restrict__ Wb,
+                                                           const float *__restrict__ Wc, const int64_t *__restrict__ bb_gt,
+                                                           const int64_t *__restrict__ inst_gt, int normalize, int N, int K,
+                                                           float *__restrict__ axis_out, float *__restrict__ eig_out)
+{
+    __shared__ float red[14][FIT_THREADS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int G = FIT_THREADS / K;            // point slices
+    const int g = tid / K, k = tid - g * K;
+    float acc[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) acc[i] = 0.f;
+    if (g < G) {
+        const float *x = X + (size_t)b * N * 3;
+        const float *wb = Wb + (size_t)b * N * K, *wc = Wc + (size_t)b * N * K;
+        for (int n = g; n < N; n += G) {
+            const float x0 = x[n * 3 + 0], x1 = x[n * 3 + 1], x2 = x[n * 3 + 2];
+            const float b_ = wb[(size_t)n * K + k], c_ = wc[(size_t)n * K + k];
+            const float b2 = b_ * b_, c2 = c_ * c_;
+            const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
+            acc[0] += b2 * p00; acc[1] += b2 * p01; acc[2] += b2 * p02; acc[3] += b2 * p11; acc[4] += b2 * p12; acc[5] += b2 * p22;
+            acc[6] += c2 * p00; acc[7] += c2 * p01; acc[8] += c2 * p02; acc[9] += c2 * p11; acc[10] += c2 * p12; acc[11] += c2 * p22;
+            if (normalize) {
+                const bool mine = inst_gt[(size_t)b * N + n] == k;
+                const int64_t bbv = bb_gt[(size_t)b * N + n];
+                acc[12] += (mine && bbv == 0) ? 1.f : 0.f;
+                acc[13] += (mine && bbv == 1) ? 1.f : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 14; ++i) red[i][tid] = acc[i];
+    __syncthreads();
+    // K*14 threads: fp64 sum over the G slices of one (k, entry); result kept in fp32 like the reference's bmm
+    const bool reducer = tid < K * 14;
+    const int rk = tid / 14, re = tid - rk * 14;
+    double rs = 0.0;
+    if (reducer)
+        for (int gg = 0; gg < G; ++gg) rs += (double)red[re][gg * K + rk];
+    __syncthreads();
+    if (reducer) red[re][rk] = (float)rs;
+    __syncthreads();
+    if (tid >= K) return;
+    double isb2 = 1.0, isc2 = 1.0;
+    if (normalize) {
+        const float sb = sqrtf(red[12][tid]) + 1.0f, sc = sqrtf(red[13][tid]) + 1.0f;   // data_utils.py:139-160
+        isb2 = 1.0 / ((double)sb * (double)sb);
+        isc2 = 1.0 / ((double)sc * (double)sc);
+    }
+    double a[6], lam[3], v[3][3];
+    for (int e = 0; e < 6; ++e) a[e] = (double)red[e][tid] * isb2 - (double)red[6 + e][tid] * isc2;
+    p2c_eigh3(a, lam, v);
+    // canonical sign: largest-magnitude component positive
+    int big = 0;
+    if (fabs(v[0][1]) > fabs(v[0][big])) big = 1;
+    if (fabs(v[0][2]) > fabs(v[0][big])) big = 2;
+    const double sgn = v[0][big] < 0 ? -1.0 : 1.0;
+    float *o = axis_out + ((size_t)b * K + tid) * 3;
+    o[0] = (float)(sgn * v[0][0]); o[1] = (float)(sgn * v[0][1]); o[2] = (float)(sgn * v[0][2]);
+    if (eig_out) {
+        float *e = eig_out + ((size_t)b * K + tid) * 12;
+        e[0] = (float)lam[0]; e[1] = (float)lam[1]; e[2] = (float)lam[2];
+        e[3] = (float)v[1][0]; e[4] = (float)v[1][1]; e[5] = (float)v[1][2];
+        e[6] = (float)v[2][0]; e[7] = (float)v[2][1]; e[8] = (float)v[2][2];
+        e[9] = (float)isb2; e[10] = (float)isc2; e[11] = (float)sgn;
+    }
+}
+
+extern "C" int p2c_extrusion_axis_f32(const float *X, const float *Wb, const float *Wc, const int64_t *bb_gt, const int64_t *inst_gt,
+                                      int normalize, int B, int N, int K, float *axis_out, float *eig_out, void *stream)
+{
+    if (!X || !Wb || !Wc || !axis_out || B <= 0 || N <= 0 || K <= 0 || K > FIT_MAXK) return P2C_EINVAL;
+    if (normalize && (!bb_gt || !inst_gt)) return P2C_EINVAL;
+    hipLaunchKernelGGL(axis_kernel, dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K, axis_out,
+                       eig_out);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// Backward.  With a = sgn*v0, g = sgn*dL/da:  dL/dM = sum_{j=1,2} (v_j.g)/(lam0-lam_j) v_j v0^T; only its
+// symmetric part Gs matters because M is built symmetrically:  M = sum_n (wb^2/sb^2 - wc^2/sc^2) x x^T
+//   dL/dwb_n =  2 wb_n/sb^2 (x^T Gs x),  dL/dwc_n = -2 wc_n/sc^2 (x^T Gs x),  dL/dx_n = sum_k alpha_nk 2 Gs_k x.
+// A zero upstream gradient yields exactly zero (masked segments), also for degenerate spectra.
+__global__ void __launch_bounds__(256) axis_bwd_kernel(const float *__restrict__ daxis, const float *__restrict__ axis,
+                                                       const float *__restrict__ eig, const float *__restrict__ X,
+                                                       const float *__restrict__ Wb, const float *__restrict__ Wc, int N, int K,
+                                                       float *__restrict__ dX, float *__restrict__ dWb, float *__restrict__ dWc)
+{
+    __shared__ float sG[FIT_MAXK][8];   // Gs (6), 1/sb^2, 1/sc^2
+    const int b = blockIdx.y;
+    if (threadIdx.x < K) {
+        const int k = threadIdx.x;
+        const float *e = eig + ((size_t)b * K + k) * 12;
+        const float *a = axis + ((size_t)b * K + k) * 3, *da = daxis + ((size_t)b * K + k) * 3;
+        const double sgn = e[11];
+        const double v0[3] = {sgn * a[0], sgn * a[1], sgn * a[2]};
+        const double g[3] = {sgn * da[0], sgn * da[1], sgn * da[2]};
+        double Gm[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        if (g[0] != 0.0 || g[1] != 0.0 || g[2] != 0.0) {
+            for (int j = 1; j <= 2; ++j) {
+                const double vj[3] = {e[3 * j], e[3 * j + 1], e[3 * j + 2]};
+                const double cj = (vj[0] * g[0] + vj[1] * g[1] + vj[2] * g[2]) / ((double)e[0] - (double)e[j]);
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) Gm[r][c] += cj * vj[r] * v0[c];
+            }
+        }
+        sG[k][0] = (float)Gm[0][0];
+        sG[k][1] = (float)(0.5 * (Gm[0][1] + Gm[1][0]));
+        sG[k][2] = (float)(0.5 * (Gm[0][2] + Gm[2][0]));
+        sG[k][3] = (float)Gm[1][1];
+        sG[k][4] = (float)(0.5 * (Gm[1][2] + Gm[2][1]));
+        sG[k][5] = (float)Gm[2][2];
+        sG[k][6] = e[9];
+        sG[k][7] = e[10];
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const size_t pn = (size_t)b * N + n;
+    const float x0 = X[pn * 3 + 0], x1 = X[pn * 3 + 1], x2 = X[pn * 3 + 2];
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const float g00 = sG[k][0], g01 = sG[k][1], g02 = sG[k][2], g11 = sG[k][3], g12 = sG[k][4], g22 = sG[k][5];
+        const float gx0 = g00 * x0 + g01 * x1 + g02 * x2, gx1 = g01 * x0 + g11 * x1 + g12 * x2, gx2 = g02 * x0 + g12 * x1 + g22 * x2;
+        const float quad = x0 * gx0 + x1 * gx1 + x2 * gx2;
+        const float wb = Wb[pn * K + k], wc = Wc[pn * K + k];
+        dWb[pn * K + k] = 2.f * wb * sG[k][6] * quad;
+        dWc[pn * K + k] = -2.f * wc * sG[k][7] * quad;
+        const float alpha = 2.f * (wb * wb * sG[k][6] - wc * wc * sG[k][7]);
+        d0 += alpha * gx0; d1 += alpha * gx1; d2 += alpha * gx2;
+    }
+    dX[pn * 3 + 0] = d0; dX[pn * 3 + 1] = d1; dX[pn * 3 + 2] = d2;
+}
+
+extern "C" int p2c_extrusion_axis_bwd_f32(const float *daxis, const float *axis, const float *eig, const float *X, const float *Wb,
+                                          const float *Wc, int B, int N, int K, float *dX, float *dWb, float *dWc, void *stream)
+{
+    if (!daxis || !axis || !eig || !X || !Wb || !Wc || !dX || !dWb || !dWc || K <= 0 || K > FIT_MAXK) return P2C_EINVAL;
+    hipLaunchKernelGGL(axis_bwd_kernel, dim3(p2c_cdiv(N, 256), B), dim3(256), 0, (hipStream_t)stream, daxis, axis, eig, X, Wb, Wc, N, K, dX, dWb,
+                       dWc);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Centres.  MODE 0: c[b,k] = (1/N) sum_n W[b,n,k] p[b,n]  (data_utils.py:253-266, a mean over N).
+//           MODE 1: hard centroids from labels (eval.py:409-436): mean of points with label == k;
+//                   found = count > 1 (a single point counts as "not found", zeros).
+// Same (slice, k) thread mapping as the axis kernel; one workgroup per cloud.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ void __launch_bounds__(FIT_THREADS) centers_kernel(const float *__restrict__ W, const int64_t *__restrict__ label,
+                                                              const float *__restrict__ P, int N, int K, float *__restrict__ out,
+                                                              float *__restrict__ found)
+{
+    __shared__ float red[4][FIT_THREADS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int G = FIT_THREADS / K;
+    const int g = tid / K, k = tid - g * K;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, cnt = 0.f;
+    if (g < G) {
+        const float *p = P + (size_t)b * N * 3;
+        for (int n = g; n < N; n += G) {
+            float w;
+            if (MODE == 0) w = W[((size_t)b * N + n) * K + k];
+            else w = (label[(size_t)b * N + n] == k) ? 1.f : 0.f;
+            a0 += w * p[n * 3 + 0]; a1 += w * p[n * 3 + 1]; a2 += w * p[n * 3 + 2];
+            cnt += w;
+        }
+    }
+    red[0][tid] = a0; red[1][tid] = a1; red[2][tid] = a2; red[3][tid] = cnt;
+    __syncthreads();
+    const bool reducer = tid < K * 4;
+    const int rk = tid >> 2, re = tid & 3;
+    double rs = 0.0;
+    if (reducer)
+        for (int gg = 0; gg < G; ++gg) rs += (double)red[re][gg * K + rk];
+    __syncthreads();
+    if (reducer) red[re][rk] = (float)rs;
+    __syncthreads();
+    if (tid < K) {
+        float *o = out + ((size_t)b * K + tid) * 3;
+        if (MODE == 0) {
+            const float inv = 1.0f / (float)N;
+            o[0] = red[0][tid] * inv; o[1] = red[1][tid] * inv; o[2] = red[2][tid] * inv;
+        } else {
+            const float c = red[3][tid];
+            const bool ok = c > 1.f;
+            o[0] = ok ? red[0][tid] / c : 0.f; o[1] = ok ? red[1][tid] / c : 0.f; o[2] = ok ? red[2][tid] / c : 0.f;
+            found[(size_t)b * K + tid] = ok ? 1.f : 0.f;
+        }
+    }
+}
+
+extern "C" int p2c_extrusion_centers_f32(const float *W, const float *P, int B, int N, int K, float *centers_out, void *stream)
+{
+    if (!W || !P || !centers_out || K <= 0 || K > FIT_MAXK) return P2C_EINVAL;
+    hipLaunchKernelGGL(centers_kernel<0>, dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, W, (const int64_t *)nullptr, P, N, K,
+                       centers_out, (float *)nullptr);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+extern "C" int p2c_segment_centroids_f32(const float *P, const int64_t *label, int B, int N, int K, float *centroids_out,
+                                         float *found_out, void *stream)
+{
+    if (!P || !label || !centroids_out || !found_out || K <= 0 || K > FIT_MAXK) return P2C_EINVAL;
+    hipLaunchKernelGGL(centers_kernel<1>, dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, (const float *)nullptr, label, P, N, K,
+                       centroids_out, found_out);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// dW[b,n,k] = (1/N) dc[b,k,:] . p[b,n,:]
+__global__ void __launch_bounds__(256) centers_bwd_kernel(const float *__restrict__ dC, const float *__restrict__ P, int N, int K,
+                                                          float *__restrict__ dW)
+{
+    const int b = blockIdx.y;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)N * K) return;
+    const int n = (int)(e / K), k = (int)(e - (long long)n * K);
+    const float *p = P + ((size_t)b * N + n) * 3, *d = dC + ((size_t)b * K + k) * 3;
+    dW[(size_t)b * N * K + e] = (d[0] * p[0] + d[1] * p[1] + d[2] * p[2]) / (float)N;
+}
+
+extern "C" int p2c_extrusion_centers_bwd_f32(const float *dcenters, const float *P, int B, int N, int K, float *dW, void *stream)
+{
+    if (!dcenters || !P || !dW) return P2C_EINVAL;
+    hipLaunchKernelGGL(centers_bwd_kernel, dim3(p2c_cdiv((long long)N * K, 256), B), dim3(256), 0, (hipStream_t)stream, dcenters, P, N, K, dW);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Extents (data_utils.py:1650-1730).  Workgroup (b,k): compact the ascending list of barrel points of
+// segment k in LDS (ballot prefix sums), then project the S sampled points (the caller's randint
+// draws index that list) on the axis and take min / max.  A second tiny kernel applies the
+// reference's batch-level rule (:1671: a segment with <= 1 barrel point in the WHOLE batch is skipped,
+// extents stay 0) and its per-cloud rule (:1690: <= 1 point => projected points are zeros).
+// ------------------------------------------------------------------------------------------------
+#define EXT_MAXN 32768
+
+__global__ void __launch_bounds__(256) extents_kernel(const float *__restrict__ P, const int64_t *__restrict__ seg,
+                                                      const int64_t *__restrict__ bb, const float *__restrict__ axes,
+                                                      const float *__restrict__ centers, const int64_t *__restrict__ rand_idx, int N, int K,
+                                                      int S, float *__restrict__ ext_tmp, int *__restrict__ counts)
+{
+    extern __shared__ int list[];          // N ints
+    __shared__ int wsum[4];
+    __shared__ float rmin[4], rmax[4];
+    __shared__ int base_s;
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int n0 = 0; n0 < N; n0 += 256) {
+        const int n = n0 + tid;
+        const bool in = n < N && seg[(size_t)b * N + n] == k && bb[(size_t)b * N + n] == 0;
+        const unsigned long long m = __ballot(in);
+        if (lane == 0) wsum[wave] = __popcll(m);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wsum[w];
+        if (in) list[off + __popcll(m & ((1ull << lane) - 1ull))] = n;
+        __syncthreads();
+        if (tid == 0) base_s += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    const int cnt = base_s;
+    if (tid == 0) counts[b * K + k] = cnt;
+    const float *a = axes + ((size_t)b * K + k) * 3, *c = centers + ((size_t)b * K + k) * 3;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int s = tid; s < S; s += 256) {
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (cnt > 1) {
+            const int n = list[(int)rand_idx[((size_t)b * K + k) * S + s]];
+            px = P[((size_t)b * N + n) * 3 + 0]; py = P[((size_t)b * N + n) * 3 + 1]; pz = P[((size_t)b * N + n) * 3 + 2];
+        }
+        const float dx = px - c[0], dy = py - c[1], dz = pz - c[2];
+        const float t = __builtin_fmaf(dz, a[2], __builtin_fmaf(dy, a[1], dx * a[0]));
+        lo = fminf(lo, t); hi = fmaxf(hi, t);
+    }
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if (lane == 0) { rmin[wave] = lo; rmax[wave] = hi; }
+    __syncthreads();
+    if (tid == 0) {
+        ext_tmp[((size_t)b * K + k) * 2 + 0] = fminf(fminf(rmin[0], rmin[1]), fminf(rmin[2], rmin[3]));
+        ext_tmp[((size_t)b * K + k) * 2 + 1] = fmaxf(fmaxf(rmax[0], rmax[1]), fmaxf(rmax[2], rmax[3]));
+    }
+}
+
+__global__ void extents_finish_kernel(const float *__restrict__ ext_tmp, const int *__restrict__ counts, int B, int K,
+                                      float *__restrict__ extents, float *__restrict__ found)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    long long total = 0;
+    for (int b = 0; b < B; ++b) total += counts[b * K + k];
+    for (int b = 0; b < B; ++b) {
+        const bool seg_ok = total > 1;
+        extents[((size_t)k * B + b) * 2 + 0] = seg_ok ? ext_tmp[((size_t)b * K + k) * 2 + 0] : 0.f;
+        extents[((size_t)k * B + b) * 2 + 1] = seg_ok ? ext_tmp[((size_t)b * K + k) * 2 + 1] : 0.f;
+        found[(size_t)b * K + k] = (seg_ok && counts[b * K + k] > 1) ? 1.f : 0.f;
+    }
+}
+
+extern "C" size_t p2c_extents_ws_bytes(int B, int K) { return (size_t)B * K * (2 * sizeof(float) + sizeof(int)); }
+
+extern "C" int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, const int64_t *bb, const float *axes, const float *centers,
+                                         const int64_t *rand_idx, int B, int N, int K, int S, float *extents_out, float *found_out,
+                                         void *ws, void *stream)
+{
+    if (!P || !seg || !bb || !axes || !centers || !rand_idx || !extents_out || !found_out || !ws || N > EXT_MAXN || K <= 0 || S <= 0)
+        return P2C_EINVAL;
+    float *ext_tmp = (float *)ws;
+    int *counts = (int *)(ext_tmp + (size_t)B * K * 2);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)N * sizeof(int);
+    (void)hipFuncSetAttribute((const void *)extents_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(extents_kernel, dim3(K, B), dim3(256), lds, s, P, seg, bb, axes, centers, rand_idx, N, K, S, ext_tmp, counts);
+    hipLaunchKernelGGL(extents_finish_kernel, dim3(p2c_cdiv(K, 64)), dim3(64), 0, s, ext_tmp, counts, B, K, extents_out, found_out);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

@@ -1,0 +1,150 @@
+// gather.hip -- grouping gather (+centring, concat) and 3-NN interpolation, forward and backward.
+// HBM-bound row gathers: each wave moves whole feature rows (contiguous, coalesced); the backward
+// passes are scatter-adds with fp32 atomics (several groups share a source point).
+#include "common.h"
+
+// out row r=(b,s,j): [xyz[b,idx]-new_xyz[b,s] | feats[b,idx,0:D] | 0...]  (pointnet_util.py:128-139)
+__global__ void __launch_bounds__(256) group_gather_kernel(const float *__restrict__ xyz, const float *__restrict__ feats, int ldf,
+                                                           const float *__restrict__ new_xyz, const int32_t *__restrict__ idx,
+                                                           int N, int S, int ns, int D, long long rows, float *__restrict__ out,
+                                                           int ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long r = wave; r < rows; r += nw) {
+        const long long g = r / ns;              // (b,s)
+        const int b = (int)(g / S);
+        const int src = idx[r];
+        const float *p = xyz + ((size_t)b * N + src) * 3;
+        const float *c = new_xyz + (size_t)g * 3;
+        const float *f = feats ? feats + ((size_t)b * N + src) * ldf : nullptr;
+        float *o = out + (size_t)r * ldo;
+        for (int col = lane; col < ldo; col += 64) {
+            float v = 0.f;
+            if (col < 3) v = p[col] - c[col];
+            else if (col < 3 + D) v = f[col - 3];
+            o[col] = v;
+        }
+    }
+}
+
+// D == 0 fast path: one thread per row, a single 16-byte store
+__global__ void __launch_bounds__(256) group_gather_xyz_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                               const int32_t *__restrict__ idx, int N, int S, int ns,
+                                                               long long rows, float4 *__restrict__ out)
+{
+    const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const long long g = r / ns;
+    const int b = (int)(g / S);
+    const float *p = xyz + ((size_t)b * N + idx[r]) * 3;
+    const float *c = new_xyz + (size_t)g * 3;
+    out[r] = make_float4(p[0] - c[0], p[1] - c[1], p[2] - c[2], 0.f);
+}
+
+extern "C" int p2c_group_gather_f32(const float *xyz, const float *feats, int ldf, const float *new_xyz, const int32_t *idx, int B,
+                                    int N, int S, int nsample, int D, float *out, int ldo, void *stream)
+{
+    if (!xyz || !new_xyz || !idx || !out || B <= 0 || D < 0 || (D > 0 && !feats) || ldo < 3 + D) return P2C_EINVAL;
+    if (ldo % 4) return P2C_EALIGN;
+    const long long rows = (long long)B * S * nsample;
+    hipStream_t s = (hipStream_t)stream;
+    if (D == 0 && ldo == 4) {
+        hipLaunchKernelGGL(group_gather_xyz_kernel, dim3(p2c_cdiv(rows, 256)), dim3(256), 0, s, xyz, new_xyz, idx, N, S, nsample, rows,
+                           reinterpret_cast<float4 *>(out));
+    } else {
+        const int blocks = (int)min((long long)p2c_cdiv(rows, 4), 16384LL);
+        hipLaunchKernelGGL(group_gather_kernel, dim3(blocks), dim3(256), 0, s, xyz, feats, ldf, new_xyz, idx, N, S, nsample, D, rows, out, ldo);
+    }
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+__global__ void __launch_bounds__(256) group_gather_bwd_kernel(const float *__restrict__ dout, int ldo, const int32_t *__restrict__ idx,
+                                                               int N, int S, int ns, int D, long long rows, float *__restrict__ dfeats,
+                                                               int ldf)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long r = wave; r < rows; r += nw) {
+        const int b = (int)(r / ((long long)S * ns));
+        float *d = dfeats + ((size_t)b * N + idx[r]) * ldf;
+        const float *g = dout + (size_t)r * ldo + 3;
+        for (int c = lane; c < D; c += 64) atomicAdd(d + c, g[c]);
+    }
+}
+
+extern "C" int p2c_group_gather_bwd_f32(const float *dout, int ldo, const int32_t *idx, int B, int N, int S, int nsample, int D,
+                                        float *dfeats, int ldf, void *stream)
+{
+    if (!dout || !idx || !dfeats || D <= 0) return P2C_EINVAL;
+    const long long rows = (long long)B * S * nsample;
+    const int blocks = (int)min((long long)p2c_cdiv(rows, 4), 16384LL);
+    hipLaunchKernelGGL(group_gather_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, ldo, idx, N, S, nsample, D, rows,
+                       dfeats, ldf);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// out[b,n,c] = (f0*w0 + f1*w1) + f2*w2   (pointnet_util.py:308: sum over the 3 neighbours in order)
+__global__ void __launch_bounds__(256) three_interp_kernel(const float *__restrict__ feats, int ldf, const int32_t *__restrict__ idx,
+                                                           const float *__restrict__ w, int N, int S, int C, long long rows,
+                                                           float *__restrict__ out, int ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long r = wave; r < rows; r += nw) {
+        const int b = (int)(r / N);
+        const int i0 = idx[r * 3 + 0], i1 = idx[r * 3 + 1], i2 = idx[r * 3 + 2];
+        const float w0 = w[r * 3 + 0], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
+        const float *f0 = feats + ((size_t)b * S + i0) * ldf, *f1 = feats + ((size_t)b * S + i1) * ldf,
+                    *f2 = feats + ((size_t)b * S + i2) * ldf;
+        float *o = out + (size_t)r * ldo;
+        for (int c = lane; c < C; c += 64) o[c] = (f0[c] * w0 + f1[c] * w1) + f2[c] * w2;
+    }
+}
+
+extern "C" int p2c_three_interp_f32(const float *feats, int ldf, const int32_t *idx, const float *weight, int B, int N, int S, int C,
+                                    float *out, int ldo, void *stream)
+{
+    if (!feats || !idx || !weight || !out || C <= 0) return P2C_EINVAL;
+    const long long rows = (long long)B * N;
+    const int blocks = (int)min((long long)p2c_cdiv(rows, 4), 16384LL);
+    hipLaunchKernelGGL(three_interp_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feats, ldf, idx, weight, N, S, C, rows, out, ldo);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+__global__ void __launch_bounds__(256) three_interp_bwd_kernel(const float *__restrict__ dout, int ldo, const int32_t *__restrict__ idx,
+                                                               const float *__restrict__ w, int N, int S, int C, long long rows,
+                                                               float *__restrict__ dfeats, int ldf)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long r = wave; r < rows; r += nw) {
+        const int b = (int)(r / N);
+        const float *g = dout + (size_t)r * ldo;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float *d = dfeats + ((size_t)b * S + idx[r * 3 + j]) * ldf;
+            const float wj = w[r * 3 + j];
+            for (int c = lane; c < C; c += 64) atomicAdd(d + c, g[c] * wj);
+        }
+    }
+}
+
+extern "C" int p2c_three_interp_bwd_f32(const float *dout, int ldo, const int32_t *idx, const float *weight, int B, int N, int S,
+                                        int C, float *dfeats, int ldf, void *stream)
+{
+    if (!dout || !idx || !weight || !dfeats || C <= 0) return P2C_EINVAL;
+    const long long rows = (long long)B * N;
+    const int blocks = (int)min((long long)p2c_cdiv(rows, 4), 16384LL);
+    hipLaunchKernelGGL(three_interp_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, ldo, idx, weight, N, S, C, rows,
+                       dfeats, ldf);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

@@ -1,0 +1,59 @@
+"""Differentiable extrusion-cylinder fitting (mirror of the reference's data_utils.py hot-path API).
+
+estimate_extrusion_axis / estimate_extrusion_centers / get_extrusion_extents keep the reference's
+signatures (data_utils.py:99, :253, :1650); the work is done by fit.hip through point2cyl_amd.ops.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+TORCH_PI = torch.acos(torch.zeros(1)).item() * 2
+
+
+def add_noise(batch_xyz, batch_normal, sigma=0.01):
+    """data_utils.py:84-96: p + N(0,sigma) * normal with NumPy's RNG, float64 result (host side)."""
+    B, N, _ = batch_xyz.shape
+    noise = np.random.normal(0.0, sigma, (B, N))
+    return batch_xyz + torch.tensor(noise).unsqueeze(-1) * batch_normal
+
+
+def estimate_extrusion_axis(X, W_barrel, W_base, gt_bb_labels, gt_extrusion_instances, normalize=False):
+    """data_utils.py:99-177 -> E_AX (B,K,3): eigenvector of the smallest eigenvalue of B^T B - C^T C.
+    The sign is arbitrary in the reference (LAPACK); here the largest component is positive.  All
+    consumers take abs(dot) (losses.py:130, :149)."""
+    return ops.extrusion_axis(X, W_barrel, W_base, gt_bb_labels, gt_extrusion_instances, normalize)
+
+
+def estimate_extrusion_centers(W, pcs):
+    """data_utils.py:253-266 -> (B,K,3) = (1/N) sum_n W[b,n,k] p[b,n]."""
+    return ops.extrusion_centers(W, pcs)
+
+
+def segment_centroids(EA_W, pcs):
+    """eval.py:409-436: per-segment mean of the points with EA_W == 1 -> (centroids (B,K,3), found (B,K))."""
+    K = EA_W.shape[2]
+    is_one = EA_W == 1
+    label = torch.where(is_one.any(dim=2), is_one.float().argmax(dim=2), torch.full_like(is_one[:, :, 0], -1, dtype=torch.long))
+    return ops.segment_centroids(pcs, label, K)
+
+
+def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample=1024, rand_idx=None):
+    """data_utils.py:1650-1730 -> extents (K,B,2), found_centers_mask (B,K).
+    The reference samples barrel points with torch.randint on the CPU generator inside a K x B loop (:1696);
+    the same draws are made here in the same order (k outer, b inner, only where > 1 barrel point exists),
+    or taken from `rand_idx` (B,K,S) when given."""
+    B, K, _ = extrusion_axes.shape
+    S = num_points_to_sample
+    if rand_idx is None:
+        barrel = (seg_label.unsqueeze(-1) == torch.arange(K, device=seg_label.device)) & (bb_labels == 0).unsqueeze(-1)
+        counts = barrel.sum(dim=1).cpu()                 # (B,K): the reference syncs K*B times here
+        rand_idx = torch.zeros(B, K, S, dtype=torch.int64)
+        for k in range(K):
+            if int(counts[:, k].sum()) <= 1:
+                continue
+            for b in range(B):
+                if int(counts[b, k]) <= 1:
+                    continue
+                rand_idx[b, k] = torch.randint(0, int(counts[b, k]), (S,))
+    return ops.extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, rand_idx.to(P.device))

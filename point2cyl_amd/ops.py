@@ -1,0 +1,377 @@
+"""Torch-facing wrappers of the HIP kernels (C ABI in include/p2c_hip.h).
+
+Everything here is plumbing: allocate outputs with torch, pass raw device pointers + the current HIP
+stream to libp2c_hip.so, and register backward passes with torch.autograd.  No arithmetic of the hot
+path happens in torch ops in this file.  All feature tensors are POINT-MAJOR: [rows, channels].
+"""
+import torch
+
+from . import _lib
+from ._lib import PROFILE, call, ptr, stream  # noqa: F401
+
+I32 = torch.int32
+
+
+def _f32c(t):
+    return t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+
+
+# ------------------------------------------------------------------------------------------ geometry
+def fps(xyz, npoint, start):
+    """farthest_point_sample (pointnet_util.py:63-84).  xyz (B,N,3) cuda, start (B,) int64 (the CPU
+    randint draw of :75) -> idx (B,npoint) int32, new_xyz (B,npoint,3)."""
+    _lib.require_device(xyz)
+    xyz = _f32c(xyz)
+    B, N, _ = xyz.shape
+    start = start.to(device=xyz.device, dtype=torch.int64).contiguous()
+    idx = torch.empty(B, npoint, dtype=I32, device=xyz.device)
+    new_xyz = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device)
+    call("p2c_fps_f32", ptr(xyz), B, N, ptr(start), npoint, ptr(idx), ptr(new_xyz), stream())
+    return idx, new_xyz
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """query_ball_point (pointnet_util.py:87-107) -> (B,S,nsample) int32."""
+    _lib.require_device(xyz, new_xyz)
+    xyz, new_xyz = _f32c(xyz), _f32c(new_xyz)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = torch.empty(B, S, nsample, dtype=I32, device=xyz.device)
+    r2 = float(torch.tensor(radius ** 2, dtype=torch.float32))
+    call("p2c_ball_query_f32", ptr(xyz), ptr(new_xyz), B, N, S, r2, nsample, ptr(idx), stream())
+    return idx
+
+
+def three_nn(xyz1, xyz2, return_dist=False):
+    """3 nearest of xyz2 for each xyz1 point + normalised inverse-distance weights (pointnet_util.py:301-307)."""
+    _lib.require_device(xyz1, xyz2)
+    xyz1, xyz2 = _f32c(xyz1), _f32c(xyz2)
+    B, N, _ = xyz1.shape
+    S = xyz2.shape[1]
+    idx = torch.empty(B, N, 3, dtype=I32, device=xyz1.device)
+    w = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device)
+    d = torch.empty(B, N, 3, dtype=torch.float32, device=xyz1.device) if return_dist else None
+    call("p2c_three_nn_f32", ptr(xyz1), ptr(xyz2), B, N, S, ptr(idx), ptr(w), ptr(d), stream())
+    return (idx, w, d) if return_dist else (idx, w)
+
+
+class _GroupGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz, feats, new_xyz, idx):
+        B, N, _ = xyz.shape
+        S, ns = idx.shape[1], idx.shape[2]
+        D = 0 if feats is None else feats.shape[-1]
+        ldo = (3 + D + 3) // 4 * 4
+        out = torch.empty(B * S * ns, ldo, dtype=torch.float32, device=xyz.device)
+        if feats is not None:
+            feats = _f32c(feats)
+        call("p2c_group_gather_f32", ptr(xyz), ptr(feats), D, ptr(new_xyz), ptr(idx), B, N, S, ns, D, ptr(out), ldo, stream())
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, N, S, ns, D, ldo)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        B, N, S, ns, D, ldo = ctx.dims
+        if D == 0 or not ctx.needs_input_grad[1]:
+            return None, None, None, None
+        dout = _f32c(dout)
+        dfeats = torch.zeros(B, N, D, dtype=torch.float32, device=dout.device)
+        call("p2c_group_gather_bwd_f32", ptr(dout), ldo, ptr(idx), B, N, S, ns, D, ptr(dfeats), D, stream())
+        return None, dfeats, None, None
+
+
+def group_gather(xyz, feats, new_xyz, idx):
+    """rows (b,s,j) = [xyz[idx]-new_xyz | feats[idx] | 0-pad]  (pointnet_util.py:128-139) -> (B*S*ns, ld)."""
+    return _GroupGather.apply(_f32c(xyz), feats, _f32c(new_xyz), idx)
+
+
+class _ThreeInterp(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, idx, w):
+        B, S, C = feats.shape
+        N = idx.shape[1]
+        feats = _f32c(feats)
+        out = torch.empty(B * N, C, dtype=torch.float32, device=feats.device)
+        call("p2c_three_interp_f32", ptr(feats), C, ptr(idx), ptr(w), B, N, S, C, ptr(out), C, stream())
+        ctx.save_for_backward(idx, w)
+        ctx.dims = (B, N, S, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, w = ctx.saved_tensors
+        B, N, S, C = ctx.dims
+        dout = _f32c(dout)
+        dfeats = torch.zeros(B, S, C, dtype=torch.float32, device=dout.device)
+        call("p2c_three_interp_bwd_f32", ptr(dout), C, ptr(idx), ptr(w), B, N, S, C, ptr(dfeats), C, stream())
+        return dfeats, None, None
+
+
+def three_interpolate(feats, idx, w):
+    """(B,S,C), idx/w (B,N,3) -> (B*N, C)  (pointnet_util.py:308)."""
+    return _ThreeInterp.apply(feats, idx, w)
+
+
+# ------------------------------------------------------------------------------------------ MLP stack
+class BNState:
+    """Per-layer BatchNorm buffers handed to the stack (updated in place by the finalize kernel)."""
+
+    def __init__(self, running_mean, running_var, num_batches_tracked, momentum, eps):
+        self.running_mean, self.running_var, self.nbt = running_mean, running_var, num_batches_tracked
+        self.momentum, self.eps = momentum, eps
+
+
+class _MLPStack(torch.autograd.Function):
+    """A chain of 1x1-conv layers  Y_i = act_{i-1}(Y_{i-1}) W_i^T + b_i  with BatchNorm+ReLU folded into the
+    NEXT layer's operand load.  tail: 'maxpool' (max over ns of relu(bn(Y_last))), 'bnrelu' (materialise
+    relu(bn(Y_last))), 'linear' (last layer has no BN; `drop_mask` multiplies its input).
+    params = [W_0, b_0, gamma_0, beta_0, W_1, ...] (gamma/beta absent for a BN-less last layer)."""
+
+    @staticmethod
+    def forward(ctx, cfg, X0, *params):
+        dev = X0.device
+        M, ldx0 = X0.shape[0], X0.stride(0)
+        K = cfg["in_channels"]
+        training = cfg["training"]
+        bns = cfg["bns"]
+        L = cfg["n_layers"]
+        tail = cfg["tail"]
+        mask = cfg.get("drop_mask")
+        dscale = cfg.get("drop_scale", 1.0)
+        Ys, aff, Ws = [], [], []
+        X, ldx, in_mode, sc, sh = X0, ldx0, 0, None, None
+        pi = 0
+        for i in range(L):
+            has_bn = not (tail == "linear" and i == L - 1)
+            W, b = params[pi], params[pi + 1]
+            pi += 2
+            Co = W.shape[0]
+            W2 = W.reshape(Co, -1)
+            assert W2.shape[1] == K, (W2.shape, K)
+            Y = torch.empty(M, Co, dtype=torch.float32, device=dev)
+            use_mask = (not has_bn) and mask is not None
+            mode = 2 if (use_mask and in_mode == 1) else in_mode
+            partials = None
+            if has_bn and training:
+                tiles = _lib.lib().p2c_linear_stat_tiles(M)
+                partials = torch.empty(tiles, 2, Co, dtype=torch.float32, device=dev)
+            call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), W2.stride(0), ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
+                 ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), ptr(partials), stream(),
+                 flops=2.0 * M * Co * K)
+            Ys.append(Y)
+            Ws.append(W2)
+            if has_bn:
+                gamma, beta = params[pi], params[pi + 1]
+                pi += 2
+                bn = bns[i]
+                st = torch.empty(4, Co, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
+                call("p2c_bn_finalize_f32", ptr(partials), 0 if partials is None else partials.shape[0], Co, M, ptr(b), ptr(gamma),
+                     ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
+                     ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
+                if training and bn.nbt is not None:
+                    bn.nbt += 1
+                aff.append(st)
+                sc, sh, in_mode = st[0], st[1], 1
+            else:
+                aff.append(None)
+                in_mode = 0
+            X, ldx, K = Y, Co, Co
+        arg = None
+        if tail == "maxpool":
+            G, ns = cfg["G"], cfg["ns"]
+            out = torch.empty(G, K, dtype=torch.float32, device=dev)
+            arg = torch.empty(G, K, dtype=I32, device=dev)
+            call("p2c_maxpool_bnrelu_f32", ptr(Ys[-1]), K, ptr(sc), ptr(sh), G, ns, K, ptr(out), K, ptr(arg), stream())
+        elif tail == "bnrelu":
+            out = torch.empty(M, K, dtype=torch.float32, device=dev)
+            call("p2c_bn_relu_apply_f32", ptr(Ys[-1]), K, ptr(sc), ptr(sh), M, K, ptr(out), K, stream())
+        else:
+            out = Ys[-1]
+        ctx.cfg = cfg
+        ctx.saved = (X0, Ys, aff, Ws, arg, params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg = ctx.cfg
+        X0, Ys, aff, Ws, arg, params = ctx.saved
+        if not cfg["training"]:
+            raise RuntimeError("point2cyl_amd: backward through an eval-mode (running-stats) stack is not implemented")
+        dev = X0.device
+        M = X0.shape[0]
+        L, tail = cfg["n_layers"], cfg["tail"]
+        mask, dscale = cfg.get("drop_mask"), cfg.get("drop_scale", 1.0)
+        dout = _f32c(dout)
+        Cl = Ys[-1].shape[1]
+        if tail == "maxpool":
+            dZ = torch.empty(M, Cl, dtype=torch.float32, device=dev)
+            call("p2c_maxpool_bwd_f32", ptr(dout), Cl, ptr(arg), cfg["G"], cfg["ns"], Cl, ptr(dZ), Cl, stream())
+            grad_mode = 1
+        elif tail == "bnrelu":
+            dZ, grad_mode = dout, 1
+        else:
+            dZ, grad_mode = dout, 0
+        grads = [None] * len(params)
+        # parameter slots per layer
+        slots, pi = [], 0
+        for i in range(L):
+            has_bn = not (tail == "linear" and i == L - 1)
+            slots.append((pi, has_bn))
+            pi += 4 if has_bn else 2
+        for i in range(L - 1, -1, -1):
+            p0, has_bn = slots[i]
+            Y, W2 = Ys[i], Ws[i]
+            Co, Ci = W2.shape
+            coef = None
+            if grad_mode == 1:
+                st = aff[i]
+                gamma = params[p0 + 2]
+                coef = torch.empty(5, Co, dtype=torch.float32, device=dev)
+                dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
+                dbeta = torch.empty(Co, dtype=torch.float32, device=dev)
+                ws = torch.empty(_lib.lib().p2c_bn_bwd_ws_bytes(M, Co) // 4 + 4, dtype=torch.float32, device=dev)
+                call("p2c_bn_relu_bwd_stats_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]),
+                     ptr(gamma), M, Co, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(ws), stream())
+                grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
+            # operand that fed this layer in the forward pass
+            if i == 0:
+                Xin, ldxin, in_mode, sc, sh = X0, X0.stride(0), 0, None, None
+            else:
+                Xin, ldxin, in_mode, sc, sh = Ys[i - 1], Ys[i - 1].shape[1], 1, aff[i - 1][0], aff[i - 1][1]
+            use_mask = (not has_bn) and mask is not None and in_mode == 1
+            mode = 2 if use_mask else in_mode
+            dW = torch.zeros(Co, Ci, dtype=torch.float32, device=dev)
+            # a conv bias in front of a train-mode BatchNorm has an exactly zero gradient (the batch mean absorbs it)
+            db = torch.zeros(Co, dtype=torch.float32, device=dev)
+            call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
+                 ptr(sh), ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), ptr(dW), Ci,
+                 ptr(db) if grad_mode == 0 else None, M, Co, Ci, stream(), flops=2.0 * M * Co * Ci)
+            grads[p0] = dW.view_as(params[p0])
+            grads[p0 + 1] = db
+            if i > 0 or ctx.needs_input_grad[1]:
+                ldd = (Ci + 3) // 4 * 4 if i == 0 else Ci
+                dX = torch.empty(M, ldd, dtype=torch.float32, device=dev)
+                call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(W2), W2.stride(0), ptr(dX),
+                     ldd, M, Co, Ci, ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), stream(),
+                     flops=2.0 * M * Co * Ci)
+                dZ, grad_mode = dX, 1
+        dX0 = None
+        if ctx.needs_input_grad[1]:
+            dX0 = dZ
+            if dX0.shape[1] > X0.shape[1]:
+                dX0 = dX0[:, : X0.shape[1]]
+            elif dX0.shape[1] < X0.shape[1]:
+                dX0 = torch.nn.functional.pad(dX0, (0, X0.shape[1] - dX0.shape[1]))
+        return (None, dX0) + tuple(grads)
+
+
+def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mask=None, drop_scale=1.0):
+    """layers: list of dicts {W, b, gamma, beta, bn: BNState} (gamma/beta/bn None for a BN-less last layer)."""
+    params, bns = [], []
+    for ly in layers:
+        params += [ly["W"], ly["b"]]
+        if ly.get("gamma") is not None:
+            params += [ly["gamma"], ly["beta"]]
+        bns.append(ly.get("bn"))
+    cfg = dict(in_channels=in_channels, n_layers=len(layers), tail=tail, training=training, bns=bns, G=G, ns=ns,
+               drop_mask=drop_mask, drop_scale=drop_scale)
+    return _MLPStack.apply(cfg, X0, *params)
+
+
+# ------------------------------------------------------------------------------------------ fitting
+class _ExtrusionAxis(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, X, Wb, Wc, bb_gt, inst_gt, normalize):
+        X, Wb, Wc = _f32c(X), _f32c(Wb), _f32c(Wc)
+        B, N, K = Wb.shape
+        axis = torch.empty(B, K, 3, dtype=torch.float32, device=X.device)
+        eig = torch.empty(B, K, 12, dtype=torch.float32, device=X.device)
+        if normalize:
+            bb_gt = bb_gt.to(torch.int64).contiguous()
+            inst_gt = inst_gt.to(torch.int64).contiguous()
+        call("p2c_extrusion_axis_f32", ptr(X), ptr(Wb), ptr(Wc), ptr(bb_gt) if normalize else None,
+             ptr(inst_gt) if normalize else None, 1 if normalize else 0, B, N, K, ptr(axis), ptr(eig), stream())
+        ctx.save_for_backward(X, Wb, Wc, axis, eig)
+        return axis
+
+    @staticmethod
+    def backward(ctx, daxis):
+        X, Wb, Wc, axis, eig = ctx.saved_tensors
+        B, N, K = Wb.shape
+        daxis = _f32c(daxis)
+        dX, dWb, dWc = torch.empty_like(X), torch.empty_like(Wb), torch.empty_like(Wc)
+        call("p2c_extrusion_axis_bwd_f32", ptr(daxis), ptr(axis), ptr(eig), ptr(X), ptr(Wb), ptr(Wc), B, N, K, ptr(dX), ptr(dWb),
+             ptr(dWc), stream())
+        return dX, dWb, dWc, None, None, None
+
+
+def extrusion_axis(X, Wb, Wc, bb_gt=None, inst_gt=None, normalize=False):
+    _lib.require_device(X, Wb, Wc)
+    return _ExtrusionAxis.apply(X, Wb, Wc, bb_gt, inst_gt, bool(normalize))
+
+
+class _ExtrusionCenters(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, P):
+        W, P = _f32c(W), _f32c(P)
+        B, N, K = W.shape
+        out = torch.empty(B, K, 3, dtype=torch.float32, device=W.device)
+        call("p2c_extrusion_centers_f32", ptr(W), ptr(P), B, N, K, ptr(out), stream())
+        ctx.save_for_backward(P)
+        ctx.dims = (B, N, K)
+        return out
+
+    @staticmethod
+    def backward(ctx, dC):
+        (P,) = ctx.saved_tensors
+        B, N, K = ctx.dims
+        dW = torch.empty(B, N, K, dtype=torch.float32, device=P.device)
+        call("p2c_extrusion_centers_bwd_f32", ptr(_f32c(dC)), ptr(P), B, N, K, ptr(dW), stream())
+        return dW, None
+
+
+def extrusion_centers(W, P):
+    _lib.require_device(W, P)
+    return _ExtrusionCenters.apply(W, P)
+
+
+def segment_centroids(P, label, K):
+    """eval.py:409-436 from integer labels (-1 = no segment) -> centroids (B,K,3), found (B,K)."""
+    _lib.require_device(P, label)
+    P = _f32c(P)
+    B, N, _ = P.shape
+    label = label.to(torch.int64).contiguous()
+    cen = torch.empty(B, K, 3, dtype=torch.float32, device=P.device)
+    found = torch.empty(B, K, dtype=torch.float32, device=P.device)
+    call("p2c_segment_centroids_f32", ptr(P), ptr(label), B, N, K, ptr(cen), ptr(found), stream())
+    return cen, found
+
+
+def extrusion_extents(P, seg, bb, axes, centers, rand_idx):
+    """data_utils.py:1650-1730.  rand_idx (B,K,S) int64 -> extents (K,B,2), found (B,K)."""
+    _lib.require_device(P, seg, bb, axes, centers, rand_idx)
+    P, axes, centers = _f32c(P), _f32c(axes), _f32c(centers)
+    B, N, _ = P.shape
+    K = axes.shape[1]
+    S = rand_idx.shape[2]
+    seg, bb, rand_idx = seg.to(torch.int64).contiguous(), bb.to(torch.int64).contiguous(), rand_idx.to(torch.int64).contiguous()
+    ext = torch.empty(K, B, 2, dtype=torch.float32, device=P.device)
+    found = torch.empty(B, K, dtype=torch.float32, device=P.device)
+    ws = torch.empty(_lib.lib().p2c_extents_ws_bytes(B, K) // 4 + 4, dtype=torch.float32, device=P.device)
+    call("p2c_extrusion_extents_f32", ptr(P), ptr(seg), ptr(bb), ptr(axes), ptr(centers), ptr(rand_idx), B, N, K, S, ptr(ext),
+         ptr(found), ptr(ws), stream())
+    return ext, found
+
+
+def hungarian(W, I_gt):
+    """losses.py:22-52 on the device -> matching_indices (B,K) int64, mask (B,K) bool.  No gradient."""
+    _lib.require_device(W, I_gt)
+    W = _f32c(W.detach())
+    B, N, K = W.shape
+    I_gt = I_gt.to(torch.int64).contiguous()
+    match = torch.empty(B, K, dtype=torch.int64, device=W.device)
+    mask = torch.empty(B, K, dtype=torch.uint8, device=W.device)
+    call("p2c_hungarian_f32", ptr(W), ptr(I_gt), B, N, K, ptr(match), ptr(mask), stream())
+    return match, mask.bool()

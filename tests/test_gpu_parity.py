@@ -1,0 +1,424 @@
+"""GPU (MI355X): the HIP path through the C ABI against the oracle and the golden vectors.
+
+Bars: bit-exact for index outputs (FPS, ball query, 3-NN, Hungarian matching, argmax labels);
+<= 1e-4 (stated per test) for fp32 values.  The oracle (oracle/) is only the checker here.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cref, ref_torch as R
+from tests.conftest import load_golden, same_up_to_sign
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from point2cyl_amd import ops, losses, fitting, step
+    from point2cyl_amd.backbone import backbone
+
+DEV = "cuda"
+t = torch.from_numpy
+
+
+def cu(a):
+    return (t(a) if isinstance(a, np.ndarray) else a).to(DEV)
+
+
+# ------------------------------------------------------------------------------------------ geometry
+@pytest.mark.parametrize("tag", ["uniform", "sa2", "grid"])
+def test_fps_golden(tag):
+    g = load_golden("g1_fps_" + tag)
+    idx, new_xyz = ops.fps(cu(g["xyz"]), int(g["npoint"]), t(g["start"]))
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), g["idx"])
+    ref_xyz = np.take_along_axis(g["xyz"], g["idx"][:, :, None], 1)
+    assert np.array_equal(new_xyz.cpu().numpy(), ref_xyz)
+
+
+@pytest.mark.parametrize("B,N,npoint", [(3, 8192, 512), (2, 512, 128), (2, 1000, 77), (1, 16384, 64), (5, 100, 100), (2, 4096, 300)])
+def test_fps_vs_oracle(B, N, npoint):
+    g = torch.Generator().manual_seed(N + npoint)
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    start = torch.randint(0, N, (B,), generator=g)
+    idx, _ = ops.fps(xyz.to(DEV), npoint, start)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), cref.fps(xyz.numpy(), start.numpy(), npoint))
+
+
+def test_fps_duplicate_points_first_index_wins():
+    xyz = torch.zeros(2, 640, 3)
+    xyz[:, 320:] = 1.0
+    start = torch.tensor([5, 400])
+    idx, _ = ops.fps(xyz.to(DEV), 8, start)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), cref.fps(xyz.numpy(), start.numpy(), 8))
+
+
+@pytest.mark.parametrize("tag", ["sparse", "dense", "r04", "grid"])
+def test_ball_query_golden(tag):
+    g = load_golden("g2_ball_" + tag)
+    gi = ops.ball_query(float(g["radius"]), int(g["nsample"]), cu(g["xyz"]), cu(g["new_xyz"]))
+    assert np.array_equal(gi.cpu().numpy().astype(np.int64), g["group_idx"])
+
+
+@pytest.mark.parametrize("B,N,S,radius,ns", [(2, 8192, 512, 0.2, 64), (2, 512, 128, 0.4, 64), (1, 3000, 45, 0.3, 32), (2, 8192, 512, 0.05, 64)])
+def test_ball_query_vs_oracle(B, N, S, radius, ns):
+    g = torch.Generator().manual_seed(S)
+    xyz = torch.rand(B, N, 3, generator=g) * 2 - 1
+    sel = torch.stack([torch.randperm(N, generator=g)[:S] for _ in range(B)])
+    new_xyz = torch.gather(xyz, 1, sel.unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    gi = ops.ball_query(radius, ns, xyz.to(DEV), new_xyz.to(DEV))
+    assert np.array_equal(gi.cpu().numpy().astype(np.int64), cref.ball_query(radius, ns, xyz.numpy(), new_xyz.numpy()))
+
+
+@pytest.mark.parametrize("tag", ["fp1", "fp2", "grid"])
+def test_three_nn_golden(tag):
+    g = load_golden("g3_3nn_" + tag)
+    idx, w, d = ops.three_nn(cu(g["xyz1"]), cu(g["xyz2"]), return_dist=True)
+    assert np.array_equal(d.cpu().numpy(), g["dist"])
+    if tag != "grid":      # exact ties are implementation-defined in the reference (see test_oracle_golden)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int64), g["idx"])
+        np.testing.assert_allclose(w.cpu().numpy(), g["weight"], rtol=1e-6, atol=0)
+    di, ii = cref.three_nn(g["xyz1"], g["xyz2"])
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ii)
+
+
+@pytest.mark.parametrize("B,N,S", [(2, 8192, 512), (3, 512, 128), (1, 1000, 3), (2, 700, 2500)])
+def test_three_nn_vs_oracle(B, N, S):
+    g = torch.Generator().manual_seed(S)
+    a, b = torch.rand(B, N, 3, generator=g), torch.rand(B, S, 3, generator=g)
+    idx, w, d = ops.three_nn(a.to(DEV), b.to(DEV), return_dist=True)
+    dd, ii = cref.three_nn(a.numpy(), b.numpy())
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ii) and np.array_equal(d.cpu().numpy(), dd)
+
+
+# ------------------------------------------------------------------------------------------ gathers
+def test_group_gather_and_interp_fwd_bwd():
+    g = torch.Generator().manual_seed(3)
+    B, N, S, ns, D = 2, 300, 20, 16, 37
+    xyz = torch.rand(B, N, 3, generator=g)
+    feats = torch.randn(B, N, D, generator=g, requires_grad=True)
+    new_xyz = xyz[:, :S].contiguous()
+    idx = torch.randint(0, N, (B, S, ns), generator=g)
+    fd = feats.detach().to(DEV).requires_grad_(True)
+    out = ops.group_gather(xyz.to(DEV), fd, new_xyz.to(DEV), idx.to(DEV).int())
+    ref = torch.cat([R.gather_rows(xyz, idx) - new_xyz.unsqueeze(2), R.gather_rows(feats, idx)], -1).reshape(B * S * ns, 3 + D)
+    assert out.shape[1] % 4 == 0
+    assert torch.equal(out[:, :3 + D].cpu(), ref.detach()) and (out[:, 3 + D:] == 0).all()
+    go = torch.randn(out.shape, generator=g)
+    out.backward(go.to(DEV))
+    ref.backward(go[:, :3 + D])
+    np.testing.assert_allclose(fd.grad.cpu().numpy(), feats.grad.numpy(), rtol=1e-5, atol=1e-5)
+    # no-feature fast path
+    out0 = ops.group_gather(xyz.to(DEV), None, new_xyz.to(DEV), idx.to(DEV).int())
+    assert out0.shape[1] == 4 and torch.equal(out0[:, :3].cpu(), ref[:, :3].detach())
+    # interpolation
+    S2, C = 50, 70
+    f2 = torch.randn(B, S2, C, generator=g, requires_grad=True)
+    nidx = torch.randint(0, S2, (B, N, 3), generator=g)
+    w = torch.rand(B, N, 3, generator=g)
+    f2d = f2.detach().to(DEV).requires_grad_(True)
+    o = ops.three_interpolate(f2d, nidx.to(DEV).int(), w.to(DEV))
+    r = (R.gather_rows(f2, nidx) * w.unsqueeze(-1)).sum(2).reshape(B * N, C)
+    np.testing.assert_allclose(o.detach().cpu().numpy(), r.detach().numpy(), rtol=1e-6, atol=1e-6)
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go.to(DEV))
+    r.backward(go)
+    np.testing.assert_allclose(f2d.grad.cpu().numpy(), f2.grad.numpy(), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ MLP stacks
+def _ref_stack(X0, params, tail, G, ns, training, mask, momentum=0.1):
+    """torch fp32 reference of a stack on CPU (conv1d/bn/relu exactly like the reference's layers)."""
+    x = X0.t().unsqueeze(0)        # (1, C, M)
+    L = len(params)
+    rstats = []
+    for i, p in enumerate(params):
+        last_linear = tail == "linear" and i == L - 1
+        if last_linear and mask is not None:
+            x = x * mask.t().unsqueeze(0) * 2.0
+        x = F.conv1d(x, p["W"].reshape(p["W"].shape[0], -1, 1), p["b"])
+        if not last_linear:
+            rm, rv = p["rm"].clone(), p["rv"].clone()
+            x = F.relu(F.batch_norm(x, rm, rv, p["gamma"], p["beta"], training, momentum, 1e-5))
+            rstats.append((rm, rv))
+    y = x.squeeze(0).t()
+    if tail == "maxpool":
+        y = y.reshape(G, ns, -1).max(1)[0]
+    return y, rstats
+
+
+@pytest.mark.parametrize("tail,M,K0,widths,G,ns", [
+    ("maxpool", 40 * 16, 3, (16, 24, 40), 40, 16),
+    ("maxpool", 6 * 64, 131, (128, 128, 256), 6, 64),
+    ("bnrelu", 1000, 384, (256, 128), None, None),
+    ("linear", 777, 128, (128, 96, 19), None, None),
+    ("maxpool", 2 * 128, 259, (256, 512, 1024), 2, 128),
+])
+def test_mlp_stack_forward_backward(tail, M, K0, widths, G, ns):
+    g = torch.Generator().manual_seed(M + K0)
+    ld = (K0 + 3) // 4 * 4
+    X0 = torch.zeros(M, ld)
+    X0[:, :K0] = torch.randn(M, K0, generator=g)
+    params, cin = [], K0
+    for i, co in enumerate(widths):
+        p = dict(W=torch.randn(co, cin, generator=g) / cin ** 0.5, b=torch.randn(co, generator=g) * 0.1)
+        if not (tail == "linear" and i == len(widths) - 1):
+            p.update(gamma=torch.rand(co, generator=g) + 0.5, beta=torch.randn(co, generator=g) * 0.2,
+                     rm=torch.zeros(co), rv=torch.ones(co))
+            if i == 0:
+                p["gamma"][0] = -0.7         # negative BN scale: max-pool must still be exact
+        params.append(p)
+        cin = co
+    mask = (torch.rand(M, widths[-2], generator=g) < 0.5).float() if tail == "linear" else None
+    # reference
+    ref_leaves = []
+    for p in params:
+        for k in ("W", "b", "gamma", "beta"):
+            if k in p:
+                p[k] = p[k].clone().requires_grad_(True)
+                ref_leaves.append(p[k])
+    X0r = X0[:, :K0].clone().requires_grad_(True)
+    yref, rstats = _ref_stack(X0r, params, tail, G, ns, True, mask)
+    go = torch.randn(yref.shape, generator=g)
+    yref.backward(go)
+    # device
+    layers, dev_leaves = [], []
+    for p in params:
+        ly = {k: p[k].detach().to(DEV).requires_grad_(True) for k in ("W", "b", "gamma", "beta") if k in p}
+        dev_leaves += [ly[k] for k in ("W", "b", "gamma", "beta") if k in ly]
+        if "gamma" in ly:
+            ly["bn"] = ops.BNState(torch.zeros(ly["W"].shape[0], device=DEV), torch.ones(ly["W"].shape[0], device=DEV),
+                                   torch.zeros((), dtype=torch.long, device=DEV), 0.1, 1e-5)
+        else:
+            ly.update(gamma=None, beta=None, bn=None)
+        layers.append(ly)
+    X0d = X0.to(DEV).requires_grad_(True)
+    y = ops.mlp_stack(X0d, K0, layers, tail, True, G=G, ns=ns, drop_mask=None if mask is None else mask.to(DEV).to(torch.uint8),
+                      drop_scale=2.0)
+    scale = max(1.0, float(yref.abs().max()))
+    np.testing.assert_allclose(y.detach().cpu().numpy(), yref.detach().numpy(), rtol=1e-4, atol=1e-4 * scale)
+    y.backward(go.to(DEV))
+    for i, (a, b) in enumerate(zip(dev_leaves, ref_leaves)):
+        ref = b.grad.numpy()
+        tol = 2e-4 * max(1e-3, float(np.abs(ref).max()))
+        if a.grad is None:
+            raise AssertionError("missing grad %d" % i)
+        got = a.grad.cpu().numpy().reshape(ref.shape)
+        if b.dim() == 1 and i % 4 == 1 and not (tail == "linear" and i >= len(dev_leaves) - 2):
+            # conv bias in front of train-mode BN: gradient is analytically zero (ours is exactly 0)
+            assert np.abs(got).max() == 0 and np.abs(ref).max() < 1e-3 * scale
+            continue
+        np.testing.assert_allclose(got, ref, rtol=2e-3, atol=tol)
+    np.testing.assert_allclose(X0d.grad[:, :K0].cpu().numpy(), X0r.grad.numpy(), rtol=2e-3,
+                               atol=2e-4 * float(X0r.grad.abs().max()))
+    for ly, (rm, rv) in zip(layers, rstats):
+        np.testing.assert_allclose(ly["bn"].running_mean.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(ly["bn"].running_var.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------ backbone
+def _model(seed, sizes):
+    torch.manual_seed(seed)
+    m = backbone(output_sizes=sizes)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_backbone_golden(mode):
+    g = load_golden("g5_backbone_" + mode)
+    m = _model(int(g["seed"]), [3, 16])
+    m.train() if mode == "train" else m.eval()
+    step.update_momentum(m, float(g["momentum"]))
+    m.sa1.fps_start, m.sa2.fps_start = t(g["start1"]), t(g["start2"])
+    m.dropout_mask = "off"
+    X, W_raw = m(cu(g["pcs"]))
+    np.testing.assert_allclose(X.detach().cpu().numpy(), g["X"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(W_raw.detach().cpu().numpy(), g["W_raw"], rtol=1e-4, atol=1e-4)
+    # integer structure is bit-exact with the oracle
+    outs, aux = R.backbone_forward(R.make_state_dict((3, 16), seed=int(g["seed"])), t(g["pcs"]), [t(g["start1"]), t(g["start2"])],
+                                   None, training=(mode == "train"), momentum=0.5, geom="c", return_aux=True)
+    assert torch.equal(m.sa1.last_aux["fps_idx"].cpu().long(), aux["sa1"]["fps_idx"])
+    assert torch.equal(m.sa1.last_aux["group_idx"].cpu().long(), aux["sa1"]["group_idx"])
+    assert torch.equal(m.sa2.last_aux["fps_idx"].cpu().long(), aux["sa2"]["fps_idx"])
+    assert torch.equal(m.sa2.last_aux["group_idx"].cpu().long(), aux["sa2"]["group_idx"])
+    assert torch.equal(m.fp1.last_aux["nn_idx"].cpu().long(), aux["fp1"]["nn_idx"])
+    assert torch.equal(m.fp2.last_aux["nn_idx"].cpu().long(), aux["fp2"]["nn_idx"])
+    assert torch.equal(W_raw.argmax(-1).cpu(), t(g["W_raw"]).argmax(-1)), "segment labels must be bit-exact"
+    if mode != "train":
+        return
+    # accuracy bar: the reference's OWN fp32 error against the same module run in float64 (fixture X64/grad64).
+    # A deep chain of train-mode BatchNorms is ill-conditioned, so "1e-4 vs the fp32 reference" is not
+    # attainable by ANY independent fp32 implementation for the early-layer gradients; "no less accurate than
+    # the reference (x3)" is.
+    for mine, r32, r64 in ((X, g["X"], g["X64"]), (W_raw, g["W_raw"], g["W_raw64"])):
+        ref_err = np.abs(r32 - r64).max()
+        assert np.abs(mine.detach().cpu().numpy() - r64).max() <= 3 * ref_err + 1e-5
+    loss = (X * X).mean() + (W_raw.softmax(-1)[..., 0]).mean() + (W_raw * W_raw).mean() * 0.1
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-4)
+    loss.backward()
+    grads = dict(m.named_parameters())
+    for k in g:
+        if k.startswith("grad:"):
+            name = k[5:]
+            r32, r64 = g[k].astype(np.float64), g["grad64:" + name]
+            got = grads[name].grad.cpu().numpy().reshape(r32.shape).astype(np.float64)
+            if name.endswith(".bias") and "mlp_convs" in name:
+                assert np.abs(got).max() == 0.0        # bias in front of train-mode BN: exactly zero here
+                continue
+            ref_err = np.abs(r32 - r64).max()
+            mine_err = np.abs(got - r64).max()
+            assert mine_err <= 3 * ref_err + 1e-6 * np.abs(r64).max(), (name, mine_err, ref_err)
+        if k.startswith("after:"):
+            np.testing.assert_allclose(m.state_dict()[k[6:]].cpu().numpy(), g[k], rtol=1e-4, atol=1e-5)
+    names = [str(n) for n in g["grad_names"]]
+    for n, ck, gmax, g32e in zip(names, g["grad_ck"], g["grad64_maxabs"], g["grad32_err"]):
+        gr = grads[n].grad
+        is_prebn_bias = n.endswith(".bias") and ("mlp_convs" in n or n == "fc1.bias")
+        if is_prebn_bias:
+            assert float(gr.abs().max()) == 0.0
+            continue
+        got = gr.double().abs().sum().item()
+        # |sum|g|| can move by at most numel * per-element error
+        assert abs(got - ck[1]) <= gr.numel() * (3 * g32e + 1e-6 * gmax) + 1e-4 * ck[1], (n, got, ck[1])
+
+
+# ------------------------------------------------------------------------------------------ losses
+def test_losses_golden():
+    g = load_golden("g6_losses")
+    W_raw = cu(g["W_raw"]).requires_grad_(True)
+    X = cu(g["X"]).requires_grad_(True)
+    W2 = torch.softmax(W_raw, 2)
+    W = W2[:, :, 0::2] + W2[:, :, 1::2]
+    seg, bb, nrm = cu(g["seg"]), cu(g["bb"]), cu(g["normals"])
+    total, nl, ml, match, mask = losses.compute_all_losses(X, W, seg, X, nrm, 1.0, 1.0, return_match_indices=True)
+    assert np.array_equal(match.cpu().numpy(), g["match"]) and np.array_equal(mask.cpu().numpy(), g["mask"])
+    np.testing.assert_allclose([total.item(), nl.item(), ml.item()], [g["total"], g["normal_loss"], g["miou_loss"]], rtol=1e-4)
+    bbl = losses.compute_bb_loss(W, W_raw[:, :, 0::2], W_raw[:, :, 1::2], match, mask, bb)
+    np.testing.assert_allclose(bbl.item(), g["bb_loss"], rtol=1e-4)
+    (total + bbl).backward()
+    np.testing.assert_allclose(W_raw.grad.cpu().numpy(), g["grad_W_raw"], rtol=1e-3, atol=1e-8)
+    np.testing.assert_allclose(X.grad.cpu().numpy(), g["grad_X"], rtol=1e-3, atol=1e-8)
+    hard = losses.hard_W_encoding(W.detach(), to_null_mask=True)
+    hm, hmask = losses.hungarian_matching(hard, seg, with_mask=True)
+    assert np.array_equal(hm.cpu().numpy(), g["hardW_match"]) and np.array_equal(hmask.cpu().numpy(), g["hardW_mask"])
+    np.testing.assert_allclose(losses.compute_segmentation_iou(hard, seg, hm, hmask.float()).cpu().numpy(), g["seg_iou"], rtol=1e-5)
+    np.testing.assert_allclose(losses.compute_normal_difference(X.detach(), nrm, in_radians=False).cpu().numpy(),
+                               g["normal_diff_deg"], rtol=1e-4)
+    assert np.array_equal(losses.get_mask_gt(seg, 8).cpu().numpy(), g["mask_gt"])
+
+
+def test_hungarian_vs_scipy_random_and_ties():
+    from scipy.optimize import linear_sum_assignment
+    g = torch.Generator().manual_seed(12)
+    B, N, K = 64, 256, 8
+    W = torch.softmax(torch.randn(B, N, K, generator=g) * 3, -1)
+    W[B // 2:] = F.one_hot(W[B // 2:].argmax(-1), K).float()       # hard encodings: many exact ties / empty columns
+    W[B // 2:, :, 5:] = 0
+    I = torch.randint(-1, K, (B, N), generator=g)
+    for b in range(B):
+        I[b] = I[b].clamp(max=b % K)
+    match, mask = ops.hungarian(W.to(DEV), I.to(DEV))
+    rm, rmask = R.hungarian_matching(W, I)
+    assert np.array_equal(mask.cpu().numpy(), rmask.numpy())
+    same = (match.cpu() == rm).all(1)
+    # fp32 summation order of the IoU sums differs from torch.mm; allow flips only where the optimum ties
+    assert same.float().mean() > 0.9
+    for b in torch.nonzero(~same).flatten().tolist():
+        n_gt = int(I[b].max()) + 1
+        oh = torch.eye(n_gt + 1)[I[b]]
+        inter = oh.t() @ W[b]
+        iou = (inter / (oh.sum(0).unsqueeze(1) + W[b].sum(0).unsqueeze(0) - inter).clamp(min=1e-10))[:n_gt]
+        a = iou[torch.arange(n_gt), match[b, :n_gt].cpu()].sum()
+        c = iou[torch.arange(n_gt), rm[b, :n_gt]].sum()
+        assert abs(float(a - c)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------ fitting
+@pytest.mark.parametrize("wtag", ["hard", "soft"])
+@pytest.mark.parametrize("norm", [0, 1])
+def test_extrusion_axis_golden(wtag, norm):
+    g = load_golden("g7_axis")
+    X = cu(g["X"]).requires_grad_(True)
+    wb = cu(g["Wb_" + wtag]).requires_grad_(True)
+    wc = cu(g["Wc_" + wtag]).requires_grad_(True)
+    seg, bb, gt = cu(g["seg"]), cu(g["bb"]), cu(g["gt_axes"])
+    E = fitting.estimate_extrusion_axis(X, wb, wc, bb, seg, normalize=bool(norm))
+    tag = "%s_%d" % (wtag, norm)
+    m = g["mask_gt"]
+    assert (same_up_to_sign(E.detach().cpu().numpy(), g["E_" + tag])[m] > 1 - 1e-6).all()
+    lo = losses.reduce_mean_masked_instance(losses.compute_normal_loss(E, gt, angle_diff=False, collapse=False), cu(m)).mean()
+    np.testing.assert_allclose(lo.item(), g["loss_" + tag], rtol=1e-4, atol=1e-6)
+    lo.backward()
+    for name, v in (("gX_", X), ("gWb_", wb), ("gWc_", wc)):
+        ref = g[name + tag]
+        got = v.grad.cpu().numpy()
+        assert np.isfinite(got).all()
+        # hard one-hot weights leave empty segments with a degenerate spectrum: the reference's eigh backward
+        # returns NaN for the whole cloud there (0 * inf); ours returns the finite masked gradient.
+        ok = np.isfinite(ref)
+        if ok.any():
+            np.testing.assert_allclose(got[ok], ref[ok], rtol=5e-3, atol=2e-5 * max(1.0, np.abs(ref[ok]).max()))
+    deg = losses.compute_normal_difference(E.detach(), gt, in_radians=False, collapse=False).cpu().numpy()
+    np.testing.assert_allclose(deg[m], g["deg_" + tag][m], rtol=1e-3, atol=2e-2)
+
+
+def test_centers_centroids_extents_golden():
+    g = load_golden("g8_centers_extents")
+    P, W = cu(g["pcs"]), cu(g["W"]).requires_grad_(True)
+    c = fitting.estimate_extrusion_centers(W, P)
+    np.testing.assert_allclose(c.detach().cpu().numpy(), g["centers_pred"], rtol=1e-5, atol=1e-6)
+    c.square().sum().backward()
+    Wr = t(g["W"]).requires_grad_(True)
+    R.estimate_extrusion_centers(Wr, t(g["pcs"])).square().sum().backward()
+    np.testing.assert_allclose(W.grad.cpu().numpy(), Wr.grad.numpy(), rtol=1e-4, atol=1e-9)
+    B, K = g["found"].shape
+    S = g["rand_idx"].shape[1]
+    ridx = torch.zeros(B, K, S, dtype=torch.int64)
+    for (k, b), r in zip(g["rand_keys"].tolist(), g["rand_idx"]):
+        ridx[b, k] = t(r)
+    ext, found = fitting.get_extrusion_extents(P, cu(g["seg"]), cu(g["bb"]), cu(g["axes"]), cu(g["centers"]), S, rand_idx=ridx)
+    assert np.array_equal(found.cpu().numpy(), g["found"])
+    np.testing.assert_allclose(ext.cpu().numpy(), g["extents"], rtol=1e-5, atol=1e-6)
+    hard = F.one_hot(t(g["seg"]), K).float()
+    hard[0, :7] = 0
+    cen, fnd = fitting.segment_centroids(hard.to(DEV), P)
+    rc, rf = R.hard_centroids(hard, t(g["pcs"]))
+    assert np.array_equal(fnd.cpu().numpy(), rf.numpy())
+    np.testing.assert_allclose(cen.cpu().numpy(), rc.numpy(), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------ whole step
+def test_train_step_golden():
+    """G9: one full step (fwd, seg+normal+bb losses, bwd, Adam) at config 1 (B=2, N=1024)."""
+    g = load_golden("g9_train_step")
+    m = _model(int(g["seed"]), [3, 16])
+    m.train()
+    step.update_momentum(m, 0.5)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    m.sa1.fps_start, m.sa2.fps_start = t(g["start1"]), t(g["start2"])
+    dmask = np.unpackbits(g["dropout_mask_bcn"])[: 2 * 128 * 1024].reshape(2, 128, 1024)
+    m.dropout_mask = t(dmask).permute(0, 2, 1).contiguous()
+    z = torch.zeros(2, 8, 3, device=DEV)
+    out = step.train_step(m, opt, (cu(g["pcs"]), cu(g["normals"]), cu(g["seg"]), cu(g["bb"]), z, z), step.StepFlags())
+    assert np.array_equal(out["match"].cpu().numpy(), g["match"])
+    assert np.array_equal(out["W"].argmax(-1).cpu().numpy(), g["label"]), "segment indices must be bit-exact"
+    # accuracy bar = the reference's own fp32 error vs the same module in float64 (see test_backbone_golden)
+    for key, r32, r64 in (("X_head", g["X_head"], g["X_head64"]), ("W_raw", g["W_raw"], g["W_raw64"])):
+        ref_err = np.abs(r32 - r64).max()
+        mine_err = np.abs(out[key].detach().cpu().numpy() - r64).max()
+        assert mine_err <= 3 * ref_err + 1e-5, (key, mine_err, ref_err)
+    # unit normals: the error of x/|x| scales with 1/|x| of the raw head output
+    nrm = np.linalg.norm(g["X_head"], axis=-1, keepdims=True)
+    tol = (3 * np.abs(g["X_head"] - g["X_head64"]).max() + 1e-5) * 2.0 / nrm
+    assert (np.abs(out["X"].detach().cpu().numpy() - g["X"]) <= tol).all()
+    np.testing.assert_allclose([out["total"].item(), out["normal"].item(), out["miou"].item(), out["bb"].item()],
+                               [g["total"], g["normal_loss"], g["miou_loss"], g["bb_loss"]], rtol=1e-4)
+    after = dict(m.named_parameters())
+    for k in g:
+        if k.startswith("delta:"):
+            ref = g[k]
+            got = (after[k[6:]].detach() - before[k[6:]]).cpu().numpy().reshape(ref.shape)
+            # Adam's first step is lr*sign(g) up to eps: compare where the reference gradient is not ~0
+            big = np.abs(ref) > 0.5e-3
+            assert (np.sign(got[big]) == np.sign(ref[big])).mean() > 0.995
+            np.testing.assert_allclose(got[big], ref[big], rtol=0.05, atol=1e-5)

@@ -84,7 +84,7 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    loss = float(out["total"])
+    loss = float(out["total"].detach())
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -114,7 +114,7 @@ def main():
         from oracle import ref_step
         cb = args.cpu_batch
         sample = tuple(x[:cb].contiguous() for x in (pcs, normals, seg, bb))
-        pps, sec, thr = ref_step.time_cpu_baseline(sample, steps=1, threads=os.cpu_count())
+        pps, sec, thr = ref_step.time_cpu_baseline(sample, steps=1, threads=min(32, os.cpu_count() or 1))
         cpu = dict(value=round(pps, 1), unit="points/s", cores=thr, kind="port",
                    sample="1 full training step (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
                           "points (same generator as the GPU batch), %.1f s" % (cb, N, sec))

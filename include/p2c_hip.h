@@ -10,6 +10,8 @@
  *   - every pointer is a DEVICE pointer (HIP, gfx950) unless the name ends in _host;
  *   - all float tensors are fp32, row-major, POINT-MAJOR: a feature map is [rows, channels] with an
  *     explicit leading dimension (ld*, in elements) so that column slices of a wider matrix can be passed;
+ *     the GEMM entry points require 16-byte aligned bases, ld % 4 == 0 and channel counts % 4 == 0
+ *     (P2C_EALIGN otherwise; the host zero-pads, e.g. 131 -> 132 input channels);
  *   - index tensors are int32 on the device (the Python boundary converts to int64 where the reference
  *     returns int64);
  *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it, nothing synchronises, nothing
@@ -101,13 +103,15 @@ int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int ldw, const f
 
 /* BatchNorm batch statistics -> affine.  training != 0: mean/var from the partials (biased var for the
  * normalisation, unbiased for running_var, torch semantics), running stats updated in place with
- * `momentum`; training == 0: affine from the running stats.  The partial sums are taken BEFORE the bias
+ * `momentum`; training == 0: affine from the running stats (stat_partials / ws unused).  ws: p2c_reduce_ws_bytes(C).  The partial sums are taken BEFORE the bias
  * add (better conditioned); `bias` (may be NULL) is added back to the mean here.  Outputs scale[c] = gamma*invstd,
  * shift[c] = beta - mean*scale, and mean / invstd (saved for backward). */
 int p2c_bn_finalize_f32(const float *stat_partials, int n_tiles, int C, long long count, const float *bias,
                         const float *gamma, const float *beta, float eps, float momentum, int training,
                         float *running_mean, float *running_var, float *scale, float *shift, float *mean,
-                        float *invstd, void *stream);
+                        float *invstd, void *ws, void *stream);
+/* bytes of the fp64 scratch (`ws`) the per-channel reductions need for C channels */
+size_t p2c_reduce_ws_bytes(int C);
 
 /* Z = relu(scale*Y + shift), materialised (only where a consumer needs the post-activation tensor) */
 int p2c_bn_relu_apply_f32(const float *Y, int ldy, const float *scale, const float *shift, int M, int C, float *Z, int ldz,
@@ -134,10 +138,19 @@ int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float *Y, int ldy
  * grad_mode 1: dY = gs*(dZ*[scale*Yfwd+shift>0]) + q*Yfwd + p   with coef [5,Co] from the stats call above */
 
 /* dX[m,ci] = sum_co dY[m,co] * W[co,ci]   (optionally multiplied by out_mask[m,ci]*out_mask_scale: the
- * dropout in front of the layer).  dX [M,K] (lddx). */
+ * dropout in front of the layer).  dX [M,K] (lddx).
+ * Fused reduction for the layer BELOW (optional, bwd_partials != NULL): dX is that layer's dZ; with its saved
+ * pre-BN output Yprev [M,K] and prev_stat = [scale|shift|mean|invstd] x K the epilogue also emits the per-tile
+ * sums s1 = sum g, s2 = sum g*xhat (g = dX*[scale*Yprev+shift > 0]) into bwd_partials[tile][2][K],
+ * tile = m / P2C_STAT_TILE_M, to be finished by p2c_bn_bwd_finalize_f32. */
 int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                             const float *W, int ldw, float *dX, int lddx, int M, int N, int K, const uint8_t *out_mask,
-                            int ldmask, float out_mask_scale, void *stream);
+                            int ldmask, float out_mask_scale, const float *Yprev, int ldyp, const float *prev_stat,
+                            float *bwd_partials, void *stream);
+/* finish the fused reduction: dgamma, dbeta and coef [5,C] (see p2c_bn_relu_bwd_stats_f32).  stat = [scale|shift|mean|invstd] x C;
+ * ws: p2c_reduce_ws_bytes(C). */
+int p2c_bn_bwd_finalize_f32(const float *partials, int n_tiles, int C, long long M, const float *stat, const float *gamma,
+                            float *dgamma, float *dbeta, float *coef_out, void *ws, void *stream);
 
 /* dW[co,ci] += sum_m dY[m,co] * act_in(X)[m,ci];  dbias[co] += sum_m dY[m,co] (dbias may be NULL).
  * dW / dbias must be zero-initialised by the caller (the kernel splits the row range over workgroups and

@@ -29,12 +29,14 @@ _SIGS = {
     "p2c_three_interp_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_three_interp_bwd_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_linear_fwd_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p],
-    "p2c_bn_finalize_f32": [c_p, c_i, c_i, c_ll, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "p2c_bn_finalize_f32": [c_p, c_i, c_i, c_ll, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "p2c_bn_bwd_finalize_f32": [c_p, c_i, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_bn_relu_apply_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p],
     "p2c_maxpool_bnrelu_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
     "p2c_maxpool_bwd_f32": [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_bn_relu_bwd_stats_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
-    "p2c_linear_bwd_data_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_f, c_p],
+    "p2c_linear_bwd_data_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_f, c_p, c_i, c_p,
+                                c_p, c_p],
     "p2c_linear_bwd_weight_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_i, c_p,
                                   c_i, c_i, c_i, c_p],
     "p2c_extrusion_axis_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
@@ -73,6 +75,8 @@ def lib():
     L.p2c_linear_stat_tiles.restype = c_i
     L.p2c_bn_bwd_ws_bytes.argtypes = [c_i, c_i]
     L.p2c_bn_bwd_ws_bytes.restype = ctypes.c_size_t
+    L.p2c_reduce_ws_bytes.argtypes = [c_i]
+    L.p2c_reduce_ws_bytes.restype = ctypes.c_size_t
     L.p2c_extents_ws_bytes.argtypes = [c_i, c_i]
     L.p2c_extents_ws_bytes.restype = ctypes.c_size_t
     _lib = L

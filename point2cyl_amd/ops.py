@@ -123,17 +123,28 @@ class BNState:
         self.momentum, self.eps = momentum, eps
 
 
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+def _red_ws(C, dev):
+    return torch.empty(_lib.lib().p2c_reduce_ws_bytes(C) // 8 + 8, dtype=torch.float64, device=dev)
+
+
 class _MLPStack(torch.autograd.Function):
     """A chain of 1x1-conv layers  Y_i = act_{i-1}(Y_{i-1}) W_i^T + b_i  with BatchNorm+ReLU folded into the
     NEXT layer's operand load.  tail: 'maxpool' (max over ns of relu(bn(Y_last))), 'bnrelu' (materialise
     relu(bn(Y_last))), 'linear' (last layer has no BN; `drop_mask` multiplies its input).
-    params = [W_0, b_0, gamma_0, beta_0, W_1, ...] (gamma/beta absent for a BN-less last layer)."""
+    params = [W_0, b_0, gamma_0, beta_0, W_1, ...] (gamma/beta absent for a BN-less last layer).
+    The kernels want channel counts that are multiples of 4: X0 carries zero columns up to pad4(in_channels)
+    and odd-sized weights are zero-padded here (131 -> 132 inputs, 19 -> 20 head outputs)."""
 
     @staticmethod
     def forward(ctx, cfg, X0, *params):
         dev = X0.device
         M, ldx0 = X0.shape[0], X0.stride(0)
-        K = cfg["in_channels"]
+        K = _pad4(cfg["in_channels"])
+        assert X0.shape[1] >= K and ldx0 % 4 == 0, (X0.shape, K)
         training = cfg["training"]
         bns = cfg["bns"]
         L = cfg["n_layers"]
@@ -147,9 +158,13 @@ class _MLPStack(torch.autograd.Function):
             has_bn = not (tail == "linear" and i == L - 1)
             W, b = params[pi], params[pi + 1]
             pi += 2
-            Co = W.shape[0]
-            W2 = W.reshape(Co, -1)
-            assert W2.shape[1] == K, (W2.shape, K)
+            Co_true = W.shape[0]
+            W2 = W.reshape(Co_true, -1)
+            Co = _pad4(Co_true)
+            if W2.shape[1] != K or Co != Co_true:
+                W2 = torch.nn.functional.pad(W2, (0, K - W2.shape[1], 0, Co - Co_true))
+                b = torch.nn.functional.pad(b, (0, Co - Co_true))
+            W2 = W2.contiguous()
             Y = torch.empty(M, Co, dtype=torch.float32, device=dev)
             use_mask = (not has_bn) and mask is not None
             mode = 2 if (use_mask and in_mode == 1) else in_mode
@@ -157,7 +172,7 @@ class _MLPStack(torch.autograd.Function):
             if has_bn and training:
                 tiles = _lib.lib().p2c_linear_stat_tiles(M)
                 partials = torch.empty(tiles, 2, Co, dtype=torch.float32, device=dev)
-            call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), W2.stride(0), ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
+            call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
                  ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), ptr(partials), stream(),
                  flops=2.0 * M * Co * K)
             Ys.append(Y)
@@ -169,7 +184,7 @@ class _MLPStack(torch.autograd.Function):
                 st = torch.empty(4, Co, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
                 call("p2c_bn_finalize_f32", ptr(partials), 0 if partials is None else partials.shape[0], Co, M, ptr(b), ptr(gamma),
                      ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
-                     ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
+                     ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(_red_ws(Co, dev)) if training else None, stream())
                 if training and bn.nbt is not None:
                     bn.nbt += 1
                 aff.append(st)
@@ -205,37 +220,41 @@ class _MLPStack(torch.autograd.Function):
         mask, dscale = cfg.get("drop_mask"), cfg.get("drop_scale", 1.0)
         dout = _f32c(dout)
         Cl = Ys[-1].shape[1]
-        if tail == "maxpool":
-            dZ = torch.empty(M, Cl, dtype=torch.float32, device=dev)
-            call("p2c_maxpool_bwd_f32", ptr(dout), Cl, ptr(arg), cfg["G"], cfg["ns"], Cl, ptr(dZ), Cl, stream())
-            grad_mode = 1
-        elif tail == "bnrelu":
-            dZ, grad_mode = dout, 1
-        else:
-            dZ, grad_mode = dout, 0
         grads = [None] * len(params)
-        # parameter slots per layer
         slots, pi = [], 0
         for i in range(L):
             has_bn = not (tail == "linear" and i == L - 1)
             slots.append((pi, has_bn))
             pi += 4 if has_bn else 2
+
+        def standalone_stats(dZ, i):
+            """coef/dgamma/dbeta of layer i from a materialised dZ (top of the stack only)."""
+            p0, _ = slots[i]
+            st, Co = aff[i], Ys[i].shape[1]
+            coef = torch.empty(5, Co, dtype=torch.float32, device=dev)
+            dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(Co, dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.lib().p2c_bn_bwd_ws_bytes(M, Co) // 4 + 4, dtype=torch.float32, device=dev)
+            call("p2c_bn_relu_bwd_stats_f32", ptr(dZ), dZ.stride(0), ptr(Ys[i]), Co, ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]),
+                 ptr(params[p0 + 2]), M, Co, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(ws), stream())
+            grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
+            return coef
+
+        if tail == "maxpool":
+            dZ = torch.empty(M, Cl, dtype=torch.float32, device=dev)
+            call("p2c_maxpool_bwd_f32", ptr(dout), Cl, ptr(arg), cfg["G"], cfg["ns"], Cl, ptr(dZ), Cl, stream())
+            grad_mode, coef = 1, standalone_stats(dZ, L - 1)
+        elif tail == "bnrelu":
+            dZ = dout
+            grad_mode, coef = 1, standalone_stats(dZ, L - 1)
+        else:
+            dZ, grad_mode, coef = dout, 0, None
+            if dZ.shape[1] != Cl:
+                dZ = torch.nn.functional.pad(dZ, (0, Cl - dZ.shape[1]))
         for i in range(L - 1, -1, -1):
             p0, has_bn = slots[i]
             Y, W2 = Ys[i], Ws[i]
             Co, Ci = W2.shape
-            coef = None
-            if grad_mode == 1:
-                st = aff[i]
-                gamma = params[p0 + 2]
-                coef = torch.empty(5, Co, dtype=torch.float32, device=dev)
-                dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
-                dbeta = torch.empty(Co, dtype=torch.float32, device=dev)
-                ws = torch.empty(_lib.lib().p2c_bn_bwd_ws_bytes(M, Co) // 4 + 4, dtype=torch.float32, device=dev)
-                call("p2c_bn_relu_bwd_stats_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]),
-                     ptr(gamma), M, Co, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(ws), stream())
-                grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
-            # operand that fed this layer in the forward pass
             if i == 0:
                 Xin, ldxin, in_mode, sc, sh = X0, X0.stride(0), 0, None, None
             else:
@@ -248,15 +267,27 @@ class _MLPStack(torch.autograd.Function):
             call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
                  ptr(sh), ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), ptr(dW), Ci,
                  ptr(db) if grad_mode == 0 else None, M, Co, Ci, stream(), flops=2.0 * M * Co * Ci)
-            grads[p0] = dW.view_as(params[p0])
-            grads[p0 + 1] = db
+            Wp = params[p0]
+            co_t, ci_t = Wp.shape[0], Wp.numel() // Wp.shape[0]
+            grads[p0] = dW[:co_t, :ci_t].reshape(Wp.shape)
+            grads[p0 + 1] = db[:co_t]
             if i > 0 or ctx.needs_input_grad[1]:
-                ldd = (Ci + 3) // 4 * 4 if i == 0 else Ci
-                dX = torch.empty(M, ldd, dtype=torch.float32, device=dev)
-                call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(W2), W2.stride(0), ptr(dX),
-                     ldd, M, Co, Ci, ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), stream(),
+                dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
+                fused = i > 0
+                part = torch.empty(_lib.lib().p2c_linear_stat_tiles(M), 2, Ci, dtype=torch.float32, device=dev) if fused else None
+                call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(W2), Ci, ptr(dX), Ci, M, Co, Ci,
+                     ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale),
+                     ptr(Ys[i - 1]) if fused else None, Ci, ptr(aff[i - 1]) if fused else None, ptr(part), stream(),
                      flops=2.0 * M * Co * Ci)
                 dZ, grad_mode = dX, 1
+                if fused:
+                    q0, _ = slots[i - 1]
+                    coef = torch.empty(5, Ci, dtype=torch.float32, device=dev)
+                    dgamma = torch.empty(Ci, dtype=torch.float32, device=dev)
+                    dbeta = torch.empty(Ci, dtype=torch.float32, device=dev)
+                    call("p2c_bn_bwd_finalize_f32", ptr(part), part.shape[0], Ci, M, ptr(aff[i - 1]), ptr(params[q0 + 2]), ptr(dgamma),
+                         ptr(dbeta), ptr(coef), ptr(_red_ws(Ci, dev)), stream())
+                    grads[q0 + 2], grads[q0 + 3] = dgamma, dbeta
         dX0 = None
         if ctx.needs_input_grad[1]:
             dX0 = dZ
@@ -277,7 +308,11 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
         bns.append(ly.get("bn"))
     cfg = dict(in_channels=in_channels, n_layers=len(layers), tail=tail, training=training, bns=bns, G=G, ns=ns,
                drop_mask=drop_mask, drop_scale=drop_scale)
-    return _MLPStack.apply(cfg, X0, *params)
+    out = _MLPStack.apply(cfg, X0, *params)
+    co_last = layers[-1]["W"].shape[0]
+    if tail == "linear" and out.shape[1] != co_last:
+        out = out[:, :co_last]          # the kernels work on 4-padded channel counts
+    return out
 
 
 # ------------------------------------------------------------------------------------------ fitting

@@ -134,8 +134,17 @@ int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float *Y, int ldy
                               const float *mean, const float *invstd, const float *gamma, int M, int C, float *dgamma,
                               float *dbeta, float *coef_out, void *ws, void *stream);
 
+/* The same reduction for the layer that feeds the max-pool, WITHOUT materialising dZ: the sums run over the
+ * pooled gradient dout [G,C] and the winners arg [G,C] only.  stat = [scale|shift|mean|invstd] x C of that layer,
+ * Y its pre-BN output [G*ns, C].  ws: p2c_bn_bwd_ws_bytes(G, C). */
+int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const int32_t *arg, const float *Y, int ldy, const float *stat,
+                                 const float *gamma, int G, int ns, int C, float *dgamma, float *dbeta, float *coef_out, void *ws,
+                                 void *stream);
+
 /* grad_mode 0: dY = G (the tensor passed as dZ is already dY; Yfwd/coef unused)
- * grad_mode 1: dY = gs*(dZ*[scale*Yfwd+shift>0]) + q*Yfwd + p   with coef [5,Co] from the stats call above */
+ * grad_mode 1: dY = gs*(dZ*[scale*Yfwd+shift>0]) + q*Yfwd + p   with coef [5,Co] from the stats call above
+ * grad_mode 2: as 1 with dZ[m,c] = (pool_arg[m/pool_ns, c] == m%pool_ns) ? dZ_pooled[m/pool_ns, c] : 0, i.e. the
+ *              `dZ` argument is the max-pool's upstream gradient [G,Co] (lddz its leading dim) */
 
 /* dX[m,ci] = sum_co dY[m,co] * W[co,ci]   (optionally multiplied by out_mask[m,ci]*out_mask_scale: the
  * dropout in front of the layer).  dX [M,K] (lddx).
@@ -146,7 +155,7 @@ int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float *Y, int ldy
 int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                             const float *W, int ldw, float *dX, int lddx, int M, int N, int K, const uint8_t *out_mask,
                             int ldmask, float out_mask_scale, const float *Yprev, int ldyp, const float *prev_stat,
-                            float *bwd_partials, void *stream);
+                            float *bwd_partials, const int32_t *pool_arg, int pool_ns, void *stream);
 /* finish the fused reduction: dgamma, dbeta and coef [5,C] (see p2c_bn_relu_bwd_stats_f32).  stat = [scale|shift|mean|invstd] x C;
  * ws: p2c_reduce_ws_bytes(C). */
 int p2c_bn_bwd_finalize_f32(const float *partials, int n_tiles, int C, long long M, const float *stat, const float *gamma,
@@ -158,7 +167,7 @@ int p2c_bn_bwd_finalize_f32(const float *partials, int n_tiles, int C, long long
 int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                               const float *X, int ldx, int in_mode, const float *in_scale, const float *in_shift,
                               const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW, int lddw, float *dbias,
-                              int M, int N, int K, void *stream);
+                              int M, int N, int K, const int32_t *pool_arg, int pool_ns, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Extrusion-cylinder fitting  (data_utils.py:99-177, :253-266, :1650-1730; eval.py:409-436)

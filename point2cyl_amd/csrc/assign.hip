@@ -56,57 +56,68 @@ __device__ void p2c_lsa_min(const double *cost, int nr, int nc, int *col4row)
     }
 }
 
-// thread (slice, k', k): k' in [0, K] where row K collects the plain column sums; slices split the points.
-__global__ void __launch_bounds__(256) hungarian_kernel(const float *__restrict__ W, const int64_t *__restrict__ I_gt, int N, int K,
-                                                        int64_t *__restrict__ match_out, uint8_t *__restrict__ mask_out)
+// One workgroup of 1024 threads per sample.  Thread (g, k) owns column k of W and the point slice
+// g, g+G, ...; it adds W[n,k] into ITS OWN LDS row at slot label(n) (slot K' = background / -1 rows are
+// skipped, slot `any` collects the plain column sum), so there are no atomics and the result is
+// deterministic.  A second phase sums the G rows per (label, k) and lane 0 solves the assignment.
+#define HM_THREADS 1024
+
+__global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__restrict__ W, const int64_t *__restrict__ I_gt, int N, int K,
+                                                              int64_t *__restrict__ match_out, uint8_t *__restrict__ mask_out)
 {
-    __shared__ float part[256];
-    __shared__ float cnt_part[256];
-    __shared__ int smax[4];
+    extern __shared__ float sacc[];                 // [HM_THREADS][2K+1] private rows: K label sums | column sum | K label counts
+    __shared__ int smax[HM_THREADS / 64];
     __shared__ double cost[HM_MAXK * HM_MAXK];
+    __shared__ float tot[(HM_MAXK + 1) * HM_MAXK], cnt[HM_MAXK];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t *lab = I_gt + (size_t)b * N;
     const float *w = W + (size_t)b * N * K;
-    // n_gt = max(I_gt)+1  (losses.py:36)
+    const int G = HM_THREADS / K, g = tid / K, k = tid - g * K;
+    const int RS = 2 * K + 1;
+    float *mine = sacc + (size_t)tid * RS;
+    for (int i = 0; i < RS; ++i) mine[i] = 0.f;
     int mx = -1;
-    for (int n = tid; n < N; n += 256) mx = max(mx, (int)lab[n]);
+    if (g < G) {
+        for (int n = g; n < N; n += G) {
+            const int l = (int)lab[n];
+            mx = max(mx, l);
+            const float v = w[(size_t)n * K + k];
+            mine[K] += v;
+            if (l >= 0 && l < K) {
+                mine[l] += v;
+                if (k == 0) mine[K + 1 + l] += 1.f;
+            }
+        }
+    }
     mx = p2c_wave_max_i32(mx);
     if (lane == 0) smax[wave] = mx;
     __syncthreads();
-    const int n_gt = max(max(smax[0], smax[1]), max(smax[2], smax[3])) + 1;
-    const int pairs = (K + 1) * K;
-    const int slices = 256 / pairs;
-    const int sl = tid / pairs, pr = tid - sl * pairs;
-    const int kp = pr / K, k = pr - kp * K;
-    float s = 0.f, c = 0.f;
-    if (sl < slices) {
-        const int per = (N + slices - 1) / slices;
-        const int n1 = min(N, (sl + 1) * per);
-        for (int n = sl * per; n < n1; ++n) {
-            const int l = (int)lab[n];
-            const bool hit = (kp == K) || (l == kp);
-            if (hit) { s += w[(size_t)n * K + k]; c += 1.f; }
-        }
+    int n_gt = -1;
+    for (int i = 0; i < HM_THREADS / 64; ++i) n_gt = max(n_gt, smax[i]);
+    n_gt += 1;                                       // losses.py:36
+    // fixed-order sums over the G slices: (K+1)*K intersections / column sums, then K label counts
+    if (tid < (K + 1) * K) {
+        const int r = tid / K, q = tid - r * K;      // r = label slot (K = column sum), q = column
+        float s = 0.f;
+        for (int gg = 0; gg < G; ++gg) s += sacc[(size_t)(gg * K + q) * RS + r];
+        tot[r * K + q] = s;
+    } else if (tid < (K + 1) * K + K) {
+        const int l = tid - (K + 1) * K;
+        float s = 0.f;
+        for (int gg = 0; gg < G; ++gg) s += sacc[(size_t)(gg * K) * RS + K + 1 + l];
+        cnt[l] = s;
     }
-    part[tid] = s;
-    cnt_part[tid] = c;
     __syncthreads();
     if (tid == 0) {
-        // dot[k'][k], colsum[k], rowcount[k'] in fp32 like the reference's torch.mm / torch.sum
-        for (int r = 0; r < n_gt && r < K; ++r)
+        const int nr = min(n_gt, K);
+        for (int r = 0; r < nr; ++r)
             for (int q = 0; q < K; ++q) {
-                float dot = 0.f, col = 0.f, rc = 0.f;
-                for (int z = 0; z < slices; ++z) {
-                    dot += part[z * pairs + r * K + q];
-                    col += part[z * pairs + K * K + q];
-                    rc += cnt_part[z * pairs + r * K + 0];
-                }
+                const float dot = tot[r * K + q], col = tot[K * K + q], rc = cnt[r];
                 const float den = (rc + col) - dot;                       // :40
                 const float iou = dot / fmaxf(den, 1e-10f);               // :41
                 cost[r * K + q] = -(double)iou;                           // :43 maximise
             }
         int col4row[HM_MAXK + 1];
-        const int nr = min(n_gt, K);
         if (nr > 0) p2c_lsa_min(cost, nr, K, col4row);
         for (int q = 0; q < K; ++q) {
             match_out[(size_t)b * K + q] = q < nr ? (int64_t)col4row[q] : 0;   // rest stays 0 (:30)
@@ -118,8 +129,10 @@ __global__ void __launch_bounds__(256) hungarian_kernel(const float *__restrict_
 extern "C" int p2c_hungarian_f32(const float *W, const int64_t *I_gt, int B, int N, int K, int64_t *match_out, uint8_t *mask_out,
                                  void *stream)
 {
-    if (!W || !I_gt || !match_out || !mask_out || B <= 0 || N <= 0 || K <= 0 || K > HM_MAXK || (K + 1) * K > 256) return P2C_EINVAL;
-    hipLaunchKernelGGL(hungarian_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, W, I_gt, N, K, match_out, mask_out);
+    if (!W || !I_gt || !match_out || !mask_out || B <= 0 || N <= 0 || K <= 0 || K > HM_MAXK) return P2C_EINVAL;
+    const size_t lds = (size_t)HM_THREADS * (2 * K + 1) * sizeof(float);
+    (void)hipFuncSetAttribute((const void *)hungarian_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(hungarian_kernel, dim3(B), dim3(HM_THREADS), lds, (hipStream_t)stream, W, I_gt, N, K, match_out, mask_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

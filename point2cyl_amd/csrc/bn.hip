@@ -238,6 +238,53 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double *__res
     coef[4 * C + c] = (float)p;
 }
 
+// Same reduction when the layer feeds the max-pool: dZ is non-zero only at the winner rows, so the sums run over
+// the G x C pooled gradients (1/ns of the rows) and read Y at the winners only.
+__global__ void __launch_bounds__(256) pool_bwd_partial_kernel(const float *__restrict__ dout, int ldo, const int32_t *__restrict__ arg,
+                                                               const float *__restrict__ Y, int ldy, const float *__restrict__ stat, int G,
+                                                               int ns, int C, float *__restrict__ ws)
+{
+    __shared__ float red[2][4][64];
+    const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cx;
+    const int g0 = blockIdx.x * BWD_ROWS, g1 = min(G, g0 + BWD_ROWS);
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        const float sc = stat[c], sh = stat[C + c], mu = stat[2 * C + c], is = stat[3 * C + c];
+        for (int g = g0 + ty; g < g1; g += 4) {
+            const int a = arg[(size_t)g * C + c];
+            const float y = Y[((size_t)g * ns + a) * ldy + c];
+            const float gr = (sc * y + sh > 0.f) ? dout[(size_t)g * ldo + c] : 0.f;
+            s1 += gr;
+            s2 += gr * ((y - mu) * is);
+        }
+    }
+    red[0][ty][cx] = s1;
+    red[1][ty][cx] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float *o = ws + (size_t)blockIdx.x * 2 * C;
+        o[c] = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+        o[C + c] = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+    }
+}
+
+extern "C" int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const int32_t *arg, const float *Y, int ldy, const float *stat,
+                                            const float *gamma, int G, int ns, int C, float *dgamma, float *dbeta, float *coef_out,
+                                            void *ws, void *stream)
+{
+    if (!dout || !arg || !Y || !stat || !gamma || !coef_out || !ws || G <= 0 || ns <= 0 || C <= 0) return P2C_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const int chunks = p2c_cdiv(G, BWD_ROWS);
+    hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dout, ldo, arg, Y, ldy, stat, G, ns, C, (float *)ws);
+    double *ws2 = (double *)((char *)ws + (((size_t)chunks * 2 * C * sizeof(float) + 63) & ~(size_t)63));
+    launch_reduce((const float *)ws, chunks, C, ws2, s);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(64), 0, s, (const double *)ws2, RED_SLICES, C,
+                       (long long)G * ns, stat, stat + C, stat + 2 * C, stat + 3 * C, gamma, dgamma, dbeta, coef_out);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
 extern "C" size_t p2c_bn_bwd_ws_bytes(int M, int C)
 {
     return (size_t)p2c_cdiv(M, BWD_ROWS) * 2 * (size_t)C * sizeof(float) + p2c_reduce_ws_bytes(C) + 64;

@@ -78,15 +78,26 @@ struct OpActIn {
 
 // dY rebuilt from the upstream gradient dZ (w.r.t. relu(bn(Y))) and the saved pre-BN Y:
 //   MODE 0: dY = dZ;   MODE 1: dY = gs*(dZ*[scale*Y+shift > 0]) + q*Y + p,  coef = [scale|shift|gs|q|p] x Cc
+//   MODE 2: as 1, but dZ is never materialised: the layer is followed by the max-pool over `ns` neighbours, so
+//           dZ[m,c] = dOut[m/ns, c] if arg[m/ns, c] == m%ns else 0  (dz = dOut [G,C], arg = winners [G,C])
 template <int MODE>
 struct OpGrad {
     const float *dz; int lddz;
     const float *y; int ldy;
     const float *coef; int Cc;
+    const int32_t *arg; int ns;
     __device__ __forceinline__ float4 load4(int r, int c, int R, int C) const
     {
         const int rr = min(r, R - 1), cc = min(c, C - 4);
-        const float4 g = *reinterpret_cast<const float4 *>(dz + (size_t)rr * lddz + cc);
+        float4 g;
+        if (MODE == 2) {
+            const int grp = rr / ns, j = rr - grp * ns;
+            const float4 d = *reinterpret_cast<const float4 *>(dz + (size_t)grp * lddz + cc);
+            const int4 a = *reinterpret_cast<const int4 *>(arg + (size_t)grp * Cc + cc);
+            g = make_float4(a.x == j ? d.x : 0.f, a.y == j ? d.y : 0.f, a.z == j ? d.z : 0.f, a.w == j ? d.w : 0.f);
+        } else {
+            g = *reinterpret_cast<const float4 *>(dz + (size_t)rr * lddz + cc);
+        }
         if (MODE == 0) return sel4(r < R && c < C, g);
         const float4 yy = *reinterpret_cast<const float4 *>(y + (size_t)rr * ldy + cc);
         const float4 s = *reinterpret_cast<const float4 *>(coef + cc), t = *reinterpret_cast<const float4 *>(coef + Cc + cc);
@@ -379,10 +390,10 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
 template <int GMODE>
 static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy, const float *coef, const float *W, int ldw, float *dX,
                            int lddx, int M, int N, int K, const uint8_t *out_mask, int ldmask, float out_mask_scale, const float *Yprev,
-                           int ldyp, const float *prev_stat, float *bwd_partials, hipStream_t s)
+                           int ldyp, const float *prev_stat, float *bwd_partials, const int32_t *pool_arg, int pool_ns, hipStream_t s)
 {
     // layer: Y[M,N] = in[M,K] . W[N,K]^T ; here the GEMM is dX[M,K] = dY[M,N] . W[N,K]
-    OpGrad<GMODE> a{dZ, lddz, Yfwd, ldy, coef, N};
+    OpGrad<GMODE> a{dZ, lddz, Yfwd, ldy, coef, N, pool_arg, pool_ns};
     OpPlain b{W, ldw};
     EpiBwdData e{dX, lddx, out_mask, ldmask, out_mask_scale, Yprev, ldyp, prev_stat, bwd_partials};
     const int kps = (N + GK - 1) / GK * GK;
@@ -400,31 +411,34 @@ static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy
 extern "C" int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                                        const float *W, int ldw, float *dX, int lddx, int M, int N, int K, const uint8_t *out_mask,
                                        int ldmask, float out_mask_scale, const float *Yprev, int ldyp, const float *prev_stat,
-                                       float *bwd_partials, void *stream)
+                                       float *bwd_partials, const int32_t *pool_arg, int pool_ns, void *stream)
 {
-    if (!dZ || !W || !dX || M <= 0 || N <= 0 || K <= 0 || grad_mode < 0 || grad_mode > 1) return P2C_EINVAL;
-    if (grad_mode == 1 && (!Yfwd || !coef)) return P2C_EINVAL;
+    if (!dZ || !W || !dX || M <= 0 || N <= 0 || K <= 0 || grad_mode < 0 || grad_mode > 2) return P2C_EINVAL;
+    if (grad_mode >= 1 && (!Yfwd || !coef)) return P2C_EINVAL;
+    if (grad_mode == 2 && (!pool_arg || pool_ns <= 0 || ((uintptr_t)pool_arg & 15))) return P2C_EINVAL;
     if (bwd_partials && (!Yprev || !prev_stat)) return P2C_EINVAL;
     if ((N & 3) || (K & 3)) return P2C_EALIGN;
     P2C_REQ_ALIGNED(dZ, lddz);
     P2C_REQ_ALIGNED(W, ldw);
-    if (grad_mode == 1) { P2C_REQ_ALIGNED(Yfwd, ldy); P2C_REQ_ALIGNED(coef, 0); }
+    if (grad_mode >= 1) { P2C_REQ_ALIGNED(Yfwd, ldy); P2C_REQ_ALIGNED(coef, 0); }
     hipStream_t s = (hipStream_t)stream;
-    if (grad_mode == 0)
-        return launch_bwd_data<0>(dZ, lddz, Yfwd, ldy, coef, W, ldw, dX, lddx, M, N, K, out_mask, ldmask, out_mask_scale, Yprev, ldyp, prev_stat,
-                                  bwd_partials, s);
-    return launch_bwd_data<1>(dZ, lddz, Yfwd, ldy, coef, W, ldw, dX, lddx, M, N, K, out_mask, ldmask, out_mask_scale, Yprev, ldyp, prev_stat,
-                              bwd_partials, s);
+#define P2C_BD(G_)                                                                                                                        \
+    return launch_bwd_data<G_>(dZ, lddz, Yfwd, ldy, coef, W, ldw, dX, lddx, M, N, K, out_mask, ldmask, out_mask_scale, Yprev, ldyp, prev_stat, \
+                               bwd_partials, pool_arg, pool_ns, s)
+    if (grad_mode == 0) P2C_BD(0);
+    if (grad_mode == 1) P2C_BD(1);
+    P2C_BD(2);
+#undef P2C_BD
 }
 
 // ---- backward weight --------------------------------------------------------------------------------
 template <int GMODE, int IMODE>
 static int launch_bwd_weight(const float *dZ, int lddz, const float *Yfwd, int ldy, const float *coef, const float *X, int ldx,
                              const float *in_scale, const float *in_shift, const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW,
-                             int lddw, float *dbias, int M, int N, int K, hipStream_t s)
+                             int lddw, float *dbias, int M, int N, int K, const int32_t *pool_arg, int pool_ns, hipStream_t s)
 {
     // dW[N,K] += sum_m dY[m,N]^T act_in(X)[m,K]: GEMM with I=N (co), J=K (ci), reduction over the M rows
-    OpGrad<GMODE> a{dZ, lddz, Yfwd, ldy, coef, N};
+    OpGrad<GMODE> a{dZ, lddz, Yfwd, ldy, coef, N, pool_arg, pool_ns};
     OpActIn<IMODE> b{X, ldx, in_scale, in_shift, drop_mask, ldmask, drop_scale};
     EpiAtomic e{dW, lddw, dbias};
     const int ti = N > 64 ? p2c_cdiv(N, 128) : 1, tj = K > 64 ? p2c_cdiv(K, 128) : 1;
@@ -450,28 +464,33 @@ static int launch_bwd_weight(const float *dZ, int lddz, const float *Yfwd, int l
 extern "C" int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                                          const float *X, int ldx, int in_mode, const float *in_scale, const float *in_shift,
                                          const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW, int lddw, float *dbias,
-                                         int M, int N, int K, void *stream)
+                                         int M, int N, int K, const int32_t *pool_arg, int pool_ns, void *stream)
 {
-    if (!dZ || !X || !dW || M <= 0 || N <= 0 || K <= 0 || grad_mode < 0 || grad_mode > 1 || in_mode < 0 || in_mode > 2) return P2C_EINVAL;
-    if (grad_mode == 1 && (!Yfwd || !coef)) return P2C_EINVAL;
+    if (!dZ || !X || !dW || M <= 0 || N <= 0 || K <= 0 || grad_mode < 0 || grad_mode > 2 || in_mode < 0 || in_mode > 2) return P2C_EINVAL;
+    if (grad_mode >= 1 && (!Yfwd || !coef)) return P2C_EINVAL;
+    if (grad_mode == 2 && (!pool_arg || pool_ns <= 0 || ((uintptr_t)pool_arg & 15))) return P2C_EINVAL;
     if (in_mode >= 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
     if (in_mode == 2 && (!drop_mask || (ldmask & 3) || ((uintptr_t)drop_mask & 3))) return P2C_EINVAL;
     if ((N & 3) || (K & 3)) return P2C_EALIGN;
     P2C_REQ_ALIGNED(dZ, lddz);
     P2C_REQ_ALIGNED(X, ldx);
-    if (grad_mode == 1) { P2C_REQ_ALIGNED(Yfwd, ldy); P2C_REQ_ALIGNED(coef, 0); }
+    if (grad_mode >= 1) { P2C_REQ_ALIGNED(Yfwd, ldy); P2C_REQ_ALIGNED(coef, 0); }
     if (in_mode >= 1) { P2C_REQ_ALIGNED(in_scale, 0); P2C_REQ_ALIGNED(in_shift, 0); }
     hipStream_t s = (hipStream_t)stream;
 #define P2C_DISPATCH(G_, I_)                                                                                                              \
     return launch_bwd_weight<G_, I_>(dZ, lddz, Yfwd, ldy, coef, X, ldx, in_scale, in_shift, drop_mask, ldmask, drop_scale, dW, lddw, dbias, M, \
-                                     N, K, s)
+                                     N, K, pool_arg, pool_ns, s)
     if (grad_mode == 0) {
         if (in_mode == 0) P2C_DISPATCH(0, 0);
         if (in_mode == 1) P2C_DISPATCH(0, 1);
         P2C_DISPATCH(0, 2);
     }
-    if (in_mode == 0) P2C_DISPATCH(1, 0);
-    if (in_mode == 1) P2C_DISPATCH(1, 1);
-    P2C_DISPATCH(1, 2);
+    if (grad_mode == 1) {
+        if (in_mode == 0) P2C_DISPATCH(1, 0);
+        if (in_mode == 1) P2C_DISPATCH(1, 1);
+        P2C_DISPATCH(1, 2);
+    }
+    if (in_mode == 0) P2C_DISPATCH(2, 0);
+    P2C_DISPATCH(2, 1);
 #undef P2C_DISPATCH
 }

@@ -29,26 +29,30 @@ def init_from_env(backend=None):
 
 
 class FlatGradSync:
-    """Owns the flat gradient buffer; call zero() before backward and allreduce() after it."""
+    """One collective per step: after backward the per-parameter gradients are packed into ONE flat buffer
+    (a single concat kernel), all-reduced, averaged, and the parameters' .grad are re-pointed at views of it
+    (no unpack copy).  With world_size 1 nothing is packed at all.  Call zero() before backward."""
 
     def __init__(self, params, world_size=None):
         self.params = [p for p in params if p.requires_grad]
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        n = sum(p.numel() for p in self.params)
-        p0 = self.params[0]
-        self.flat = torch.zeros(n, dtype=p0.dtype, device=p0.device)
-        o = 0
-        for p in self.params:
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
-            o += p.numel()
+        self.flat = None
 
     def zero(self):
-        self.flat.zero_()
+        for p in self.params:
+            p.grad = None          # autograd then adopts the kernels' output buffers: no accumulate kernels
 
     def allreduce(self):
-        if self.world > 1:
+        if self.world <= 1:
+            return
+        with torch.no_grad():
+            self.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(self.world)
+            o = 0
+            for p in self.params:
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
 
 
 def broadcast_module(module, src=0):

@@ -240,10 +240,19 @@ class _MLPStack(torch.autograd.Function):
             grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
             return coef
 
+        pool_ns = 0
         if tail == "maxpool":
-            dZ = torch.empty(M, Cl, dtype=torch.float32, device=dev)
-            call("p2c_maxpool_bwd_f32", ptr(dout), Cl, ptr(arg), cfg["G"], cfg["ns"], Cl, ptr(dZ), Cl, stream())
-            grad_mode, coef = 1, standalone_stats(dZ, L - 1)
+            # dZ of the pooled layer is never materialised (grad_mode 2): winners + pooled gradient are enough
+            G, pool_ns = cfg["G"], cfg["ns"]
+            p0, _ = slots[L - 1]
+            dZ, grad_mode = dout, 2
+            coef = torch.empty(5, Cl, dtype=torch.float32, device=dev)
+            dgamma = torch.empty(Cl, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(Cl, dtype=torch.float32, device=dev)
+            ws = torch.empty(_lib.lib().p2c_bn_bwd_ws_bytes(G, Cl) // 4 + 4, dtype=torch.float32, device=dev)
+            call("p2c_maxpool_bn_bwd_stats_f32", ptr(dout), Cl, ptr(arg), ptr(Ys[-1]), Cl, ptr(aff[-1]), ptr(params[p0 + 2]), G, pool_ns, Cl,
+                 ptr(dgamma), ptr(dbeta), ptr(coef), ptr(ws), stream())
+            grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
         elif tail == "bnrelu":
             dZ = dout
             grad_mode, coef = 1, standalone_stats(dZ, L - 1)
@@ -266,7 +275,8 @@ class _MLPStack(torch.autograd.Function):
             db = torch.zeros(Co, dtype=torch.float32, device=dev)
             call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
                  ptr(sh), ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), ptr(dW), Ci,
-                 ptr(db) if grad_mode == 0 else None, M, Co, Ci, stream(), flops=2.0 * M * Co * Ci)
+                 ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
+                 flops=2.0 * M * Co * Ci)
             Wp = params[p0]
             co_t, ci_t = Wp.shape[0], Wp.numel() // Wp.shape[0]
             grads[p0] = dW[:co_t, :ci_t].reshape(Wp.shape)
@@ -277,8 +287,8 @@ class _MLPStack(torch.autograd.Function):
                 part = torch.empty(_lib.lib().p2c_linear_stat_tiles(M), 2, Ci, dtype=torch.float32, device=dev) if fused else None
                 call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(W2), Ci, ptr(dX), Ci, M, Co, Ci,
                      ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale),
-                     ptr(Ys[i - 1]) if fused else None, Ci, ptr(aff[i - 1]) if fused else None, ptr(part), stream(),
-                     flops=2.0 * M * Co * Ci)
+                     ptr(Ys[i - 1]) if fused else None, Ci, ptr(aff[i - 1]) if fused else None, ptr(part),
+                     ptr(arg) if grad_mode == 2 else None, pool_ns, stream(), flops=2.0 * M * Co * Ci)
                 dZ, grad_mode = dX, 1
                 if fused:
                     q0, _ = slots[i - 1]

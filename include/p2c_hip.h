@@ -94,9 +94,9 @@ int p2c_three_interp_bwd_f32(const float *dout, int ldo, const int32_t *idx, con
 /* Forward.  X [M,K] (ldx), W [N,K] row-major (ldw) = the conv weight (Co,Ci,1[,1]) as stored in the
  * reference's state_dict, bias [N] (may be NULL), Y [M,N] (ldy).  If stat_partials != NULL the kernel also
  * writes per-row-tile partial sums: stat_partials[tile][0][n] = sum_m y, [tile][1][n] = sum_m y*y with
- * tile = m / P2C_STAT_TILE_M; size from p2c_linear_stat_tiles(M). */
-#define P2C_STAT_TILE_M 128
-int p2c_linear_stat_tiles(int M);
+ * tile = m / p2c_linear_tile_m(); size from p2c_linear_stat_tiles(M). */
+int p2c_linear_tile_m(void);         /* row-tile height (64, or 128 with P2C_TILE_M=128 in the environment) */
+int p2c_linear_stat_tiles(int M);    /* ceil(M / p2c_linear_tile_m()) */
 int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
                        int K, int in_mode, const float *in_scale, const float *in_shift, const uint8_t *drop_mask,
                        int ldmask, float drop_scale, float *stat_partials, void *stream);
@@ -151,7 +151,7 @@ int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const int32_t *arg,
  * Fused reduction for the layer BELOW (optional, bwd_partials != NULL): dX is that layer's dZ; with its saved
  * pre-BN output Yprev [M,K] and prev_stat = [scale|shift|mean|invstd] x K the epilogue also emits the per-tile
  * sums s1 = sum g, s2 = sum g*xhat (g = dX*[scale*Yprev+shift > 0]) into bwd_partials[tile][2][K],
- * tile = m / P2C_STAT_TILE_M, to be finished by p2c_bn_bwd_finalize_f32. */
+ * tile = m / p2c_linear_tile_m(), to be finished by p2c_bn_bwd_finalize_f32. */
 int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                             const float *W, int ldw, float *dX, int lddx, int M, int N, int K, const uint8_t *out_mask,
                             int ldmask, float out_mask_scale, const float *Yprev, int ldyp, const float *prev_stat,
@@ -168,6 +168,17 @@ int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int 
                               const float *X, int ldx, int in_mode, const float *in_scale, const float *in_shift,
                               const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW, int lddw, float *dbias,
                               int M, int N, int K, const int32_t *pool_arg, int pool_ns, void *stream);
+
+/* One-pass backward of a narrow layer (Co, Ci in {64,128}; in_mode 0/1): dX, dW, dbias and the fused reduction
+ * for the layer below from a single stream over (dZ, Yfwd, X) -- see csrc/bwd_fused.hip.  Same argument meaning as
+ * the two entry points above; dX may be NULL (then prev_stat/bwd_partials must be NULL too).
+ * bwd_partials [p2c_linear_bwd_fused_parts(M,Ci)][2][Ci]: one row per persistent workgroup. */
+int p2c_linear_bwd_fused_supported(int Co, int Ci, int in_mode);
+int p2c_linear_bwd_fused_parts(int M, int Ci);
+int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
+                             const int32_t *pool_arg, int pool_ns, const float *X, int ldx, int in_mode, const float *in_scale,
+                             const float *in_shift, const float *W, int ldw, float *dX, int lddx, float *dW, int lddw,
+                             float *dbias, const float *prev_stat, float *bwd_partials, int M, int Co, int Ci, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Extrusion-cylinder fitting  (data_utils.py:99-177, :253-266, :1650-1730; eval.py:409-436)

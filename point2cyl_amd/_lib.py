@@ -40,6 +40,8 @@ _SIGS = {
     "p2c_maxpool_bn_bwd_stats_f32": [c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "p2c_linear_bwd_weight_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_i, c_p,
                                   c_i, c_i, c_i, c_p, c_i, c_p],
+    "p2c_linear_bwd_fused_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p,
+                                 c_p, c_p, c_i, c_i, c_i, c_p],
     "p2c_extrusion_axis_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "p2c_extrusion_axis_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_extrusion_centers_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
@@ -76,6 +78,11 @@ def lib():
     L.p2c_linear_stat_tiles.restype = c_i
     L.p2c_bn_bwd_ws_bytes.argtypes = [c_i, c_i]
     L.p2c_bn_bwd_ws_bytes.restype = ctypes.c_size_t
+    L.p2c_linear_bwd_fused_supported.argtypes = [c_i, c_i, c_i]
+    L.p2c_linear_bwd_fused_supported.restype = c_i
+    L.p2c_linear_bwd_fused_parts.argtypes = [c_i, c_i]
+    L.p2c_linear_bwd_fused_parts.restype = c_i
+    L.p2c_linear_tile_m.restype = c_i
     L.p2c_reduce_ws_bytes.argtypes = [c_i]
     L.p2c_reduce_ws_bytes.restype = ctypes.c_size_t
     L.p2c_extents_ws_bytes.argtypes = [c_i, c_i]

@@ -1,0 +1,335 @@
+// bwd_fused.hip -- one-pass backward of a 1x1-conv layer for the narrow layers (Co, Ci in {64,128}) that
+// carry most of the traffic (M = 262144 .. 1048576 rows).
+//
+// The two backward GEMMs of a layer,  dX = dY . W  and  dW = dY^T . act_in(X),  read the same three row
+// streams (dZ, this layer's pre-BN Y, the layer-below pre-BN X).  Run separately they stream ~7 M*C*4 bytes
+// and are HBM-bound (fp32 MFMA at 64 cycles per 32x32x2 block gives ~16-32 FLOP/B at these widths); fused
+// they stream each tensor ONCE (3 reads + 1 write) and the matrix pipe sees twice the work per byte, which puts
+// HBM and MFMA in balance (~8 B/cycle/CU at full MFMA rate).
+//
+// Structure (persistent, weight-stationary): one workgroup per CU; W [Co,Ci] is loaded into LDS once; the
+// workgroup walks row tiles of BM rows:  global->register prefetch of tile t+1 overlaps the MFMAs of tile t,
+// one barrier per tile, tiles double-buffered in LDS.  dW lives in the accumulators for the whole kernel
+// (one atomic flush at the end); the dX tile is produced, stored, and reduced on the fly into the
+// ReLU+BatchNorm-backward sums of the layer below (s1 = sum g, s2 = sum g*xhat), which also stay in
+// registers until the end: one partial row per workgroup.
+//
+//   LDS:  Ws [Co][Ci+4]            B operand of dX  (k = co, j = ci)
+//         dYs[2][Co][BM+1]         A operand of dX  (k = co, i = m)  and A operand of dW (i = co, k = m)
+//         Xr [2][BM][Ci+4]         raw X tile: B operand of dW after act_in on the fly (k = m, j = ci), and the
+//                                  y values the fused reduction needs in the dX epilogue
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copy can pin an array in scratch)
+
+struct BwdFusedArgs {
+    const float *dz; int lddz;            // upstream gradient (or pooled gradient [G,Co] when gmode == 2)
+    const float *y; int ldy;              // this layer's pre-BN output [M,Co]
+    const float *coef;                    // [5][Co] (gmode >= 1)
+    const int32_t *arg; int ns;           // gmode == 2
+    const float *x; int ldx;              // layer-below pre-BN output (or raw input) [M,Ci]
+    const float *in_scale, *in_shift;     // imode == 1
+    const float *w; int ldw;              // [Co,Ci]
+    float *dx; int lddx;                  // [M,Ci] or NULL
+    float *dw; int lddw;                  // [Co,Ci], accumulated atomically
+    float *dbias;                         // [Co] or NULL
+    const float *pstat;                   // [4][Ci] of the layer below, or NULL
+    float *partials;                      // [gridDim.x][2][Ci]
+    int M;
+};
+
+// Raw tile fetch (no arithmetic: the values stay in flight during the MFMAs of the previous tile).
+template <int GMODE, int Co, int Ci, int BM, int UDY, int UX>
+__device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int t, float4 (&rdz)[UDY], float4 (&ry)[UDY], int4 (&rarg)[UDY],
+                                                v4f (&rx)[UX])
+{
+    const int tid = threadIdx.x, m0 = t * BM;
+#pragma unroll
+    for (int i = 0; i < UDY; ++i) {
+        const int u = tid + 256 * i, row = u / (Co / 4), c4 = u % (Co / 4);
+        const int r = min(m0 + row, a.M - 1);
+        if (GMODE == 2) {
+            const int grp = r / a.ns;
+            rdz[i] = *reinterpret_cast<const float4 *>(a.dz + (size_t)grp * a.lddz + c4 * 4);
+            rarg[i] = *reinterpret_cast<const int4 *>(a.arg + (size_t)grp * Co + c4 * 4);
+        } else {
+            rdz[i] = *reinterpret_cast<const float4 *>(a.dz + (size_t)r * a.lddz + c4 * 4);
+        }
+        if (GMODE >= 1) ry[i] = *reinterpret_cast<const float4 *>(a.y + (size_t)r * a.ldy + c4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < UX; ++i) {
+        const int u = tid + 256 * i, row = u / (Ci / 4), c4 = u % (Ci / 4);
+        rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)min(m0 + row, a.M - 1) * a.ldx + c4 * 4);
+    }
+}
+
+// dY = gs*(dZ*[scale*Y+shift>0]) + q*Y + p from the raw registers (cf[] = this thread's 4 channels of coef),
+// transposed into dYs[co][m]; raw X into Xr[m][ci].
+template <int GMODE, int Co, int Ci, int BM, int LDY, int LDX, int UDY, int UX>
+__device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int t, float *dy, float *xr, const float4 (&rdz)[UDY],
+                                                 const float4 (&ry)[UDY], const int4 (&rarg)[UDY], const v4f (&rx)[UX],
+                                                 const float4 (&cf)[5])
+{
+    const int tid = threadIdx.x, m0 = t * BM;
+#pragma unroll
+    for (int i = 0; i < UDY; ++i) {
+        const int u = tid + 256 * i, row = u / (Co / 4), c4 = u % (Co / 4);
+        const int m = m0 + row;
+        float4 g = rdz[i];
+        if (GMODE == 2) {
+            const int r = min(m, a.M - 1);
+            const int j = r - (r / a.ns) * a.ns;
+            g = make_float4(rarg[i].x == j ? g.x : 0.f, rarg[i].y == j ? g.y : 0.f, rarg[i].z == j ? g.z : 0.f, rarg[i].w == j ? g.w : 0.f);
+        }
+        float4 o = g;
+        if (GMODE >= 1) {
+            const float4 yy = ry[i];
+            o.x = cf[2].x * ((cf[0].x * yy.x + cf[1].x > 0.f) ? g.x : 0.f) + cf[3].x * yy.x + cf[4].x;
+            o.y = cf[2].y * ((cf[0].y * yy.y + cf[1].y > 0.f) ? g.y : 0.f) + cf[3].y * yy.y + cf[4].y;
+            o.z = cf[2].z * ((cf[0].z * yy.z + cf[1].z > 0.f) ? g.z : 0.f) + cf[3].z * yy.z + cf[4].z;
+            o.w = cf[2].w * ((cf[0].w * yy.w + cf[1].w > 0.f) ? g.w : 0.f) + cf[3].w * yy.w + cf[4].w;
+        }
+        const bool ok = m < a.M;
+        dy[(c4 * 4 + 0) * LDY + row] = ok ? o.x : 0.f;
+        dy[(c4 * 4 + 1) * LDY + row] = ok ? o.y : 0.f;
+        dy[(c4 * 4 + 2) * LDY + row] = ok ? o.z : 0.f;
+        dy[(c4 * 4 + 3) * LDY + row] = ok ? o.w : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < UX; ++i) {
+        const int u = tid + 256 * i, row = u / (Ci / 4), c4 = u % (Ci / 4);
+        *reinterpret_cast<v4f *>(&xr[row * LDX + c4 * 4]) = rx[i];
+    }
+}
+
+// COT = Co/64, CIT = Ci/64 (1 or 2).  Waves: for dW a 2x2 grid over Co x Ci (wave tile COT*32 x CIT*32);
+// for dX a WR x WC grid with WC = Ci/32 columns of 32, WR = 4/WC, so BM = 32*WR rows per tile.
+template <int COT, int CIT, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS>
+__global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
+{
+    constexpr int Co = 64 * COT, Ci = 64 * CIT;
+    constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
+    constexpr int LDW = Ci + 4, LDY = BM + 1, LDX = Ci + 4;
+    constexpr int UDY = BM * Co / 4 / 256, UX = BM * Ci / 4 / 256;     // float4 units per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ws = smem;                              // [Co][LDW]
+    float *dYs = Ws + Co * LDW;                    // [2][Co][LDY]
+    float *Xr = dYs + 2 * Co * LDY;                // [2][BM][LDX]
+    float *red = Xr + 2 * BM * LDX;                // [2][Ci] final cross-wave combine
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;       // dW wave grid
+    const int wr = wave / WC, wc = wave % WC;      // dX wave grid
+    const int ntiles = (a.M + BM - 1) / BM;
+
+    // ---- W -> LDS (once) ---------------------------------------------------------------------------
+    if (NEED_DX) {
+        for (int u = tid; u < Co * Ci / 4; u += 256) {
+            const int r = u / (Ci / 4), c4 = u % (Ci / 4);
+            *reinterpret_cast<float4 *>(&Ws[r * LDW + c4 * 4]) = *reinterpret_cast<const float4 *>(a.w + (size_t)r * a.ldw + c4 * 4);
+        }
+    }
+    // per-lane constants
+    float isc[CIT], ish[CIT];                      // act_in scale/shift of the dW B-operand columns this lane reads
+#pragma unroll
+    for (int t = 0; t < CIT; ++t) {
+        const int ci = wj * (CIT * 32) + t * 32 + l31;
+        isc[t] = IMODE == 1 ? a.in_scale[ci] : 1.f;
+        ish[t] = IMODE == 1 ? a.in_shift[ci] : 0.f;
+    }
+    const int xcol = wc * 32 + l31;                // dX column of this lane
+    float psc = 0.f, psh = 0.f, pmu = 0.f, pis = 0.f;
+    if (NEED_DX && HAS_STATS) { psc = a.pstat[xcol]; psh = a.pstat[Ci + xcol]; pmu = a.pstat[2 * Ci + xcol]; pis = a.pstat[3 * Ci + xcol]; }
+    // this thread always stages the same 4 channels of dY (256 % (Co/4) == 0): keep their coefficients in registers
+    float4 cf[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+        cf[i] = GMODE >= 1 ? *reinterpret_cast<const float4 *>(a.coef + i * Co + (tid % (Co / 4)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s1 = 0.f, s2 = 0.f, dbacc = 0.f;
+
+    f32x16 accW[COT][CIT];
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+        for (int j = 0; j < CIT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW[i][j][r] = 0.f;
+
+    float4 rdz[UDY], ry[UDY];
+    v4f rx[UX];
+    int4 rarg[UDY];
+    int t = blockIdx.x;                                     // gridDim.x <= ntiles: every workgroup owns at least one tile
+    fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, t, rdz, ry, rarg, rx);
+    fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, t, dYs, Xr, rdz, ry, rarg, rx, cf);
+    __syncthreads();
+    int buf = 0;
+    for (; t < ntiles; t += gridDim.x) {
+        const int tn = t + gridDim.x;
+        const int tl = tn < ntiles ? tn : t;
+        fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tl, rdz, ry, rarg, rx);   // in flight during the MFMAs below (unconditional: stays in registers)
+        const float *dy = dYs + buf * Co * LDY;
+        const float *xr = Xr + buf * BM * LDX;
+        const int m0 = t * BM;
+        // ---------------- dW += dY^T . act_in(X): reduction over the BM rows of the tile
+#pragma unroll 4
+        for (int s = 0; s < BM; s += 2) {
+            float av[COT], bv[CIT];
+#pragma unroll
+            for (int i = 0; i < COT; ++i) av[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + s + lh];
+#pragma unroll
+            for (int j = 0; j < CIT; ++j) {
+                float v = xr[(s + lh) * LDX + wj * (CIT * 32) + j * 32 + l31];
+                if (IMODE == 1) v = fmaxf(isc[j] * v + ish[j], 0.f);
+                if (m0 + s + lh >= a.M) v = 0.f;            // rows past the end carry clamped (non-zero) X values
+                bv[j] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < COT; ++i)
+#pragma unroll
+                for (int j = 0; j < CIT; ++j) accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], accW[i][j], 0, 0, 0);
+        }
+        if (GMODE == 0 && a.dbias && tid < Co) {
+            float sb = 0.f;
+#pragma unroll 8
+            for (int s = 0; s < BM; ++s) sb += dy[tid * LDY + s];
+            dbacc += sb;
+        }
+        // ---------------- dX tile = dY . W, reduction over Co
+        if (NEED_DX) {
+            f32x16 accX;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accX[r] = 0.f;
+#pragma unroll 8
+            for (int k = 0; k < Co; k += 2) {
+                const float av = dy[(k + lh) * LDY + wr * 32 + l31];
+                const float bv = Ws[(k + lh) * LDW + wc * 32 + l31];
+                accX = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accX, 0, 0, 0);
+            }
+            // rows past M are exactly 0 (their dY rows were zeroed); only the last tile can be ragged (uniform branch)
+            if (m0 + BM <= a.M) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    a.dx[(size_t)(m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * a.lddx + xcol] = accX[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < a.M) a.dx[(size_t)m * a.lddx + xcol] = accX[r];
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float v = accX[r];
+                if (HAS_STATS) {
+                    const float yp = xr[row * LDX + xcol];
+                    const float g = (psc * yp + psh > 0.f) ? v : 0.f;
+                    s1 += g;
+                    s2 += g * ((yp - pmu) * pis);
+                }
+            }
+        }
+        fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tl, dYs + (buf ^ 1) * Co * LDY, Xr + (buf ^ 1) * BM * LDX, rdz, ry, rarg, rx, cf);
+        __syncthreads();
+        buf ^= 1;
+    }
+    // ---------------- flush
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+        for (int j = 0; j < CIT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = wi * (COT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ci = wj * (CIT * 32) + j * 32 + l31;
+                atomicAdd(&a.dw[(size_t)co * a.lddw + ci], accW[i][j][r]);
+            }
+    if (GMODE == 0 && a.dbias && tid < Co) atomicAdd(&a.dbias[tid], dbacc);
+    if (NEED_DX && HAS_STATS) {
+        if (tid < 2 * Ci) red[tid] = 0.f;
+        __syncthreads();
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0) {                                      // WR waves share a column: WR <= 2 adds per slot (order-free)
+            atomicAdd(&red[xcol], s1);
+            atomicAdd(&red[Ci + xcol], s2);
+        }
+        __syncthreads();
+        if (tid < Ci) {
+            float *o = a.partials + (size_t)blockIdx.x * 2 * Ci;
+            o[tid] = red[tid];
+            o[Ci + tid] = red[Ci + tid];
+        }
+    }
+}
+
+static int fused_grid(int M, int Ci)
+{
+    const int BM = Ci >= 128 ? 32 : 64;
+    const int ntiles = (M + BM - 1) / BM;
+    return ntiles < 256 ? ntiles : 256;
+}
+
+extern "C" int p2c_linear_bwd_fused_parts(int M, int Ci) { return fused_grid(M, Ci); }
+extern "C" int p2c_linear_bwd_fused_supported(int Co, int Ci, int in_mode)
+{
+    return (Co == 64 || Co == 128) && (Ci == 64 || Ci == 128) && (in_mode == 0 || in_mode == 1);
+}
+
+template <int COT, int CIT, int GMODE, int IMODE>
+static int launch_fused(const BwdFusedArgs &a, hipStream_t s)
+{
+    constexpr int Co = 64 * COT, Ci = 64 * CIT;
+    constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
+    const size_t lds = (size_t)(Co * (Ci + 4) + 2 * Co * (BM + 1) + 2 * BM * (Ci + 4) + 2 * Ci) * sizeof(float);
+    const int grid = fused_grid(a.M, Ci);
+#define P2C_FL(DX_, ST_)                                                                                                             \
+    do {                                                                                                                             \
+        (void)hipFuncSetAttribute((const void *)bwd_fused_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                                         \
+        hipLaunchKernelGGL((bwd_fused_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>), dim3(grid), dim3(256), lds, s, a);                    \
+    } while (0)
+    if (a.dx && a.pstat) P2C_FL(true, true);
+    else if (a.dx) P2C_FL(true, false);
+    else P2C_FL(false, false);
+#undef P2C_FL
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+template <int GMODE, int IMODE>
+static int dispatch_shape(int Co, int Ci, const BwdFusedArgs &a, hipStream_t s)
+{
+    if (Co == 128 && Ci == 128) return launch_fused<2, 2, GMODE, IMODE>(a, s);
+    if (Co == 128 && Ci == 64) return launch_fused<2, 1, GMODE, IMODE>(a, s);
+    if (Co == 64 && Ci == 128) return launch_fused<1, 2, GMODE, IMODE>(a, s);
+    return launch_fused<1, 1, GMODE, IMODE>(a, s);
+}
+
+extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
+                                        const int32_t *pool_arg, int pool_ns, const float *X, int ldx, int in_mode, const float *in_scale,
+                                        const float *in_shift, const float *W, int ldw, float *dX, int lddx, float *dW, int lddw,
+                                        float *dbias, const float *prev_stat, float *bwd_partials, int M, int Co, int Ci, void *stream)
+{
+    if (!dZ || !X || !W || !dW || M <= 0 || grad_mode < 0 || grad_mode > 2) return P2C_EINVAL;
+    if (!p2c_linear_bwd_fused_supported(Co, Ci, in_mode)) return P2C_EINVAL;
+    if (grad_mode >= 1 && (!Yfwd || !coef)) return P2C_EINVAL;
+    if (grad_mode == 2 && (!pool_arg || pool_ns <= 0)) return P2C_EINVAL;
+    if (in_mode == 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
+    if (prev_stat && (!bwd_partials || !dX)) return P2C_EINVAL;
+    if ((lddz & 3) || (ldx & 3) || (ldw & 3) || (grad_mode >= 1 && (ldy & 3)) || ((uintptr_t)dZ & 15) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
+        return P2C_EALIGN;
+    BwdFusedArgs a{dZ, lddz, Yfwd, ldy, coef, pool_arg, pool_ns, X, ldx, in_scale, in_shift, W, ldw, dX, lddx, dW, lddw, dbias, prev_stat,
+                   bwd_partials, M};
+    hipStream_t s = (hipStream_t)stream;
+#define P2C_F(G_, I_) return dispatch_shape<G_, I_>(Co, Ci, a, s)
+    if (grad_mode == 0) { if (in_mode == 0) P2C_F(0, 0); P2C_F(0, 1); }
+    if (grad_mode == 1) { if (in_mode == 0) P2C_F(1, 0); P2C_F(1, 1); }
+    if (in_mode == 0) P2C_F(2, 0);
+    P2C_F(2, 1);
+#undef P2C_F
+}

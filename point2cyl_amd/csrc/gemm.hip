@@ -26,6 +26,7 @@
 // multiples of 4 (the host pads), so the compiler can keep the 16-byte loads in flight across the MFMAs.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -344,7 +345,18 @@ static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
         if (!al16(ptr_) || ((ld_) & 3)) return P2C_EALIGN;           \
     } while (0)
 
-extern "C" int p2c_linear_stat_tiles(int M) { return (M + P2C_STAT_TILE_M - 1) / P2C_STAT_TILE_M; }
+// Row-tile height of the forward / backward-data kernels (also the granularity of the per-tile partial sums).
+static int tile_m()
+{
+    static int v = 0;
+    if (!v) {
+        const char *e = getenv("P2C_TILE_M");
+        v = (e && atoi(e) == 128) ? 128 : 64;
+    }
+    return v;
+}
+extern "C" int p2c_linear_tile_m(void) { return tile_m(); }
+extern "C" int p2c_linear_stat_tiles(int M) { return (M + tile_m() - 1) / tile_m(); }
 
 // ---- forward --------------------------------------------------------------------------------------
 template <int MODE>
@@ -356,13 +368,12 @@ static int launch_fwd(const float *X, int ldx, const float *W, int ldw, const fl
     OpPlain b{W, ldw};
     EpiFwd e{Y, ldy, bias, stat_partials};
     const int kps = (K + GK - 1) / GK * GK;
-    if (N > 64) {
-        dim3 grid(p2c_cdiv(M, 128), p2c_cdiv(N, 128), 1);
-        hipLaunchKernelGGL((gemm_kernel<2, 2, true, true, OpActIn<MODE>, OpPlain, EpiFwd>), grid, dim3(256), 0, s, a, b, e, M, N, K, kps);
-    } else {
-        dim3 grid(p2c_cdiv(M, 128), 1, 1);
-        hipLaunchKernelGGL((gemm_kernel<2, 1, true, true, OpActIn<MODE>, OpPlain, EpiFwd>), grid, dim3(256), 0, s, a, b, e, M, N, K, kps);
-    }
+#define P2C_FW(TM_, TN_)                                                                                                          \
+    hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, true, OpActIn<MODE>, OpPlain, EpiFwd>), dim3(p2c_cdiv(M, 64 * TM_), p2c_cdiv(N, 64 * TN_), 1), \
+                       dim3(256), 0, s, a, b, e, M, N, K, kps)
+    if (tile_m() == 128) { if (N > 64) P2C_FW(2, 2); else P2C_FW(2, 1); }
+    else { if (N > 64) P2C_FW(1, 2); else P2C_FW(1, 1); }
+#undef P2C_FW
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -397,13 +408,12 @@ static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy
     OpPlain b{W, ldw};
     EpiBwdData e{dX, lddx, out_mask, ldmask, out_mask_scale, Yprev, ldyp, prev_stat, bwd_partials};
     const int kps = (N + GK - 1) / GK * GK;
-    if (K > 64) {
-        dim3 grid(p2c_cdiv(M, 128), p2c_cdiv(K, 128), 1);
-        hipLaunchKernelGGL((gemm_kernel<2, 2, true, false, OpGrad<GMODE>, OpPlain, EpiBwdData>), grid, dim3(256), 0, s, a, b, e, M, K, N, kps);
-    } else {
-        dim3 grid(p2c_cdiv(M, 128), 1, 1);
-        hipLaunchKernelGGL((gemm_kernel<2, 1, true, false, OpGrad<GMODE>, OpPlain, EpiBwdData>), grid, dim3(256), 0, s, a, b, e, M, K, N, kps);
-    }
+#define P2C_BDL(TM_, TN_)                                                                                                          \
+    hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, false, OpGrad<GMODE>, OpPlain, EpiBwdData>),                                    \
+                       dim3(p2c_cdiv(M, 64 * TM_), p2c_cdiv(K, 64 * TN_), 1), dim3(256), 0, s, a, b, e, M, K, N, kps)
+    if (tile_m() == 128) { if (K > 64) P2C_BDL(2, 2); else P2C_BDL(2, 1); }
+    else { if (K > 64) P2C_BDL(1, 2); else P2C_BDL(1, 1); }
+#undef P2C_BDL
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

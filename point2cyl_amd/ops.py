@@ -4,12 +4,15 @@ Everything here is plumbing: allocate outputs with torch, pass raw device pointe
 stream to libp2c_hip.so, and register backward passes with torch.autograd.  No arithmetic of the hot
 path happens in torch ops in this file.  All feature tensors are POINT-MAJOR: [rows, channels].
 """
+import os
+
 import torch
 
 from . import _lib
 from ._lib import PROFILE, call, ptr, stream  # noqa: F401
 
 I32 = torch.int32
+USE_FUSED_BWD = os.environ.get("P2C_FUSED_BWD", "1") != "0"
 
 
 def _f32c(t):
@@ -273,24 +276,36 @@ class _MLPStack(torch.autograd.Function):
             dW = torch.zeros(Co, Ci, dtype=torch.float32, device=dev)
             # a conv bias in front of a train-mode BatchNorm has an exactly zero gradient (the batch mean absorbs it)
             db = torch.zeros(Co, dtype=torch.float32, device=dev)
-            call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
-                 ptr(sh), ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), ptr(dW), Ci,
-                 ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
-                 flops=2.0 * M * Co * Ci)
             Wp = params[p0]
             co_t, ci_t = Wp.shape[0], Wp.numel() // Wp.shape[0]
             grads[p0] = dW[:co_t, :ci_t].reshape(Wp.shape)
             grads[p0 + 1] = db[:co_t]
-            if i > 0 or ctx.needs_input_grad[1]:
-                dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
-                fused = i > 0
-                part = torch.empty(_lib.lib().p2c_linear_stat_tiles(M), 2, Ci, dtype=torch.float32, device=dev) if fused else None
-                call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(W2), Ci, ptr(dX), Ci, M, Co, Ci,
-                     ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale),
-                     ptr(Ys[i - 1]) if fused else None, Ci, ptr(aff[i - 1]) if fused else None, ptr(part),
-                     ptr(arg) if grad_mode == 2 else None, pool_ns, stream(), flops=2.0 * M * Co * Ci)
+            need_dx = i > 0 or ctx.needs_input_grad[1]
+            stats_below = i > 0                       # the layer below has a BatchNorm whose backward sums we produce here
+            L_ = _lib.lib()
+            if USE_FUSED_BWD and mode != 2 and M >= 4096 and L_.p2c_linear_bwd_fused_supported(Co, Ci, mode):
+                dX = torch.empty(M, Ci, dtype=torch.float32, device=dev) if need_dx else None
+                part = torch.empty(L_.p2c_linear_bwd_fused_parts(M, Ci), 2, Ci, dtype=torch.float32, device=dev) if stats_below else None
+                call("p2c_linear_bwd_fused_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(arg) if grad_mode == 2 else None,
+                     pool_ns, ptr(Xin), ldxin, mode, ptr(sc), ptr(sh), ptr(W2), Ci, ptr(dX), Ci, ptr(dW), Ci,
+                     ptr(db) if grad_mode == 0 else None, ptr(aff[i - 1]) if stats_below else None, ptr(part), M, Co, Ci, stream(),
+                     flops=(4.0 if need_dx else 2.0) * M * Co * Ci)
+            else:
+                call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
+                     ptr(sh), ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), ptr(dW), Ci,
+                     ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
+                     flops=2.0 * M * Co * Ci)
+                dX = part = None
+                if need_dx:
+                    dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
+                    part = torch.empty(L_.p2c_linear_stat_tiles(M), 2, Ci, dtype=torch.float32, device=dev) if stats_below else None
+                    call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(W2), Ci, ptr(dX), Ci, M, Co, Ci,
+                         ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale),
+                         ptr(Ys[i - 1]) if stats_below else None, Ci, ptr(aff[i - 1]) if stats_below else None, ptr(part),
+                         ptr(arg) if grad_mode == 2 else None, pool_ns, stream(), flops=2.0 * M * Co * Ci)
+            if need_dx:
                 dZ, grad_mode = dX, 1
-                if fused:
+                if stats_below:
                     q0, _ = slots[i - 1]
                     coef = torch.empty(5, Ci, dtype=torch.float32, device=dev)
                     dgamma = torch.empty(Ci, dtype=torch.float32, device=dev)

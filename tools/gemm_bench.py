@@ -62,6 +62,12 @@ def main():
                                     ptr(dW), K, None, M, N, K, None, 0, stream()))
             by = 4.0 * M * (2 * N + K)
             res.append("bwd_w %7.1f us %6.1f TF %5.2f TB/s" % (t * 1e6, fl / t / 1e12, by / t / 1e12))
+        if which in ("fused", "all") and L.p2c_linear_bwd_fused_supported(N, K, 1):
+            parts = torch.empty(L.p2c_linear_bwd_fused_parts(M, K), 2, K, device=dev)
+            t = timeit(lambda: call("p2c_linear_bwd_fused_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), None, 0, ptr(X), K, 1, ptr(sc), ptr(sh), ptr(W), K,
+                                    ptr(dX), K, ptr(dW), K, None, ptr(pstat), ptr(parts), M, N, K, stream()))
+            by = 4.0 * M * (2 * N + 2 * K)
+            res.append("FUSED %7.1f us %6.1f TF %5.2f TB/s" % (t * 1e6, 2 * fl / t / 1e12, by / t / 1e12))
         print("%-6s M=%8d K=%4d N=%4d | %s" % (name, M, K, N, " | ".join(res)))
 
 

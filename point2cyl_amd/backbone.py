@@ -43,7 +43,7 @@ class PointNetSetAbstraction(nn.Module):
             self.mlp_bns.append(nn.BatchNorm2d(co))
             last = co
         self.group_all = group_all
-        self.fps_start = None      # test hook: force the FPS start indices (B,) instead of drawing them
+        self.fps_start = None      # hook: (B,) tensor of FPS start indices, or a callable (N, B) -> device tensor, instead of drawing
         self.last_aux = {}
 
     def forward_pm(self, xyz, feats):
@@ -60,7 +60,10 @@ class PointNetSetAbstraction(nn.Module):
             X0 = torch.cat(cols, 1)                       # sample_and_group_all: no centring (:157-160)
             G, ns = B, N
         else:
-            start = self.fps_start if self.fps_start is not None else draw_fps_start(N, B)
+            if callable(self.fps_start):
+                start = self.fps_start(N, B)
+            else:
+                start = self.fps_start if self.fps_start is not None else draw_fps_start(N, B)
             fps_idx, new_xyz = ops.fps(xyz, self.npoint, start)
             gidx = ops.ball_query(self.radius, self.nsample, xyz, new_xyz)
             X0 = ops.group_gather(xyz, feats, new_xyz, gidx)
@@ -174,7 +177,6 @@ class backbone(nn.Module):
                       bn=ops.BNState(self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
                                      0.1 if self.bn1.momentum is None else self.bn1.momentum, self.bn1.eps)),
                  dict(W=Wh, b=bh, gamma=None, beta=None, bn=None)]
-        self.fp1.training = self.training
         heads = self.fp1.forward_pm(xyz, l1_xyz, feats0, l5, tail="linear", extra_layers=extra, drop_mask=mask, drop_scale=dscale)
         outs, o = [], 0
         for s in sizes:

@@ -174,23 +174,40 @@ __global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
         const float *dy = dYs + buf * Co * LDY;
         const float *xr = Xr + buf * BM * LDX;
         const int m0 = t * BM;
-        // ---------------- dW += dY^T . act_in(X): reduction over the BM rows of the tile
-#pragma unroll 4
-        for (int s = 0; s < BM; s += 2) {
-            float av[COT], bv[CIT];
+        // ---------------- dW += dY^T . act_in(X): reduction over the BM rows of the tile.
+        // The wave issues in order and each MFMA occupies the matrix pipe for 64 cycles, so the LDS reads of step
+        // s+1 are issued BEFORE the MFMAs of step s (register double buffering): their latency and the act_in
+        // VALU work then sit in the shadow of the matrix pipe instead of in front of it.
+        {
+            float av[COT], bv[CIT], an[COT], bn[CIT];
 #pragma unroll
-            for (int i = 0; i < COT; ++i) av[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + s + lh];
+            for (int i = 0; i < COT; ++i) av[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + lh];
 #pragma unroll
-            for (int j = 0; j < CIT; ++j) {
-                float v = xr[(s + lh) * LDX + wj * (CIT * 32) + j * 32 + l31];
-                if (IMODE == 1) v = fmaxf(isc[j] * v + ish[j], 0.f);
-                if (m0 + s + lh >= a.M) v = 0.f;            // rows past the end carry clamped (non-zero) X values
-                bv[j] = v;
+            for (int j = 0; j < CIT; ++j) bv[j] = xr[lh * LDX + wj * (CIT * 32) + j * 32 + l31];
+#pragma unroll 8
+            for (int s = 0; s < BM; s += 2) {
+                const int sn = (s + 2 < BM) ? s + 2 : s;            // last step re-reads itself (harmless)
+#pragma unroll
+                for (int i = 0; i < COT; ++i) an[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + sn + lh];
+#pragma unroll
+                for (int j = 0; j < CIT; ++j) bn[j] = xr[(sn + lh) * LDX + wj * (CIT * 32) + j * 32 + l31];
+                float bz[CIT];
+#pragma unroll
+                for (int j = 0; j < CIT; ++j) {
+                    float v = bv[j];
+                    if (IMODE == 1) v = fmaxf(isc[j] * v + ish[j], 0.f);
+                    if (m0 + s + lh >= a.M) v = 0.f;            // rows past the end carry clamped (non-zero) X values
+                    bz[j] = v;
+                }
+#pragma unroll
+                for (int i = 0; i < COT; ++i)
+#pragma unroll
+                    for (int j = 0; j < CIT; ++j) accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bz[j], accW[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < COT; ++i) av[i] = an[i];
+#pragma unroll
+                for (int j = 0; j < CIT; ++j) bv[j] = bn[j];
             }
-#pragma unroll
-            for (int i = 0; i < COT; ++i)
-#pragma unroll
-                for (int j = 0; j < CIT; ++j) accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], accW[i][j], 0, 0, 0);
         }
         if (GMODE == 0 && a.dbias && tid < Co) {
             float sb = 0.f;
@@ -203,11 +220,17 @@ __global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
             f32x16 accX;
 #pragma unroll
             for (int r = 0; r < 16; ++r) accX[r] = 0.f;
-#pragma unroll 8
-            for (int k = 0; k < Co; k += 2) {
-                const float av = dy[(k + lh) * LDY + wr * 32 + l31];
-                const float bv = Ws[(k + lh) * LDW + wc * 32 + l31];
-                accX = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accX, 0, 0, 0);
+            {
+                float av = dy[lh * LDY + wr * 32 + l31], bv = Ws[lh * LDW + wc * 32 + l31];
+#pragma unroll 16
+                for (int k = 0; k < Co; k += 2) {
+                    const int kn = (k + 2 < Co) ? k + 2 : k;
+                    const float an = dy[(kn + lh) * LDY + wr * 32 + l31];     // next step's operands first ...
+                    const float bn = Ws[(kn + lh) * LDW + wc * 32 + l31];
+                    accX = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accX, 0, 0, 0);   // ... then this step's MFMA
+                    av = an;
+                    bv = bn;
+                }
             }
             // rows past M are exactly 0 (their dY rows were zeroed); only the last tile can be ragged (uniform branch)
             if (m0 + BM <= a.M) {

@@ -19,6 +19,10 @@ for _ in range(it):
     elif which == "bwd_data":
         call("p2c_linear_bwd_data_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), ptr(W), K, ptr(dX), K, M, N, K, None, 0, 1.0, ptr(X), K, ptr(pstat),
              ptr(partk), None, 0, stream())
+    elif which == "fused":
+        parts = torch.empty(L.p2c_linear_bwd_fused_parts(M, K), 2, K, device=dev)
+        call("p2c_linear_bwd_fused_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), None, 0, ptr(X), K, 1, ptr(sc), ptr(sh), ptr(W), K, ptr(dX), K, ptr(dW), K,
+             None, ptr(pstat), ptr(parts), M, N, K, stream())
     else:
         call("p2c_linear_bwd_weight_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), ptr(X), K, 1, ptr(sc), ptr(sh), None, 0, 1.0, ptr(dW), K, None, M, N, K,
              None, 0, stream())

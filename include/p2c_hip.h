@@ -89,6 +89,9 @@ int p2c_three_interp_bwd_f32(const float *dout, int ldo, const int32_t *idx, con
  *   in_mode 0: act_in(x) = x
  *   in_mode 1: act_in(x) = relu(in_scale[k]*x + in_shift[k])
  *   in_mode 2: act_in(x) = relu(in_scale[k]*x + in_shift[k]) * drop_mask[m,k] * drop_scale   (F.dropout, :60)
+ *   in_mode 3: as 2, but the keep-mask is regenerated from a counter hash: drop_mask points to a device
+ *              uint32_t seed[2]; keep(m,k) = hash(seed, m*K+k) >= (1 - 1/drop_scale) * 2^32; ldmask is ignored.
+ *              (backward-data: pass the same seed pointer as out_mask with ldmask = -1)
  * ------------------------------------------------------------------------------------------- */
 
 /* Forward.  X [M,K] (ldx), W [N,K] row-major (ldw) = the conv weight (Co,Ci,1[,1]) as stored in the
@@ -118,9 +121,9 @@ int p2c_bn_relu_apply_f32(const float *Y, int ldy, const float *scale, const flo
                           void *stream);
 
 /* max over the nsample axis of relu(bn(Y)) (models/pointnet_util.py:205): Y [G*ns, C] -> out [G,C],
- * arg [G,C] (row offset j of the winner, first on ties). */
+ * arg [G,C] (row offset j of the winner, first on ties), ywin [G,C] (optional: Y at the winner, for backward). */
 int p2c_maxpool_bnrelu_f32(const float *Y, int ldy, const float *scale, const float *shift, int G, int ns, int C, float *out,
-                           int ldo, int32_t *arg, void *stream);
+                           int ldo, int32_t *arg, float *ywin, void *stream);
 /* dZ [G*ns, C] (dense, zero except the winners) from dOut [G,C] */
 int p2c_maxpool_bwd_f32(const float *dout, int ldo, const int32_t *arg, int G, int ns, int C, float *dZ, int ldz, void *stream);
 
@@ -135,11 +138,10 @@ int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float *Y, int ldy
                               float *dbeta, float *coef_out, void *ws, void *stream);
 
 /* The same reduction for the layer that feeds the max-pool, WITHOUT materialising dZ: the sums run over the
- * pooled gradient dout [G,C] and the winners arg [G,C] only.  stat = [scale|shift|mean|invstd] x C of that layer,
- * Y its pre-BN output [G*ns, C].  ws: p2c_bn_bwd_ws_bytes(G, C). */
-int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const int32_t *arg, const float *Y, int ldy, const float *stat,
-                                 const float *gamma, int G, int ns, int C, float *dgamma, float *dbeta, float *coef_out, void *ws,
-                                 void *stream);
+ * pooled gradient dout [G,C] and the winners' pre-BN values ywin [G,C] (from p2c_maxpool_bnrelu_f32) only.
+ * stat = [scale|shift|mean|invstd] x C of that layer.  ws: p2c_bn_bwd_ws_bytes(G, C). */
+int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const float *ywin, const float *stat, const float *gamma, int G,
+                                 int ns, int C, float *dgamma, float *dbeta, float *coef_out, void *ws, void *stream);
 
 /* grad_mode 0: dY = G (the tensor passed as dZ is already dY; Yfwd/coef unused)
  * grad_mode 1: dY = gs*(dZ*[scale*Yfwd+shift>0]) + q*Yfwd + p   with coef [5,Co] from the stats call above

@@ -105,12 +105,12 @@ class PointNetFeaturePropagation(nn.Module):
             return torch.cat([feats1.reshape(B * N, -1), interp], 1)              # [skip | interpolated] :312
         return interp
 
-    def forward_pm(self, xyz1, xyz2, feats1, feats2, tail="bnrelu", extra_layers=(), drop_mask=None, drop_scale=1.0):
+    def forward_pm(self, xyz1, xyz2, feats1, feats2, tail="bnrelu", extra_layers=(), drop_mask=None, drop_scale=1.0, drop_seed=None):
         """xyz1 (B,N,3) dense, xyz2 (B,S,3) sparse, feats1 (B,N,D1)|None, feats2 (B,S,D2) -> (B,N,C')."""
         B, N, _ = xyz1.shape
         X0 = self._input_pm(xyz1, xyz2, feats1, feats2)
         layers = _layers(self.mlp_convs, self.mlp_bns) + list(extra_layers)
-        out = ops.mlp_stack(X0, X0.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale)
+        out = ops.mlp_stack(X0, X0.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed)
         return out.view(B, N, -1)
 
     def forward(self, xyz1, xyz2, points1, points2):
@@ -149,6 +149,7 @@ class backbone(nn.Module):
             self.fc2.append(nn.Conv1d(128, o, 1))
         self.dropout_p = 0.5
         self.dropout_mask = None   # test hook: (B,N,128) {0,1} mask to use instead of drawing one; "off" disables dropout
+        self._drop_seed = None     # device int64 counter feeding the in-kernel dropout hash (advanced every forward)
 
     def forward(self, x):
         if not x.is_cuda:
@@ -163,13 +164,18 @@ class backbone(nn.Module):
         l4 = self.fp3.forward_pm(l2_xyz, l3_xyz, l2, l3)
         l5 = self.fp2.forward_pm(l1_xyz, l2_xyz, l1, l4)
         # FP1 -> fc1/bn1/relu -> dropout -> fc2 heads as ONE stack: l6 and the head activations stay out of HBM
+        seed = None
         if isinstance(self.dropout_mask, str) and self.dropout_mask == "off":
             mask, dscale = None, 1.0
         elif self.dropout_mask is not None:
             mask, dscale = self.dropout_mask.reshape(B * N, 128).to(device=x.device, dtype=torch.uint8).contiguous(), 1.0 / (1.0 - self.dropout_p)
-        else:   # F.dropout(p=0.5) is ALWAYS on in the reference, also in eval (pointnet_extrusion.py:60)
-            mask = (torch.rand(B * N, 128, device=x.device) >= self.dropout_p).to(torch.uint8)
-            dscale = 1.0 / (1.0 - self.dropout_p)
+        else:   # F.dropout(p=0.5) is ALWAYS on in the reference, also in eval (pointnet_extrusion.py:60).
+            # The keep-mask is never stored: the kernels regenerate it from (seed, element index); the seed is a
+            # device counter drawn once from torch's generator and advanced per forward (HIP-graph safe).
+            if self._drop_seed is None or self._drop_seed.device != x.device:
+                self._drop_seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(x.device)
+            self._drop_seed += 0x9E3779B97F4A7C15 % (2 ** 62)
+            mask, seed, dscale = None, self._drop_seed, 1.0 / (1.0 - self.dropout_p)
         sizes = [m.weight.shape[0] for m in self.fc2]
         Wh = torch.cat([m.weight.reshape(m.weight.shape[0], 128) for m in self.fc2], 0)
         bh = torch.cat([m.bias for m in self.fc2], 0)
@@ -177,7 +183,8 @@ class backbone(nn.Module):
                       bn=ops.BNState(self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
                                      0.1 if self.bn1.momentum is None else self.bn1.momentum, self.bn1.eps)),
                  dict(W=Wh, b=bh, gamma=None, beta=None, bn=None)]
-        heads = self.fp1.forward_pm(xyz, l1_xyz, feats0, l5, tail="linear", extra_layers=extra, drop_mask=mask, drop_scale=dscale)
+        heads = self.fp1.forward_pm(xyz, l1_xyz, feats0, l5, tail="linear", extra_layers=extra, drop_mask=mask, drop_scale=dscale,
+                                    drop_seed=seed)
         outs, o = [], 0
         for s in sizes:
             outs.append(heads[:, :, o:o + s])

@@ -125,31 +125,34 @@ extern "C" int p2c_bn_relu_apply_f32(const float *Y, int ldy, const float *scale
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) maxpool_bnrelu_kernel(const float *__restrict__ Y, int ldy, const float *__restrict__ scale,
                                                              const float *__restrict__ shift, int G, int ns, int C,
-                                                             float *__restrict__ out, int ldo, int32_t *__restrict__ arg)
+                                                             float *__restrict__ out, int ldo, int32_t *__restrict__ arg,
+                                                             float *__restrict__ ywin)
 {
     const int c = blockIdx.y * blockDim.x + threadIdx.x;
     const int g = blockIdx.x;
     if (c >= C) return;
     const float sc = scale[c], sh = shift[c];
     const float *y = Y + (size_t)g * ns * ldy + c;
-    float best = -INFINITY;
+    float best = -INFINITY, yb = 0.f;
     int bj = 0;
 #pragma unroll 8
     for (int j = 0; j < ns; ++j) {
-        const float z = fmaxf(sc * y[(size_t)j * ldy] + sh, 0.f);
-        if (z > best) { best = z; bj = j; }
+        const float yv = y[(size_t)j * ldy];
+        const float z = fmaxf(sc * yv + sh, 0.f);
+        if (z > best) { best = z; bj = j; yb = yv; }
     }
     out[(size_t)g * ldo + c] = best;
     arg[(size_t)g * C + c] = bj;
+    if (ywin) ywin[(size_t)g * C + c] = yb;      // pre-BN value of the winner: all the backward reduction needs
 }
 
 extern "C" int p2c_maxpool_bnrelu_f32(const float *Y, int ldy, const float *scale, const float *shift, int G, int ns, int C, float *out,
-                                      int ldo, int32_t *arg, void *stream)
+                                      int ldo, int32_t *arg, float *ywin, void *stream)
 {
     if (!Y || !scale || !shift || !out || !arg || G <= 0 || ns <= 0 || C <= 0) return P2C_EINVAL;
     const int bx = C >= 256 ? 256 : ((C + 63) & ~63);
     hipLaunchKernelGGL(maxpool_bnrelu_kernel, dim3(G, p2c_cdiv(C, bx)), dim3(bx), 0, (hipStream_t)stream, Y, ldy, scale, shift, G, ns, C, out,
-                       ldo, arg);
+                       ldo, arg, ywin);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -240,9 +243,8 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double *__res
 
 // Same reduction when the layer feeds the max-pool: dZ is non-zero only at the winner rows, so the sums run over
 // the G x C pooled gradients (1/ns of the rows) and read Y at the winners only.
-__global__ void __launch_bounds__(256) pool_bwd_partial_kernel(const float *__restrict__ dout, int ldo, const int32_t *__restrict__ arg,
-                                                               const float *__restrict__ Y, int ldy, const float *__restrict__ stat, int G,
-                                                               int ns, int C, float *__restrict__ ws)
+__global__ void __launch_bounds__(256) pool_bwd_partial_kernel(const float *__restrict__ dout, int ldo, const float *__restrict__ ywin,
+                                                               const float *__restrict__ stat, int G, int C, float *__restrict__ ws)
 {
     __shared__ float red[2][4][64];
     const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -252,8 +254,7 @@ __global__ void __launch_bounds__(256) pool_bwd_partial_kernel(const float *__re
     if (c < C) {
         const float sc = stat[c], sh = stat[C + c], mu = stat[2 * C + c], is = stat[3 * C + c];
         for (int g = g0 + ty; g < g1; g += 4) {
-            const int a = arg[(size_t)g * C + c];
-            const float y = Y[((size_t)g * ns + a) * ldy + c];
+            const float y = ywin[(size_t)g * C + c];
             const float gr = (sc * y + sh > 0.f) ? dout[(size_t)g * ldo + c] : 0.f;
             s1 += gr;
             s2 += gr * ((y - mu) * is);
@@ -269,14 +270,13 @@ __global__ void __launch_bounds__(256) pool_bwd_partial_kernel(const float *__re
     }
 }
 
-extern "C" int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const int32_t *arg, const float *Y, int ldy, const float *stat,
-                                            const float *gamma, int G, int ns, int C, float *dgamma, float *dbeta, float *coef_out,
-                                            void *ws, void *stream)
+extern "C" int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const float *ywin, const float *stat, const float *gamma, int G,
+                                            int ns, int C, float *dgamma, float *dbeta, float *coef_out, void *ws, void *stream)
 {
-    if (!dout || !arg || !Y || !stat || !gamma || !coef_out || !ws || G <= 0 || ns <= 0 || C <= 0) return P2C_EINVAL;
+    if (!dout || !ywin || !stat || !gamma || !coef_out || !ws || G <= 0 || ns <= 0 || C <= 0) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int chunks = p2c_cdiv(G, BWD_ROWS);
-    hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dout, ldo, arg, Y, ldy, stat, G, ns, C, (float *)ws);
+    hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dout, ldo, ywin, stat, G, C, (float *)ws);
     double *ws2 = (double *)((char *)ws + (((size_t)chunks * 2 * C * sizeof(float) + 63) & ~(size_t)63));
     launch_reduce((const float *)ws, chunks, C, ws2, s);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(64), 0, s, (const double *)ws2, RED_SLICES, C,

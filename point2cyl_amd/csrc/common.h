@@ -53,3 +53,23 @@ __device__ __forceinline__ double p2c_wave_sum_f64(double v)
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+
+// Counter-based dropout bits: keep(row, col) = hash(seed, row*C + col) >= threshold.  Stateless, so the forward
+// and the two backward kernels regenerate the same mask from (seed, element index) instead of storing M x C bytes.
+__device__ __forceinline__ uint32_t p2c_hash32(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx)
+{
+    uint32_t x = idx * 0x9E3779B1u ^ seed_lo;
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16; x += seed_hi * 0x27D4EB2Fu;
+    x ^= x >> 15; x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    return x;
+}
+static inline uint32_t p2c_drop_threshold(float scale)     // scale = 1/(1-p)  ->  p * 2^32
+{
+    double p = 1.0 - 1.0 / (double)scale;
+    if (p < 0) p = 0;
+    if (p > 0.999999) p = 0.999999;
+    return (uint32_t)(p * 4294967296.0);
+}

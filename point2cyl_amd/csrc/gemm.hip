@@ -49,7 +49,8 @@ struct OpPlain {
     }
 };
 
-// act_in(X): MODE 0 identity, 1 relu(scale*x+shift), 2 same * dropout mask * dscale
+// act_in(X): MODE 0 identity, 1 relu(scale*x+shift), 2 same * dropout mask * dscale (mask bytes [M,C]),
+//            3 same with the mask regenerated from a counter hash (mask -> const uint32_t seed[2], ldmask -> threshold)
 template <int MODE>
 struct OpActIn {
     const float *p; int ld;
@@ -72,6 +73,14 @@ struct OpActIn {
             v.y = m.y ? v.y * dscale : 0.f;
             v.z = m.z ? v.z * dscale : 0.f;
             v.w = m.w ? v.w * dscale : 0.f;
+        }
+        if (MODE == 3) {
+            const uint32_t *sd = reinterpret_cast<const uint32_t *>(mask);
+            const uint32_t lo = sd[0], hi = sd[1], thr = (uint32_t)ldmask, e = (uint32_t)rr * (uint32_t)C + (uint32_t)cc;
+            v.x = p2c_hash32(lo, hi, e + 0) >= thr ? v.x * dscale : 0.f;
+            v.y = p2c_hash32(lo, hi, e + 1) >= thr ? v.y * dscale : 0.f;
+            v.z = p2c_hash32(lo, hi, e + 2) >= thr ? v.z * dscale : 0.f;
+            v.w = p2c_hash32(lo, hi, e + 3) >= thr ? v.w * dscale : 0.f;
         }
         return sel4(r < R && c < C, v);
     }
@@ -161,7 +170,8 @@ struct EpiFwd {
     float *Y; int ldy; const float *bias; float *partials;   // partials[tile][2][N] or NULL
 };
 struct EpiBwdData {
-    float *dX; int lddx; const uint8_t *mask; int ldmask; float mscale;
+    float *dX; int lddx; const uint8_t *mask; int ldmask; float mscale;   // ldmask < 0: hashed mask, mask -> seed[2], thr below
+    uint32_t thr;
     // fused ReLU+BN-backward reduction of the layer BELOW (whose pre-BN output is Yp, same shape as dX):
     const float *Yp; int ldyp; const float *pstat;   // pstat [4][J]: scale, shift, mean, invstd
     float *partials;                                 // [tile][2][J] or NULL
@@ -296,7 +306,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
                     const int row = i0 + wm * (TM * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * rquad;
                     if (row < I && cok) {
                         float v = acc[ta][tb][r];
-                        if (epi.mask) v = epi.mask[(size_t)row * epi.ldmask + col] ? v * epi.mscale : 0.f;
+                        if (epi.mask) {
+                            bool keep;
+                            if (epi.ldmask < 0) {
+                                const uint32_t *sd = reinterpret_cast<const uint32_t *>(epi.mask);
+                                keep = p2c_hash32(sd[0], sd[1], (uint32_t)row * (uint32_t)J + (uint32_t)col) >= epi.thr;
+                            } else {
+                                keep = epi.mask[(size_t)row * epi.ldmask + col] != 0;
+                            }
+                            v = keep ? v * epi.mscale : 0.f;
+                        }
                         epi.dX[(size_t)row * epi.lddx + col] = v;
                         if (epi.partials) {
                             const float yp = epi.Yp[(size_t)row * epi.ldyp + col];
@@ -382,9 +401,10 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
                                   int K, int in_mode, const float *in_scale, const float *in_shift, const uint8_t *drop_mask,
                                   int ldmask, float drop_scale, float *stat_partials, void *stream)
 {
-    if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0 || in_mode < 0 || in_mode > 2) return P2C_EINVAL;
+    if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0 || in_mode < 0 || in_mode > 3) return P2C_EINVAL;
     if (in_mode >= 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
     if (in_mode == 2 && (!drop_mask || (ldmask & 3) || ((uintptr_t)drop_mask & 3))) return P2C_EINVAL;
+    if (in_mode == 3) { if (!drop_mask) return P2C_EINVAL; ldmask = (int)p2c_drop_threshold(drop_scale); }
     if (K & 3) return P2C_EALIGN;
     P2C_REQ_ALIGNED(X, ldx);
     P2C_REQ_ALIGNED(W, ldw);
@@ -393,7 +413,8 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     switch (in_mode) {
     case 0: return launch_fwd<0>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
     case 1: return launch_fwd<1>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
-    default: return launch_fwd<2>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
+    case 2: return launch_fwd<2>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
+    default: return launch_fwd<3>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
     }
 }
 
@@ -406,7 +427,7 @@ static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy
     // layer: Y[M,N] = in[M,K] . W[N,K]^T ; here the GEMM is dX[M,K] = dY[M,N] . W[N,K]
     OpGrad<GMODE> a{dZ, lddz, Yfwd, ldy, coef, N, pool_arg, pool_ns};
     OpPlain b{W, ldw};
-    EpiBwdData e{dX, lddx, out_mask, ldmask, out_mask_scale, Yprev, ldyp, prev_stat, bwd_partials};
+    EpiBwdData e{dX, lddx, out_mask, ldmask, out_mask_scale, p2c_drop_threshold(out_mask_scale), Yprev, ldyp, prev_stat, bwd_partials};
     const int kps = (N + GK - 1) / GK * GK;
 #define P2C_BDL(TM_, TN_)                                                                                                          \
     hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, false, OpGrad<GMODE>, OpPlain, EpiBwdData>),                                    \
@@ -476,7 +497,8 @@ extern "C" int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float 
                                          const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW, int lddw, float *dbias,
                                          int M, int N, int K, const int32_t *pool_arg, int pool_ns, void *stream)
 {
-    if (!dZ || !X || !dW || M <= 0 || N <= 0 || K <= 0 || grad_mode < 0 || grad_mode > 2 || in_mode < 0 || in_mode > 2) return P2C_EINVAL;
+    if (!dZ || !X || !dW || M <= 0 || N <= 0 || K <= 0 || grad_mode < 0 || grad_mode > 2 || in_mode < 0 || in_mode > 3) return P2C_EINVAL;
+    if (in_mode == 3) { if (!drop_mask) return P2C_EINVAL; ldmask = (int)p2c_drop_threshold(drop_scale); }
     if (grad_mode >= 1 && (!Yfwd || !coef)) return P2C_EINVAL;
     if (grad_mode == 2 && (!pool_arg || pool_ns <= 0 || ((uintptr_t)pool_arg & 15))) return P2C_EINVAL;
     if (in_mode >= 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
@@ -493,8 +515,10 @@ extern "C" int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float 
     if (grad_mode == 0) {
         if (in_mode == 0) P2C_DISPATCH(0, 0);
         if (in_mode == 1) P2C_DISPATCH(0, 1);
-        P2C_DISPATCH(0, 2);
+        if (in_mode == 2) P2C_DISPATCH(0, 2);
+        P2C_DISPATCH(0, 3);
     }
+    if (in_mode == 3) return P2C_EINVAL;      // dropout only ever precedes the BN-less head layer (grad_mode 0)
     if (grad_mode == 1) {
         if (in_mode == 0) P2C_DISPATCH(1, 0);
         if (in_mode == 1) P2C_DISPATCH(1, 1);

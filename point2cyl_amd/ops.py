@@ -153,6 +153,7 @@ class _MLPStack(torch.autograd.Function):
         L = cfg["n_layers"]
         tail = cfg["tail"]
         mask = cfg.get("drop_mask")
+        seed = cfg.get("drop_seed")       # device int64 scalar: counter-hash dropout (no mask tensor)
         dscale = cfg.get("drop_scale", 1.0)
         Ys, aff, Ws = [], [], []
         X, ldx, in_mode, sc, sh = X0, ldx0, 0, None, None
@@ -169,15 +170,18 @@ class _MLPStack(torch.autograd.Function):
                 b = torch.nn.functional.pad(b, (0, Co - Co_true))
             W2 = W2.contiguous()
             Y = torch.empty(M, Co, dtype=torch.float32, device=dev)
-            use_mask = (not has_bn) and mask is not None
-            mode = 2 if (use_mask and in_mode == 1) else in_mode
+            mode, mptr, mld = in_mode, None, 0
+            if (not has_bn) and in_mode == 1:
+                if mask is not None:
+                    mode, mptr, mld = 2, ptr(mask), mask.stride(0)
+                elif seed is not None:
+                    mode, mptr, mld = 3, ptr(seed), 0
             partials = None
             if has_bn and training:
                 tiles = _lib.lib().p2c_linear_stat_tiles(M)
                 partials = torch.empty(tiles, 2, Co, dtype=torch.float32, device=dev)
             call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
-                 ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), ptr(partials), stream(),
-                 flops=2.0 * M * Co * K)
+                 mptr, mld, float(dscale), ptr(partials), stream(), flops=2.0 * M * Co * K)
             Ys.append(Y)
             Ws.append(W2)
             if has_bn:
@@ -201,7 +205,9 @@ class _MLPStack(torch.autograd.Function):
             G, ns = cfg["G"], cfg["ns"]
             out = torch.empty(G, K, dtype=torch.float32, device=dev)
             arg = torch.empty(G, K, dtype=I32, device=dev)
-            call("p2c_maxpool_bnrelu_f32", ptr(Ys[-1]), K, ptr(sc), ptr(sh), G, ns, K, ptr(out), K, ptr(arg), stream())
+            ywin = torch.empty(G, K, dtype=torch.float32, device=dev)
+            call("p2c_maxpool_bnrelu_f32", ptr(Ys[-1]), K, ptr(sc), ptr(sh), G, ns, K, ptr(out), K, ptr(arg), ptr(ywin), stream())
+            arg = (arg, ywin)
         elif tail == "bnrelu":
             out = torch.empty(M, K, dtype=torch.float32, device=dev)
             call("p2c_bn_relu_apply_f32", ptr(Ys[-1]), K, ptr(sc), ptr(sh), M, K, ptr(out), K, stream())
@@ -215,12 +221,13 @@ class _MLPStack(torch.autograd.Function):
     def backward(ctx, dout):
         cfg = ctx.cfg
         X0, Ys, aff, Ws, arg, params = ctx.saved
+        arg, ywin = arg if isinstance(arg, tuple) else (arg, None)
         if not cfg["training"]:
             raise RuntimeError("point2cyl_amd: backward through an eval-mode (running-stats) stack is not implemented")
         dev = X0.device
         M = X0.shape[0]
         L, tail = cfg["n_layers"], cfg["tail"]
-        mask, dscale = cfg.get("drop_mask"), cfg.get("drop_scale", 1.0)
+        mask, seed, dscale = cfg.get("drop_mask"), cfg.get("drop_seed"), cfg.get("drop_scale", 1.0)
         dout = _f32c(dout)
         Cl = Ys[-1].shape[1]
         grads = [None] * len(params)
@@ -253,7 +260,7 @@ class _MLPStack(torch.autograd.Function):
             dgamma = torch.empty(Cl, dtype=torch.float32, device=dev)
             dbeta = torch.empty(Cl, dtype=torch.float32, device=dev)
             ws = torch.empty(_lib.lib().p2c_bn_bwd_ws_bytes(G, Cl) // 4 + 4, dtype=torch.float32, device=dev)
-            call("p2c_maxpool_bn_bwd_stats_f32", ptr(dout), Cl, ptr(arg), ptr(Ys[-1]), Cl, ptr(aff[-1]), ptr(params[p0 + 2]), G, pool_ns, Cl,
+            call("p2c_maxpool_bn_bwd_stats_f32", ptr(dout), Cl, ptr(ywin), ptr(aff[-1]), ptr(params[p0 + 2]), G, pool_ns, Cl,
                  ptr(dgamma), ptr(dbeta), ptr(coef), ptr(ws), stream())
             grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
         elif tail == "bnrelu":
@@ -263,6 +270,11 @@ class _MLPStack(torch.autograd.Function):
             dZ, grad_mode, coef = dout, 0, None
             if dZ.shape[1] != Cl:
                 dZ = torch.nn.functional.pad(dZ, (0, Cl - dZ.shape[1]))
+        zoff, ztot = [], 0
+        for W2 in Ws:
+            zoff.append(ztot)
+            ztot += (W2.shape[0] * W2.shape[1] + W2.shape[0] + 3) // 4 * 4
+        zbuf = torch.zeros(ztot, dtype=torch.float32, device=dev)
         for i in range(L - 1, -1, -1):
             p0, has_bn = slots[i]
             Y, W2 = Ys[i], Ws[i]
@@ -271,11 +283,16 @@ class _MLPStack(torch.autograd.Function):
                 Xin, ldxin, in_mode, sc, sh = X0, X0.stride(0), 0, None, None
             else:
                 Xin, ldxin, in_mode, sc, sh = Ys[i - 1], Ys[i - 1].shape[1], 1, aff[i - 1][0], aff[i - 1][1]
-            use_mask = (not has_bn) and mask is not None and in_mode == 1
-            mode = 2 if use_mask else in_mode
-            dW = torch.zeros(Co, Ci, dtype=torch.float32, device=dev)
+            mode, mptr, mld, omld = in_mode, None, 0, 0
+            if (not has_bn) and in_mode == 1:
+                if mask is not None:
+                    mode, mptr, mld, omld = 2, ptr(mask), mask.stride(0), mask.stride(0)
+                elif seed is not None:
+                    mode, mptr, mld, omld = 3, ptr(seed), 0, -1
+            # one zero-fill for all weight/bias gradients of the stack (they are accumulated with atomics)
+            dW = zbuf[zoff[i]: zoff[i] + Co * Ci].view(Co, Ci)
             # a conv bias in front of a train-mode BatchNorm has an exactly zero gradient (the batch mean absorbs it)
-            db = torch.zeros(Co, dtype=torch.float32, device=dev)
+            db = zbuf[zoff[i] + Co * Ci: zoff[i] + Co * Ci + Co]
             Wp = params[p0]
             co_t, ci_t = Wp.shape[0], Wp.numel() // Wp.shape[0]
             grads[p0] = dW[:co_t, :ci_t].reshape(Wp.shape)
@@ -283,7 +300,7 @@ class _MLPStack(torch.autograd.Function):
             need_dx = i > 0 or ctx.needs_input_grad[1]
             stats_below = i > 0                       # the layer below has a BatchNorm whose backward sums we produce here
             L_ = _lib.lib()
-            if USE_FUSED_BWD and mode != 2 and M >= 4096 and L_.p2c_linear_bwd_fused_supported(Co, Ci, mode):
+            if USE_FUSED_BWD and mode <= 1 and M >= 4096 and L_.p2c_linear_bwd_fused_supported(Co, Ci, mode):
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev) if need_dx else None
                 part = torch.empty(L_.p2c_linear_bwd_fused_parts(M, Ci), 2, Ci, dtype=torch.float32, device=dev) if stats_below else None
                 call("p2c_linear_bwd_fused_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(arg) if grad_mode == 2 else None,
@@ -292,7 +309,7 @@ class _MLPStack(torch.autograd.Function):
                      flops=(4.0 if need_dx else 2.0) * M * Co * Ci)
             else:
                 call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
-                     ptr(sh), ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale), ptr(dW), Ci,
+                     ptr(sh), mptr, mld, float(dscale), ptr(dW), Ci,
                      ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
                      flops=2.0 * M * Co * Ci)
                 dX = part = None
@@ -300,7 +317,7 @@ class _MLPStack(torch.autograd.Function):
                     dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
                     part = torch.empty(L_.p2c_linear_stat_tiles(M), 2, Ci, dtype=torch.float32, device=dev) if stats_below else None
                     call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(W2), Ci, ptr(dX), Ci, M, Co, Ci,
-                         ptr(mask) if mode == 2 else None, mask.stride(0) if mode == 2 else 0, float(dscale),
+                         mptr, omld, float(dscale),
                          ptr(Ys[i - 1]) if stats_below else None, Ci, ptr(aff[i - 1]) if stats_below else None, ptr(part),
                          ptr(arg) if grad_mode == 2 else None, pool_ns, stream(), flops=2.0 * M * Co * Ci)
             if need_dx:
@@ -323,7 +340,7 @@ class _MLPStack(torch.autograd.Function):
         return (None, dX0) + tuple(grads)
 
 
-def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mask=None, drop_scale=1.0):
+def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mask=None, drop_scale=1.0, drop_seed=None):
     """layers: list of dicts {W, b, gamma, beta, bn: BNState} (gamma/beta/bn None for a BN-less last layer)."""
     params, bns = [], []
     for ly in layers:
@@ -332,7 +349,7 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
             params += [ly["gamma"], ly["beta"]]
         bns.append(ly.get("bn"))
     cfg = dict(in_channels=in_channels, n_layers=len(layers), tail=tail, training=training, bns=bns, G=G, ns=ns,
-               drop_mask=drop_mask, drop_scale=drop_scale)
+               drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed)
     out = _MLPStack.apply(cfg, X0, *params)
     co_last = layers[-1]["W"].shape[0]
     if tail == "linear" and out.shape[1] != co_last:

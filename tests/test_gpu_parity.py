@@ -423,3 +423,43 @@ def test_train_step_golden():
             assert (np.sign(got[big]) == np.sign(ref[big])).mean() > 0.98
             same = np.sign(got[big]) == np.sign(ref[big])
             np.testing.assert_allclose(got[big][same], ref[big][same], rtol=0.05, atol=1e-5)
+
+
+def test_hashed_dropout_consistency_and_rate():
+    """in_mode 3: the keep-mask is regenerated from (seed, element) in forward, backward-weight and backward-data;
+    the gradients must agree with autograd on the mask the forward implied, and ~half the units are kept."""
+    g = torch.Generator().manual_seed(5)
+    M, C, Co = 1000, 128, 20
+    Y = torch.randn(M, C, generator=g).to(DEV)
+    layers = [dict(W=(torch.randn(C, C, generator=g) / 11).to(DEV).requires_grad_(True), b=torch.zeros(C, device=DEV, requires_grad=True),
+                   gamma=torch.ones(C, device=DEV, requires_grad=True), beta=torch.zeros(C, device=DEV, requires_grad=True),
+                   bn=ops.BNState(torch.zeros(C, device=DEV), torch.ones(C, device=DEV), None, 0.1, 1e-5)),
+              dict(W=(torch.randn(Co, C, generator=g) / 11).to(DEV).requires_grad_(True), b=torch.zeros(Co, device=DEV, requires_grad=True),
+                   gamma=None, beta=None, bn=None)]
+    seed = torch.tensor([123456789], dtype=torch.int64, device=DEV)
+    out = ops.mlp_stack(Y, C, layers, "linear", True, drop_scale=2.0, drop_seed=seed)
+    # recover the implied mask: feed one-hot head weights? simpler: compare with an explicit-mask run that reproduces `out`
+    with torch.no_grad():
+        W0, b0 = layers[0]["W"], layers[0]["b"]
+        h = Y @ W0.t() + b0
+        z = torch.relu((h - h.mean(0)) / torch.sqrt(h.var(0, unbiased=False) + 1e-5))
+        # solve for the mask per unit from a second run with identity-like probe weights
+    probe = [layers[0], dict(W=torch.eye(C, device=DEV).requires_grad_(True), b=torch.zeros(C, device=DEV, requires_grad=True), gamma=None,
+                             beta=None, bn=None)]
+    pz = ops.mlp_stack(Y, C, probe, "linear", True, drop_scale=2.0, drop_seed=seed).detach()
+    mask = (pz != 0) | (z == 0)
+    keep_rate = ((pz != 0).float().sum() / (z != 0).float().sum()).item()
+    assert 0.47 < keep_rate < 0.53
+    np.testing.assert_allclose(pz.cpu().numpy(), (z * mask * 2.0).cpu().numpy(), rtol=1e-4, atol=1e-5)
+    go = torch.randn(M, Co, generator=g).to(DEV)
+    out.backward(go)
+    g_hash = [layers[0]["W"].grad.clone(), layers[1]["W"].grad.clone(), layers[0]["gamma"].grad.clone()]
+    for ly in layers:
+        for k in ("W", "b", "gamma", "beta"):
+            if ly.get(k) is not None:
+                ly[k].grad = None
+    out2 = ops.mlp_stack(Y, C, layers, "linear", True, drop_mask=mask.to(torch.uint8), drop_scale=2.0)
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), out.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
+    out2.backward(go)
+    for a, b in zip(g_hash, [layers[0]["W"].grad, layers[1]["W"].grad, layers[0]["gamma"].grad]):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5)

@@ -1,0 +1,113 @@
+"""CPU: host-side logic (no GPU, no kernels): synthetic data, schedules, drop-in import names, data-parallel glue
+(world_size 2 over gloo)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from point2cyl_amd import ddp, step, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_synthetic_batch_layout_and_determinism():
+    b1 = synth.make_batch(3, 512, 8, seed=7)
+    b2 = synth.make_batch(3, 512, 8, seed=7)
+    pcs, nrm, seg, bb, pax, pdist, axes, dist, cen = b1
+    assert all(torch.equal(x, y) for x, y in zip(b1, b2))
+    assert pcs.shape == (3, 512, 3) and pcs.dtype == torch.float32 and seg.dtype == torch.int64 and bb.dtype == torch.int64
+    assert axes.shape == (3, 8, 3) and cen.shape == (3, 8, 3) and dist.shape == (3, 8)
+    np.testing.assert_allclose(pcs.norm(dim=-1).max(dim=1)[0].numpy(), 1.0, rtol=1e-5)       # unit max-norm (utils.py:938-950)
+    np.testing.assert_allclose(nrm.norm(dim=-1).numpy(), 1.0, rtol=1e-4)
+    for b in range(3):
+        k = int(seg[b].max()) + 1
+        assert set(seg[b].tolist()) == set(range(k)), "labels must be gap-free (losses.py:35)"
+        assert (axes[b, k:] == 0).all() and (cen[b, k:] == 0).all()
+        # barrel normals are perpendicular to the axis, base normals parallel
+        d = (nrm[b] * pax[b]).sum(-1).abs()
+        assert d[bb[b] == 0].max() < 1e-4 and (d[bb[b] == 1] - 1).abs().max() < 1e-4
+
+
+def test_schedules_match_reference_formulas():
+    assert step.get_batch_norm_decay(0, 32, 200000) == 0.5
+    assert step.get_batch_norm_decay(6250, 32, 200000) == 0.25            # 200000 samples seen
+    assert step.get_batch_norm_decay(10 ** 7, 32, 200000) == pytest.approx(0.01)
+    assert step.get_learning_rate(1e-3, 6250, 32, 200000, 0.7) == pytest.approx(0.7e-3)
+    from point2cyl_amd.backbone import backbone
+    m = backbone(output_sizes=[3, 16])
+    step.update_momentum(m, 0.123)
+    hit = [n for n, mod in m.named_modules() if "bn" in n]
+    assert len(hit) == 23 and all(getattr(mod, "momentum") == 0.123 for n, mod in m.named_modules() if "bn" in n)
+    assert step.StepFlags().pred_sizes() == [3, 16]
+
+
+def test_state_dict_is_the_reference_checkpoint_abi():
+    from point2cyl_amd.backbone import backbone
+    sd = backbone(output_sizes=[3, 16]).state_dict()
+    assert len(sd) == 123
+    assert tuple(sd["sa1.mlp_convs.0.weight"].shape) == (64, 3, 1, 1)
+    assert tuple(sd["fp3.mlp_convs.0.weight"].shape) == (256, 1280, 1)
+    assert tuple(sd["fc2.1.weight"].shape) == (16, 128, 1)
+    assert sum(v.numel() for k, v in sd.items() if "running" not in k and "num_batches" not in k) == 1404243
+
+
+def test_dropin_import_names():
+    code = ("import importlib,sys;"
+            "m=importlib.import_module('pointnet_extrusion');"
+            "from models.pointnet_util import PointNetSetAbstractionMsg,PointNetSetAbstraction,PointNetFeaturePropagation;"
+            "from losses import *;from data_utils import *;from global_variables import *;"
+            "assert callable(m.backbone) and callable(compute_all_losses) and callable(estimate_extrusion_axis) and g_zero_tol==1e-6;"
+            "print('ok')")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "point2cyl_amd", "dropin"),
+                                                       os.path.join(ROOT, "point2cyl_amd", "dropin", "models"), ROOT]))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+def test_shard_range_covers_everything():
+    for n, w in ((32, 8), (10, 4), (3, 8), (1250, 8)):
+        got = [ddp.shard_range(n, r, w) for r in range(w)]
+        assert got[0][0] == 0 and got[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from point2cyl_amd import ddp
+rank, world, _ = ddp.init_from_env(backend="gloo")
+torch.manual_seed(100 + rank)
+m = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 2))
+ddp.broadcast_module(m)
+w0 = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+ref = [torch.zeros_like(w0) for _ in range(world)]
+dist.all_gather(ref, w0)
+assert all(torch.equal(ref[0], r) for r in ref), "broadcast_module must equalise the replicas"
+sync = ddp.FlatGradSync(m.parameters(), world)
+x = torch.randn(4, 6)                      # different shard per rank (seeded by rank)
+sync.zero()
+m(x).square().mean().backward()
+local = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+sync.allreduce()
+avg = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
+gathered = [torch.zeros_like(local) for _ in range(world)]
+dist.all_gather(gathered, local)
+assert torch.allclose(avg, sum(gathered) / world, atol=1e-7)
+assert all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in m.parameters()), "grads must be views of the flat buffer"
+lo, hi = ddp.shard_range(10, rank, world)
+print("rank", rank, "ok", lo, hi)
+dist.destroy_process_group()
+"""
+
+
+def test_grad_sync_two_ranks_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ok") == 2

@@ -165,22 +165,27 @@ int p2c_bn_bwd_finalize_f32(const float *partials, int n_tiles, int C, long long
 
 /* dW[co,ci] += sum_m dY[m,co] * act_in(X)[m,ci];  dbias[co] += sum_m dY[m,co] (dbias may be NULL).
  * dW / dbias must be zero-initialised by the caller (the kernel splits the row range over workgroups and
- * accumulates with fp32 atomics). */
+ * accumulates with fp32 atomics).  With dw_slot_stride != 0 the atomics are spread over 8 copies of dW
+ * (copy s at dW + s*dw_slot_stride elements) that the caller sums: 8x less contention per address. */
 int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                               const float *X, int ldx, int in_mode, const float *in_scale, const float *in_shift,
-                              const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW, int lddw, float *dbias,
-                              int M, int N, int K, const int32_t *pool_arg, int pool_ns, void *stream);
+                              const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW, int lddw,
+                              long long dw_slot_stride, float *dbias, int M, int N, int K, const int32_t *pool_arg, int pool_ns,
+                              void *stream);
 
 /* One-pass backward of a narrow layer (Co, Ci in {64,128}; in_mode 0/1): dX, dW, dbias and the fused reduction
  * for the layer below from a single stream over (dZ, Yfwd, X) -- see csrc/bwd_fused.hip.  Same argument meaning as
  * the two entry points above; dX may be NULL (then prev_stat/bwd_partials must be NULL too).
- * bwd_partials [p2c_linear_bwd_fused_parts(M,Ci)][2][Ci]: one row per persistent workgroup. */
+ * bwd_partials [p2c_linear_bwd_fused_parts(M,Ci)][2][Ci]: one row per persistent workgroup.
+ * dW is accumulated into 8 copies (one per XCD, copy s at dW + s*dw_slot_stride elements, all zero-initialised by the
+ * caller, who sums them); dw_slot_stride = 0 selects a single copy. */
 int p2c_linear_bwd_fused_supported(int Co, int Ci, int in_mode);
 int p2c_linear_bwd_fused_parts(int M, int Ci);
 int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                              const int32_t *pool_arg, int pool_ns, const float *X, int ldx, int in_mode, const float *in_scale,
                              const float *in_shift, const float *W, int ldw, float *dX, int lddx, float *dW, int lddw,
-                             float *dbias, const float *prev_stat, float *bwd_partials, int M, int Co, int Ci, void *stream);
+                             long long dw_slot_stride, float *dbias, const float *prev_stat, float *bwd_partials, int M, int Co,
+                             int Ci, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Extrusion-cylinder fitting  (data_utils.py:99-177, :253-266, :1650-1730; eval.py:409-436)

@@ -38,10 +38,10 @@ _SIGS = {
     "p2c_linear_bwd_data_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_f, c_p, c_i, c_p,
                                 c_p, c_p, c_i, c_p],
     "p2c_maxpool_bn_bwd_stats_f32": [c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
-    "p2c_linear_bwd_weight_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_i, c_p,
+    "p2c_linear_bwd_weight_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_i, c_ll, c_p,
                                   c_i, c_i, c_i, c_p, c_i, c_p],
-    "p2c_linear_bwd_fused_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p,
-                                 c_p, c_p, c_i, c_i, c_i, c_p],
+    "p2c_linear_bwd_fused_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_ll,
+                                 c_p, c_p, c_p, c_i, c_i, c_i, c_p],
     "p2c_extrusion_axis_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
     "p2c_extrusion_axis_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_extrusion_centers_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],

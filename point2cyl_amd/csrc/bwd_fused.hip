@@ -21,6 +21,11 @@
 #include "common.h"
 #include <stdlib.h>
 
+// Workgroup barrier that only drains the LDS queue.  __syncthreads() also waits for every outstanding global
+// load/store of the wave (vmcnt(0)), which would turn the register prefetch that is meant to stay in flight across
+// the barrier into an exposed HBM round trip per phase.  LDS hand-offs only need lgkmcnt(0).
+#define P2C_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copy can pin an array in scratch)
 
@@ -38,14 +43,15 @@ struct BwdFusedArgs {
     const float *pstat;                   // [4][Ci] of the layer below, or NULL
     float *partials;                      // [gridDim.x][2][Ci]
     int M;
+    long long dw_slot_stride;        // elements between the 8 per-XCD copies of dW (0: a single copy)
 };
 
 // Raw tile fetch (no arithmetic: the values stay in flight during the MFMAs of the previous tile).
 template <int GMODE, int Co, int Ci, int BM, int UDY, int UX>
-__device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int t, float4 (&rdz)[UDY], float4 (&ry)[UDY], int4 (&rarg)[UDY],
-                                                v4f (&rx)[UX])
+__device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, int t, float4 (&rdz)[UDY], float4 (&ry)[UDY],
+                                                int4 (&rarg)[UDY], v4f (&rx)[UX])
 {
-    const int tid = threadIdx.x, m0 = t * BM;
+    const int m0 = t * BM;
 #pragma unroll
     for (int i = 0; i < UDY; ++i) {
         const int u = tid + 256 * i, row = u / (Co / 4), c4 = u % (Co / 4);
@@ -69,11 +75,11 @@ __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int t, fl
 // dY = gs*(dZ*[scale*Y+shift>0]) + q*Y + p from the raw registers (cf[] = this thread's 4 channels of coef),
 // transposed into dYs[co][m]; raw X into Xr[m][ci].
 template <int GMODE, int Co, int Ci, int BM, int LDY, int LDX, int UDY, int UX>
-__device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int t, float *dy, float *xr, const float4 (&rdz)[UDY],
+__device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid, int t, float *dy, float *xr, const float4 (&rdz)[UDY],
                                                  const float4 (&ry)[UDY], const int4 (&rarg)[UDY], const v4f (&rx)[UX],
                                                  const float4 (&cf)[5])
 {
-    const int tid = threadIdx.x, m0 = t * BM;
+    const int m0 = t * BM;
 #pragma unroll
     for (int i = 0; i < UDY; ++i) {
         const int u = tid + 256 * i, row = u / (Co / 4), c4 = u % (Co / 4);
@@ -163,14 +169,14 @@ __global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
     v4f rx[UX];
     int4 rarg[UDY];
     int t = blockIdx.x;                                     // gridDim.x <= ntiles: every workgroup owns at least one tile
-    fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, t, rdz, ry, rarg, rx);
-    fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, t, dYs, Xr, rdz, ry, rarg, rx, cf);
+    fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, t, rdz, ry, rarg, rx);
+    fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, t, dYs, Xr, rdz, ry, rarg, rx, cf);
     __syncthreads();
     int buf = 0;
     for (; t < ntiles; t += gridDim.x) {
         const int tn = t + gridDim.x;
         const int tl = tn < ntiles ? tn : t;
-        fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tl, rdz, ry, rarg, rx);   // in flight during the MFMAs below (unconditional: stays in registers)
+        fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tl, rdz, ry, rarg, rx);   // in flight during the MFMAs below (unconditional: stays in registers)
         const float *dy = dYs + buf * Co * LDY;
         const float *xr = Xr + buf * BM * LDX;
         const int m0 = t * BM;
@@ -256,7 +262,7 @@ __global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
                 }
             }
         }
-        fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tl, dYs + (buf ^ 1) * Co * LDY, Xr + (buf ^ 1) * BM * LDX, rdz, ry, rarg, rx, cf);
+        fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, tl, dYs + (buf ^ 1) * Co * LDY, Xr + (buf ^ 1) * BM * LDX, rdz, ry, rarg, rx, cf);
         __syncthreads();
         buf ^= 1;
     }
@@ -269,7 +275,7 @@ __global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
             for (int r = 0; r < 16; ++r) {
                 const int co = wi * (COT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 const int ci = wj * (CIT * 32) + j * 32 + l31;
-                atomicAdd(&a.dw[(size_t)co * a.lddw + ci], accW[i][j][r]);
+                atomicAdd(&a.dw[(size_t)(blockIdx.x & 7) * a.dw_slot_stride + (size_t)co * a.lddw + ci], accW[i][j][r]);
             }
     if (GMODE == 0 && a.dbias && tid < Co) atomicAdd(&a.dbias[tid], dbacc);
     if (NEED_DX && HAS_STATS) {
@@ -286,6 +292,231 @@ __global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
             float *o = a.partials + (size_t)blockIdx.x * 2 * Ci;
             o[tid] = red[tid];
             o[Ci + tid] = red[Ci + tid];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ping-pong variant (default): 512 threads = two half-workgroups of 4 waves that share W in LDS and own one tile
+// buffer each.  A wave issues in order, so inside ONE wave the ~350 non-MFMA instructions of a tile (epilogue
+// stores, BN-backward sums, staging the next tile into LDS, issuing the prefetch) cannot hide behind its own
+// MFMAs; PMC on the single-group kernel shows MFMA busy 48 % + issue-active 29 % + parked 20 % with no overlap.
+// Here the two halves run one phase apart (an extra barrier at the start of half 1 / end of half 0): while half A
+// streams its 128 MFMAs per wave, half B - resident on the same SIMDs - does its non-MFMA phase, then they swap.
+// Every barrier is workgroup-wide; both halves execute the same number of them.
+// ------------------------------------------------------------------------------------------------
+template <int COT, int CIT, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS>
+__global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
+{
+    constexpr int Co = 64 * COT, Ci = 64 * CIT;
+    constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
+    constexpr int LDW = Ci + 4, LDY = BM + 1, LDX = Ci + 4;
+    constexpr int UDY = BM * Co / 4 / 256, UX = BM * Ci / 4 / 256;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ws = smem;                              // [Co][LDW]          shared by both halves
+    float *dYs = Ws + Co * LDW;                    // [2 halves][Co][LDY]
+    float *Xr = dYs + 2 * Co * LDY;                // [2 halves][BM][LDX]
+    float *red = Xr + 2 * BM * LDX;                // [2][Ci]
+
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wi = wave >> 1, wj = wave & 1;       // dW wave grid (within the half)
+    const int wr = wave / WC, wc = wave % WC;      // dX wave grid
+    const int ntiles = (a.M + BM - 1) / BM;
+    const int nk = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup: blockIdx.x + k*gridDim.x
+    const int niter = (nk + 1) / 2;                // per half
+    float *dy = dYs + half * Co * LDY;
+    float *xr = Xr + half * BM * LDX;
+
+    if (NEED_DX) {
+        for (int u = threadIdx.x; u < Co * Ci / 4; u += 512) {
+            const int r = u / (Ci / 4), c4 = u % (Ci / 4);
+            *reinterpret_cast<float4 *>(&Ws[r * LDW + c4 * 4]) = *reinterpret_cast<const float4 *>(a.w + (size_t)r * a.ldw + c4 * 4);
+        }
+    }
+    float isc[CIT], ish[CIT];
+#pragma unroll
+    for (int t = 0; t < CIT; ++t) {
+        const int ci = wj * (CIT * 32) + t * 32 + l31;
+        isc[t] = IMODE == 1 ? a.in_scale[ci] : 1.f;
+        ish[t] = IMODE == 1 ? a.in_shift[ci] : 0.f;
+    }
+    const int xcol = wc * 32 + l31;
+    float psc = 0.f, psh = 0.f, pmu = 0.f, pis = 0.f;
+    if (NEED_DX && HAS_STATS) { psc = a.pstat[xcol]; psh = a.pstat[Ci + xcol]; pmu = a.pstat[2 * Ci + xcol]; pis = a.pstat[3 * Ci + xcol]; }
+    float4 cf[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+        cf[i] = GMODE >= 1 ? *reinterpret_cast<const float4 *>(a.coef + i * Co + (tid % (Co / 4)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float s1 = 0.f, s2 = 0.f, dbacc = 0.f;
+    f32x16 accW[COT][CIT];
+#pragma unroll
+    for (int i = 0; i < COT; ++i)
+#pragma unroll
+        for (int j = 0; j < CIT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW[i][j][r] = 0.f;
+    f32x16 accX;
+    float yp[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accX[r] = 0.f; yp[r] = 0.f; }
+
+    float4 rdz[UDY], ry[UDY];
+    v4f rx[UX];
+    int4 rarg[UDY];
+    auto tile_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
+    // prologue: this half's first tile -> its LDS buffer; its second tile -> registers (in flight)
+    {
+        const int k0 = half, k1 = half + 2;
+        fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
+        fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xr, rdz, ry, rarg, rx, cf);
+        fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k1 < nk ? k1 : 0), rdz, ry, rarg, rx);
+    }
+    __syncthreads();
+    if (half == 1) P2C_LDS_BARRIER();             // run one phase behind half 0
+    for (int it = 0; it < niter; ++it) {
+        const int k = 2 * it + half;
+        const bool valid = k < nk;                 // uniform within the half
+        const int m0 = tile_of(valid ? k : 0) * BM;
+        // ================= MFMA phase =================
+        if (valid) {
+            {
+                float av[COT], bv[CIT], an[COT], bn[CIT];
+#pragma unroll
+                for (int i = 0; i < COT; ++i) av[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + lh];
+#pragma unroll
+                for (int j = 0; j < CIT; ++j) bv[j] = xr[lh * LDX + wj * (CIT * 32) + j * 32 + l31];
+#pragma unroll 8
+                for (int s = 0; s < BM; s += 2) {
+                    const int sn = (s + 2 < BM) ? s + 2 : s;
+#pragma unroll
+                    for (int i = 0; i < COT; ++i) an[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + sn + lh];
+#pragma unroll
+                    for (int j = 0; j < CIT; ++j) bn[j] = xr[(sn + lh) * LDX + wj * (CIT * 32) + j * 32 + l31];
+                    float bz[CIT];
+#pragma unroll
+                    for (int j = 0; j < CIT; ++j) {
+                        float v = bv[j];
+                        if (IMODE == 1) v = fmaxf(isc[j] * v + ish[j], 0.f);
+                        if (m0 + s + lh >= a.M) v = 0.f;
+                        bz[j] = v;
+                    }
+#pragma unroll
+                    for (int i = 0; i < COT; ++i)
+#pragma unroll
+                        for (int j = 0; j < CIT; ++j) accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bz[j], accW[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < COT; ++i) av[i] = an[i];
+#pragma unroll
+                    for (int j = 0; j < CIT; ++j) bv[j] = bn[j];
+                }
+            }
+            if (GMODE == 0 && a.dbias && tid < Co) {
+                float sb = 0.f;
+#pragma unroll 8
+                for (int s = 0; s < BM; ++s) sb += dy[tid * LDY + s];
+                dbacc += sb;
+            }
+            if (NEED_DX) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accX[r] = 0.f;
+                float av = dy[lh * LDY + wr * 32 + l31], bv = Ws[lh * LDW + wc * 32 + l31];
+#pragma unroll 16
+                for (int kk = 0; kk < Co; kk += 2) {
+                    const int kn = (kk + 2 < Co) ? kk + 2 : kk;
+                    const float an = dy[(kn + lh) * LDY + wr * 32 + l31];
+                    const float bn = Ws[(kn + lh) * LDW + wc * 32 + l31];
+                    accX = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accX, 0, 0, 0);
+                    av = an;
+                    bv = bn;
+                }
+                if (HAS_STATS) {                    // the epilogue runs after the barrier, when xr may already be restaged
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) yp[r] = xr[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDX + xcol];
+                }
+            }
+        }
+        P2C_LDS_BARRIER();
+        // ================= non-MFMA phase (the other half is in its MFMA phase) =================
+        // The co-resident wave of the other half needs an issue slot only once per 64-cycle MFMA; give this phase's
+        // VALU / LDS / VMEM instructions priority so it finishes inside the other half's MFMA phase.
+        __builtin_amdgcn_s_setprio(1);
+        if (valid && NEED_DX) {
+            if (m0 + BM <= a.M) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    a.dx[(size_t)(m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * a.lddx + xcol] = accX[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < a.M) a.dx[(size_t)m * a.lddx + xcol] = accX[r];
+                }
+            }
+            if (HAS_STATS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = accX[r];
+                    const float g = (psc * yp[r] + psh > 0.f) ? v : 0.f;
+                    s1 += g;
+                    s2 += g * ((yp[r] - pmu) * pis);
+                }
+            }
+        }
+        {
+            const int k2 = k + 2, k4 = k + 4;
+            if (k2 < nk) fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, tile_of(k2), dy, xr, rdz, ry, rarg, rx, cf);
+            fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
+        }
+        __builtin_amdgcn_s_setprio(0);
+        P2C_LDS_BARRIER();                         // the prefetch above stays in flight across this barrier
+    }
+    if (half == 0) P2C_LDS_BARRIER();
+    // ---------------- flush: half 1 hands its dW accumulators to half 0 through LDS (the tile buffers and W are dead
+    // now), half 0 adds them and issues ONE set of atomics per workgroup into the slot of its XCD (blockIdx % 8 is the
+    // XCD the dispatcher places the workgroup on, so the read-modify-writes stay inside one L2; the host sums the 8
+    // slots).  256 workgroups hammering one copy of dW cost ~50 us of serialized L2 atomics per launch.
+    __syncthreads();
+    {
+        float *ex = smem;                          // [COT*CIT*16][256] floats <= Co*Ci: fits in the W region for every shape
+        if (half == 1) {
+#pragma unroll
+            for (int i = 0; i < COT; ++i)
+#pragma unroll
+                for (int j = 0; j < CIT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ex[((i * CIT + j) * 16 + r) * 256 + tid] = accW[i][j][r];
+        }
+        __syncthreads();
+        if (half == 0) {
+            float *dws = a.dw + (size_t)(blockIdx.x & 7) * a.dw_slot_stride;
+#pragma unroll
+            for (int i = 0; i < COT; ++i)
+#pragma unroll
+                for (int j = 0; j < CIT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = wi * (COT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int ci = wj * (CIT * 32) + j * 32 + l31;
+                        atomicAdd(&dws[(size_t)co * a.lddw + ci], accW[i][j][r] + ex[((i * CIT + j) * 16 + r) * 256 + tid]);
+                    }
+        }
+    }
+    if (GMODE == 0 && a.dbias && tid < Co) atomicAdd(&a.dbias[tid], dbacc);
+    if (NEED_DX && HAS_STATS) {
+        if (threadIdx.x < 2 * Ci) red[threadIdx.x] = 0.f;
+        __syncthreads();
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (lh == 0) {
+            atomicAdd(&red[xcol], s1);
+            atomicAdd(&red[Ci + xcol], s2);
+        }
+        __syncthreads();
+        if (threadIdx.x < Ci) {
+            float *o = a.partials + (size_t)blockIdx.x * 2 * Ci;
+            o[threadIdx.x] = red[threadIdx.x];
+            o[Ci + threadIdx.x] = red[Ci + threadIdx.x];
         }
     }
 }
@@ -310,11 +541,18 @@ static int launch_fused(const BwdFusedArgs &a, hipStream_t s)
     constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
     const size_t lds = (size_t)(Co * (Ci + 4) + 2 * Co * (BM + 1) + 2 * BM * (Ci + 4) + 2 * Ci) * sizeof(float);
     const int grid = fused_grid(a.M, Ci);
+    static const bool pingpong = !(getenv("P2C_FUSED_PP") && atoi(getenv("P2C_FUSED_PP")) == 0);
 #define P2C_FL(DX_, ST_)                                                                                                             \
     do {                                                                                                                             \
-        (void)hipFuncSetAttribute((const void *)bwd_fused_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                  (int)lds);                                                                                         \
-        hipLaunchKernelGGL((bwd_fused_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>), dim3(grid), dim3(256), lds, s, a);                    \
+        if (pingpong) {                                                                                                              \
+            (void)hipFuncSetAttribute((const void *)bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
+            hipLaunchKernelGGL((bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>), dim3(grid), dim3(512), lds, s, a);             \
+        } else {                                                                                                                     \
+            (void)hipFuncSetAttribute((const void *)bwd_fused_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>,                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
+            hipLaunchKernelGGL((bwd_fused_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>), dim3(grid), dim3(256), lds, s, a);                \
+        }                                                                                                                            \
     } while (0)
     if (a.dx && a.pstat) P2C_FL(true, true);
     else if (a.dx) P2C_FL(true, false);
@@ -336,7 +574,8 @@ static int dispatch_shape(int Co, int Ci, const BwdFusedArgs &a, hipStream_t s)
 extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                                         const int32_t *pool_arg, int pool_ns, const float *X, int ldx, int in_mode, const float *in_scale,
                                         const float *in_shift, const float *W, int ldw, float *dX, int lddx, float *dW, int lddw,
-                                        float *dbias, const float *prev_stat, float *bwd_partials, int M, int Co, int Ci, void *stream)
+                                        long long dw_slot_stride, float *dbias, const float *prev_stat, float *bwd_partials, int M, int Co,
+                                        int Ci, void *stream)
 {
     if (!dZ || !X || !W || !dW || M <= 0 || grad_mode < 0 || grad_mode > 2) return P2C_EINVAL;
     if (!p2c_linear_bwd_fused_supported(Co, Ci, in_mode)) return P2C_EINVAL;
@@ -347,7 +586,7 @@ extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *
     if ((lddz & 3) || (ldx & 3) || (ldw & 3) || (grad_mode >= 1 && (ldy & 3)) || ((uintptr_t)dZ & 15) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return P2C_EALIGN;
     BwdFusedArgs a{dZ, lddz, Yfwd, ldy, coef, pool_arg, pool_ns, X, ldx, in_scale, in_shift, W, ldw, dX, lddx, dW, lddw, dbias, prev_stat,
-                   bwd_partials, M};
+                   bwd_partials, M, dw_slot_stride};
     hipStream_t s = (hipStream_t)stream;
 #define P2C_F(G_, I_) return dispatch_shape<G_, I_>(Co, Ci, a, s)
     if (grad_mode == 0) { if (in_mode == 0) P2C_F(0, 0); P2C_F(0, 1); }

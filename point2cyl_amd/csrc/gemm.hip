@@ -178,6 +178,7 @@ struct EpiBwdData {
 };
 struct EpiAtomic {
     float *dW; int lddw; float *dbias;
+    long long slot_stride;     // elements between the 8 copies of dW the split-k workgroups spread their atomics over (0: one copy)
 };
 
 template <int TM, int TN, bool AK, bool BK_, class OpA, class OpB, class Epi>
@@ -351,7 +352,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = i0 + wm * (TM * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * rquad;
-                    if (row < I && col < J) atomicAdd(&epi.dW[(size_t)row * epi.lddw + col], acc[ta][tb][r]);
+                    if (row < I && col < J) atomicAdd(&epi.dW[(size_t)(blockIdx.z & 7) * epi.slot_stride + (size_t)row * epi.lddw + col], acc[ta][tb][r]);
                 }
         }
         if (epi.dbias && blockIdx.y == 0 && tid < BM && i0 + tid < I) atomicAdd(&epi.dbias[i0 + tid], dbias_acc);
@@ -466,12 +467,13 @@ extern "C" int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Y
 template <int GMODE, int IMODE>
 static int launch_bwd_weight(const float *dZ, int lddz, const float *Yfwd, int ldy, const float *coef, const float *X, int ldx,
                              const float *in_scale, const float *in_shift, const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW,
-                             int lddw, float *dbias, int M, int N, int K, const int32_t *pool_arg, int pool_ns, hipStream_t s)
+                             int lddw, long long slot_stride, float *dbias, int M, int N, int K, const int32_t *pool_arg, int pool_ns,
+                             hipStream_t s)
 {
     // dW[N,K] += sum_m dY[m,N]^T act_in(X)[m,K]: GEMM with I=N (co), J=K (ci), reduction over the M rows
     OpGrad<GMODE> a{dZ, lddz, Yfwd, ldy, coef, N, pool_arg, pool_ns};
     OpActIn<IMODE> b{X, ldx, in_scale, in_shift, drop_mask, ldmask, drop_scale};
-    EpiAtomic e{dW, lddw, dbias};
+    EpiAtomic e{dW, lddw, dbias, slot_stride};
     const int ti = N > 64 ? p2c_cdiv(N, 128) : 1, tj = K > 64 ? p2c_cdiv(K, 128) : 1;
     const int ktiles = (M + GK - 1) / GK;
     int splits = 2048 / (ti * tj);
@@ -494,8 +496,9 @@ static int launch_bwd_weight(const float *dZ, int lddz, const float *Yfwd, int l
 
 extern "C" int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                                          const float *X, int ldx, int in_mode, const float *in_scale, const float *in_shift,
-                                         const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW, int lddw, float *dbias,
-                                         int M, int N, int K, const int32_t *pool_arg, int pool_ns, void *stream)
+                                         const uint8_t *drop_mask, int ldmask, float drop_scale, float *dW, int lddw,
+                                         long long dw_slot_stride, float *dbias, int M, int N, int K, const int32_t *pool_arg, int pool_ns,
+                                         void *stream)
 {
     if (!dZ || !X || !dW || M <= 0 || N <= 0 || K <= 0 || grad_mode < 0 || grad_mode > 2 || in_mode < 0 || in_mode > 3) return P2C_EINVAL;
     if (in_mode == 3) { if (!drop_mask) return P2C_EINVAL; ldmask = (int)p2c_drop_threshold(drop_scale); }
@@ -510,8 +513,8 @@ extern "C" int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float 
     if (in_mode >= 1) { P2C_REQ_ALIGNED(in_scale, 0); P2C_REQ_ALIGNED(in_shift, 0); }
     hipStream_t s = (hipStream_t)stream;
 #define P2C_DISPATCH(G_, I_)                                                                                                              \
-    return launch_bwd_weight<G_, I_>(dZ, lddz, Yfwd, ldy, coef, X, ldx, in_scale, in_shift, drop_mask, ldmask, drop_scale, dW, lddw, dbias, M, \
-                                     N, K, pool_arg, pool_ns, s)
+    return launch_bwd_weight<G_, I_>(dZ, lddz, Yfwd, ldy, coef, X, ldx, in_scale, in_shift, drop_mask, ldmask, drop_scale, dW, lddw,        \
+                                     dw_slot_stride, dbias, M, N, K, pool_arg, pool_ns, s)
     if (grad_mode == 0) {
         if (in_mode == 0) P2C_DISPATCH(0, 0);
         if (in_mode == 1) P2C_DISPATCH(0, 1);

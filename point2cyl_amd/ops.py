@@ -303,15 +303,21 @@ class _MLPStack(torch.autograd.Function):
             if USE_FUSED_BWD and mode <= 1 and M >= 4096 and L_.p2c_linear_bwd_fused_supported(Co, Ci, mode):
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev) if need_dx else None
                 part = torch.empty(L_.p2c_linear_bwd_fused_parts(M, Ci), 2, Ci, dtype=torch.float32, device=dev) if stats_below else None
+                dW8 = torch.zeros(8, Co, Ci, dtype=torch.float32, device=dev)     # one copy per XCD, summed below
                 call("p2c_linear_bwd_fused_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(arg) if grad_mode == 2 else None,
-                     pool_ns, ptr(Xin), ldxin, mode, ptr(sc), ptr(sh), ptr(W2), Ci, ptr(dX), Ci, ptr(dW), Ci,
+                     pool_ns, ptr(Xin), ldxin, mode, ptr(sc), ptr(sh), ptr(W2), Ci, ptr(dX), Ci, ptr(dW8), Ci, Co * Ci,
                      ptr(db) if grad_mode == 0 else None, ptr(aff[i - 1]) if stats_below else None, ptr(part), M, Co, Ci, stream(),
                      flops=(4.0 if need_dx else 2.0) * M * Co * Ci)
+                grads[p0] = dW8.sum(0)[:co_t, :ci_t].reshape(Wp.shape)
             else:
+                use_slots = M >= 65536       # many split-k workgroups: spread the atomics over 8 copies of dW
+                dWs = torch.zeros(8, Co, Ci, dtype=torch.float32, device=dev) if use_slots else dW
                 call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
-                     ptr(sh), mptr, mld, float(dscale), ptr(dW), Ci,
+                     ptr(sh), mptr, mld, float(dscale), ptr(dWs), Ci, Co * Ci if use_slots else 0,
                      ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
                      flops=2.0 * M * Co * Ci)
+                if use_slots:
+                    grads[p0] = dWs.sum(0)[:co_t, :ci_t].reshape(Wp.shape)
                 dX = part = None
                 if need_dx:
                     dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)

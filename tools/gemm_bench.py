@@ -44,7 +44,7 @@ def main():
         dX = torch.empty(M, K, device=dev)
         pstat = torch.rand(4, K, device=dev)
         partk = torch.empty(tiles, 2, K, device=dev)
-        dW = torch.zeros(N, K, device=dev)
+        dW = torch.zeros(N, K, device=dev); dW8 = torch.zeros(8, N, K, device=dev)
         fl = 2.0 * M * N * K
         res = []
         if which in ("fwd", "all"):
@@ -59,13 +59,13 @@ def main():
             res.append("bwd_data %7.1f us %6.1f TF %5.2f TB/s" % (t * 1e6, fl / t / 1e12, by / t / 1e12))
         if which in ("bwd_weight", "all"):
             t = timeit(lambda: call("p2c_linear_bwd_weight_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), ptr(X), K, 1, ptr(sc), ptr(sh), None, 0, 1.0,
-                                    ptr(dW), K, None, M, N, K, None, 0, stream()))
+                                    ptr(dW), K, 0, None, M, N, K, None, 0, stream()))
             by = 4.0 * M * (2 * N + K)
             res.append("bwd_w %7.1f us %6.1f TF %5.2f TB/s" % (t * 1e6, fl / t / 1e12, by / t / 1e12))
         if which in ("fused", "all") and L.p2c_linear_bwd_fused_supported(N, K, 1):
             parts = torch.empty(L.p2c_linear_bwd_fused_parts(M, K), 2, K, device=dev)
             t = timeit(lambda: call("p2c_linear_bwd_fused_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), None, 0, ptr(X), K, 1, ptr(sc), ptr(sh), ptr(W), K,
-                                    ptr(dX), K, ptr(dW), K, None, ptr(pstat), ptr(parts), M, N, K, stream()))
+                                    ptr(dX), K, ptr(dW8), K, N * K, None, ptr(pstat), ptr(parts), M, N, K, stream()))
             by = 4.0 * M * (2 * N + 2 * K)
             res.append("FUSED %7.1f us %6.1f TF %5.2f TB/s" % (t * 1e6, 2 * fl / t / 1e12, by / t / 1e12))
         print("%-6s M=%8d K=%4d N=%4d | %s" % (name, M, K, N, " | ".join(res)))

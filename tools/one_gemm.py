@@ -12,7 +12,7 @@ X = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.1; b = 
 Y = torch.empty(M, N, device=dev); sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
 tiles = L.p2c_linear_stat_tiles(M); part = torch.empty(tiles, 2, N, device=dev)
 dZ = torch.randn(M, N, device=dev); coef = torch.randn(5, N, device=dev); dX = torch.empty(M, K, device=dev)
-pstat = torch.rand(4, K, device=dev); partk = torch.empty(tiles, 2, K, device=dev); dW = torch.zeros(N, K, device=dev)
+pstat = torch.rand(4, K, device=dev); partk = torch.empty(tiles, 2, K, device=dev); dW = torch.zeros(N, K, device=dev); dW8 = torch.zeros(8, N, K, device=dev)
 for _ in range(it):
     if which == "fwd":
         call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, ptr(b), ptr(Y), N, M, N, K, 1, ptr(sc), ptr(sh), None, 0, 1.0, ptr(part), stream())
@@ -22,8 +22,8 @@ for _ in range(it):
     elif which == "fused":
         parts = torch.empty(L.p2c_linear_bwd_fused_parts(M, K), 2, K, device=dev)
         call("p2c_linear_bwd_fused_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), None, 0, ptr(X), K, 1, ptr(sc), ptr(sh), ptr(W), K, ptr(dX), K, ptr(dW), K,
-             None, ptr(pstat), ptr(parts), M, N, K, stream())
+             0, None, ptr(pstat), ptr(parts), M, N, K, stream())
     else:
-        call("p2c_linear_bwd_weight_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), ptr(X), K, 1, ptr(sc), ptr(sh), None, 0, 1.0, ptr(dW), K, None, M, N, K,
+        call("p2c_linear_bwd_weight_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), ptr(X), K, 1, ptr(sc), ptr(sh), None, 0, 1.0, ptr(dW), K, 0, None, M, N, K,
              None, 0, stream())
 torch.cuda.synchronize()

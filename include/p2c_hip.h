@@ -94,27 +94,29 @@ int p2c_three_interp_bwd_f32(const float *dout, int ldo, const int32_t *idx, con
  *              (backward-data: pass the same seed pointer as out_mask with ldmask = -1)
  * ------------------------------------------------------------------------------------------- */
 
+/* Per-channel reductions (BatchNorm sums forward and backward) are accumulated by the producing kernels with fp64
+ * atomics into P2C_STAT_SLOTS rows:  slots[s][0][c], slots[s][1][c]  (workgroup b adds into row b % 64); the
+ * caller zero-initialises p2c_stat_slots_bytes(C) bytes and hands the same buffer to the matching finalize call. */
+#define P2C_STAT_SLOTS 64
+size_t p2c_stat_slots_bytes(int C);
+
 /* Forward.  X [M,K] (ldx), W [N,K] row-major (ldw) = the conv weight (Co,Ci,1[,1]) as stored in the
- * reference's state_dict, bias [N] (may be NULL), Y [M,N] (ldy).  If stat_partials != NULL the kernel also
- * writes per-row-tile partial sums: stat_partials[tile][0][n] = sum_m y, [tile][1][n] = sum_m y*y with
- * tile = m / p2c_linear_tile_m(); size from p2c_linear_stat_tiles(M). */
+ * reference's state_dict, bias [N] (may be NULL), Y [M,N] (ldy).  If stat_slots != NULL the kernel also
+ * accumulates sum_m (y-bias) and sum_m (y-bias)^2 per output channel into it (see above). */
 int p2c_linear_tile_m(void);         /* row-tile height (64, or 128 with P2C_TILE_M=128 in the environment) */
 int p2c_linear_stat_tiles(int M);    /* ceil(M / p2c_linear_tile_m()) */
 int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
                        int K, int in_mode, const float *in_scale, const float *in_shift, const uint8_t *drop_mask,
-                       int ldmask, float drop_scale, float *stat_partials, void *stream);
+                       int ldmask, float drop_scale, double *stat_slots, void *stream);
 
-/* BatchNorm batch statistics -> affine.  training != 0: mean/var from the partials (biased var for the
+/* BatchNorm batch statistics -> affine.  training != 0: mean/var from the slots (biased var for the
  * normalisation, unbiased for running_var, torch semantics), running stats updated in place with
- * `momentum`; training == 0: affine from the running stats (stat_partials / ws unused).  ws: p2c_reduce_ws_bytes(C).  The partial sums are taken BEFORE the bias
+ * `momentum`; training == 0: affine from the running stats (stat_slots unused).  The sums are taken BEFORE the bias
  * add (better conditioned); `bias` (may be NULL) is added back to the mean here.  Outputs scale[c] = gamma*invstd,
  * shift[c] = beta - mean*scale, and mean / invstd (saved for backward). */
-int p2c_bn_finalize_f32(const float *stat_partials, int n_tiles, int C, long long count, const float *bias,
-                        const float *gamma, const float *beta, float eps, float momentum, int training,
-                        float *running_mean, float *running_var, float *scale, float *shift, float *mean,
-                        float *invstd, void *ws, void *stream);
-/* bytes of the fp64 scratch (`ws`) the per-channel reductions need for C channels */
-size_t p2c_reduce_ws_bytes(int C);
+int p2c_bn_finalize_f32(const double *stat_slots, int C, long long count, const float *bias, const float *gamma,
+                        const float *beta, float eps, float momentum, int training, float *running_mean, float *running_var,
+                        float *scale, float *shift, float *mean, float *invstd, void *stream);
 
 /* Z = relu(scale*Y + shift), materialised (only where a consumer needs the post-activation tensor) */
 int p2c_bn_relu_apply_f32(const float *Y, int ldy, const float *scale, const float *shift, int M, int C, float *Z, int ldz,
@@ -131,17 +133,16 @@ int p2c_maxpool_bwd_f32(const float *dout, int ldo, const int32_t *arg, int G, i
  *   g = dZ * [scale*Y+shift > 0],   s1 = sum g,   s2 = sum g * (Y-mean)*invstd
  * then step 2 (finalize): dgamma = s2, dbeta = s1 and the coefficients that let a GEMM rebuild
  *   dY = gs*g + q*Y + p      (gs = gamma*invstd, q = -gs*invstd*s2/M, p = -gs*s1/M - q*mean)
- * coef_out [5,C] = {scale, shift, gs, q, p}.  ws: p2c_bn_bwd_ws_bytes(M,C) bytes. */
-size_t p2c_bn_bwd_ws_bytes(int M, int C);
+ * coef_out [5,C] = {scale, shift, gs, q, p}.  slots: zeroed p2c_stat_slots_bytes(C) bytes. */
 int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float *Y, int ldy, const float *scale, const float *shift,
                               const float *mean, const float *invstd, const float *gamma, int M, int C, float *dgamma,
-                              float *dbeta, float *coef_out, void *ws, void *stream);
+                              float *dbeta, float *coef_out, double *slots, void *stream);
 
 /* The same reduction for the layer that feeds the max-pool, WITHOUT materialising dZ: the sums run over the
  * pooled gradient dout [G,C] and the winners' pre-BN values ywin [G,C] (from p2c_maxpool_bnrelu_f32) only.
- * stat = [scale|shift|mean|invstd] x C of that layer.  ws: p2c_bn_bwd_ws_bytes(G, C). */
+ * stat = [scale|shift|mean|invstd] x C of that layer.  slots: zeroed p2c_stat_slots_bytes(C) bytes. */
 int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const float *ywin, const float *stat, const float *gamma, int G,
-                                 int ns, int C, float *dgamma, float *dbeta, float *coef_out, void *ws, void *stream);
+                                 int ns, int C, float *dgamma, float *dbeta, float *coef_out, double *slots, void *stream);
 
 /* grad_mode 0: dY = G (the tensor passed as dZ is already dY; Yfwd/coef unused)
  * grad_mode 1: dY = gs*(dZ*[scale*Yfwd+shift>0]) + q*Yfwd + p   with coef [5,Co] from the stats call above
@@ -151,17 +152,16 @@ int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const float *ywin, 
 /* dX[m,ci] = sum_co dY[m,co] * W[co,ci]   (optionally multiplied by out_mask[m,ci]*out_mask_scale: the
  * dropout in front of the layer).  dX [M,K] (lddx).
  * Fused reduction for the layer BELOW (optional, bwd_partials != NULL): dX is that layer's dZ; with its saved
- * pre-BN output Yprev [M,K] and prev_stat = [scale|shift|mean|invstd] x K the epilogue also emits the per-tile
- * sums s1 = sum g, s2 = sum g*xhat (g = dX*[scale*Yprev+shift > 0]) into bwd_partials[tile][2][K],
- * tile = m / p2c_linear_tile_m(), to be finished by p2c_bn_bwd_finalize_f32. */
+ * pre-BN output Yprev [M,K] and prev_stat = [scale|shift|mean|invstd] x K the epilogue also accumulates
+ * s1 = sum g, s2 = sum g*xhat (g = dX*[scale*Yprev+shift > 0]) into the slots bwd_partials (zeroed,
+ * p2c_stat_slots_bytes(K)), to be finished by p2c_bn_bwd_finalize_f32. */
 int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                             const float *W, int ldw, float *dX, int lddx, int M, int N, int K, const uint8_t *out_mask,
                             int ldmask, float out_mask_scale, const float *Yprev, int ldyp, const float *prev_stat,
-                            float *bwd_partials, const int32_t *pool_arg, int pool_ns, void *stream);
-/* finish the fused reduction: dgamma, dbeta and coef [5,C] (see p2c_bn_relu_bwd_stats_f32).  stat = [scale|shift|mean|invstd] x C;
- * ws: p2c_reduce_ws_bytes(C). */
-int p2c_bn_bwd_finalize_f32(const float *partials, int n_tiles, int C, long long M, const float *stat, const float *gamma,
-                            float *dgamma, float *dbeta, float *coef_out, void *ws, void *stream);
+                            double *bwd_partials, const int32_t *pool_arg, int pool_ns, void *stream);
+/* finish the fused reduction: dgamma, dbeta and coef [5,C] (see p2c_bn_relu_bwd_stats_f32).  stat = [scale|shift|mean|invstd] x C */
+int p2c_bn_bwd_finalize_f32(const double *slots, int C, long long M, const float *stat, const float *gamma, float *dgamma,
+                            float *dbeta, float *coef_out, void *stream);
 
 /* dW[co,ci] += sum_m dY[m,co] * act_in(X)[m,ci];  dbias[co] += sum_m dY[m,co] (dbias may be NULL).
  * dW / dbias must be zero-initialised by the caller (the kernel splits the row range over workgroups and
@@ -176,7 +176,7 @@ int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int 
 /* One-pass backward of a narrow layer (Co, Ci in {64,128}; in_mode 0/1): dX, dW, dbias and the fused reduction
  * for the layer below from a single stream over (dZ, Yfwd, X) -- see csrc/bwd_fused.hip.  Same argument meaning as
  * the two entry points above; dX may be NULL (then prev_stat/bwd_partials must be NULL too).
- * bwd_partials [p2c_linear_bwd_fused_parts(M,Ci)][2][Ci]: one row per persistent workgroup.
+ * bwd_partials: the zeroed fp64 slots of the layer below (p2c_stat_slots_bytes(Ci)).
  * dW is accumulated into 8 copies (one per XCD, copy s at dW + s*dw_slot_stride elements, all zero-initialised by the
  * caller, who sums them); dw_slot_stride = 0 selects a single copy. */
 int p2c_linear_bwd_fused_supported(int Co, int Ci, int in_mode);
@@ -184,7 +184,7 @@ int p2c_linear_bwd_fused_parts(int M, int Ci);
 int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                              const int32_t *pool_arg, int pool_ns, const float *X, int ldx, int in_mode, const float *in_scale,
                              const float *in_shift, const float *W, int ldw, float *dX, int lddx, float *dW, int lddw,
-                             long long dw_slot_stride, float *dbias, const float *prev_stat, float *bwd_partials, int M, int Co,
+                             long long dw_slot_stride, float *dbias, const float *prev_stat, double *bwd_partials, int M, int Co,
                              int Ci, void *stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -29,8 +29,8 @@ _SIGS = {
     "p2c_three_interp_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_three_interp_bwd_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_linear_fwd_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p],
-    "p2c_bn_finalize_f32": [c_p, c_i, c_i, c_ll, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
-    "p2c_bn_bwd_finalize_f32": [c_p, c_i, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "p2c_bn_finalize_f32": [c_p, c_i, c_ll, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "p2c_bn_bwd_finalize_f32": [c_p, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_bn_relu_apply_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p],
     "p2c_maxpool_bnrelu_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p],
     "p2c_maxpool_bwd_f32": [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p],
@@ -76,15 +76,13 @@ def lib():
     L.p2c_build_arch.restype = ctypes.c_char_p
     L.p2c_linear_stat_tiles.argtypes = [c_i]
     L.p2c_linear_stat_tiles.restype = c_i
-    L.p2c_bn_bwd_ws_bytes.argtypes = [c_i, c_i]
-    L.p2c_bn_bwd_ws_bytes.restype = ctypes.c_size_t
+    L.p2c_stat_slots_bytes.argtypes = [c_i]
+    L.p2c_stat_slots_bytes.restype = ctypes.c_size_t
     L.p2c_linear_bwd_fused_supported.argtypes = [c_i, c_i, c_i]
     L.p2c_linear_bwd_fused_supported.restype = c_i
     L.p2c_linear_bwd_fused_parts.argtypes = [c_i, c_i]
     L.p2c_linear_bwd_fused_parts.restype = c_i
     L.p2c_linear_tile_m.restype = c_i
-    L.p2c_reduce_ws_bytes.argtypes = [c_i]
-    L.p2c_reduce_ws_bytes.restype = ctypes.c_size_t
     L.p2c_extents_ws_bytes.argtypes = [c_i, c_i]
     L.p2c_extents_ws_bytes.restype = ctypes.c_size_t
     _lib = L

@@ -10,53 +10,40 @@
 // Block = 64 channels x 16 tile-lanes, fp64 accumulation.  torch semantics: biased variance normalises,
 // unbiased variance feeds running_var; running = (1-momentum)*running + momentum*batch.
 // ------------------------------------------------------------------------------------------------
-// Stage 1 of every per-channel reduction: [T][2][C] fp32 tile partials -> [RED_SLICES][2][C] fp64.
-// grid (C/64, RED_SLICES), block = 64 channels x 16 tile-lanes.
-#define RED_SLICES 16
-__global__ void __launch_bounds__(1024) reduce_partials_kernel(const float *__restrict__ partials, int n_tiles, int C, double *__restrict__ out)
+// Sum the P2C_STAT_SLOTS fp64 rows of one channel with 4 threads (16 independent loads each), combined through LDS.
+// Block = 64 channels x 4 slot-lanes; returns the totals to the slot-lane-0 thread of each channel.
+__device__ __forceinline__ void p2c_sum_slots(const double *__restrict__ slots, int n_slots, int C, int c, bool active, double &s1, double &s2)
 {
-    __shared__ double red[2][16][64];
+    __shared__ double red[2][4][64];
     const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
-    const int per = (n_tiles + RED_SLICES - 1) / RED_SLICES;
-    const int t0 = blockIdx.y * per, t1 = min(n_tiles, t0 + per);
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int t = t0 + ty; t < t1; t += 16) {
-            s1 += (double)partials[(size_t)t * 2 * C + c];
-            s2 += (double)partials[(size_t)t * 2 * C + C + c];
+    double a = 0.0, b = 0.0;
+    if (active && c < C) {
+#pragma unroll 4
+        for (int t = ty; t < n_slots; t += 4) {
+            a += slots[(size_t)t * 2 * C + c];
+            b += slots[(size_t)t * 2 * C + C + c];
         }
-    red[0][ty][cx] = s1;
-    red[1][ty][cx] = s2;
-    __syncthreads();
-    if (ty == 0 && c < C) {
-        s1 = 0.0; s2 = 0.0;
-        for (int t = 0; t < 16; ++t) { s1 += red[0][t][cx]; s2 += red[1][t][cx]; }
-        out[(size_t)blockIdx.y * 2 * C + c] = s1;
-        out[(size_t)blockIdx.y * 2 * C + C + c] = s2;
     }
+    red[0][ty][cx] = a;
+    red[1][ty][cx] = b;
+    __syncthreads();
+    s1 = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
+    s2 = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
 }
 
-extern "C" size_t p2c_reduce_ws_bytes(int C) { return (size_t)RED_SLICES * 2 * (size_t)C * sizeof(double); }
-
-static void launch_reduce(const float *partials, int n_tiles, int C, double *ws, hipStream_t s)
-{
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(p2c_cdiv(C, 64), RED_SLICES), dim3(1024), 0, s, partials, n_tiles, C, ws);
-}
-
-__global__ void __launch_bounds__(64) bn_finalize_kernel(const double *__restrict__ partials, int n_tiles, int C, long long count,
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const double *__restrict__ partials, int n_tiles, int C, long long count,
                                                            const float *__restrict__ bias, const float *__restrict__ gamma,
                                                            const float *__restrict__ beta, float eps, float momentum, int training,
                                                            float *__restrict__ running_mean, float *__restrict__ running_var,
                                                            float *__restrict__ scale, float *__restrict__ shift,
                                                            float *__restrict__ mean_out, float *__restrict__ invstd_out)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     double s1 = 0.0, s2 = 0.0;
+    p2c_sum_slots(partials, n_tiles, C, c, training != 0, s1, s2);
+    if (c >= C || threadIdx.x >= 64) return;
     float mean, invstd;
     if (training) {
-        for (int t = 0; t < n_tiles; ++t) { s1 += partials[(size_t)t * 2 * C + c]; s2 += partials[(size_t)t * 2 * C + C + c]; }
         const double m0 = s1 / (double)count;
         double var = s2 / (double)count - m0 * m0;
         if (var < 0.0) var = 0.0;
@@ -79,17 +66,15 @@ __global__ void __launch_bounds__(64) bn_finalize_kernel(const double *__restric
     if (invstd_out) invstd_out[c] = invstd;
 }
 
-extern "C" int p2c_bn_finalize_f32(const float *stat_partials, int n_tiles, int C, long long count, const float *bias,
-                                   const float *gamma, const float *beta, float eps, float momentum, int training,
-                                   float *running_mean, float *running_var, float *scale, float *shift, float *mean,
-                                   float *invstd, void *ws, void *stream)
+extern "C" int p2c_bn_finalize_f32(const double *stat_slots, int C, long long count, const float *bias, const float *gamma,
+                                   const float *beta, float eps, float momentum, int training, float *running_mean, float *running_var,
+                                   float *scale, float *shift, float *mean, float *invstd, void *stream)
 {
     if (C <= 0 || !gamma || !beta || !scale || !shift) return P2C_EINVAL;
-    if (training && (!stat_partials || n_tiles <= 0 || count <= 0 || !ws)) return P2C_EINVAL;
+    if (training && (!stat_slots || count <= 0)) return P2C_EINVAL;
     if (!training && (!running_mean || !running_var)) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    if (training) launch_reduce(stat_partials, n_tiles, C, (double *)ws, s);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(64), 0, s, (const double *)ws, RED_SLICES, C, count, bias,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, stat_slots, P2C_STAT_SLOTS, C, count, bias,
                        gamma, beta, eps, momentum, training, running_mean, running_var, scale, shift, mean, invstd);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -191,7 +176,7 @@ extern "C" int p2c_maxpool_bwd_f32(const float *dout, int ldo, const int32_t *ar
 __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float *__restrict__ dZ, int lddz, const float *__restrict__ Y, int ldy,
                                                              const float *__restrict__ scale, const float *__restrict__ shift,
                                                              const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                             long long M, int C, float *__restrict__ ws)
+                                                             long long M, int C, double *__restrict__ ws)
 {
     __shared__ float red[2][4][64];
     const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -213,22 +198,22 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float *__rest
     red[1][ty][cx] = s2;
     __syncthreads();
     if (ty == 0 && c < C) {
-        float *o = ws + (size_t)blockIdx.x * 2 * C;
-        o[c] = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
-        o[C + c] = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+        double *o = ws + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * C;
+        atomicAdd(&o[c], (double)((red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx])));
+        atomicAdd(&o[C + c], (double)((red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx])));
     }
 }
 
-__global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double *__restrict__ ws, int n_chunks, int C, long long M,
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double *__restrict__ ws, int n_chunks, int C, long long M,
                                                              const float *__restrict__ scale, const float *__restrict__ shift,
                                                              const float *__restrict__ mean, const float *__restrict__ invstd,
                                                              const float *__restrict__ gamma, float *__restrict__ dgamma,
                                                              float *__restrict__ dbeta, float *__restrict__ coef)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     double s1 = 0.0, s2 = 0.0;
-    for (int t = 0; t < n_chunks; ++t) { s1 += ws[(size_t)t * 2 * C + c]; s2 += ws[(size_t)t * 2 * C + C + c]; }
+    p2c_sum_slots(ws, n_chunks, C, c, true, s1, s2);
+    if (c >= C || threadIdx.x >= 64) return;
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
     const double is = (double)invstd[c], gs = (double)gamma[c] * is;
@@ -244,7 +229,7 @@ __global__ void __launch_bounds__(64) bn_bwd_finalize_kernel(const double *__res
 // Same reduction when the layer feeds the max-pool: dZ is non-zero only at the winner rows, so the sums run over
 // the G x C pooled gradients (1/ns of the rows) and read Y at the winners only.
 __global__ void __launch_bounds__(256) pool_bwd_partial_kernel(const float *__restrict__ dout, int ldo, const float *__restrict__ ywin,
-                                                               const float *__restrict__ stat, int G, int C, float *__restrict__ ws)
+                                                               const float *__restrict__ stat, int G, int C, double *__restrict__ ws)
 {
     __shared__ float red[2][4][64];
     const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -264,40 +249,34 @@ __global__ void __launch_bounds__(256) pool_bwd_partial_kernel(const float *__re
     red[1][ty][cx] = s2;
     __syncthreads();
     if (ty == 0 && c < C) {
-        float *o = ws + (size_t)blockIdx.x * 2 * C;
-        o[c] = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
-        o[C + c] = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+        double *o = ws + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * C;
+        atomicAdd(&o[c], (double)((red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx])));
+        atomicAdd(&o[C + c], (double)((red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx])));
     }
 }
 
 extern "C" int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const float *ywin, const float *stat, const float *gamma, int G,
-                                            int ns, int C, float *dgamma, float *dbeta, float *coef_out, void *ws, void *stream)
+                                            int ns, int C, float *dgamma, float *dbeta, float *coef_out, double *slots, void *stream)
 {
-    if (!dout || !ywin || !stat || !gamma || !coef_out || !ws || G <= 0 || ns <= 0 || C <= 0) return P2C_EINVAL;
+    if (!dout || !ywin || !stat || !gamma || !coef_out || !slots || G <= 0 || ns <= 0 || C <= 0) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int chunks = p2c_cdiv(G, BWD_ROWS);
-    hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dout, ldo, ywin, stat, G, C, (float *)ws);
-    double *ws2 = (double *)((char *)ws + (((size_t)chunks * 2 * C * sizeof(float) + 63) & ~(size_t)63));
-    launch_reduce((const float *)ws, chunks, C, ws2, s);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(64), 0, s, (const double *)ws2, RED_SLICES, C,
+    hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dout, ldo, ywin, stat, G, C, slots);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, (const double *)slots, P2C_STAT_SLOTS, C,
                        (long long)G * ns, stat, stat + C, stat + 2 * C, stat + 3 * C, gamma, dgamma, dbeta, coef_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
 
-extern "C" size_t p2c_bn_bwd_ws_bytes(int M, int C)
-{
-    return (size_t)p2c_cdiv(M, BWD_ROWS) * 2 * (size_t)C * sizeof(float) + p2c_reduce_ws_bytes(C) + 64;
-}
+extern "C" size_t p2c_stat_slots_bytes(int C) { return (size_t)P2C_STAT_SLOTS * 2 * (size_t)C * sizeof(double); }
 
 // finalize from per-tile partials produced elsewhere (the fused backward-data epilogue): stat = [scale|shift|mean|invstd] x C
-extern "C" int p2c_bn_bwd_finalize_f32(const float *partials, int n_tiles, int C, long long M, const float *stat, const float *gamma,
-                                       float *dgamma, float *dbeta, float *coef_out, void *ws, void *stream)
+extern "C" int p2c_bn_bwd_finalize_f32(const double *slots, int C, long long M, const float *stat, const float *gamma, float *dgamma,
+                                       float *dbeta, float *coef_out, void *stream)
 {
-    if (!partials || !stat || !gamma || !coef_out || !ws || n_tiles <= 0 || C <= 0) return P2C_EINVAL;
+    if (!slots || !stat || !gamma || !coef_out || C <= 0) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    launch_reduce(partials, n_tiles, C, (double *)ws, s);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(64), 0, s, (const double *)ws, RED_SLICES, C, M, stat, stat + C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, slots, P2C_STAT_SLOTS, C, M, stat, stat + C,
                        stat + 2 * C, stat + 3 * C, gamma, dgamma, dbeta, coef_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -305,16 +284,14 @@ extern "C" int p2c_bn_bwd_finalize_f32(const float *partials, int n_tiles, int C
 
 extern "C" int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float *Y, int ldy, const float *scale, const float *shift,
                                          const float *mean, const float *invstd, const float *gamma, int M, int C, float *dgamma,
-                                         float *dbeta, float *coef_out, void *ws, void *stream)
+                                         float *dbeta, float *coef_out, double *slots, void *stream)
 {
-    if (!dZ || !Y || !scale || !shift || !mean || !invstd || !gamma || !coef_out || !ws || M <= 0 || C <= 0) return P2C_EINVAL;
+    if (!dZ || !Y || !scale || !shift || !mean || !invstd || !gamma || !coef_out || !slots || M <= 0 || C <= 0) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     const int chunks = p2c_cdiv(M, BWD_ROWS);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dZ, lddz, Y, ldy, scale, shift, mean, invstd,
-                       (long long)M, C, (float *)ws);
-    double *ws2 = (double *)((char *)ws + (((size_t)chunks * 2 * C * sizeof(float) + 63) & ~(size_t)63));
-    launch_reduce((const float *)ws, chunks, C, ws2, s);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(64), 0, s, (const double *)ws2, RED_SLICES, C, (long long)M, scale, shift,
+                       (long long)M, C, slots);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, (const double *)slots, P2C_STAT_SLOTS, C, (long long)M, scale, shift,
                        mean, invstd, gamma, dgamma, dbeta, coef_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;

@@ -41,7 +41,7 @@ struct BwdFusedArgs {
     float *dw; int lddw;                  // [Co,Ci], accumulated atomically
     float *dbias;                         // [Co] or NULL
     const float *pstat;                   // [4][Ci] of the layer below, or NULL
-    float *partials;                      // [gridDim.x][2][Ci]
+    double *partials;                     // [P2C_STAT_SLOTS][2][Ci] fp64 accumulators (atomic)
     int M;
     long long dw_slot_stride;        // elements between the 8 per-XCD copies of dW (0: a single copy)
 };
@@ -289,9 +289,9 @@ __global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
         }
         __syncthreads();
         if (tid < Ci) {
-            float *o = a.partials + (size_t)blockIdx.x * 2 * Ci;
-            o[tid] = red[tid];
-            o[Ci + tid] = red[Ci + tid];
+            double *o = a.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * Ci;
+            atomicAdd(&o[tid], (double)red[tid]);
+            atomicAdd(&o[Ci + tid], (double)red[Ci + tid]);
         }
     }
 }
@@ -514,9 +514,9 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         }
         __syncthreads();
         if (threadIdx.x < Ci) {
-            float *o = a.partials + (size_t)blockIdx.x * 2 * Ci;
-            o[threadIdx.x] = red[threadIdx.x];
-            o[Ci + threadIdx.x] = red[Ci + threadIdx.x];
+            double *o = a.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * Ci;
+            atomicAdd(&o[threadIdx.x], (double)red[threadIdx.x]);
+            atomicAdd(&o[Ci + threadIdx.x], (double)red[Ci + threadIdx.x]);
         }
     }
 }
@@ -574,7 +574,7 @@ static int dispatch_shape(int Co, int Ci, const BwdFusedArgs &a, hipStream_t s)
 extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                                         const int32_t *pool_arg, int pool_ns, const float *X, int ldx, int in_mode, const float *in_scale,
                                         const float *in_shift, const float *W, int ldw, float *dX, int lddx, float *dW, int lddw,
-                                        long long dw_slot_stride, float *dbias, const float *prev_stat, float *bwd_partials, int M, int Co,
+                                        long long dw_slot_stride, float *dbias, const float *prev_stat, double *bwd_partials, int M, int Co,
                                         int Ci, void *stream)
 {
     if (!dZ || !X || !W || !dW || M <= 0 || grad_mode < 0 || grad_mode > 2) return P2C_EINVAL;

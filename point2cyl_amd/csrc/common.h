@@ -5,6 +5,7 @@
 #include "../../include/p2c_hip.h"
 
 #define P2C_WAVE 64
+#define P2C_STAT_SLOTS 64   // fp64 accumulator rows every per-channel reduction is spread over (workgroup b -> row b % 64)
 
 #define P2C_LAUNCH_CHECK()                         \
     do {                                           \

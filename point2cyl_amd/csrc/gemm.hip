@@ -167,14 +167,14 @@ struct Tile {
 // Epilogues.  C/D fragment of mfma 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // ------------------------------------------------------------------------------------------------
 struct EpiFwd {
-    float *Y; int ldy; const float *bias; float *partials;   // partials[tile][2][N] or NULL
+    float *Y; int ldy; const float *bias; double *partials;  // [P2C_STAT_SLOTS][2][N] fp64 accumulators (atomic) or NULL
 };
 struct EpiBwdData {
     float *dX; int lddx; const uint8_t *mask; int ldmask; float mscale;   // ldmask < 0: hashed mask, mask -> seed[2], thr below
     uint32_t thr;
     // fused ReLU+BN-backward reduction of the layer BELOW (whose pre-BN output is Yp, same shape as dX):
     const float *Yp; int ldyp; const float *pstat;   // pstat [4][J]: scale, shift, mean, invstd
-    float *partials;                                 // [tile][2][J] or NULL
+    double *partials;                                // [P2C_STAT_SLOTS][2][J] fp64 accumulators (atomic) or NULL
 };
 struct EpiAtomic {
     float *dW; int lddw; float *dbias;
@@ -279,10 +279,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
         }
         if (epi.partials) {
             __syncthreads();
-            if (tid < BN && j0 + tid < J) {
-                float *o = epi.partials + (size_t)blockIdx.x * 2 * J;
-                o[j0 + tid] = sstat[tid];
-                o[J + j0 + tid] = sstat[BN + tid];
+            if (tid < BN && j0 + tid < J) {        // one fp64 atomic per column and workgroup into its slot
+                double *o = epi.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * J;
+                atomicAdd(&o[j0 + tid], (double)sstat[tid]);
+                atomicAdd(&o[J + j0 + tid], (double)sstat[BN + tid]);
             }
         }
     } else if constexpr (std::is_same<Epi, EpiBwdData>::value) {
@@ -337,10 +337,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
         }
         if (epi.partials) {
             __syncthreads();
-            if (tid < BN && j0 + tid < J) {
-                float *o = epi.partials + (size_t)blockIdx.x * 2 * J;
-                o[j0 + tid] = sstat[tid];
-                o[J + j0 + tid] = sstat[BN + tid];
+            if (tid < BN && j0 + tid < J) {        // one fp64 atomic per column and workgroup into its slot
+                double *o = epi.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * J;
+                atomicAdd(&o[j0 + tid], (double)sstat[tid]);
+                atomicAdd(&o[J + j0 + tid], (double)sstat[BN + tid]);
             }
         }
     } else {
@@ -382,7 +382,7 @@ extern "C" int p2c_linear_stat_tiles(int M) { return (M + tile_m() - 1) / tile_m
 template <int MODE>
 static int launch_fwd(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
                       const float *in_scale, const float *in_shift, const uint8_t *drop_mask, int ldmask, float drop_scale,
-                      float *stat_partials, hipStream_t s)
+                      double *stat_partials, hipStream_t s)
 {
     OpActIn<MODE> a{X, ldx, in_scale, in_shift, drop_mask, ldmask, drop_scale};
     OpPlain b{W, ldw};
@@ -400,7 +400,7 @@ static int launch_fwd(const float *X, int ldx, const float *W, int ldw, const fl
 
 extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
                                   int K, int in_mode, const float *in_scale, const float *in_shift, const uint8_t *drop_mask,
-                                  int ldmask, float drop_scale, float *stat_partials, void *stream)
+                                  int ldmask, float drop_scale, double *stat_partials, void *stream)
 {
     if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0 || in_mode < 0 || in_mode > 3) return P2C_EINVAL;
     if (in_mode >= 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
@@ -423,7 +423,7 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
 template <int GMODE>
 static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy, const float *coef, const float *W, int ldw, float *dX,
                            int lddx, int M, int N, int K, const uint8_t *out_mask, int ldmask, float out_mask_scale, const float *Yprev,
-                           int ldyp, const float *prev_stat, float *bwd_partials, const int32_t *pool_arg, int pool_ns, hipStream_t s)
+                           int ldyp, const float *prev_stat, double *bwd_partials, const int32_t *pool_arg, int pool_ns, hipStream_t s)
 {
     // layer: Y[M,N] = in[M,K] . W[N,K]^T ; here the GEMM is dX[M,K] = dY[M,N] . W[N,K]
     OpGrad<GMODE> a{dZ, lddz, Yfwd, ldy, coef, N, pool_arg, pool_ns};
@@ -443,7 +443,7 @@ static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy
 extern "C" int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
                                        const float *W, int ldw, float *dX, int lddx, int M, int N, int K, const uint8_t *out_mask,
                                        int ldmask, float out_mask_scale, const float *Yprev, int ldyp, const float *prev_stat,
-                                       float *bwd_partials, const int32_t *pool_arg, int pool_ns, void *stream)
+                                       double *bwd_partials, const int32_t *pool_arg, int pool_ns, void *stream)
 {
     if (!dZ || !W || !dX || M <= 0 || N <= 0 || K <= 0 || grad_mode < 0 || grad_mode > 2) return P2C_EINVAL;
     if (grad_mode >= 1 && (!Yfwd || !coef)) return P2C_EINVAL;

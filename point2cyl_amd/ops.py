@@ -130,8 +130,12 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
-def _red_ws(C, dev):
-    return torch.empty(_lib.lib().p2c_reduce_ws_bytes(C) // 8 + 8, dtype=torch.float64, device=dev)
+STAT_SLOTS = 64
+
+
+def _slots(C, dev):
+    """Zeroed fp64 accumulator rows for one per-channel reduction (see include/p2c_hip.h, P2C_STAT_SLOTS)."""
+    return torch.zeros(STAT_SLOTS, 2, C, dtype=torch.float64, device=dev)
 
 
 class _MLPStack(torch.autograd.Function):
@@ -176,10 +180,7 @@ class _MLPStack(torch.autograd.Function):
                     mode, mptr, mld = 2, ptr(mask), mask.stride(0)
                 elif seed is not None:
                     mode, mptr, mld = 3, ptr(seed), 0
-            partials = None
-            if has_bn and training:
-                tiles = _lib.lib().p2c_linear_stat_tiles(M)
-                partials = torch.empty(tiles, 2, Co, dtype=torch.float32, device=dev)
+            partials = _slots(Co, dev) if (has_bn and training) else None
             call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
                  mptr, mld, float(dscale), ptr(partials), stream(), flops=2.0 * M * Co * K)
             Ys.append(Y)
@@ -189,9 +190,9 @@ class _MLPStack(torch.autograd.Function):
                 pi += 2
                 bn = bns[i]
                 st = torch.empty(4, Co, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
-                call("p2c_bn_finalize_f32", ptr(partials), 0 if partials is None else partials.shape[0], Co, M, ptr(b), ptr(gamma),
+                call("p2c_bn_finalize_f32", ptr(partials), Co, M, ptr(b), ptr(gamma),
                      ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
-                     ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), ptr(_red_ws(Co, dev)) if training else None, stream())
+                     ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
                 if training and bn.nbt is not None:
                     bn.nbt += 1
                 aff.append(st)
@@ -244,9 +245,8 @@ class _MLPStack(torch.autograd.Function):
             coef = torch.empty(5, Co, dtype=torch.float32, device=dev)
             dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
             dbeta = torch.empty(Co, dtype=torch.float32, device=dev)
-            ws = torch.empty(_lib.lib().p2c_bn_bwd_ws_bytes(M, Co) // 4 + 4, dtype=torch.float32, device=dev)
             call("p2c_bn_relu_bwd_stats_f32", ptr(dZ), dZ.stride(0), ptr(Ys[i]), Co, ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]),
-                 ptr(params[p0 + 2]), M, Co, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(ws), stream())
+                 ptr(params[p0 + 2]), M, Co, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(_slots(Co, dev)), stream())
             grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
             return coef
 
@@ -259,9 +259,8 @@ class _MLPStack(torch.autograd.Function):
             coef = torch.empty(5, Cl, dtype=torch.float32, device=dev)
             dgamma = torch.empty(Cl, dtype=torch.float32, device=dev)
             dbeta = torch.empty(Cl, dtype=torch.float32, device=dev)
-            ws = torch.empty(_lib.lib().p2c_bn_bwd_ws_bytes(G, Cl) // 4 + 4, dtype=torch.float32, device=dev)
             call("p2c_maxpool_bn_bwd_stats_f32", ptr(dout), Cl, ptr(ywin), ptr(aff[-1]), ptr(params[p0 + 2]), G, pool_ns, Cl,
-                 ptr(dgamma), ptr(dbeta), ptr(coef), ptr(ws), stream())
+                 ptr(dgamma), ptr(dbeta), ptr(coef), ptr(_slots(Cl, dev)), stream())
             grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
         elif tail == "bnrelu":
             dZ = dout
@@ -302,7 +301,7 @@ class _MLPStack(torch.autograd.Function):
             L_ = _lib.lib()
             if USE_FUSED_BWD and mode <= 1 and M >= 4096 and L_.p2c_linear_bwd_fused_supported(Co, Ci, mode):
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev) if need_dx else None
-                part = torch.empty(L_.p2c_linear_bwd_fused_parts(M, Ci), 2, Ci, dtype=torch.float32, device=dev) if stats_below else None
+                part = _slots(Ci, dev) if stats_below else None
                 dW8 = torch.zeros(8, Co, Ci, dtype=torch.float32, device=dev)     # one copy per XCD, summed below
                 call("p2c_linear_bwd_fused_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(arg) if grad_mode == 2 else None,
                      pool_ns, ptr(Xin), ldxin, mode, ptr(sc), ptr(sh), ptr(W2), Ci, ptr(dX), Ci, ptr(dW8), Ci, Co * Ci,
@@ -321,7 +320,7 @@ class _MLPStack(torch.autograd.Function):
                 dX = part = None
                 if need_dx:
                     dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
-                    part = torch.empty(L_.p2c_linear_stat_tiles(M), 2, Ci, dtype=torch.float32, device=dev) if stats_below else None
+                    part = _slots(Ci, dev) if stats_below else None
                     call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(W2), Ci, ptr(dX), Ci, M, Co, Ci,
                          mptr, omld, float(dscale),
                          ptr(Ys[i - 1]) if stats_below else None, Ci, ptr(aff[i - 1]) if stats_below else None, ptr(part),
@@ -333,8 +332,8 @@ class _MLPStack(torch.autograd.Function):
                     coef = torch.empty(5, Ci, dtype=torch.float32, device=dev)
                     dgamma = torch.empty(Ci, dtype=torch.float32, device=dev)
                     dbeta = torch.empty(Ci, dtype=torch.float32, device=dev)
-                    call("p2c_bn_bwd_finalize_f32", ptr(part), part.shape[0], Ci, M, ptr(aff[i - 1]), ptr(params[q0 + 2]), ptr(dgamma),
-                         ptr(dbeta), ptr(coef), ptr(_red_ws(Ci, dev)), stream())
+                    call("p2c_bn_bwd_finalize_f32", ptr(part), Ci, M, ptr(aff[i - 1]), ptr(params[q0 + 2]), ptr(dgamma),
+                         ptr(dbeta), ptr(coef), stream())
                     grads[q0 + 2], grads[q0 + 3] = dgamma, dbeta
         dX0 = None
         if ctx.needs_input_grad[1]:

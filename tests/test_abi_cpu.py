@@ -29,7 +29,7 @@ def test_stat_tile_helper_matches_header():
     tm = L.p2c_linear_tile_m()
     assert tm in (64, 128)
     assert L.p2c_linear_stat_tiles(1) == 1 and L.p2c_linear_stat_tiles(tm + 1) == 2
-    assert L.p2c_bn_bwd_ws_bytes(1024, 64) > 0
+    assert L.p2c_stat_slots_bytes(64) == 64 * 2 * 64 * 8
 
 
 def test_bad_arguments_are_rejected_without_touching_the_device():

@@ -38,12 +38,12 @@ def main():
         Y = torch.empty(M, N, device=dev)
         sc, sh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
         tiles = L.p2c_linear_stat_tiles(M)
-        part = torch.empty(tiles, 2, N, device=dev)
+        part = torch.zeros(64, 2, N, device=dev, dtype=torch.float64)
         dZ = torch.randn(M, N, device=dev)
         coef = torch.randn(5, N, device=dev)
         dX = torch.empty(M, K, device=dev)
         pstat = torch.rand(4, K, device=dev)
-        partk = torch.empty(tiles, 2, K, device=dev)
+        partk = torch.zeros(64, 2, K, device=dev, dtype=torch.float64)
         dW = torch.zeros(N, K, device=dev); dW8 = torch.zeros(8, N, K, device=dev)
         fl = 2.0 * M * N * K
         res = []
@@ -63,7 +63,7 @@ def main():
             by = 4.0 * M * (2 * N + K)
             res.append("bwd_w %7.1f us %6.1f TF %5.2f TB/s" % (t * 1e6, fl / t / 1e12, by / t / 1e12))
         if which in ("fused", "all") and L.p2c_linear_bwd_fused_supported(N, K, 1):
-            parts = torch.empty(L.p2c_linear_bwd_fused_parts(M, K), 2, K, device=dev)
+            parts = torch.zeros(64, 2, K, device=dev, dtype=torch.float64)
             t = timeit(lambda: call("p2c_linear_bwd_fused_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), None, 0, ptr(X), K, 1, ptr(sc), ptr(sh), ptr(W), K,
                                     ptr(dX), K, ptr(dW8), K, N * K, None, ptr(pstat), ptr(parts), M, N, K, stream()))
             by = 4.0 * M * (2 * N + 2 * K)

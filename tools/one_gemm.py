@@ -10,9 +10,9 @@ dev = "cuda"
 L = _lib.lib()
 X = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.1; b = torch.randn(N, device=dev)
 Y = torch.empty(M, N, device=dev); sc = torch.rand(K, device=dev) + 0.5; sh = torch.randn(K, device=dev) * 0.1
-tiles = L.p2c_linear_stat_tiles(M); part = torch.empty(tiles, 2, N, device=dev)
+tiles = L.p2c_linear_stat_tiles(M); part = torch.zeros(64, 2, N, device=dev, dtype=torch.float64)
 dZ = torch.randn(M, N, device=dev); coef = torch.randn(5, N, device=dev); dX = torch.empty(M, K, device=dev)
-pstat = torch.rand(4, K, device=dev); partk = torch.empty(tiles, 2, K, device=dev); dW = torch.zeros(N, K, device=dev); dW8 = torch.zeros(8, N, K, device=dev)
+pstat = torch.rand(4, K, device=dev); partk = torch.zeros(64, 2, K, device=dev, dtype=torch.float64); dW = torch.zeros(N, K, device=dev); dW8 = torch.zeros(8, N, K, device=dev)
 for _ in range(it):
     if which == "fwd":
         call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, ptr(b), ptr(Y), N, M, N, K, 1, ptr(sc), ptr(sh), None, 0, 1.0, ptr(part), stream())
@@ -20,7 +20,7 @@ for _ in range(it):
         call("p2c_linear_bwd_data_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), ptr(W), K, ptr(dX), K, M, N, K, None, 0, 1.0, ptr(X), K, ptr(pstat),
              ptr(partk), None, 0, stream())
     elif which == "fused":
-        parts = torch.empty(L.p2c_linear_bwd_fused_parts(M, K), 2, K, device=dev)
+        parts = torch.zeros(64, 2, K, device=dev, dtype=torch.float64)
         call("p2c_linear_bwd_fused_f32", ptr(dZ), N, ptr(Y), N, 1, ptr(coef), None, 0, ptr(X), K, 1, ptr(sc), ptr(sh), ptr(W), K, ptr(dX), K, ptr(dW), K,
              0, None, ptr(pstat), ptr(parts), M, N, K, stream())
     else:

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_batch", type=int, default=2)
     ap.add_argument("--full_losses", action="store_true", help="configs[2]: + --pred_extrusion --pred_center")
+    ap.add_argument("--torch_losses", action="store_true", help="evaluate the losses with torch ops instead of csrc/loss.hip")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     args = ap.parse_args()
 
@@ -58,8 +59,10 @@ def main():
     sync = ddp.FlatGradSync(model.parameters(), world)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
 
+    loss_fn = step.compute_losses_fused if (step.fused_loss_applicable(fl) and not args.torch_losses) else step.compute_losses
+
     def fwd_bwd():
-        out = step.compute_losses(model, *batch, fl)
+        out = loss_fn(model, *batch, fl)
         sync.zero()
         out["total"].backward()
         return {"total": out["total"].detach()}

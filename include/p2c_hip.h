@@ -227,6 +227,20 @@ int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, const int64_t 
  * mask_out [B,K] uint8.  K <= 15. */
 int p2c_hungarian_f32(const float *W, const int64_t *I_gt, int B, int N, int K, int64_t *match_out, uint8_t *mask_out,
                       void *stream);
+/* same, from the raw head output [B*N, ld] whose 2K segmentation logits start at column woff: W = pairwise sums of
+ * softmax(logits) (train_Point2Cyl_without_sketch.py:254-265) formed on the fly */
+int p2c_hungarian_logits_f32(const float *heads, int ld, int woff, const int64_t *I_gt, int B, int N, int K, int64_t *match_out,
+                             uint8_t *mask_out, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The training losses fused (losses.py:90-143, :317-351 with collapse=True; train…:247-307):
+ * normal loss mean(1-|X.n_gt|), Hungarian-matched mIoU loss, base/barrel weighted cross-entropy, forward AND gradient
+ * w.r.t. the head output in two passes.  heads [B*N, ld]: normals at columns [xoff,xoff+3), 2K logits at [woff,woff+2K).
+ * out[4] = {total, normal, miou, bb}; dheads [B*N, ld] = d total / d heads.  ws: zeroed p2c_seg_losses_ws_bytes(B,K).  K == 8. */
+size_t p2c_seg_losses_ws_bytes(int B, int K);
+int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff, const float *normals_gt, const int64_t *I_gt,
+                       const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
+                       float w_normal, float w_bb, float *out, float *dheads, void *ws, void *stream);
 
 #ifdef __cplusplus
 }

@@ -49,6 +49,8 @@ _SIGS = {
     "p2c_segment_centroids_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "p2c_extrusion_extents_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_hungarian_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "p2c_hungarian_logits_f32": [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "p2c_seg_losses_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
 }
 
 
@@ -76,6 +78,8 @@ def lib():
     L.p2c_build_arch.restype = ctypes.c_char_p
     L.p2c_linear_stat_tiles.argtypes = [c_i]
     L.p2c_linear_stat_tiles.restype = c_i
+    L.p2c_seg_losses_ws_bytes.argtypes = [c_i, c_i]
+    L.p2c_seg_losses_ws_bytes.restype = ctypes.c_size_t
     L.p2c_stat_slots_bytes.argtypes = [c_i]
     L.p2c_stat_slots_bytes.restype = ctypes.c_size_t
     L.p2c_linear_bwd_fused_supported.argtypes = [c_i, c_i, c_i]

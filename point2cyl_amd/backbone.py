@@ -105,12 +105,14 @@ class PointNetFeaturePropagation(nn.Module):
             return torch.cat([feats1.reshape(B * N, -1), interp], 1)              # [skip | interpolated] :312
         return interp
 
-    def forward_pm(self, xyz1, xyz2, feats1, feats2, tail="bnrelu", extra_layers=(), drop_mask=None, drop_scale=1.0, drop_seed=None):
+    def forward_pm(self, xyz1, xyz2, feats1, feats2, tail="bnrelu", extra_layers=(), drop_mask=None, drop_scale=1.0, drop_seed=None,
+                   keep_padding=False):
         """xyz1 (B,N,3) dense, xyz2 (B,S,3) sparse, feats1 (B,N,D1)|None, feats2 (B,S,D2) -> (B,N,C')."""
         B, N, _ = xyz1.shape
         X0 = self._input_pm(xyz1, xyz2, feats1, feats2)
         layers = _layers(self.mlp_convs, self.mlp_bns) + list(extra_layers)
-        out = ops.mlp_stack(X0, X0.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed)
+        out = ops.mlp_stack(X0, X0.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
+                            keep_padding=keep_padding)
         return out.view(B, N, -1)
 
     def forward(self, xyz1, xyz2, points1, points2):
@@ -152,6 +154,17 @@ class backbone(nn.Module):
         self._drop_seed = None     # device int64 counter feeding the in-kernel dropout hash (advanced every forward)
 
     def forward(self, x):
+        heads, sizes = self.forward_heads(x)
+        B, N = x.shape[0], x.shape[1]
+        heads = heads.view(B, N, heads.shape[-1])
+        outs, o = [], 0
+        for s in sizes:
+            outs.append(heads[:, :, o:o + s])
+            o += s
+        return outs
+
+    def forward_heads(self, x):
+        """-> (heads (B*N, ld) with the outputs of all fc2 heads side by side, [o_0, o_1, ...])."""
         if not x.is_cuda:
             raise RuntimeError("point2cyl_amd.backbone runs on the HIP device only (got %s); there is no CPU path" % x.device)
         B, N, C = x.shape
@@ -184,9 +197,5 @@ class backbone(nn.Module):
                                      0.1 if self.bn1.momentum is None else self.bn1.momentum, self.bn1.eps)),
                  dict(W=Wh, b=bh, gamma=None, beta=None, bn=None)]
         heads = self.fp1.forward_pm(xyz, l1_xyz, feats0, l5, tail="linear", extra_layers=extra, drop_mask=mask, drop_scale=dscale,
-                                    drop_seed=seed)
-        outs, o = [], 0
-        for s in sizes:
-            outs.append(heads[:, :, o:o + s])
-            o += s
-        return outs
+                                    drop_seed=seed, keep_padding=True)
+        return heads.reshape(B * N, heads.shape[-1]), sizes

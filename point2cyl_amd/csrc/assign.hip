@@ -62,7 +62,10 @@ __device__ void p2c_lsa_min(const double *cost, int nr, int nc, int *col4row)
 // deterministic.  A second phase sums the G rows per (label, k) and lane 0 solves the assignment.
 #define HM_THREADS 1024
 
-__global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__restrict__ W, const int64_t *__restrict__ I_gt, int N, int K,
+// ld/woff/from_logits: W may be given as the raw head output (row stride ld, 2K logits starting at column woff); the
+// per-point softmax and the barrel+base pair sums W[k] = p[2k] + p[2k+1] (train…:254-265) are then formed on the fly.
+__global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__restrict__ W, int ld, int woff, int from_logits,
+                                                              const int64_t *__restrict__ I_gt, int N, int K,
                                                               int64_t *__restrict__ match_out, uint8_t *__restrict__ mask_out)
 {
     extern __shared__ float sacc[];                 // [HM_THREADS][2K+1] private rows: K label sums | column sum | K label counts
@@ -71,7 +74,7 @@ __global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__re
     __shared__ float tot[(HM_MAXK + 1) * HM_MAXK], cnt[HM_MAXK];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t *lab = I_gt + (size_t)b * N;
-    const float *w = W + (size_t)b * N * K;
+    const float *w = W + (size_t)b * N * ld;
     const int G = HM_THREADS / K, g = tid / K, k = tid - g * K;
     const int RS = 2 * K + 1;
     float *mine = sacc + (size_t)tid * RS;
@@ -81,7 +84,16 @@ __global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__re
         for (int n = g; n < N; n += G) {
             const int l = (int)lab[n];
             mx = max(mx, l);
-            const float v = w[(size_t)n * K + k];
+            float v;
+            if (from_logits) {
+                const float *l = w + (size_t)n * ld + woff;
+                float mx = -INFINITY, sum = 0.f;
+                for (int j = 0; j < 2 * K; ++j) mx = fmaxf(mx, l[j]);
+                for (int j = 0; j < 2 * K; ++j) sum += expf(l[j] - mx);
+                v = (expf(l[2 * k] - mx) + expf(l[2 * k + 1] - mx)) / sum;
+            } else {
+                v = w[(size_t)n * ld + k];
+            }
             mine[K] += v;
             if (l >= 0 && l < K) {
                 mine[l] += v;
@@ -132,7 +144,19 @@ extern "C" int p2c_hungarian_f32(const float *W, const int64_t *I_gt, int B, int
     if (!W || !I_gt || !match_out || !mask_out || B <= 0 || N <= 0 || K <= 0 || K > HM_MAXK) return P2C_EINVAL;
     const size_t lds = (size_t)HM_THREADS * (2 * K + 1) * sizeof(float);
     (void)hipFuncSetAttribute((const void *)hungarian_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(hungarian_kernel, dim3(B), dim3(HM_THREADS), lds, (hipStream_t)stream, W, I_gt, N, K, match_out, mask_out);
+    hipLaunchKernelGGL(hungarian_kernel, dim3(B), dim3(HM_THREADS), lds, (hipStream_t)stream, W, K, 0, 0, I_gt, N, K, match_out, mask_out);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// Same matching, taking the raw head output: rows of `ld` floats with the 2K segmentation logits at column `woff`.
+extern "C" int p2c_hungarian_logits_f32(const float *heads, int ld, int woff, const int64_t *I_gt, int B, int N, int K, int64_t *match_out,
+                                        uint8_t *mask_out, void *stream)
+{
+    if (!heads || !I_gt || !match_out || !mask_out || B <= 0 || N <= 0 || K <= 0 || K > HM_MAXK || ld < woff + 2 * K) return P2C_EINVAL;
+    const size_t lds = (size_t)HM_THREADS * (2 * K + 1) * sizeof(float);
+    (void)hipFuncSetAttribute((const void *)hungarian_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(hungarian_kernel, dim3(B), dim3(HM_THREADS), lds, (hipStream_t)stream, heads, ld, woff, 1, I_gt, N, K, match_out, mask_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

@@ -1,0 +1,227 @@
+// loss.hip -- the three training losses of Point2Cyl-without-sketch fused into two passes over the head output.
+//
+// The reference evaluates them as ~60 small torch ops (losses.py:90-143, :317-351; the base/barrel block inline in
+// train_Point2Cyl_without_sketch.py:283-307) on (B,N,2K) / (B,N,K) tensors.  Here the head output `heads`
+// [M = B*N, ld] (columns: 3 normal components, then 2K segmentation logits) is read twice:
+//   pass 1 (loss_reduce_kernel): per cloud, the sums every loss needs -- for the mIoU  dot[k] = sum_n 1[gt=k] Wr[n,k],
+//           sumW[k] = sum_n Wr[n,k], cnt[k] = sum_n 1[gt=k]  (Wr = W reordered by the Hungarian matching), the
+//           normal term sum_n (1 - |X.n_gt|) and the base/barrel term sum_n sum_k q_k ce_k;
+//   finalize (one small block): the three scalars and the per-(b,k) mIoU gradient coefficients;
+//   pass 2 (loss_grad_kernel): d total / d heads, written in the layout of `heads` (no slicing / cat kernels).
+// Per point (all in registers): p = softmax(logits[2K]); W[k] = p[2k] + p[2k+1] (:254-265); X = x/max(|x|,1e-12) (:247);
+// q = softmax_k(mask_k * W[match_k]) (:289-290); ce_k = logaddexp(l[2k], l[2k+1]) - l[2k + bb]  (:295-303, the reference
+// gathers the RAW logits of column k for the k-th reordered segment; sum_k ce_k*q_k does not depend on its sort).
+#include "common.h"
+
+#define LOSS_MAXK 8
+
+struct LossArgs {
+    const float *heads; int ld; int xoff; int woff;      // X at cols [xoff, xoff+3), logits at [woff, woff+2K)
+    const float *ngt;                                    // [M,3]
+    const int64_t *igt, *bbgt;                           // [M]
+    const int64_t *match; const uint8_t *mask;           // [B,K]
+    int B, N, K;
+    float w_seg, w_normal, w_bb;
+    double *acc;                                         // [B][3K+2] zeroed: dot[K] | sumW[K] | cnt[K] | normal | bb
+    float *out;                                          // [4]: total, normal, miou, bb
+    float *coef;                                         // [B][2K]: a_bk (on the gt point) | c_bk (on every point)
+    float *dheads;                                       // [M, ld]
+};
+
+struct PointEval {
+    float p[2 * LOSS_MAXK], W[LOSS_MAXK], q[LOSS_MAXK], ce[LOSS_MAXK], sb[LOSS_MAXK];   // sb = sigmoid-like P(barrel | pair k)
+    float X[3], inv_norm, cosv, bbsum;
+};
+
+template <int K>
+__device__ __forceinline__ void eval_point(const LossArgs &a, size_t m, int b, int bb, PointEval &e)
+{
+    const float *h = a.heads + m * a.ld;
+    float l[2 * K], mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 2 * K; ++j) { l[j] = h[a.woff + j]; mx = fmaxf(mx, l[j]); }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * K; ++j) { e.p[j] = expf(l[j] - mx); s += e.p[j]; }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int j = 0; j < 2 * K; ++j) e.p[j] *= inv;
+#pragma unroll
+    for (int k = 0; k < K; ++k) e.W[k] = e.p[2 * k] + e.p[2 * k + 1];
+    // q = softmax over k of mask_k * W[match_k]
+    float u[K], qs = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int mk = (int)a.match[b * K + k];
+        float wr = 0.f;
+#pragma unroll
+        for (int j = 0; j < K; ++j) wr = (j == mk) ? e.W[j] : wr;
+        u[k] = a.mask[b * K + k] ? wr : 0.f;
+        e.q[k] = expf(u[k] - 1.f);          // u in [0,1]: shift by the upper bound
+        qs += e.q[k];
+    }
+    const float qinv = 1.f / qs;
+    e.bbsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        e.q[k] *= qinv;
+        const float lb = l[2 * k], lc = l[2 * k + 1];
+        const float hi = fmaxf(lb, lc), lo = fminf(lb, lc);
+        const float lse = hi + log1pf(expf(lo - hi));
+        e.ce[k] = lse - (bb == 0 ? lb : lc);
+        e.sb[k] = expf(lb - lse);
+        e.bbsum += e.q[k] * e.ce[k];
+    }
+    const float x0 = h[a.xoff], x1 = h[a.xoff + 1], x2 = h[a.xoff + 2];
+    const float nrm = fmaxf(sqrtf(x0 * x0 + x1 * x1 + x2 * x2), 1e-12f);
+    e.inv_norm = 1.f / nrm;
+    e.X[0] = x0 * e.inv_norm; e.X[1] = x1 * e.inv_norm; e.X[2] = x2 * e.inv_norm;
+    const float *g = a.ngt + m * 3;
+    e.cosv = e.X[0] * g[0] + e.X[1] * g[1] + e.X[2] * g[2];
+}
+
+// ---- pass 1: block = 256 points of one cloud; per-wave shuffle reduce, then fp64 atomics per cloud ----------------
+template <int K>
+__global__ void __launch_bounds__(256) loss_reduce_kernel(LossArgs a)
+{
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    float acc[3 * K + 2];
+#pragma unroll
+    for (int i = 0; i < 3 * K + 2; ++i) acc[i] = 0.f;
+    if (n < a.N) {
+        const size_t m = (size_t)b * a.N + n;
+        const int lab = (int)a.igt[m], bb = (int)a.bbgt[m];
+        PointEval e;
+        eval_point<K>(a, m, b, bb, e);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int mk = (int)a.match[b * K + k];
+            float wr = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) wr = (j == mk) ? e.W[j] : wr;
+            acc[k] = (lab == k) ? wr : 0.f;
+            acc[K + k] = wr;
+            acc[2 * K + k] = (lab == k) ? 1.f : 0.f;
+        }
+        acc[3 * K] = 1.f - fabsf(e.cosv);
+        acc[3 * K + 1] = e.bbsum;
+    }
+    __shared__ float red[4][3 * K + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 3 * K + 2; ++i) {
+        const float v = p2c_wave_sum_f32(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * K + 2) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        atomicAdd(&a.acc[(size_t)b * (3 * K + 2) + threadIdx.x], (double)v);
+    }
+}
+
+// ---- finalize: one block, thread b handles cloud b ----------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256) loss_finalize_kernel(LossArgs a)
+{
+    __shared__ double sm[256], sn[256], sbb[256];
+    double miou = 0.0, nrm = 0.0, bbl = 0.0;
+    for (int b = threadIdx.x; b < a.B; b += 256) {
+        const double *c = a.acc + (size_t)b * (3 * K + 2);
+        int nv = 0;
+        for (int k = 0; k < K; ++k) nv += a.mask[b * K + k] ? 1 : 0;      // mask_gt == the matching mask (k < max(I_gt)+1)
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double dot = c[k], den = c[2 * K + k] + c[K + k] - dot + 1e-10;      // losses.py:99-101
+            const bool valid = a.mask[b * K + k] != 0;
+            if (valid) s += 1.0 - dot / den;
+            const double g = (valid && nv > 0) ? (double)a.w_seg / ((double)a.B * nv) : 0.0;
+            a.coef[(size_t)b * 2 * K + k] = (float)(-g * (den + dot) / (den * den));   // d/d dot  (through dot and den)
+            a.coef[(size_t)b * 2 * K + K + k] = (float)(g * dot / (den * den));        // d/d sumW
+        }
+        miou += nv > 0 ? s / nv : 0.0;
+        nrm += c[3 * K] / a.N;
+        bbl += c[3 * K + 1] / a.N;
+    }
+    sm[threadIdx.x] = miou; sn[threadIdx.x] = nrm; sbb[threadIdx.x] = bbl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = 0, n = 0, q = 0;
+        for (int i = 0; i < 256; ++i) { m += sm[i]; n += sn[i]; q += sbb[i]; }
+        m /= a.B; n /= a.B; q /= a.B;
+        a.out[1] = (float)n; a.out[2] = (float)m; a.out[3] = (float)q;
+        a.out[0] = (float)(a.w_seg * m + a.w_normal * n + a.w_bb * q);
+    }
+}
+
+// ---- pass 2: gradient w.r.t. the head output ------------------------------------------------------------------------
+template <int K>
+__global__ void __launch_bounds__(256) loss_grad_kernel(LossArgs a)
+{
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.N) return;
+    const size_t m = (size_t)b * a.N + n;
+    const int lab = (int)a.igt[m], bb = (int)a.bbgt[m];
+    PointEval e;
+    eval_point<K>(a, m, b, bb, e);
+    const float cpt = 1.f / ((float)a.B * (float)a.N);
+    // d total / d W[j]  (j = original column)
+    float dW[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) dW[j] = 0.f;
+    // base/barrel: dq_k = ce_k * c ; du_k = q_k (dq_k - sum_j q_j dq_j) ; dW[match_k] += mask_k du_k
+    const float cb = a.w_bb * cpt;
+    float qd = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) qd += e.q[k] * e.ce[k];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int mk = (int)a.match[b * K + k];
+        const float du = a.mask[b * K + k] ? cb * e.q[k] * (e.ce[k] - qd) : 0.f;
+        const float dmi = a.coef[(size_t)b * 2 * K + K + k] + ((lab == k) ? a.coef[(size_t)b * 2 * K + k] : 0.f);   // mIoU
+#pragma unroll
+        for (int j = 0; j < K; ++j) dW[j] += (j == mk) ? (du + dmi) : 0.f;
+    }
+    // softmax over the 2K logits: dp[2k] = dp[2k+1] = dW[k];  dl_j = p_j (dp_j - sum_i p_i dp_i)  + direct ce terms
+    float pd = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) pd += e.W[k] * dW[k];
+    float *o = a.dheads + m * a.ld;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float dce = cb * e.q[k];                       // d total / d ce_k
+        o[a.woff + 2 * k] = e.p[2 * k] * (dW[k] - pd) + dce * (e.sb[k] - (bb == 0 ? 1.f : 0.f));
+        o[a.woff + 2 * k + 1] = e.p[2 * k + 1] * (dW[k] - pd) + dce * ((1.f - e.sb[k]) - (bb == 0 ? 0.f : 1.f));
+    }
+    // normal: L = c (1 - |X.g|) ; dX = -c sign(X.g) g ; dx = (dX - (dX.X) X) / |x|
+    const float *g = a.ngt + m * 3;
+    const float cn = -a.w_normal * cpt * (e.cosv > 0.f ? 1.f : (e.cosv < 0.f ? -1.f : 0.f));
+    const float d0 = cn * g[0], d1 = cn * g[1], d2 = cn * g[2];
+    const float dd = d0 * e.X[0] + d1 * e.X[1] + d2 * e.X[2];
+    o[a.xoff + 0] = (d0 - dd * e.X[0]) * e.inv_norm;
+    o[a.xoff + 1] = (d1 - dd * e.X[1]) * e.inv_norm;
+    o[a.xoff + 2] = (d2 - dd * e.X[2]) * e.inv_norm;
+    for (int c = 0; c < a.ld; ++c)
+        if ((c < a.xoff || c >= a.xoff + 3) && (c < a.woff || c >= a.woff + 2 * K)) o[c] = 0.f;   // padding columns
+}
+
+extern "C" size_t p2c_seg_losses_ws_bytes(int B, int K) { return (size_t)B * (3 * K + 2) * sizeof(double) + (size_t)B * 2 * K * sizeof(float); }
+
+// losses.py:317-351 (compute_all_losses, collapse=True) + the base/barrel block of train…:283-307, forward AND gradient.
+// ws: zeroed p2c_seg_losses_ws_bytes(B,K).  out[4] = {total, normal, miou, bb}.  K must be 8.
+extern "C" int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff, const float *normals_gt, const int64_t *I_gt,
+                                  const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
+                                  float w_normal, float w_bb, float *out, float *dheads, void *ws, void *stream)
+{
+    if (!heads || !normals_gt || !I_gt || !bb_gt || !match || !mask || !out || !dheads || !ws || B <= 0 || N <= 0) return P2C_EINVAL;
+    if (K != LOSS_MAXK) return P2C_EINVAL;
+    LossArgs a{heads, ld, xoff, woff, normals_gt, I_gt, bb_gt, match, mask, B, N, K, w_seg, w_normal, w_bb, (double *)ws, out,
+               (float *)((char *)ws + (size_t)B * (3 * K + 2) * sizeof(double)), dheads};
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(p2c_cdiv(N, 256), B);
+    hipLaunchKernelGGL(loss_reduce_kernel<LOSS_MAXK>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_finalize_kernel<LOSS_MAXK>, dim3(1), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(loss_grad_kernel<LOSS_MAXK>, grid, dim3(256), 0, s, a);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

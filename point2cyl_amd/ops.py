@@ -345,7 +345,8 @@ class _MLPStack(torch.autograd.Function):
         return (None, dX0) + tuple(grads)
 
 
-def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mask=None, drop_scale=1.0, drop_seed=None):
+def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mask=None, drop_scale=1.0, drop_seed=None,
+              keep_padding=False):
     """layers: list of dicts {W, b, gamma, beta, bn: BNState} (gamma/beta/bn None for a BN-less last layer)."""
     params, bns = [], []
     for ly in layers:
@@ -357,7 +358,7 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
                drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed)
     out = _MLPStack.apply(cfg, X0, *params)
     co_last = layers[-1]["W"].shape[0]
-    if tail == "linear" and out.shape[1] != co_last:
+    if tail == "linear" and out.shape[1] != co_last and not keep_padding:
         out = out[:, :co_last]          # the kernels work on 4-padded channel counts
     return out
 
@@ -457,3 +458,37 @@ def hungarian(W, I_gt):
     mask = torch.empty(B, K, dtype=torch.uint8, device=W.device)
     call("p2c_hungarian_f32", ptr(W), ptr(I_gt), B, N, K, ptr(match), ptr(mask), stream())
     return match, mask.bool()
+
+
+class _SegLosses(torch.autograd.Function):
+    """total = w_seg*mIoU + w_normal*normal + w_bb*base/barrel on the raw head output (fused forward + gradient)."""
+
+    @staticmethod
+    def forward(ctx, heads, normals_gt, I_gt, bb_gt, B, N, K, xoff, woff, w_seg, w_normal, w_bb):
+        dev = heads.device
+        M, ld = heads.shape
+        assert heads.stride(0) == ld and heads.stride(1) == 1
+        I_gt, bb_gt = I_gt.to(torch.int64).contiguous(), bb_gt.to(torch.int64).contiguous()
+        match = torch.empty(B, K, dtype=torch.int64, device=dev)
+        mask = torch.empty(B, K, dtype=torch.uint8, device=dev)
+        hd = heads.detach()
+        call("p2c_hungarian_logits_f32", ptr(hd), ld, woff, ptr(I_gt), B, N, K, ptr(match), ptr(mask), stream())
+        out = torch.empty(4, dtype=torch.float32, device=dev)
+        dheads = torch.empty(M, ld, dtype=torch.float32, device=dev)
+        ws = torch.zeros(_lib.lib().p2c_seg_losses_ws_bytes(B, K) // 8 + 8, dtype=torch.float64, device=dev)
+        call("p2c_seg_losses_f32", ptr(hd), ld, xoff, woff, ptr(_f32c(normals_gt)), ptr(I_gt), ptr(bb_gt), ptr(match), ptr(mask), B, N, K,
+             float(w_seg), float(w_normal), float(w_bb), ptr(out), ptr(dheads), ptr(ws), stream())
+        ctx.save_for_backward(dheads)
+        ctx.mark_non_differentiable(match, mask)
+        return out, match, mask
+
+    @staticmethod
+    def backward(ctx, gout, gmatch, gmask):
+        (dheads,) = ctx.saved_tensors
+        return (dheads * gout[0],) + (None,) * 11      # only d/d total is propagated (the other three scalars are logging values)
+
+
+def seg_losses(heads, normals_gt, I_gt, bb_gt, B, N, K, xoff, woff, w_seg=1.0, w_normal=1.0, w_bb=1.0):
+    """-> (out[4] = total, normal, miou, bb ; matching_indices (B,K) int64 ; mask (B,K) bool)."""
+    out, match, mask = _SegLosses.apply(heads, normals_gt, I_gt, bb_gt, B, N, K, xoff, woff, w_seg, w_normal, w_bb)
+    return out, match, mask.bool()

@@ -54,6 +54,44 @@ def get_learning_rate(init_lr, global_step, batch_size, decay_step, decay_rate, 
     return init_lr * (decay_rate ** p)
 
 
+def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags):
+    """Same result as compute_losses for --pred_seg --pred_normal --pred_bb (K=8), with the head post-processing, the
+    Hungarian matching and the three losses (forward + gradient) in csrc/loss.hip instead of ~60 torch launches.
+    The optional extrusion-axis / centre terms are added on top from the same head output."""
+    from . import ops
+    B, N, _ = pcs.shape
+    K = fl.K
+    heads, sizes = model.forward_heads(pcs)
+    assert sizes == [3, 2 * K] and fl.pred_seg and fl.pred_normal and fl.pred_bb and K == 8
+    out4, match, mask = ops.seg_losses(heads, gt_normals, gt_inst, gt_bb, B, N, K, 0, 3, fl.weight_seg, fl.weight_normal, fl.weight_bb)
+    total = out4[0]
+    zero = torch.zeros((), device=pcs.device)
+    ext_loss = center_loss = zero
+    res = dict(normal=out4[1].detach(), miou=out4[2].detach(), bb=out4[3].detach(), match=match, mask=mask)
+    if fl.pred_extrusion or fl.pred_center:
+        h = heads.view(B, N, -1)
+        X = F.normalize(h[:, :, 0:3], p=2, dim=2, eps=1e-12)
+        W_2K = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2)
+        W_barrel, W_base = W_2K[:, :, 0::2], W_2K[:, :, 1::2]
+        mask_gt = losses.get_mask_gt(gt_inst, K)
+        if fl.pred_extrusion:
+            E_AX = fitting.estimate_extrusion_axis(X, losses._reorder(W_barrel, match), losses._reorder(W_base, match), gt_bb, gt_inst,
+                                                   normalize=fl.norm_eig)
+            ext = losses.compute_normal_loss(E_AX, gt_axes, angle_diff=False, collapse=False)
+            ext_loss = losses.reduce_mean_masked_instance(ext, mask_gt).mean() * fl.weight_extrusion
+        if fl.pred_center:
+            cen = fitting.estimate_extrusion_centers(losses._reorder(W_barrel + W_base, match), pcs)
+            diff = torch.square(cen - gt_centers).sum(dim=-1)
+            center_loss = losses.reduce_mean_masked_instance(diff, mask_gt).mean() * fl.weight_center
+        total = total + ext_loss + center_loss
+    res.update(total=total, ext=ext_loss, center=center_loss, heads=heads)
+    return res
+
+
+def fused_loss_applicable(fl: StepFlags):
+    return fl.pred_seg and fl.pred_normal and fl.pred_bb and fl.K == 8
+
+
 def compute_losses(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags):
     """Forward + all loss terms -> dict of scalars (tensors) incl. 'total'."""
     B, N, _ = pcs.shape
@@ -104,10 +142,11 @@ def compute_losses(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, 
                 match=match, mask=mask, X=X, W=W, W_raw=W_raw, X_head=X_head)
 
 
-def train_step(model, optimizer, batch, fl: StepFlags, sync_grads=None):
+def train_step(model, optimizer, batch, fl: StepFlags, sync_grads=None, fused=False):
     """batch = (pcs, normals, inst, bb, axes, centers) already on the device.  Returns the loss dict.
-    `sync_grads`, if given, is called between backward and optimizer.step (data-parallel all-reduce)."""
-    out = compute_losses(model, *batch, fl)
+    `sync_grads`, if given, is called between backward and optimizer.step (data-parallel all-reduce).
+    fused=True evaluates the losses with csrc/loss.hip when the flag set allows it."""
+    out = (compute_losses_fused if (fused and fused_loss_applicable(fl)) else compute_losses)(model, *batch, fl)
     optimizer.zero_grad(set_to_none=True)
     out["total"].backward()                                                     # :368
     if sync_grads is not None:

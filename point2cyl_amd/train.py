@@ -102,7 +102,7 @@ def main(argv=None):
                 for g in opt.param_groups:
                     g["lr"] = lr
                 old_lr = lr
-            out = step.compute_losses(model, *batch, fl)
+            out = (step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses)(model, *batch, fl)
             sync.zero()
             out["total"].backward()
             sync.allreduce()

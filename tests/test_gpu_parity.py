@@ -463,3 +463,41 @@ def test_hashed_dropout_consistency_and_rate():
     out2.backward(go)
     for a, b in zip(g_hash, [layers[0]["W"].grad, layers[1]["W"].grad, layers[0]["gamma"].grad]):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("full", [False, True])
+def test_fused_losses_match_the_torch_expressions(full):
+    """csrc/loss.hip (matching from logits + three losses + gradient w.r.t. the head output) == the torch mirror of
+    losses.py / train…:283-307, which test_losses_golden pins against the reference."""
+    g = load_golden("g6_losses")
+    B, N, K = 2, 1024, 8
+    heads = torch.zeros(B * N, 20)
+    heads[:, 0:3] = t(g["X"]).reshape(-1, 3) * (0.5 + torch.rand(B * N, 1, generator=torch.Generator().manual_seed(1)))   # un-normalised
+    heads[:, 3:19] = t(g["W_raw"]).reshape(-1, 16)
+    seg, bb, nrm = cu(g["seg"]), cu(g["bb"]), cu(g["normals"])
+    fl = step.StepFlags(pred_extrusion=full, pred_center=full, weight_seg=0.7, weight_normal=1.3, weight_bb=0.9)
+
+    class Head(torch.nn.Module):
+        def __init__(self, h):
+            super().__init__()
+            self.h = torch.nn.Parameter(h.to(DEV))
+
+        def forward_heads(self, x):
+            return self.h * 1.0, [3, 16]
+
+        def forward(self, x):
+            h = self.h.view(B, N, 20)
+            return [h[:, :, 0:3], h[:, :, 3:19]]
+
+    axes, cen = torch.randn(B, K, 3, device=DEV), torch.randn(B, K, 3, device=DEV) * 0.1
+    pcs = torch.rand(B, N, 3, device=DEV)
+    m1, m2 = Head(heads), Head(heads)
+    o1 = step.compute_losses(m1, pcs, nrm, seg, bb, axes, cen, fl)
+    o2 = step.compute_losses_fused(m2, pcs, nrm, seg, bb, axes, cen, fl)
+    assert torch.equal(o1["match"], o2["match"]) and torch.equal(o1["mask"], o2["mask"])
+    for k in ("total", "normal", "miou", "bb", "ext", "center"):
+        np.testing.assert_allclose(float(o2[k]), float(o1[k]), rtol=2e-5, atol=1e-7)
+    o1["total"].backward()
+    o2["total"].backward()
+    ref = m1.h.grad.cpu().numpy()
+    np.testing.assert_allclose(m2.h.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())

@@ -57,7 +57,7 @@ def main():
     ddp.broadcast_module(model)
     step.update_momentum(model, step.get_batch_norm_decay(0, B, 200000))
     sync = ddp.FlatGradSync(model.parameters(), world)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)     # same update rule as the reference's Adam, one kernel
 
     loss_fn = step.compute_losses_fused if (step.fused_loss_applicable(fl) and not args.torch_losses) else step.compute_losses
 

@@ -169,6 +169,7 @@ class backbone(nn.Module):
             raise RuntimeError("point2cyl_amd.backbone runs on the HIP device only (got %s); there is no CPU path" % x.device)
         B, N, C = x.shape
         x = x.float()
+        ops._DEFER_NBT[0] = True          # one multi-tensor "+= 1" for all 17 num_batches_tracked at the end
         xyz = x[:, :, :3].contiguous()
         feats0 = x[:, :, 3:].contiguous() if C > 3 else None
         l1_xyz, l1 = self.sa1.forward_pm(xyz, feats0)
@@ -198,4 +199,6 @@ class backbone(nn.Module):
                  dict(W=Wh, b=bh, gamma=None, beta=None, bn=None)]
         heads = self.fp1.forward_pm(xyz, l1_xyz, feats0, l5, tail="linear", extra_layers=extra, drop_mask=mask, drop_scale=dscale,
                                     drop_seed=seed, keep_padding=True)
+        ops._DEFER_NBT[0] = False
+        ops.flush_nbt()
         return heads.reshape(B * N, heads.shape[-1]), sizes

@@ -138,6 +138,79 @@ __global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__re
     }
 }
 
+// From-logits variant for K == 8: one thread per point slice; the point's softmax is evaluated ONCE (16 exps) and its
+// 8 pair sums W[k] are added to the (label, k) accumulators held in registers with compile-time-unrolled selects;
+// a wave-shuffle + LDS reduction yields the (K+1) x K sums and the K label counts.
+__global__ void __launch_bounds__(HM_THREADS) hungarian_logits8_kernel(const float *__restrict__ heads, int ld, int woff,
+                                                                      const int64_t *__restrict__ I_gt, int N,
+                                                                      int64_t *__restrict__ match_out, uint8_t *__restrict__ mask_out)
+{
+    constexpr int K = 8, NA = (K + 1) * K + K;          // 72 sums + 8 counts
+    __shared__ float red[HM_THREADS / 64][NA];
+    __shared__ int smax[HM_THREADS / 64];
+    __shared__ double cost[HM_MAXK * HM_MAXK];
+    __shared__ float tot[NA];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t *lab = I_gt + (size_t)b * N;
+    const float *h = heads + (size_t)b * N * ld + woff;
+    float acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    int mx = -1;
+    for (int n = tid; n < N; n += HM_THREADS) {
+        const int l = (int)lab[n];
+        mx = max(mx, l);
+        const float *lg = h + (size_t)n * ld;
+        float e[2 * K], m = -INFINITY, sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2 * K; ++j) { e[j] = lg[j]; m = fmaxf(m, e[j]); }
+#pragma unroll
+        for (int j = 0; j < 2 * K; ++j) { e[j] = expf(e[j] - m); sum += e[j]; }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float w = (e[2 * k] + e[2 * k + 1]) * inv;
+            acc[K * K + k] += w;                                   // column sum
+#pragma unroll
+            for (int r = 0; r < K; ++r) acc[r * K + k] += (l == r) ? w : 0.f;
+        }
+#pragma unroll
+        for (int r = 0; r < K; ++r) acc[(K + 1) * K + r] += (l == r) ? 1.f : 0.f;
+    }
+    mx = p2c_wave_max_i32(mx);
+    if (lane == 0) smax[wave] = mx;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const float v = p2c_wave_sum_f32(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (tid < NA) {
+        float s = 0.f;
+        for (int w = 0; w < HM_THREADS / 64; ++w) s += red[w][tid];
+        tot[tid] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n_gt = -1;
+        for (int i = 0; i < HM_THREADS / 64; ++i) n_gt = max(n_gt, smax[i]);
+        n_gt += 1;
+        const int nr = min(n_gt, K);
+        for (int r = 0; r < nr; ++r)
+            for (int q = 0; q < K; ++q) {
+                const float dot = tot[r * K + q], col = tot[K * K + q], rc = tot[(K + 1) * K + r];
+                const float den = (rc + col) - dot;
+                cost[r * K + q] = -(double)(dot / fmaxf(den, 1e-10f));
+            }
+        int col4row[HM_MAXK + 1];
+        if (nr > 0) p2c_lsa_min(cost, nr, K, col4row);
+        for (int q = 0; q < K; ++q) {
+            match_out[(size_t)b * K + q] = q < nr ? (int64_t)col4row[q] : 0;
+            mask_out[(size_t)b * K + q] = q < nr ? 1 : 0;
+        }
+    }
+}
+
 extern "C" int p2c_hungarian_f32(const float *W, const int64_t *I_gt, int B, int N, int K, int64_t *match_out, uint8_t *mask_out,
                                  void *stream)
 {
@@ -154,6 +227,11 @@ extern "C" int p2c_hungarian_logits_f32(const float *heads, int ld, int woff, co
                                         uint8_t *mask_out, void *stream)
 {
     if (!heads || !I_gt || !match_out || !mask_out || B <= 0 || N <= 0 || K <= 0 || K > HM_MAXK || ld < woff + 2 * K) return P2C_EINVAL;
+    if (K == 8) {
+        hipLaunchKernelGGL(hungarian_logits8_kernel, dim3(B), dim3(HM_THREADS), 0, (hipStream_t)stream, heads, ld, woff, I_gt, N, match_out, mask_out);
+        P2C_LAUNCH_CHECK();
+        return P2C_OK;
+    }
     const size_t lds = (size_t)HM_THREADS * (2 * K + 1) * sizeof(float);
     (void)hipFuncSetAttribute((const void *)hungarian_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(hungarian_kernel, dim3(B), dim3(HM_THREADS), lds, (hipStream_t)stream, heads, ld, woff, 1, I_gt, N, K, match_out, mask_out);

@@ -12,6 +12,7 @@ from . import _lib
 from ._lib import PROFILE, call, ptr, stream  # noqa: F401
 
 I32 = torch.int32
+PENDING_NBT = []      # num_batches_tracked counters to bump with ONE foreach add per forward (see backbone.forward)
 USE_FUSED_BWD = os.environ.get("P2C_FUSED_BWD", "1") != "0"
 
 
@@ -118,6 +119,16 @@ def three_interpolate(feats, idx, w):
 
 
 # ------------------------------------------------------------------------------------------ MLP stack
+_DEFER_NBT = [False]
+
+
+def flush_nbt():
+    """num_batches_tracked += 1 for every BatchNorm touched since the last flush, as one multi-tensor add."""
+    if PENDING_NBT:
+        torch._foreach_add_(PENDING_NBT, 1)
+        del PENDING_NBT[:]
+
+
 class BNState:
     """Per-layer BatchNorm buffers handed to the stack (updated in place by the finalize kernel)."""
 
@@ -130,12 +141,47 @@ def _pad4(n):
     return (n + 3) // 4 * 4
 
 
+def _weight_slots(L, tail):
+    """Indices of the weight tensors in the flat params list [W,b,(gamma,beta)]*."""
+    out, pi = [], 0
+    for i in range(L):
+        out.append(pi)
+        pi += 2 if (tail == "linear" and i == L - 1) else 4
+    return out
+
+
 STAT_SLOTS = 64
 
 
 def _slots(C, dev):
     """Zeroed fp64 accumulator rows for one per-channel reduction (see include/p2c_hip.h, P2C_STAT_SLOTS)."""
     return torch.zeros(STAT_SLOTS, 2, C, dtype=torch.float64, device=dev)
+
+
+class _ZeroArena:
+    """One zero-filled allocation carved into the many small accumulators a stack needs (fp64 stat slots, the 8
+    per-XCD copies of each dW, bias gradients): one fill kernel instead of dozens."""
+
+    def __init__(self, n_f64, dev):
+        self.buf = torch.zeros(n_f64, dtype=torch.float64, device=dev)
+        self.off = 0
+
+    def f64(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        out = self.buf[self.off:self.off + n].view(*shape)
+        self.off += n
+        return out
+
+    def f32(self, *shape):
+        n = 1
+        for d in shape:
+            n *= d
+        n64 = (n + 1) // 2
+        out = self.buf[self.off:self.off + n64].view(torch.float32)[:n].view(*shape)
+        self.off += n64
+        return out
 
 
 class _MLPStack(torch.autograd.Function):
@@ -162,6 +208,10 @@ class _MLPStack(torch.autograd.Function):
         Ys, aff, Ws = [], [], []
         X, ldx, in_mode, sc, sh = X0, ldx0, 0, None, None
         pi = 0
+        arena = None
+        if training:
+            widths = [_pad4(params[j].shape[0]) for j in _weight_slots(L, tail)]
+            arena = _ZeroArena(sum(STAT_SLOTS * 2 * c for c in widths), dev)
         for i in range(L):
             has_bn = not (tail == "linear" and i == L - 1)
             W, b = params[pi], params[pi + 1]
@@ -180,7 +230,7 @@ class _MLPStack(torch.autograd.Function):
                     mode, mptr, mld = 2, ptr(mask), mask.stride(0)
                 elif seed is not None:
                     mode, mptr, mld = 3, ptr(seed), 0
-            partials = _slots(Co, dev) if (has_bn and training) else None
+            partials = arena.f64(STAT_SLOTS, 2, Co) if (has_bn and training) else None
             call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
                  mptr, mld, float(dscale), ptr(partials), stream(), flops=2.0 * M * Co * K)
             Ys.append(Y)
@@ -194,7 +244,7 @@ class _MLPStack(torch.autograd.Function):
                      ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
                      ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
                 if training and bn.nbt is not None:
-                    bn.nbt += 1
+                    PENDING_NBT.append(bn.nbt)
                 aff.append(st)
                 sc, sh, in_mode = st[0], st[1], 1
             else:
@@ -232,6 +282,10 @@ class _MLPStack(torch.autograd.Function):
         dout = _f32c(dout)
         Cl = Ys[-1].shape[1]
         grads = [None] * len(params)
+        n64 = 0
+        for W2 in Ws:       # per layer: 8 dW copies + dW + dbias (fp32) and two sets of fp64 stat slots (own top-of-stack + layer below)
+            n64 += (9 * W2.shape[0] * W2.shape[1] + W2.shape[0]) // 2 + 8 + STAT_SLOTS * 2 * (W2.shape[0] + W2.shape[1])
+        arena = _ZeroArena(n64, dev)
         slots, pi = [], 0
         for i in range(L):
             has_bn = not (tail == "linear" and i == L - 1)
@@ -246,7 +300,7 @@ class _MLPStack(torch.autograd.Function):
             dgamma = torch.empty(Co, dtype=torch.float32, device=dev)
             dbeta = torch.empty(Co, dtype=torch.float32, device=dev)
             call("p2c_bn_relu_bwd_stats_f32", ptr(dZ), dZ.stride(0), ptr(Ys[i]), Co, ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]),
-                 ptr(params[p0 + 2]), M, Co, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(_slots(Co, dev)), stream())
+                 ptr(params[p0 + 2]), M, Co, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(arena.f64(STAT_SLOTS, 2, Co)), stream())
             grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
             return coef
 
@@ -260,7 +314,7 @@ class _MLPStack(torch.autograd.Function):
             dgamma = torch.empty(Cl, dtype=torch.float32, device=dev)
             dbeta = torch.empty(Cl, dtype=torch.float32, device=dev)
             call("p2c_maxpool_bn_bwd_stats_f32", ptr(dout), Cl, ptr(ywin), ptr(aff[-1]), ptr(params[p0 + 2]), G, pool_ns, Cl,
-                 ptr(dgamma), ptr(dbeta), ptr(coef), ptr(_slots(Cl, dev)), stream())
+                 ptr(dgamma), ptr(dbeta), ptr(coef), ptr(arena.f64(STAT_SLOTS, 2, Cl)), stream())
             grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
         elif tail == "bnrelu":
             dZ = dout
@@ -269,11 +323,6 @@ class _MLPStack(torch.autograd.Function):
             dZ, grad_mode, coef = dout, 0, None
             if dZ.shape[1] != Cl:
                 dZ = torch.nn.functional.pad(dZ, (0, Cl - dZ.shape[1]))
-        zoff, ztot = [], 0
-        for W2 in Ws:
-            zoff.append(ztot)
-            ztot += (W2.shape[0] * W2.shape[1] + W2.shape[0] + 3) // 4 * 4
-        zbuf = torch.zeros(ztot, dtype=torch.float32, device=dev)
         for i in range(L - 1, -1, -1):
             p0, has_bn = slots[i]
             Y, W2 = Ys[i], Ws[i]
@@ -289,9 +338,9 @@ class _MLPStack(torch.autograd.Function):
                 elif seed is not None:
                     mode, mptr, mld, omld = 3, ptr(seed), 0, -1
             # one zero-fill for all weight/bias gradients of the stack (they are accumulated with atomics)
-            dW = zbuf[zoff[i]: zoff[i] + Co * Ci].view(Co, Ci)
+            dW = arena.f32(Co, Ci)
             # a conv bias in front of a train-mode BatchNorm has an exactly zero gradient (the batch mean absorbs it)
-            db = zbuf[zoff[i] + Co * Ci: zoff[i] + Co * Ci + Co]
+            db = arena.f32(Co)
             Wp = params[p0]
             co_t, ci_t = Wp.shape[0], Wp.numel() // Wp.shape[0]
             grads[p0] = dW[:co_t, :ci_t].reshape(Wp.shape)
@@ -301,8 +350,8 @@ class _MLPStack(torch.autograd.Function):
             L_ = _lib.lib()
             if USE_FUSED_BWD and mode <= 1 and M >= 4096 and L_.p2c_linear_bwd_fused_supported(Co, Ci, mode):
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev) if need_dx else None
-                part = _slots(Ci, dev) if stats_below else None
-                dW8 = torch.zeros(8, Co, Ci, dtype=torch.float32, device=dev)     # one copy per XCD, summed below
+                part = arena.f64(STAT_SLOTS, 2, Ci) if stats_below else None
+                dW8 = arena.f32(8, Co, Ci)     # one copy per XCD, summed below
                 call("p2c_linear_bwd_fused_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(arg) if grad_mode == 2 else None,
                      pool_ns, ptr(Xin), ldxin, mode, ptr(sc), ptr(sh), ptr(W2), Ci, ptr(dX), Ci, ptr(dW8), Ci, Co * Ci,
                      ptr(db) if grad_mode == 0 else None, ptr(aff[i - 1]) if stats_below else None, ptr(part), M, Co, Ci, stream(),
@@ -310,7 +359,7 @@ class _MLPStack(torch.autograd.Function):
                 grads[p0] = dW8.sum(0)[:co_t, :ci_t].reshape(Wp.shape)
             else:
                 use_slots = M >= 65536       # many split-k workgroups: spread the atomics over 8 copies of dW
-                dWs = torch.zeros(8, Co, Ci, dtype=torch.float32, device=dev) if use_slots else dW
+                dWs = arena.f32(8, Co, Ci) if use_slots else dW
                 call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
                      ptr(sh), mptr, mld, float(dscale), ptr(dWs), Ci, Co * Ci if use_slots else 0,
                      ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
@@ -320,7 +369,7 @@ class _MLPStack(torch.autograd.Function):
                 dX = part = None
                 if need_dx:
                     dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
-                    part = _slots(Ci, dev) if stats_below else None
+                    part = arena.f64(STAT_SLOTS, 2, Ci) if stats_below else None
                     call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(W2), Ci, ptr(dX), Ci, M, Co, Ci,
                          mptr, omld, float(dscale),
                          ptr(Ys[i - 1]) if stats_below else None, Ci, ptr(aff[i - 1]) if stats_below else None, ptr(part),
@@ -357,6 +406,8 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
     cfg = dict(in_channels=in_channels, n_layers=len(layers), tail=tail, training=training, bns=bns, G=G, ns=ns,
                drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed)
     out = _MLPStack.apply(cfg, X0, *params)
+    if not _DEFER_NBT[0]:
+        flush_nbt()
     co_last = layers[-1]["W"].shape[0]
     if tail == "linear" and out.shape[1] != co_last and not keep_padding:
         out = out[:, :co_last]          # the kernels work on 4-padded channel counts

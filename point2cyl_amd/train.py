@@ -75,7 +75,7 @@ def main(argv=None):
     loader = torch.utils.data.DataLoader(ds, batch_size=a.batch_size, num_workers=0, pin_memory=True, shuffle=sampler is None, sampler=sampler)
     model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
     ddp.broadcast_module(model)
-    opt = torch.optim.Adam(model.parameters(), lr=a.learning_rate)
+    opt = torch.optim.Adam(model.parameters(), lr=a.learning_rate, fused=True)    # train…:204, single multi-tensor kernel
     sync = ddp.FlatGradSync(model.parameters(), world)
     if rank == 0:
         os.makedirs(a.logdir, exist_ok=True)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--cpu_batch", type=int, default=2)
     ap.add_argument("--full_losses", action="store_true", help="configs[2]: + --pred_extrusion --pred_center")
     ap.add_argument("--torch_losses", action="store_true", help="evaluate the losses with torch ops instead of csrc/loss.hip")
+    ap.add_argument("--no_prefetch", action="store_true", help="compute FPS/ball-query/3-NN inline instead of one step ahead on a side stream")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     args = ap.parse_args()
 
@@ -61,8 +62,8 @@ def main():
 
     loss_fn = step.compute_losses_fused if (step.fused_loss_applicable(fl) and not args.torch_losses) else step.compute_losses
 
-    def fwd_bwd():
-        out = loss_fn(model, *batch, fl)
+    def fwd_bwd(geom=None):
+        out = loss_fn(model, *batch, fl, geom=geom)
         sync.zero()
         out["total"].backward()
         return {"total": out["total"].detach()}
@@ -71,7 +72,7 @@ def main():
     if not args.no_graph:
         from point2cyl_amd.graph import GraphedForwardBackward
         try:
-            graphed = GraphedForwardBackward(model, fwd_bwd)
+            graphed = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=None if args.no_prefetch else batch[0])
         except Exception as e:      # keep the bench alive: fall back to eager launches
             sys.stderr.write("bench: HIP graph capture failed (%s: %s); running eager\n" % (type(e).__name__, e))
             for m in model.modules():
@@ -157,7 +158,7 @@ def main():
                                      (2 if args.full_losses else 1, B, N, K,
                                       "full loss set" if args.full_losses else "pred_seg+pred_normal+pred_bb"),
                             batch_per_gpu=B, global_batch=B * world, num_point=N, parallelism="dp%d" % world, loss=round(loss, 5),
-                            launch="hip_graph(fwd+bwd)+eager(allreduce,adam)" if graphed is not None else "eager"),
+                            launch=("hip_graph(fwd+bwd%s)+eager(allreduce,adam)" % ("" if args.no_prefetch else ", next batch's FPS/ball-query/3-NN on a forked stream")) if graphed is not None else "eager"),
                 roofline=roofline, cpu_baseline=cpu,
                 kernels={k: dict(ms_per_step=round(v["ms"] / prof_steps, 3), launches_per_step=v["launches"] / prof_steps)
                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])})

@@ -54,14 +54,14 @@ def get_learning_rate(init_lr, global_step, batch_size, decay_step, decay_rate, 
     return init_lr * (decay_rate ** p)
 
 
-def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags):
+def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags, geom=None):
     """Same result as compute_losses for --pred_seg --pred_normal --pred_bb (K=8), with the head post-processing, the
     Hungarian matching and the three losses (forward + gradient) in csrc/loss.hip instead of ~60 torch launches.
     The optional extrusion-axis / centre terms are added on top from the same head output."""
     from . import ops
     B, N, _ = pcs.shape
     K = fl.K
-    heads, sizes = model.forward_heads(pcs)
+    heads, sizes = model.forward_heads(pcs, geom) if geom is not None else model.forward_heads(pcs)
     assert sizes == [3, 2 * K] and fl.pred_seg and fl.pred_normal and fl.pred_bb and K == 8
     out4, match, mask = ops.seg_losses(heads, gt_normals, gt_inst, gt_bb, B, N, K, 0, 3, fl.weight_seg, fl.weight_normal, fl.weight_bb)
     total = out4[0]
@@ -92,12 +92,17 @@ def fused_loss_applicable(fl: StepFlags):
     return fl.pred_seg and fl.pred_normal and fl.pred_bb and fl.K == 8
 
 
-def compute_losses(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags):
+def compute_losses(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags, geom=None):
     """Forward + all loss terms -> dict of scalars (tensors) incl. 'total'."""
     B, N, _ = pcs.shape
     K = fl.K
     dev = pcs.device
-    X, W_raw = model(pcs)                                                       # :244
+    if geom is not None:
+        hh, _sz = model.forward_heads(pcs, geom)
+        hh = hh.view(B, N, -1)
+        X, W_raw = hh[:, :, 0:_sz[0]], hh[:, :, _sz[0]:_sz[0] + _sz[1]]
+    else:
+        X, W_raw = model(pcs)                                                   # :244
     X_head = X
     if fl.pred_normal:
         X = F.normalize(X, p=2, dim=2, eps=1e-12)                               # :247

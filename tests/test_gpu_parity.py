@@ -501,3 +501,50 @@ def test_fused_losses_match_the_torch_expressions(full):
     o2["total"].backward()
     ref = m1.h.grad.cpu().numpy()
     np.testing.assert_allclose(m2.h.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
+
+
+def test_precomputed_geometry_gives_the_same_forward():
+    """backbone.compute_geometry(x) (the parameter-free FPS / ball-query / 3-NN part) fed back through
+    forward_heads(x, geom) must reproduce the inline forward bit for bit (same start indices, dropout off)."""
+    g = load_golden("g5_backbone_train")
+    m = _model(int(g["seed"]), [3, 16]).train()
+    m.dropout_mask = "off"
+    x = cu(g["pcs"])
+    m.sa1.fps_start, m.sa2.fps_start = t(g["start1"]), t(g["start2"])
+    with torch.no_grad():
+        h1, _ = m.forward_heads(x)
+        geom = m.compute_geometry(x)
+        h2, _ = m.forward_heads(x, geom)
+    assert torch.equal(h1, h2)
+    assert torch.equal(geom["sa1"]["fps_idx"].cpu().long(), m.sa1.last_aux["fps_idx"].cpu().long())
+
+
+def test_hip_graph_replay_trains():
+    """Graph capture of forward+backward with the next batch's geometry on a forked stream: replays must keep producing
+    finite, changing losses while Adam (outside the graph) updates the parameters the graph reads in place."""
+    from point2cyl_amd import synth
+    from point2cyl_amd.graph import GraphedForwardBackward
+    B, N, K = 2, 1024, 8
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=3)
+    batch = tuple(v.to(DEV) for v in (pcs, nrm, seg, bb, axes, cen))
+    torch.manual_seed(0)
+    fl = step.StepFlags(K=K)
+    m = backbone(output_sizes=fl.pred_sizes()).to(DEV).train()
+    step.update_momentum(m, 0.5)
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+
+    def fwd_bwd(geom=None):
+        out = step.compute_losses_fused(m, *batch, fl, geom=geom)
+        for p in m.parameters():
+            p.grad = None
+        out["total"].backward()
+        return {"total": out["total"].detach()}
+
+    gr = GraphedForwardBackward(m, fwd_bwd, prefetch_xyz=batch[0])
+    losses_ = []
+    for _ in range(6):
+        out = gr()
+        opt.step()
+        losses_.append(float(out["total"]))
+    assert all(np.isfinite(losses_)) and len(set(losses_)) == 6
+    assert losses_[-1] < losses_[0] + 0.05

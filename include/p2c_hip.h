@@ -65,13 +65,15 @@ int p2c_three_nn_f32(const float *xyz1, const float *xyz2, int B, int N, int S, 
  * ------------------------------------------------------------------------------------------- */
 
 /* sample_and_group's gather + centring + concat, models/pointnet_util.py:128-139.
- * out row (b,s,j) = [xyz[b,idx]-new_xyz[b,s] (3) | feats[b,idx,:D] | 0-pad up to ldo], ldo % 4 == 0.
- * feats may be NULL (D=0).  ldf = leading dimension of feats rows. */
+ * out row (b,s,j) = [xyz[b,idx]-new_xyz[b,s] (3) | feats[b,idx,:D] | 0-pad up to ldo], ldo % 4 == 0  (the reference's
+ * channel order, :137), or with xyz_last != 0  [feats | xyz_rel | 0-pad]: the 16-byte aligned feature block first, so the
+ * backward GEMMs can skip the 3 coordinate columns whose gradient nobody needs (the host permutes the conv weight's input
+ * channels to match).  feats may be NULL (D=0).  ldf = leading dimension of feats rows. */
 int p2c_group_gather_f32(const float *xyz, const float *feats, int ldf, const float *new_xyz, const int32_t *idx, int B,
-                         int N, int S, int nsample, int D, float *out, int ldo, void *stream);
-/* backward of the feature part: dfeats[b,idx[b,s,j],:] += dout[(b,s,j), 3:3+D]   (dfeats pre-zeroed) */
+                         int N, int S, int nsample, int D, float *out, int ldo, int xyz_last, void *stream);
+/* backward of the feature part: dfeats[b,idx[b,s,j],:] += dout[(b,s,j), c0:c0+D], c0 = 0 if xyz_last else 3 (dfeats pre-zeroed) */
 int p2c_group_gather_bwd_f32(const float *dout, int ldo, const int32_t *idx, int B, int N, int S, int nsample, int D,
-                             float *dfeats, int ldf, void *stream);
+                             float *dfeats, int ldf, int xyz_last, void *stream);
 
 /* weighted 3-NN interpolation, models/pointnet_util.py:308.
  * out[b,n,:C] = sum_j w[b,n,j] * feats[b, idx[b,n,j], :C] */

@@ -24,8 +24,8 @@ _SIGS = {
     "p2c_fps_f32": [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p],
     "p2c_ball_query_f32": [c_p, c_p, c_i, c_i, c_i, c_f, c_i, c_p, c_p],
     "p2c_three_nn_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
-    "p2c_group_gather_f32": [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
-    "p2c_group_gather_bwd_f32": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
+    "p2c_group_gather_f32": [c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p],
+    "p2c_group_gather_bwd_f32": [c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p],
     "p2c_three_interp_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_three_interp_bwd_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_linear_fwd_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p],

@@ -65,11 +65,11 @@ class PointNetSetAbstraction(nn.Module):
         cin = self.mlp_convs[0].weight.shape[1]
         if self.group_all:
             new_xyz = torch.zeros(B, 1, 3, device=xyz.device)
-            cols = [xyz.reshape(B * N, 3)] + ([] if feats is None else [feats.reshape(B * N, -1)])
+            cols = ([] if feats is None else [feats.reshape(B * N, -1)]) + [xyz.reshape(B * N, 3)]
             pad = (-cin) % 4
             if pad:
                 cols.append(torch.zeros(B * N, pad, device=xyz.device))
-            X0 = torch.cat(cols, 1)                       # sample_and_group_all: no centring (:157-160)
+            X0 = torch.cat(cols, 1)                       # sample_and_group_all: no centring (:157-160); [feats | xyz | pad]
             G, ns = B, N
         else:
             if geom is None:
@@ -78,7 +78,7 @@ class PointNetSetAbstraction(nn.Module):
             X0 = geom["X0"] if (feats is None and "X0" in geom) else ops.group_gather(xyz, feats, new_xyz, gidx)
             G, ns = B * self.npoint, self.nsample
             self.last_aux = dict(fps_idx=fps_idx, group_idx=gidx)
-        out = ops.mlp_stack(X0, cin, layers, "maxpool", self.training, G=G, ns=ns)
+        out = ops.mlp_stack(X0, cin, layers, "maxpool", self.training, G=G, ns=ns, xyz_last=True)
         return new_xyz, out.view(B, -1, out.shape[-1])
 
     def forward(self, xyz, points):

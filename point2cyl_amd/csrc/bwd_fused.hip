@@ -305,7 +305,9 @@ __global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
 // streams its 128 MFMAs per wave, half B - resident on the same SIMDs - does its non-MFMA phase, then they swap.
 // Every barrier is workgroup-wide; both halves execute the same number of them.
 // ------------------------------------------------------------------------------------------------
-template <int COT, int CIT, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS>
+// EX: extra input columns [Ci, Ci+EX) of X (the 3 relative coordinates + pad of a grouped layer, laid out AFTER the
+// feature block): they only contribute EX more columns of dW (no dX, no act_in), accumulated on the VALU.
+template <int COT, int CIT, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS, int EX>
 __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 {
     constexpr int Co = 64 * COT, Ci = 64 * CIT;
@@ -317,6 +319,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     float *dYs = Ws + Co * LDW;                    // [2 halves][Co][LDY]
     float *Xr = dYs + 2 * Co * LDY;                // [2 halves][BM][LDX]
     float *red = Xr + 2 * BM * LDX;                // [2][Ci]
+    float *Xe = red + 2 * Ci;                      // [2 halves][BM][4] extra input columns (EX > 0)
 
     const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -327,6 +330,12 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     const int niter = (nk + 1) / 2;                // per half
     float *dy = dYs + half * Co * LDY;
     float *xr = Xr + half * BM * LDX;
+    float *xe = Xe + half * BM * 4;
+    constexpr int EPT = EX > 0 ? (EX * Co + 255) / 256 : 1;     // extra dW columns per thread (thread -> co = tid % Co)
+    float acce[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) acce[i] = 0.f;
+    v4f rxe = {0.f, 0.f, 0.f, 0.f};
 
     if (NEED_DX) {
         for (int u = threadIdx.x; u < Co * Ci / 4; u += 512) {
@@ -370,7 +379,15 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         const int k0 = half, k1 = half + 2;
         fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
         fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xr, rdz, ry, rarg, rx, cf);
+        if (EX > 0 && tid < BM) {
+            const int m = min(tile_of(k0 < nk ? k0 : 0) * BM + tid, a.M - 1);
+            *reinterpret_cast<v4f *>(&xe[tid * 4]) = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
+        }
         fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k1 < nk ? k1 : 0), rdz, ry, rarg, rx);
+        if (EX > 0 && tid < BM) {
+            const int m = min(tile_of(k1 < nk ? k1 : 0) * BM + tid, a.M - 1);
+            rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
+        }
     }
     __syncthreads();
     if (half == 1) P2C_LDS_BARRIER();             // run one phase behind half 0
@@ -416,6 +433,15 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 #pragma unroll 8
                 for (int s = 0; s < BM; ++s) sb += dy[tid * LDY + s];
                 dbacc += sb;
+            }
+            if (EX > 0) {                               // dW[co, Ci + e] += sum_m dY[m,co] * x[m, Ci + e]   (rows past M have dY == 0)
+                const int co = tid % Co, e0 = (tid / Co) * EPT;
+#pragma unroll 8
+                for (int s = 0; s < BM; ++s) {
+                    const float d = dy[co * LDY + s];
+#pragma unroll
+                    for (int i = 0; i < EPT; ++i) acce[i] += d * xe[s * 4 + e0 + i];
+                }
             }
             if (NEED_DX) {
 #pragma unroll
@@ -466,7 +492,12 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         {
             const int k2 = k + 2, k4 = k + 4;
             if (k2 < nk) fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, tile_of(k2), dy, xr, rdz, ry, rarg, rx, cf);
+            if (EX > 0 && tid < BM) *reinterpret_cast<v4f *>(&xe[tid * 4]) = rxe;
             fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
+            if (EX > 0 && tid < BM) {
+                const int m = min(tile_of(k4 < nk ? k4 : 0) * BM + tid, a.M - 1);
+                rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         P2C_LDS_BARRIER();                         // the prefetch above stays in flight across this barrier
@@ -502,6 +533,13 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                     }
         }
     }
+    if (EX > 0) {
+        float *dws = a.dw + (size_t)(blockIdx.x & 7) * a.dw_slot_stride;
+        const int co = tid % Co, e0 = (tid / Co) * EPT;
+#pragma unroll
+        for (int i = 0; i < EPT; ++i)
+            if (e0 + i < EX) atomicAdd(&dws[(size_t)co * a.lddw + Ci + e0 + i], acce[i]);
+    }
     if (GMODE == 0 && a.dbias && tid < Co) atomicAdd(&a.dbias[tid], dbacc);
     if (NEED_DX && HAS_STATS) {
         if (threadIdx.x < 2 * Ci) red[threadIdx.x] = 0.f;
@@ -531,23 +569,36 @@ static int fused_grid(int M, int Ci)
 extern "C" int p2c_linear_bwd_fused_parts(int M, int Ci) { return fused_grid(M, Ci); }
 extern "C" int p2c_linear_bwd_fused_supported(int Co, int Ci, int in_mode)
 {
+    if (Co == 128 && Ci == 132 && in_mode == 0) return 2;      // 128 feature columns + 4 trailing (xyz | pad) columns
     return (Co == 64 || Co == 128) && (Ci == 64 || Ci == 128) && (in_mode == 0 || in_mode == 1);
 }
 
 template <int COT, int CIT, int GMODE, int IMODE>
-static int launch_fused(const BwdFusedArgs &a, hipStream_t s)
+static int launch_fused(const BwdFusedArgs &a, int extra, hipStream_t s)
 {
     constexpr int Co = 64 * COT, Ci = 64 * CIT;
     constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
-    const size_t lds = (size_t)(Co * (Ci + 4) + 2 * Co * (BM + 1) + 2 * BM * (Ci + 4) + 2 * Ci) * sizeof(float);
+    const size_t lds = (size_t)(Co * (Ci + 4) + 2 * Co * (BM + 1) + 2 * BM * (Ci + 4) + 2 * Ci + 2 * BM * 4) * sizeof(float);
     const int grid = fused_grid(a.M, Ci);
+    if (extra) {      // grouped first layer: [feats(128) | xyz(3) | pad] -> 4 extra dW columns (only this shape needs it)
+        if constexpr (COT == 2 && CIT == 2 && GMODE == 1 && IMODE == 0) {
+            if (!a.dx || a.pstat) return P2C_EINVAL;
+            (void)hipFuncSetAttribute((const void *)bwd_fused_pp_kernel<2, 2, 1, 0, true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds);
+            hipLaunchKernelGGL((bwd_fused_pp_kernel<2, 2, 1, 0, true, false, 4>), dim3(grid), dim3(512), lds, s, a);
+            P2C_LAUNCH_CHECK();
+            return P2C_OK;
+        } else {
+            return P2C_EINVAL;
+        }
+    }
     static const bool pingpong = !(getenv("P2C_FUSED_PP") && atoi(getenv("P2C_FUSED_PP")) == 0);
 #define P2C_FL(DX_, ST_)                                                                                                             \
     do {                                                                                                                             \
         if (pingpong) {                                                                                                              \
-            (void)hipFuncSetAttribute((const void *)bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>,                           \
+            (void)hipFuncSetAttribute((const void *)bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_, 0>,                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
-            hipLaunchKernelGGL((bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>), dim3(grid), dim3(512), lds, s, a);             \
+            hipLaunchKernelGGL((bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_, 0>), dim3(grid), dim3(512), lds, s, a);             \
         } else {                                                                                                                     \
             (void)hipFuncSetAttribute((const void *)bwd_fused_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>,                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
@@ -563,12 +614,12 @@ static int launch_fused(const BwdFusedArgs &a, hipStream_t s)
 }
 
 template <int GMODE, int IMODE>
-static int dispatch_shape(int Co, int Ci, const BwdFusedArgs &a, hipStream_t s)
+static int dispatch_shape(int Co, int Ci, int extra, const BwdFusedArgs &a, hipStream_t s)
 {
-    if (Co == 128 && Ci == 128) return launch_fused<2, 2, GMODE, IMODE>(a, s);
-    if (Co == 128 && Ci == 64) return launch_fused<2, 1, GMODE, IMODE>(a, s);
-    if (Co == 64 && Ci == 128) return launch_fused<1, 2, GMODE, IMODE>(a, s);
-    return launch_fused<1, 1, GMODE, IMODE>(a, s);
+    if (Co == 128 && Ci == 128) return launch_fused<2, 2, GMODE, IMODE>(a, extra, s);
+    if (Co == 128 && Ci == 64) return launch_fused<2, 1, GMODE, IMODE>(a, extra, s);
+    if (Co == 64 && Ci == 128) return launch_fused<1, 2, GMODE, IMODE>(a, extra, s);
+    return launch_fused<1, 1, GMODE, IMODE>(a, extra, s);
 }
 
 extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
@@ -578,7 +629,10 @@ extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *
                                         int Ci, void *stream)
 {
     if (!dZ || !X || !W || !dW || M <= 0 || grad_mode < 0 || grad_mode > 2) return P2C_EINVAL;
-    if (!p2c_linear_bwd_fused_supported(Co, Ci, in_mode)) return P2C_EINVAL;
+    const int sup = p2c_linear_bwd_fused_supported(Co, Ci, in_mode);
+    if (!sup) return P2C_EINVAL;
+    const int extra = sup == 2 ? 4 : 0;
+    if (extra) Ci -= extra;
     if (grad_mode >= 1 && (!Yfwd || !coef)) return P2C_EINVAL;
     if (grad_mode == 2 && (!pool_arg || pool_ns <= 0)) return P2C_EINVAL;
     if (in_mode == 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
@@ -588,7 +642,7 @@ extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *
     BwdFusedArgs a{dZ, lddz, Yfwd, ldy, coef, pool_arg, pool_ns, X, ldx, in_scale, in_shift, W, ldw, dX, lddx, dW, lddw, dbias, prev_stat,
                    bwd_partials, M, dw_slot_stride};
     hipStream_t s = (hipStream_t)stream;
-#define P2C_F(G_, I_) return dispatch_shape<G_, I_>(Co, Ci, a, s)
+#define P2C_F(G_, I_) return dispatch_shape<G_, I_>(Co, Ci, extra, a, s)
     if (grad_mode == 0) { if (in_mode == 0) P2C_F(0, 0); P2C_F(0, 1); }
     if (grad_mode == 1) { if (in_mode == 0) P2C_F(1, 0); P2C_F(1, 1); }
     if (in_mode == 0) P2C_F(2, 0);

@@ -7,7 +7,7 @@
 __global__ void __launch_bounds__(256) group_gather_kernel(const float *__restrict__ xyz, const float *__restrict__ feats, int ldf,
                                                            const float *__restrict__ new_xyz, const int32_t *__restrict__ idx,
                                                            int N, int S, int ns, int D, long long rows, float *__restrict__ out,
-                                                           int ldo)
+                                                           int ldo, int xyz_last)
 {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -20,10 +20,11 @@ __global__ void __launch_bounds__(256) group_gather_kernel(const float *__restri
         const float *c = new_xyz + (size_t)g * 3;
         const float *f = feats ? feats + ((size_t)b * N + src) * ldf : nullptr;
         float *o = out + (size_t)r * ldo;
+        const int xo = xyz_last ? D : 0, fo = xyz_last ? 0 : 3;      // column offsets of the xyz / feature parts
         for (int col = lane; col < ldo; col += 64) {
             float v = 0.f;
-            if (col < 3) v = p[col] - c[col];
-            else if (col < 3 + D) v = f[col - 3];
+            if (col >= xo && col < xo + 3) v = p[col - xo] - c[col - xo];
+            else if (col >= fo && col < fo + D) v = f[col - fo];
             o[col] = v;
         }
     }
@@ -44,7 +45,7 @@ __global__ void __launch_bounds__(256) group_gather_xyz_kernel(const float *__re
 }
 
 extern "C" int p2c_group_gather_f32(const float *xyz, const float *feats, int ldf, const float *new_xyz, const int32_t *idx, int B,
-                                    int N, int S, int nsample, int D, float *out, int ldo, void *stream)
+                                    int N, int S, int nsample, int D, float *out, int ldo, int xyz_last, void *stream)
 {
     if (!xyz || !new_xyz || !idx || !out || B <= 0 || D < 0 || (D > 0 && !feats) || ldo < 3 + D) return P2C_EINVAL;
     if (ldo % 4) return P2C_EALIGN;
@@ -55,7 +56,7 @@ extern "C" int p2c_group_gather_f32(const float *xyz, const float *feats, int ld
                            reinterpret_cast<float4 *>(out));
     } else {
         const int blocks = (int)min((long long)p2c_cdiv(rows, 4), 16384LL);
-        hipLaunchKernelGGL(group_gather_kernel, dim3(blocks), dim3(256), 0, s, xyz, feats, ldf, new_xyz, idx, N, S, nsample, D, rows, out, ldo);
+        hipLaunchKernelGGL(group_gather_kernel, dim3(blocks), dim3(256), 0, s, xyz, feats, ldf, new_xyz, idx, N, S, nsample, D, rows, out, ldo, xyz_last);
     }
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -63,7 +64,7 @@ extern "C" int p2c_group_gather_f32(const float *xyz, const float *feats, int ld
 
 __global__ void __launch_bounds__(256) group_gather_bwd_kernel(const float *__restrict__ dout, int ldo, const int32_t *__restrict__ idx,
                                                                int N, int S, int ns, int D, long long rows, float *__restrict__ dfeats,
-                                                               int ldf)
+                                                               int ldf, int coff)
 {
     const int lane = threadIdx.x & 63;
     const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -71,19 +72,19 @@ __global__ void __launch_bounds__(256) group_gather_bwd_kernel(const float *__re
     for (long long r = wave; r < rows; r += nw) {
         const int b = (int)(r / ((long long)S * ns));
         float *d = dfeats + ((size_t)b * N + idx[r]) * ldf;
-        const float *g = dout + (size_t)r * ldo + 3;
+        const float *g = dout + (size_t)r * ldo + coff;
         for (int c = lane; c < D; c += 64) atomicAdd(d + c, g[c]);
     }
 }
 
 extern "C" int p2c_group_gather_bwd_f32(const float *dout, int ldo, const int32_t *idx, int B, int N, int S, int nsample, int D,
-                                        float *dfeats, int ldf, void *stream)
+                                        float *dfeats, int ldf, int xyz_last, void *stream)
 {
     if (!dout || !idx || !dfeats || D <= 0) return P2C_EINVAL;
     const long long rows = (long long)B * S * nsample;
     const int blocks = (int)min((long long)p2c_cdiv(rows, 4), 16384LL);
     hipLaunchKernelGGL(group_gather_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dout, ldo, idx, N, S, nsample, D, rows,
-                       dfeats, ldf);
+                       dfeats, ldf, xyz_last ? 0 : 3);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

@@ -187,7 +187,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
     constexpr int BM = 64 * TM, BN = 64 * TN;
     using TA = Tile<BM, AK>;
     using TB = Tile<BN, BK_>;
-    __shared__ __attribute__((aligned(16))) float smem[GK * TA::LD + GK * TB::LD + 2 * BN + BM];
+    // operand tiles + [2][BN] stat scratch (+BM), or the BM x (BN+4) output tile the epilogue stages for full-row stores
+    constexpr int SMEM_OPS = GK * TA::LD + GK * TB::LD, SMEM_OUT = BM * (BN + 4);
+    __shared__ __attribute__((aligned(16))) float smem[(SMEM_OPS > SMEM_OUT ? SMEM_OPS : SMEM_OUT) + 2 * BN + BM];
     float *As = smem, *Bs = smem + GK * TA::LD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -243,16 +245,18 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
 
     // ---------------------------------------------------------------- epilogue
     const int col_l = lane & 31, rquad = lane >> 5;
-    float *sstat = smem + GK * TA::LD + GK * TB::LD;      // [2][BN]: the two wm-waves of a column combine here
+    float *sstat = smem + (SMEM_OPS > SMEM_OUT ? SMEM_OPS : SMEM_OUT);      // [2][BN]: the two wm-waves of a column combine here
     if constexpr (std::is_same<Epi, EpiFwd>::value) {
-        if (epi.partials) {
-            __syncthreads();
-            if (tid < 2 * BN) sstat[tid] = 0.f;
-            __syncthreads();
-        }
+        // The C/D fragment gives each lane one column of 16 scattered rows: stored directly, a wave instruction writes
+        // two 128-byte pieces of two different rows.  Stage the tile in LDS instead (the operand tiles are dead) and
+        // write whole rows, 16 bytes per lane: the 512-byte rows of Y then reach HBM as full bursts.
+        constexpr int LDO = BN + 4;
+        __syncthreads();
+        if (epi.partials && tid < 2 * BN) sstat[tid] = 0.f;
 #pragma unroll
         for (int tb = 0; tb < TN; ++tb) {
-            const int col = j0 + wn * (TN * 32) + tb * 32 + col_l;
+            const int cl = wn * (TN * 32) + tb * 32 + col_l;
+            const int col = j0 + cl;
             const bool cok = col < J;
             const float bv = (epi.bias && cok) ? epi.bias[col] : 0.f;
             float s1 = 0.f, s2 = 0.f;
@@ -260,10 +264,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
             for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int row = i0 + wm * (TM * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * rquad;
+                    const int rl = wm * (TM * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * rquad;
                     const float v = acc[ta][tb][r];
-                    if (row < I && cok) {
-                        epi.Y[(size_t)row * epi.ldy + col] = v + bv;
+                    smem[rl * LDO + cl] = v + bv;
+                    if (i0 + rl < I && cok) {
                         s1 += v;
                         s2 += v * v;
                     }
@@ -271,14 +275,34 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
             if (epi.partials) {
                 s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 32);
+                __syncthreads();                                              // sstat zeroed (first tb) / tile rows landed
                 if (rquad == 0) {
-                    atomicAdd(&sstat[wn * (TN * 32) + tb * 32 + col_l], s1);     // exactly two adds per slot: order-independent
-                    atomicAdd(&sstat[BN + wn * (TN * 32) + tb * 32 + col_l], s2);
+                    atomicAdd(&sstat[cl], s1);                               // exactly two adds per slot: order-independent
+                    atomicAdd(&sstat[BN + cl], s2);
+                }
+            }
+        }
+        __syncthreads();
+        {
+            constexpr int V = BN / 4;                                        // float4 per tile row
+            const bool vec_ok = (epi.ldy & 3) == 0 && (((uintptr_t)epi.Y) & 15) == 0;
+            for (int u = tid; u < BM * V; u += 256) {
+                const int rl = u / V, c4 = (u % V) * 4;
+                const int row = i0 + rl, col = j0 + c4;
+                if (row >= I || col >= J) continue;
+                const float4 v = *reinterpret_cast<const float4 *>(&smem[rl * LDO + c4]);
+                float *o = epi.Y + (size_t)row * epi.ldy + col;
+                if (vec_ok && col + 3 < J) {
+                    *reinterpret_cast<float4 *>(o) = v;
+                } else {
+                    o[0] = v.x;
+                    if (col + 1 < J) o[1] = v.y;
+                    if (col + 2 < J) o[2] = v.z;
+                    if (col + 3 < J) o[3] = v.w;
                 }
             }
         }
         if (epi.partials) {
-            __syncthreads();
             if (tid < BN && j0 + tid < J) {        // one fp64 atomic per column and workgroup into its slot
                 double *o = epi.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * J;
                 atomicAdd(&o[j0 + tid], (double)sstat[tid]);

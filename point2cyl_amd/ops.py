@@ -69,7 +69,7 @@ class _GroupGather(torch.autograd.Function):
         out = torch.empty(B * S * ns, ldo, dtype=torch.float32, device=xyz.device)
         if feats is not None:
             feats = _f32c(feats)
-        call("p2c_group_gather_f32", ptr(xyz), ptr(feats), D, ptr(new_xyz), ptr(idx), B, N, S, ns, D, ptr(out), ldo, stream())
+        call("p2c_group_gather_f32", ptr(xyz), ptr(feats), D, ptr(new_xyz), ptr(idx), B, N, S, ns, D, ptr(out), ldo, 1, stream())
         ctx.save_for_backward(idx)
         ctx.dims = (B, N, S, ns, D, ldo)
         return out
@@ -80,14 +80,16 @@ class _GroupGather(torch.autograd.Function):
         B, N, S, ns, D, ldo = ctx.dims
         if D == 0 or not ctx.needs_input_grad[1]:
             return None, None, None, None
-        dout = _f32c(dout)
+        if dout.stride(1) != 1:
+            dout = dout.contiguous()
         dfeats = torch.zeros(B, N, D, dtype=torch.float32, device=dout.device)
-        call("p2c_group_gather_bwd_f32", ptr(dout), ldo, ptr(idx), B, N, S, ns, D, ptr(dfeats), D, stream())
+        call("p2c_group_gather_bwd_f32", ptr(dout), dout.stride(0), ptr(idx), B, N, S, ns, D, ptr(dfeats), D, 1, stream())
         return None, dfeats, None, None
 
 
 def group_gather(xyz, feats, new_xyz, idx):
-    """rows (b,s,j) = [xyz[idx]-new_xyz | feats[idx] | 0-pad]  (pointnet_util.py:128-139) -> (B*S*ns, ld)."""
+    """rows (b,s,j) = [feats[idx] | xyz[idx]-new_xyz | 0-pad] -> (B*S*ns, ld): the reference's concat (pointnet_util.py:137)
+    with the feature block first ("xyz_last"); mlp_stack(..., xyz_last=True) permutes the first conv's input channels to match."""
     return _GroupGather.apply(_f32c(xyz), feats, _f32c(new_xyz), idx)
 
 
@@ -218,6 +220,8 @@ class _MLPStack(torch.autograd.Function):
             pi += 2
             Co_true = W.shape[0]
             W2 = W.reshape(Co_true, -1)
+            if i == 0 and cfg.get("xyz_last") and W2.shape[1] > 3:
+                W2 = torch.cat([W2[:, 3:], W2[:, :3]], 1)          # reference order [xyz(3) | feats] -> [feats | xyz(3)]
             Co = _pad4(Co_true)
             if W2.shape[1] != K or Co != Co_true:
                 W2 = torch.nn.functional.pad(W2, (0, K - W2.shape[1], 0, Co - Co_true))
@@ -343,8 +347,14 @@ class _MLPStack(torch.autograd.Function):
             db = arena.f32(Co)
             Wp = params[p0]
             co_t, ci_t = Wp.shape[0], Wp.numel() // Wp.shape[0]
-            grads[p0] = dW[:co_t, :ci_t].reshape(Wp.shape)
+            def _to_param_layout(g):
+                g = g[:co_t, :ci_t]
+                if i == 0 and cfg.get("xyz_last") and ci_t > 3:
+                    g = torch.cat([g[:, ci_t - 3:], g[:, :ci_t - 3]], 1)     # back to the reference's [xyz | feats] input order
+                return g.reshape(Wp.shape)
+
             grads[p0 + 1] = db[:co_t]
+            dW_final = dW                     # replaced by the sum of the per-XCD copies where those are used
             need_dx = i > 0 or ctx.needs_input_grad[1]
             stats_below = i > 0                       # the layer below has a BatchNorm whose backward sums we produce here
             L_ = _lib.lib()
@@ -356,7 +366,7 @@ class _MLPStack(torch.autograd.Function):
                      pool_ns, ptr(Xin), ldxin, mode, ptr(sc), ptr(sh), ptr(W2), Ci, ptr(dX), Ci, ptr(dW8), Ci, Co * Ci,
                      ptr(db) if grad_mode == 0 else None, ptr(aff[i - 1]) if stats_below else None, ptr(part), M, Co, Ci, stream(),
                      flops=(4.0 if need_dx else 2.0) * M * Co * Ci)
-                grads[p0] = dW8.sum(0)[:co_t, :ci_t].reshape(Wp.shape)
+                dW_final = dW8.sum(0)
             else:
                 use_slots = M >= 65536       # many split-k workgroups: spread the atomics over 8 copies of dW
                 dWs = arena.f32(8, Co, Ci) if use_slots else dW
@@ -365,7 +375,7 @@ class _MLPStack(torch.autograd.Function):
                      ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
                      flops=2.0 * M * Co * Ci)
                 if use_slots:
-                    grads[p0] = dWs.sum(0)[:co_t, :ci_t].reshape(Wp.shape)
+                    dW_final = dWs.sum(0)
                 dX = part = None
                 if need_dx:
                     dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
@@ -374,6 +384,7 @@ class _MLPStack(torch.autograd.Function):
                          mptr, omld, float(dscale),
                          ptr(Ys[i - 1]) if stats_below else None, Ci, ptr(aff[i - 1]) if stats_below else None, ptr(part),
                          ptr(arg) if grad_mode == 2 else None, pool_ns, stream(), flops=2.0 * M * Co * Ci)
+            grads[p0] = _to_param_layout(dW_final)       # after the kernels are enqueued (the permuted layout is a copy)
             if need_dx:
                 dZ, grad_mode = dX, 1
                 if stats_below:
@@ -395,7 +406,7 @@ class _MLPStack(torch.autograd.Function):
 
 
 def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mask=None, drop_scale=1.0, drop_seed=None,
-              keep_padding=False):
+              keep_padding=False, xyz_last=False):
     """layers: list of dicts {W, b, gamma, beta, bn: BNState} (gamma/beta/bn None for a BN-less last layer)."""
     params, bns = [], []
     for ly in layers:
@@ -404,7 +415,7 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
             params += [ly["gamma"], ly["beta"]]
         bns.append(ly.get("bn"))
     cfg = dict(in_channels=in_channels, n_layers=len(layers), tail=tail, training=training, bns=bns, G=G, ns=ns,
-               drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed)
+               drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed, xyz_last=xyz_last)
     out = _MLPStack.apply(cfg, X0, *params)
     if not _DEFER_NBT[0]:
         flush_nbt()

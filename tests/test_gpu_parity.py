@@ -100,7 +100,8 @@ def test_group_gather_and_interp_fwd_bwd():
     idx = torch.randint(0, N, (B, S, ns), generator=g)
     fd = feats.detach().to(DEV).requires_grad_(True)
     out = ops.group_gather(xyz.to(DEV), fd, new_xyz.to(DEV), idx.to(DEV).int())
-    ref = torch.cat([R.gather_rows(xyz, idx) - new_xyz.unsqueeze(2), R.gather_rows(feats, idx)], -1).reshape(B * S * ns, 3 + D)
+    # device layout: [feats | xyz_rel | 0-pad] (feature block first, see ops.group_gather)
+    ref = torch.cat([R.gather_rows(feats, idx), R.gather_rows(xyz, idx) - new_xyz.unsqueeze(2)], -1).reshape(B * S * ns, 3 + D)
     assert out.shape[1] % 4 == 0
     assert torch.equal(out[:, :3 + D].cpu(), ref.detach()) and (out[:, 3 + D:] == 0).all()
     go = torch.randn(out.shape, generator=g)
@@ -109,7 +110,7 @@ def test_group_gather_and_interp_fwd_bwd():
     np.testing.assert_allclose(fd.grad.cpu().numpy(), feats.grad.numpy(), rtol=1e-5, atol=1e-5)
     # no-feature fast path
     out0 = ops.group_gather(xyz.to(DEV), None, new_xyz.to(DEV), idx.to(DEV).int())
-    assert out0.shape[1] == 4 and torch.equal(out0[:, :3].cpu(), ref[:, :3].detach())
+    assert out0.shape[1] == 4 and torch.equal(out0[:, :3].cpu(), ref[:, D:D + 3].detach())
     # interpolation
     S2, C = 50, 70
     f2 = torch.randn(B, S2, C, generator=g, requires_grad=True)

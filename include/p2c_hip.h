@@ -82,6 +82,18 @@ int p2c_three_interp_f32(const float *feats, int ldf, const int32_t *idx, const 
 int p2c_three_interp_bwd_f32(const float *dout, int ldo, const int32_t *idx, const float *weight, int B, int N, int S,
                              int C, float *dfeats, int ldf, void *stream);
 
+/* Atomic-free backward of both gathers: the inverse map (target row -> entries reading it) depends only on the
+ * geometry, so it is built once per batch and the backward becomes a gather.
+ * p2c_build_csr_i32: idx [B,E] with values in [0,T) (w [B,E] or NULL) -> offsets [B,T+1]; rows [B,E] = source row
+ *   (entry / ediv) of every entry, grouped by target; wsorted [B,E] = w in the same order.
+ * p2c_csr_gather_f32: out[b,t,:C] = sum_{k in bucket(b,t)} wsorted[b,k] * src[b*rows_b + rows[b,k], coff:coff+C].
+ *   three_interp backward: E = 3N, ediv = 3, rows_b = N, T = S, src = dout;  group_gather backward: E = S*nsample,
+ *   ediv = 1, rows_b = E, T = N, src = dout (coff = column of the feature block), wsorted = NULL. */
+int p2c_build_csr_i32(const int32_t *idx, const float *w, int B, int E, int ediv, int T, int32_t *offsets, int32_t *rows,
+                      float *wsorted, void *stream);
+int p2c_csr_gather_f32(const float *src, int ld_src, int coff, const int32_t *offsets, const int32_t *rows, const float *wsorted,
+                       int B, int E, int rows_b, int T, int C, float *out, int ldo, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Shared per-point MLP: 1x1 conv (+ train-mode BatchNorm + ReLU) as fp32 MFMA GEMMs
  * (models/pointnet_util.py:201-205, :317-319; models/pointnet_extrusion.py:58-65)

@@ -56,7 +56,10 @@ class PointNetSetAbstraction(nn.Module):
             start = self.fps_start if self.fps_start is not None else draw_fps_start(N, B)
         fps_idx, new_xyz = ops.fps(xyz, self.npoint, start)
         gidx = ops.ball_query(self.radius, self.nsample, xyz, new_xyz)
-        return dict(fps_idx=fps_idx, new_xyz=new_xyz, group_idx=gidx)
+        g = dict(fps_idx=fps_idx, new_xyz=new_xyz, group_idx=gidx)
+        if self.mlp_convs[0].weight.shape[1] > 3:          # grouped FEATURES exist -> their backward wants the inverse map
+            g["csr"] = ops.build_csr(gidx, N)
+        return g
 
     def forward_pm(self, xyz, feats, geom=None):
         """xyz (B,N,3), feats (B,N,D) or None -> new_xyz (B,S,3), new_feats (B,S,C')."""
@@ -75,7 +78,7 @@ class PointNetSetAbstraction(nn.Module):
             if geom is None:
                 geom = self.geometry(xyz)
             fps_idx, new_xyz, gidx = geom["fps_idx"], geom["new_xyz"], geom["group_idx"]
-            X0 = geom["X0"] if (feats is None and "X0" in geom) else ops.group_gather(xyz, feats, new_xyz, gidx)
+            X0 = geom["X0"] if (feats is None and "X0" in geom) else ops.group_gather(xyz, feats, new_xyz, gidx, geom.get("csr"))
             G, ns = B * self.npoint, self.nsample
             self.last_aux = dict(fps_idx=fps_idx, group_idx=gidx)
         out = ops.mlp_stack(X0, cin, layers, "maxpool", self.training, G=G, ns=ns, xyz_last=True)
@@ -107,8 +110,11 @@ class PointNetFeaturePropagation(nn.Module):
         if S == 1:
             interp = feats2.expand(B, N, feats2.shape[-1]).reshape(B * N, -1)     # :298-299
         else:
-            idx, w = nn_ if nn_ is not None else ops.three_nn(xyz1, xyz2)
-            interp = ops.three_interpolate(feats2, idx, w)
+            if nn_ is None:
+                idx, w = ops.three_nn(xyz1, xyz2)
+                nn_ = (idx, w, ops.build_csr(idx, S, w, 3))
+            idx, w, csr = nn_
+            interp = ops.three_interpolate(feats2, idx, w, csr)
             self.last_aux = dict(nn_idx=idx, nn_w=w)
         if feats1 is not None:
             return torch.cat([feats1.reshape(B * N, -1), interp], 1)              # [skip | interpolated] :312
@@ -173,7 +179,11 @@ class backbone(nn.Module):
         if x.shape[2] == 3:
             g1["X0"] = ops.group_gather(xyz, None, g1["new_xyz"], g1["group_idx"])
         g2 = self.sa2.geometry(g1["new_xyz"])
-        return dict(sa1=g1, sa2=g2, fp2=ops.three_nn(g1["new_xyz"], g2["new_xyz"]), fp1=ops.three_nn(xyz, g1["new_xyz"]))
+        def nn_with_csr(dense, sparse):
+            idx, w = ops.three_nn(dense, sparse)
+            return idx, w, ops.build_csr(idx, sparse.shape[1], w, 3)
+
+        return dict(sa1=g1, sa2=g2, fp2=nn_with_csr(g1["new_xyz"], g2["new_xyz"]), fp1=nn_with_csr(xyz, g1["new_xyz"]))
 
     def forward(self, x):
         heads, sizes = self.forward_heads(x)

@@ -149,3 +149,124 @@ extern "C" int p2c_three_interp_bwd_f32(const float *dout, int ldo, const int32_
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Gather-formulated backward of the two gathers.  The scatter targets are known before the step starts (they depend
+// only on the coordinates), so the inverse map "target row -> list of entries that read it" is built once per batch
+// (p2c_build_csr_i32, a counting sort per cloud in LDS; part of the geometry that can be prefetched) and the backward
+// becomes a gather: one wave per target row sums  w[e] * src[row(e), :]  over its entries with coalesced row reads.
+// No read-modify-write traffic, no 100 M fp32 atomics per step.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) build_csr_kernel(const int32_t *__restrict__ idx, const float *__restrict__ w, int E, int ediv, int T,
+                                                         int32_t *__restrict__ offsets, int32_t *__restrict__ entries,
+                                                         float *__restrict__ wsorted)
+{
+    extern __shared__ int cnt[];                 // [T] counts -> cursors, then [T+1] offsets
+    int *off = cnt + T;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int32_t *ib = idx + (size_t)b * E;
+    for (int t = tid; t < T; t += 1024) cnt[t] = 0;
+    __syncthreads();
+    for (int e = tid; e < E; e += 1024) {
+        const int t = ib[e];
+        if (t >= 0 && t < T) atomicAdd(&cnt[t], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {                              // T <= 8192: a serial scan is a few microseconds and off the critical path
+        int run = 0;
+        for (int t = 0; t < T; ++t) { off[t] = run; run += cnt[t]; }
+        off[T] = run;
+    }
+    __syncthreads();
+    for (int t = tid; t <= T; t += 1024) offsets[(size_t)b * (T + 1) + t] = off[t];
+    for (int t = tid; t < T; t += 1024) cnt[t] = off[t];
+    __syncthreads();
+    for (int e = tid; e < E; e += 1024) {
+        const int t = ib[e];
+        if (t >= 0 && t < T) {
+            const size_t k = (size_t)b * E + atomicAdd(&cnt[t], 1);
+            entries[k] = e / ediv;               // the source ROW of the entry (what the gather needs), not the entry id
+            if (w) wsorted[k] = w[(size_t)b * E + e];
+        }
+    }
+}
+
+extern "C" int p2c_build_csr_i32(const int32_t *idx, const float *w, int B, int E, int ediv, int T, int32_t *offsets, int32_t *rows,
+                                 float *wsorted, void *stream)
+{
+    int32_t *entries = rows;
+    if (!idx || !offsets || !entries || B <= 0 || E <= 0 || T <= 0 || T > 16000 || ediv <= 0 || (w && !wsorted)) return P2C_EINVAL;
+    const size_t lds = (size_t)(2 * T + 1) * sizeof(int);
+    (void)hipFuncSetAttribute((const void *)build_csr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(build_csr_kernel, dim3(B), dim3(1024), lds, (hipStream_t)stream, idx, w, E, ediv, T, offsets, entries, wsorted);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+template <int CPL>
+__global__ void __launch_bounds__(256) csr_gather_kernel(const float *__restrict__ src, int lds_, int coff, const int32_t *__restrict__ offsets,
+                                                         const int32_t *__restrict__ entries, const float *__restrict__ w, int E,
+                                                         int rows_b, int T, int C, long long total, float *__restrict__ out, int ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= total) return;
+    const int b = (int)(wv / T), t = (int)(wv - (long long)b * T);
+    const int k0 = offsets[(size_t)b * (T + 1) + t], k1 = offsets[(size_t)b * (T + 1) + t + 1];
+    const int32_t *eb = entries + (size_t)b * E;
+    const float *wb = w ? w + (size_t)b * E : nullptr;
+    float acc[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
+    int k = k0;
+    for (; k + 4 <= k1; k += 4) {                // four independent row reads in flight
+        int e[4]; float we[4]; const float *row[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            e[u] = eb[k + u];
+            we[u] = wb ? wb[k + u] : 1.f;
+            row[u] = src + ((size_t)b * rows_b + e[u]) * lds_ + coff;
+        }
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                const float v0 = row[0][c], v1 = row[1][c], v2 = row[2][c], v3 = row[3][c];
+                acc[i] += we[0] * v0; acc[i] += we[1] * v1; acc[i] += we[2] * v2; acc[i] += we[3] * v3;
+            }
+        }
+    }
+    for (; k < k1; ++k) {
+        const int e = eb[k];
+        const float we = wb ? wb[k] : 1.f;
+        const float *row = src + ((size_t)b * rows_b + e) * lds_ + coff;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) acc[i] += we * row[c];
+        }
+    }
+    float *o = out + ((size_t)b * T + t) * ldo;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) o[c] = acc[i];
+    }
+}
+
+// out[b,t,0:C] = sum_{k in bucket(b,t)} wsorted[b,k] * src[b*rows_b + rows[b,k], coff:coff+C]   (wsorted NULL = 1; overwrites out)
+extern "C" int p2c_csr_gather_f32(const float *src, int ld_src, int coff, const int32_t *offsets, const int32_t *entries, const float *w,
+                                  int B, int E, int rows_b, int T, int C, float *out, int ldo, void *stream)
+{
+    if (!src || !offsets || !entries || !out || B <= 0 || E <= 0 || T <= 0 || C <= 0 || C > 256) return P2C_EINVAL;
+    const long long total = (long long)B * T;
+    dim3 grid(p2c_cdiv(total, 4));
+    hipStream_t s = (hipStream_t)stream;
+#define P2C_CG(CPL_) hipLaunchKernelGGL(csr_gather_kernel<CPL_>, grid, dim3(256), 0, s, src, ld_src, coff, offsets, entries, w, E, rows_b, T, C, total, out, ldo)
+    if (C <= 64) P2C_CG(1);
+    else if (C <= 128) P2C_CG(2);
+    else P2C_CG(4);
+#undef P2C_CG
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

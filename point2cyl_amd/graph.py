@@ -46,8 +46,8 @@ def _flatten(g):
         if isinstance(v, dict):
             out += _flatten(v)
         elif isinstance(v, (tuple, list)):
-            out += list(v)
-        else:
+            out += _flatten(dict(enumerate(v)))
+        elif v is not None:
             out.append(v)
     return out
 

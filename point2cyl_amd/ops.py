@@ -14,6 +14,7 @@ from ._lib import PROFILE, call, ptr, stream  # noqa: F401
 I32 = torch.int32
 PENDING_NBT = []      # num_batches_tracked counters to bump with ONE foreach add per forward (see backbone.forward)
 USE_FUSED_BWD = os.environ.get("P2C_FUSED_BWD", "1") != "0"
+USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated backward of the gathers (no atomics)
 
 
 def _f32c(t):
@@ -59,9 +60,23 @@ def three_nn(xyz1, xyz2, return_dist=False):
     return (idx, w, d) if return_dist else (idx, w)
 
 
+def build_csr(idx, T, w=None, ediv=1):
+    """Inverse map of a gather: idx (B, ...) int32 with values in [0,T) -> (offsets (B,T+1), rows (B,E) int32, wsorted (B,E) | None):
+    for every target t the source rows (entry // ediv) of the entries that read it, and their weights in the same order."""
+    B = idx.shape[0]
+    flat = idx.reshape(B, -1)
+    E = flat.shape[1]
+    offsets = torch.empty(B, T + 1, dtype=I32, device=idx.device)
+    rows = torch.empty(B, E, dtype=I32, device=idx.device)
+    ws = torch.empty(B, E, dtype=torch.float32, device=idx.device) if w is not None else None
+    call("p2c_build_csr_i32", ptr(flat), ptr(w) if w is not None else None, B, E, ediv, T, ptr(offsets), ptr(rows),
+         ptr(ws) if ws is not None else None, stream())
+    return offsets, rows, ws
+
+
 class _GroupGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xyz, feats, new_xyz, idx):
+    def forward(ctx, xyz, feats, new_xyz, idx, csr=None):
         B, N, _ = xyz.shape
         S, ns = idx.shape[1], idx.shape[2]
         D = 0 if feats is None else feats.shape[-1]
@@ -71,6 +86,7 @@ class _GroupGather(torch.autograd.Function):
             feats = _f32c(feats)
         call("p2c_group_gather_f32", ptr(xyz), ptr(feats), D, ptr(new_xyz), ptr(idx), B, N, S, ns, D, ptr(out), ldo, 1, stream())
         ctx.save_for_backward(idx)
+        ctx.csr = csr
         ctx.dims = (B, N, S, ns, D, ldo)
         return out
 
@@ -79,29 +95,36 @@ class _GroupGather(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         B, N, S, ns, D, ldo = ctx.dims
         if D == 0 or not ctx.needs_input_grad[1]:
-            return None, None, None, None
+            return None, None, None, None, None
         if dout.stride(1) != 1:
             dout = dout.contiguous()
-        dfeats = torch.zeros(B, N, D, dtype=torch.float32, device=dout.device)
-        call("p2c_group_gather_bwd_f32", ptr(dout), dout.stride(0), ptr(idx), B, N, S, ns, D, ptr(dfeats), D, 1, stream())
-        return None, dfeats, None, None
+        if USE_CSR_BWD and D <= 256:
+            offsets, rows, _ = ctx.csr if ctx.csr is not None else build_csr(idx, N)
+            dfeats = torch.empty(B, N, D, dtype=torch.float32, device=dout.device)
+            call("p2c_csr_gather_f32", ptr(dout), dout.stride(0), 0, ptr(offsets), ptr(rows), None, B, S * ns, S * ns, N, D,
+                 ptr(dfeats), D, stream())
+        else:
+            dfeats = torch.zeros(B, N, D, dtype=torch.float32, device=dout.device)
+            call("p2c_group_gather_bwd_f32", ptr(dout), dout.stride(0), ptr(idx), B, N, S, ns, D, ptr(dfeats), D, 1, stream())
+        return None, dfeats, None, None, None
 
 
-def group_gather(xyz, feats, new_xyz, idx):
+def group_gather(xyz, feats, new_xyz, idx, csr=None):
     """rows (b,s,j) = [feats[idx] | xyz[idx]-new_xyz | 0-pad] -> (B*S*ns, ld): the reference's concat (pointnet_util.py:137)
     with the feature block first ("xyz_last"); mlp_stack(..., xyz_last=True) permutes the first conv's input channels to match."""
-    return _GroupGather.apply(_f32c(xyz), feats, _f32c(new_xyz), idx)
+    return _GroupGather.apply(_f32c(xyz), feats, _f32c(new_xyz), idx, csr)
 
 
 class _ThreeInterp(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, idx, w):
+    def forward(ctx, feats, idx, w, csr=None):
         B, S, C = feats.shape
         N = idx.shape[1]
         feats = _f32c(feats)
         out = torch.empty(B * N, C, dtype=torch.float32, device=feats.device)
         call("p2c_three_interp_f32", ptr(feats), C, ptr(idx), ptr(w), B, N, S, C, ptr(out), C, stream())
         ctx.save_for_backward(idx, w)
+        ctx.csr = csr
         ctx.dims = (B, N, S, C)
         return out
 
@@ -109,15 +132,22 @@ class _ThreeInterp(torch.autograd.Function):
     def backward(ctx, dout):
         idx, w = ctx.saved_tensors
         B, N, S, C = ctx.dims
-        dout = _f32c(dout)
-        dfeats = torch.zeros(B, S, C, dtype=torch.float32, device=dout.device)
-        call("p2c_three_interp_bwd_f32", ptr(dout), C, ptr(idx), ptr(w), B, N, S, C, ptr(dfeats), C, stream())
-        return dfeats, None, None
+        if dout.stride(1) != 1:
+            dout = dout.contiguous()
+        if USE_CSR_BWD and C <= 256:
+            offsets, rows, ws = ctx.csr if ctx.csr is not None else build_csr(idx, S, w, 3)
+            dfeats = torch.empty(B, S, C, dtype=torch.float32, device=dout.device)
+            call("p2c_csr_gather_f32", ptr(dout), dout.stride(0), 0, ptr(offsets), ptr(rows), ptr(ws), B, N * 3, N, S, C, ptr(dfeats), C,
+                 stream())
+        else:
+            dfeats = torch.zeros(B, S, C, dtype=torch.float32, device=dout.device)
+            call("p2c_three_interp_bwd_f32", ptr(dout), dout.stride(0), ptr(idx), ptr(w), B, N, S, C, ptr(dfeats), C, stream())
+        return dfeats, None, None, None
 
 
-def three_interpolate(feats, idx, w):
-    """(B,S,C), idx/w (B,N,3) -> (B*N, C)  (pointnet_util.py:308)."""
-    return _ThreeInterp.apply(feats, idx, w)
+def three_interpolate(feats, idx, w, csr=None):
+    """(B,S,C), idx/w (B,N,3) -> (B*N, C)  (pointnet_util.py:308).  csr = build_csr(idx, S) if already available."""
+    return _ThreeInterp.apply(feats, idx, w, csr)
 
 
 # ------------------------------------------------------------------------------------------ MLP stack

@@ -63,9 +63,10 @@ def main():
     loss_fn = step.compute_losses_fused if (step.fused_loss_applicable(fl) and not args.torch_losses) else step.compute_losses
 
     def fwd_bwd(geom=None):
-        out = loss_fn(model, *batch, fl, geom=geom)
-        sync.zero()
-        out["total"].backward()
+        with ops.step_arena(dev):          # every zero-initialised accumulator of the step out of one buffer, one fill
+            out = loss_fn(model, *batch, fl, geom=geom)
+            sync.zero()
+            out["total"].backward()
         return {"total": out["total"].detach()}
 
     graphed = None

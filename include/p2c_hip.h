@@ -242,9 +242,12 @@ int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, const int64_t 
 int p2c_hungarian_f32(const float *W, const int64_t *I_gt, int B, int N, int K, int64_t *match_out, uint8_t *mask_out,
                       void *stream);
 /* same, from the raw head output [B*N, ld] whose 2K segmentation logits start at column woff: W = pairwise sums of
- * softmax(logits) (train_Point2Cyl_without_sketch.py:254-265) formed on the fly */
+ * softmax(logits) (train_Point2Cyl_without_sketch.py:254-265) formed on the fly.
+ * ws: optional scratch of p2c_hungarian_ws_bytes(B) bytes (no initialisation needed): with it (and K == 8) a cloud is
+ * reduced by 8 workgroups and a second small kernel solves the assignments.  NULL = one workgroup per cloud. */
+size_t p2c_hungarian_ws_bytes(int B);
 int p2c_hungarian_logits_f32(const float *heads, int ld, int woff, const int64_t *I_gt, int B, int N, int K, int64_t *match_out,
-                             uint8_t *mask_out, void *stream);
+                             uint8_t *mask_out, void *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The training losses fused (losses.py:90-143, :317-351 with collapse=True; train…:247-307):

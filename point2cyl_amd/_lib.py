@@ -51,7 +51,7 @@ _SIGS = {
     "p2c_segment_centroids_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "p2c_extrusion_extents_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_hungarian_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
-    "p2c_hungarian_logits_f32": [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
+    "p2c_hungarian_logits_f32": [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_seg_losses_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
 }
 
@@ -89,6 +89,8 @@ def lib():
     L.p2c_linear_bwd_fused_parts.argtypes = [c_i, c_i]
     L.p2c_linear_bwd_fused_parts.restype = c_i
     L.p2c_linear_tile_m.restype = c_i
+    L.p2c_hungarian_ws_bytes.argtypes = [c_i]
+    L.p2c_hungarian_ws_bytes.restype = ctypes.c_size_t
     L.p2c_extents_ws_bytes.argtypes = [c_i, c_i]
     L.p2c_extents_ws_bytes.restype = ctypes.c_size_t
     _lib = L

@@ -141,23 +141,27 @@ __global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__re
 // From-logits variant for K == 8: one thread per point slice; the point's softmax is evaluated ONCE (16 exps) and its
 // 8 pair sums W[k] are added to the (label, k) accumulators held in registers with compile-time-unrolled selects;
 // a wave-shuffle + LDS reduction yields the (K+1) x K sums and the K label counts.
-__global__ void __launch_bounds__(HM_THREADS) hungarian_logits8_kernel(const float *__restrict__ heads, int ld, int woff,
-                                                                      const int64_t *__restrict__ I_gt, int N,
-                                                                      int64_t *__restrict__ match_out, uint8_t *__restrict__ mask_out)
+// A cloud is split over `split` workgroups (B workgroups alone leave 7/8 of the chip idle and the point loop is
+// latency-bound); each writes its 80 partial sums and a second tiny kernel adds them in split order (deterministic)
+// and solves the assignment.  (A "last workgroup finishes" single-kernel version was 3x SLOWER: the agent-scope
+// fence it needs writes back the whole dirty L2 of the XCD, which at this point holds the head GEMM's output.)
+#define HL_THREADS 256
+__global__ void __launch_bounds__(HL_THREADS) hungarian_logits8_kernel(const float *__restrict__ heads, int ld, int woff,
+                                                                      const int64_t *__restrict__ I_gt, int N, int split, float *__restrict__ ws)
 {
-    constexpr int K = 8, NA = (K + 1) * K + K;          // 72 sums + 8 counts
-    __shared__ float red[HM_THREADS / 64][NA];
-    __shared__ int smax[HM_THREADS / 64];
-    __shared__ double cost[HM_MAXK * HM_MAXK];
-    __shared__ float tot[NA];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int K = 8, NA = (K + 1) * K + K, NP = NA + 1;          // 72 sums + 8 counts (+ max label)
+    __shared__ float red[HL_THREADS / 64][NA];
+    __shared__ int smax[HL_THREADS / 64];
+    __shared__ float tot[NP];
+    const int b = blockIdx.x / split, part = blockIdx.x % split, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t *lab = I_gt + (size_t)b * N;
     const float *h = heads + (size_t)b * N * ld + woff;
+    const int per = (N + split - 1) / split, n0 = part * per, n1 = min(N, n0 + per);
     float acc[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0.f;
     int mx = -1;
-    for (int n = tid; n < N; n += HM_THREADS) {
+    for (int n = n0 + tid; n < n1; n += HL_THREADS) {
         const int l = (int)lab[n];
         mx = max(mx, l);
         const float *lg = h + (size_t)n * ld;
@@ -187,14 +191,36 @@ __global__ void __launch_bounds__(HM_THREADS) hungarian_logits8_kernel(const flo
     __syncthreads();
     if (tid < NA) {
         float s = 0.f;
-        for (int w = 0; w < HM_THREADS / 64; ++w) s += red[w][tid];
+        for (int w = 0; w < HL_THREADS / 64; ++w) s += red[w][tid];
+        tot[tid] = s;
+    }
+    if (tid == NA) {
+        int m2 = -1;
+        for (int i = 0; i < HL_THREADS / 64; ++i) m2 = max(m2, smax[i]);
+        tot[NA] = (float)m2;
+    }
+    __syncthreads();
+    if (tid < NP) ws[((size_t)b * split + part) * NP + tid] = tot[tid];
+}
+
+__global__ void __launch_bounds__(128) hungarian_finish8_kernel(const float *__restrict__ ws, int split, int64_t *__restrict__ match_out,
+                                                               uint8_t *__restrict__ mask_out)
+{
+    constexpr int K = 8, NA = (K + 1) * K + K, NP = NA + 1;
+    __shared__ double cost[HM_MAXK * HM_MAXK];
+    __shared__ float tot[NP];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < NP) {
+        float s = tid < NA ? 0.f : -1.f;
+        for (int q = 0; q < split; ++q) {
+            const float v = ws[((size_t)b * split + q) * NP + tid];
+            s = tid < NA ? s + v : fmaxf(s, v);
+        }
         tot[tid] = s;
     }
     __syncthreads();
     if (tid == 0) {
-        int n_gt = -1;
-        for (int i = 0; i < HM_THREADS / 64; ++i) n_gt = max(n_gt, smax[i]);
-        n_gt += 1;
+        const int n_gt = (int)tot[NA] + 1;
         const int nr = min(n_gt, K);
         for (int r = 0; r < nr; ++r)
             for (int q = 0; q < K; ++q) {
@@ -222,13 +248,18 @@ extern "C" int p2c_hungarian_f32(const float *W, const int64_t *I_gt, int B, int
     return P2C_OK;
 }
 
-// Same matching, taking the raw head output: rows of `ld` floats with the 2K segmentation logits at column `woff`.
+#define HL_SPLIT 8
+extern "C" size_t p2c_hungarian_ws_bytes(int B) { return (size_t)B * HL_SPLIT * 81 * sizeof(float); }
+
 extern "C" int p2c_hungarian_logits_f32(const float *heads, int ld, int woff, const int64_t *I_gt, int B, int N, int K, int64_t *match_out,
-                                        uint8_t *mask_out, void *stream)
+                                        uint8_t *mask_out, void *ws, void *stream)
 {
     if (!heads || !I_gt || !match_out || !mask_out || B <= 0 || N <= 0 || K <= 0 || K > HM_MAXK || ld < woff + 2 * K) return P2C_EINVAL;
-    if (K == 8) {
-        hipLaunchKernelGGL(hungarian_logits8_kernel, dim3(B), dim3(HM_THREADS), 0, (hipStream_t)stream, heads, ld, woff, I_gt, N, match_out, mask_out);
+    if (K == 8 && ws) {
+        const int split = N >= 2048 ? HL_SPLIT : 1;
+        hipLaunchKernelGGL(hungarian_logits8_kernel, dim3(B * split), dim3(HL_THREADS), 0, (hipStream_t)stream, heads, ld, woff, I_gt, N, split,
+                           (float *)ws);
+        hipLaunchKernelGGL(hungarian_finish8_kernel, dim3(B), dim3(128), 0, (hipStream_t)stream, (const float *)ws, split, match_out, mask_out);
         P2C_LAUNCH_CHECK();
         return P2C_OK;
     }

@@ -228,16 +228,18 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double *__re
 
 // Same reduction when the layer feeds the max-pool: dZ is non-zero only at the winner rows, so the sums run over
 // the G x C pooled gradients (1/ns of the rows) and read Y at the winners only.
+#define POOL_ROWS 64     // G is 1/ns of the rows: small chunks, or a 16k-group layer is reduced by 8 workgroups
 __global__ void __launch_bounds__(256) pool_bwd_partial_kernel(const float *__restrict__ dout, int ldo, const float *__restrict__ ywin,
                                                                const float *__restrict__ stat, int G, int C, double *__restrict__ ws)
 {
     __shared__ float red[2][4][64];
     const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cx;
-    const int g0 = blockIdx.x * BWD_ROWS, g1 = min(G, g0 + BWD_ROWS);
+    const int g0 = blockIdx.x * POOL_ROWS, g1 = min(G, g0 + POOL_ROWS);
     float s1 = 0.f, s2 = 0.f;
     if (c < C) {
         const float sc = stat[c], sh = stat[C + c], mu = stat[2 * C + c], is = stat[3 * C + c];
+#pragma unroll 4
         for (int g = g0 + ty; g < g1; g += 4) {
             const float y = ywin[(size_t)g * C + c];
             const float gr = (sc * y + sh > 0.f) ? dout[(size_t)g * ldo + c] : 0.f;
@@ -260,7 +262,7 @@ extern "C" int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const fl
 {
     if (!dout || !ywin || !stat || !gamma || !coef_out || !slots || G <= 0 || ns <= 0 || C <= 0) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = p2c_cdiv(G, BWD_ROWS);
+    const int chunks = p2c_cdiv(G, POOL_ROWS);
     hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dout, ldo, ywin, stat, G, C, slots);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, (const double *)slots, P2C_STAT_SLOTS, C,
                        (long long)G * ns, stat, stat + C, stat + 2 * C, stat + 3 * C, gamma, dgamma, dbeta, coef_out);

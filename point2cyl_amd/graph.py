@@ -81,8 +81,7 @@ class GraphedForwardBackward:
                 nxt = model.compute_geometry(prefetch_xyz)
             out = fn(self.cur)
             cap.wait_stream(side)                                   # join
-            for dst, src in zip(_flatten(self.cur), _flatten(nxt)):
-                dst.copy_(src)
+            torch._foreach_copy_(_flatten(self.cur), _flatten(nxt))  # one launch per dtype instead of ~25 copies
             return out
 
         self._side = torch.cuda.Stream() if self.prefetch else None

@@ -190,12 +190,54 @@ def _slots(C, dev):
     return torch.zeros(STAT_SLOTS, 2, C, dtype=torch.float64, device=dev)
 
 
+class _StepArena:
+    """All zero-initialised scratch of one training step (fp64 stat slots, per-XCD dW copies, bias gradients) comes out
+    of ONE buffer that is cleared by one fill at the start of the step instead of one fill per stack and direction.
+    Only active inside `with ops.step_arena(dev):`; the first step measures the size, later steps reuse the buffer
+    (static address: HIP-graph friendly).  Tensors handed out alias the buffer and die at the next step's start, so the
+    caller must have consumed the gradients by then - true when .grad already exists and autograd accumulates into it
+    (ddp.FlatGradSync) or when the optimizer steps before the next forward."""
+
+    def __init__(self):
+        self.buf, self.off, self.need, self.run, self.active = None, 0, 0, 0, False
+
+    def take(self, n_f64, dev):
+        self.run += n_f64
+        if self.active and self.buf is not None and self.buf.device == dev and self.off + n_f64 <= self.buf.numel():
+            out = self.buf[self.off:self.off + n_f64]
+            self.off += n_f64
+            return out
+        return torch.zeros(n_f64, dtype=torch.float64, device=dev)
+
+
+STEP_ARENA = _StepArena()
+
+
+class step_arena:
+    def __init__(self, dev):
+        self.dev = torch.device(dev)
+
+    def __enter__(self):
+        A = STEP_ARENA
+        if A.buf is None or A.buf.numel() < A.need or A.buf.device != self.dev:
+            A.buf = torch.zeros(max(A.need, 1), dtype=torch.float64, device=self.dev)
+        else:
+            A.buf.zero_()
+        A.off, A.run, A.active = 0, 0, True
+        return A
+
+    def __exit__(self, *exc):
+        A = STEP_ARENA
+        A.need, A.active = max(A.need, A.run), False
+        return False
+
+
 class _ZeroArena:
     """One zero-filled allocation carved into the many small accumulators a stack needs (fp64 stat slots, the 8
-    per-XCD copies of each dW, bias gradients): one fill kernel instead of dozens."""
+    per-XCD copies of each dW, bias gradients): one fill kernel instead of dozens (none inside a step_arena)."""
 
     def __init__(self, n_f64, dev):
-        self.buf = torch.zeros(n_f64, dtype=torch.float64, device=dev)
+        self.buf = STEP_ARENA.take(n_f64, dev)
         self.off = 0
 
     def f64(self, *shape):
@@ -552,6 +594,17 @@ def hungarian(W, I_gt):
     return match, mask.bool()
 
 
+_HUNG_WS = {}
+
+
+def _hungarian_ws(B, dev):
+    """Partial sums of the split matching kernel (p2c_hip.h); one buffer per (B, device), reused."""
+    key = (B, dev.index)
+    if key not in _HUNG_WS:
+        _HUNG_WS[key] = torch.empty(_lib.lib().p2c_hungarian_ws_bytes(B) // 4 + 4, dtype=torch.float32, device=dev)
+    return _HUNG_WS[key]
+
+
 class _SegLosses(torch.autograd.Function):
     """total = w_seg*mIoU + w_normal*normal + w_bb*base/barrel on the raw head output (fused forward + gradient)."""
 
@@ -564,7 +617,7 @@ class _SegLosses(torch.autograd.Function):
         match = torch.empty(B, K, dtype=torch.int64, device=dev)
         mask = torch.empty(B, K, dtype=torch.uint8, device=dev)
         hd = heads.detach()
-        call("p2c_hungarian_logits_f32", ptr(hd), ld, woff, ptr(I_gt), B, N, K, ptr(match), ptr(mask), stream())
+        call("p2c_hungarian_logits_f32", ptr(hd), ld, woff, ptr(I_gt), B, N, K, ptr(match), ptr(mask), ptr(_hungarian_ws(B, dev)), stream())
         out = torch.empty(4, dtype=torch.float32, device=dev)
         dheads = torch.empty(M, ld, dtype=torch.float32, device=dev)
         ws = torch.zeros(_lib.lib().p2c_seg_losses_ws_bytes(B, K) // 8 + 8, dtype=torch.float64, device=dev)

@@ -17,7 +17,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-from . import ddp, step, synth
+from . import ops, ddp, step, synth
 from .backbone import backbone
 
 
@@ -102,9 +102,10 @@ def main(argv=None):
                 for g in opt.param_groups:
                     g["lr"] = lr
                 old_lr = lr
-            out = (step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses)(model, *batch, fl)
-            sync.zero()
-            out["total"].backward()
+            with ops.step_arena(dev):
+                out = (step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses)(model, *batch, fl)
+                sync.zero()
+                out["total"].backward()
             sync.allreduce()
             opt.step()
             gstep += 1

@@ -26,6 +26,24 @@
 // the barrier into an exposed HBM round trip per phase.  LDS hand-offs only need lgkmcnt(0).
 #define P2C_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
+// -DP2C_TRACE (tools/fused_trace.py builds that variant; never the product): workgroup 0 stamps the shader clock at
+// the phase boundaries of a few iterations so the overlap of the two halves can be read off directly.
+#ifdef P2C_TRACE
+#define P2C_TR_IT 12
+#define P2C_TR_PT 8
+__device__ unsigned long long p2c_trace_buf[2][P2C_TR_IT][P2C_TR_PT];
+#define P2C_TR(pt)                                                                                   \
+    do {                                                                                             \
+        if (blockIdx.x == 0 && tid == 0 && it < P2C_TR_IT) p2c_trace_buf[half][it][pt] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int p2c_trace_read(void *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(p2c_trace_buf), sizeof(unsigned long long) * 2 * P2C_TR_IT * P2C_TR_PT);
+}
+#else
+#define P2C_TR(pt) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copy can pin an array in scratch)
 
@@ -113,191 +131,8 @@ __device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid,
 
 // COT = Co/64, CIT = Ci/64 (1 or 2).  Waves: for dW a 2x2 grid over Co x Ci (wave tile COT*32 x CIT*32);
 // for dX a WR x WC grid with WC = Ci/32 columns of 32, WR = 4/WC, so BM = 32*WR rows per tile.
-template <int COT, int CIT, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS>
-__global__ void __launch_bounds__(256, 1) bwd_fused_kernel(BwdFusedArgs a)
-{
-    constexpr int Co = 64 * COT, Ci = 64 * CIT;
-    constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
-    constexpr int LDW = Ci + 4, LDY = BM + 1, LDX = Ci + 4;
-    constexpr int UDY = BM * Co / 4 / 256, UX = BM * Ci / 4 / 256;     // float4 units per thread
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Ws = smem;                              // [Co][LDW]
-    float *dYs = Ws + Co * LDW;                    // [2][Co][LDY]
-    float *Xr = dYs + 2 * Co * LDY;                // [2][BM][LDX]
-    float *red = Xr + 2 * BM * LDX;                // [2][Ci] final cross-wave combine
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int wi = wave >> 1, wj = wave & 1;       // dW wave grid
-    const int wr = wave / WC, wc = wave % WC;      // dX wave grid
-    const int ntiles = (a.M + BM - 1) / BM;
-
-    // ---- W -> LDS (once) ---------------------------------------------------------------------------
-    if (NEED_DX) {
-        for (int u = tid; u < Co * Ci / 4; u += 256) {
-            const int r = u / (Ci / 4), c4 = u % (Ci / 4);
-            *reinterpret_cast<float4 *>(&Ws[r * LDW + c4 * 4]) = *reinterpret_cast<const float4 *>(a.w + (size_t)r * a.ldw + c4 * 4);
-        }
-    }
-    // per-lane constants
-    float isc[CIT], ish[CIT];                      // act_in scale/shift of the dW B-operand columns this lane reads
-#pragma unroll
-    for (int t = 0; t < CIT; ++t) {
-        const int ci = wj * (CIT * 32) + t * 32 + l31;
-        isc[t] = IMODE == 1 ? a.in_scale[ci] : 1.f;
-        ish[t] = IMODE == 1 ? a.in_shift[ci] : 0.f;
-    }
-    const int xcol = wc * 32 + l31;                // dX column of this lane
-    float psc = 0.f, psh = 0.f, pmu = 0.f, pis = 0.f;
-    if (NEED_DX && HAS_STATS) { psc = a.pstat[xcol]; psh = a.pstat[Ci + xcol]; pmu = a.pstat[2 * Ci + xcol]; pis = a.pstat[3 * Ci + xcol]; }
-    // this thread always stages the same 4 channels of dY (256 % (Co/4) == 0): keep their coefficients in registers
-    float4 cf[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
-        cf[i] = GMODE >= 1 ? *reinterpret_cast<const float4 *>(a.coef + i * Co + (tid % (Co / 4)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    float s1 = 0.f, s2 = 0.f, dbacc = 0.f;
-
-    f32x16 accW[COT][CIT];
-#pragma unroll
-    for (int i = 0; i < COT; ++i)
-#pragma unroll
-        for (int j = 0; j < CIT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accW[i][j][r] = 0.f;
-
-    float4 rdz[UDY], ry[UDY];
-    v4f rx[UX];
-    int4 rarg[UDY];
-    int t = blockIdx.x;                                     // gridDim.x <= ntiles: every workgroup owns at least one tile
-    fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, t, rdz, ry, rarg, rx);
-    fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, t, dYs, Xr, rdz, ry, rarg, rx, cf);
-    __syncthreads();
-    int buf = 0;
-    for (; t < ntiles; t += gridDim.x) {
-        const int tn = t + gridDim.x;
-        const int tl = tn < ntiles ? tn : t;
-        fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tl, rdz, ry, rarg, rx);   // in flight during the MFMAs below (unconditional: stays in registers)
-        const float *dy = dYs + buf * Co * LDY;
-        const float *xr = Xr + buf * BM * LDX;
-        const int m0 = t * BM;
-        // ---------------- dW += dY^T . act_in(X): reduction over the BM rows of the tile.
-        // The wave issues in order and each MFMA occupies the matrix pipe for 64 cycles, so the LDS reads of step
-        // s+1 are issued BEFORE the MFMAs of step s (register double buffering): their latency and the act_in
-        // VALU work then sit in the shadow of the matrix pipe instead of in front of it.
-        {
-            float av[COT], bv[CIT], an[COT], bn[CIT];
-#pragma unroll
-            for (int i = 0; i < COT; ++i) av[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + lh];
-#pragma unroll
-            for (int j = 0; j < CIT; ++j) bv[j] = xr[lh * LDX + wj * (CIT * 32) + j * 32 + l31];
-#pragma unroll 8
-            for (int s = 0; s < BM; s += 2) {
-                const int sn = (s + 2 < BM) ? s + 2 : s;            // last step re-reads itself (harmless)
-#pragma unroll
-                for (int i = 0; i < COT; ++i) an[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + sn + lh];
-#pragma unroll
-                for (int j = 0; j < CIT; ++j) bn[j] = xr[(sn + lh) * LDX + wj * (CIT * 32) + j * 32 + l31];
-                float bz[CIT];
-#pragma unroll
-                for (int j = 0; j < CIT; ++j) {
-                    float v = bv[j];
-                    if (IMODE == 1) v = fmaxf(isc[j] * v + ish[j], 0.f);
-                    if (m0 + s + lh >= a.M) v = 0.f;            // rows past the end carry clamped (non-zero) X values
-                    bz[j] = v;
-                }
-#pragma unroll
-                for (int i = 0; i < COT; ++i)
-#pragma unroll
-                    for (int j = 0; j < CIT; ++j) accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bz[j], accW[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < COT; ++i) av[i] = an[i];
-#pragma unroll
-                for (int j = 0; j < CIT; ++j) bv[j] = bn[j];
-            }
-        }
-        if (GMODE == 0 && a.dbias && tid < Co) {
-            float sb = 0.f;
-#pragma unroll 8
-            for (int s = 0; s < BM; ++s) sb += dy[tid * LDY + s];
-            dbacc += sb;
-        }
-        // ---------------- dX tile = dY . W, reduction over Co
-        if (NEED_DX) {
-            f32x16 accX;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accX[r] = 0.f;
-            {
-                float av = dy[lh * LDY + wr * 32 + l31], bv = Ws[lh * LDW + wc * 32 + l31];
-#pragma unroll 16
-                for (int k = 0; k < Co; k += 2) {
-                    const int kn = (k + 2 < Co) ? k + 2 : k;
-                    const float an = dy[(kn + lh) * LDY + wr * 32 + l31];     // next step's operands first ...
-                    const float bn = Ws[(kn + lh) * LDW + wc * 32 + l31];
-                    accX = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accX, 0, 0, 0);   // ... then this step's MFMA
-                    av = an;
-                    bv = bn;
-                }
-            }
-            // rows past M are exactly 0 (their dY rows were zeroed); only the last tile can be ragged (uniform branch)
-            if (m0 + BM <= a.M) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    a.dx[(size_t)(m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * a.lddx + xcol] = accX[r];
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < a.M) a.dx[(size_t)m * a.lddx + xcol] = accX[r];
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float v = accX[r];
-                if (HAS_STATS) {
-                    const float yp = xr[row * LDX + xcol];
-                    const float g = (psc * yp + psh > 0.f) ? v : 0.f;
-                    s1 += g;
-                    s2 += g * ((yp - pmu) * pis);
-                }
-            }
-        }
-        fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, tl, dYs + (buf ^ 1) * Co * LDY, Xr + (buf ^ 1) * BM * LDX, rdz, ry, rarg, rx, cf);
-        __syncthreads();
-        buf ^= 1;
-    }
-    // ---------------- flush
-#pragma unroll
-    for (int i = 0; i < COT; ++i)
-#pragma unroll
-        for (int j = 0; j < CIT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = wi * (COT * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int ci = wj * (CIT * 32) + j * 32 + l31;
-                atomicAdd(&a.dw[(size_t)(blockIdx.x & 7) * a.dw_slot_stride + (size_t)co * a.lddw + ci], accW[i][j][r]);
-            }
-    if (GMODE == 0 && a.dbias && tid < Co) atomicAdd(&a.dbias[tid], dbacc);
-    if (NEED_DX && HAS_STATS) {
-        if (tid < 2 * Ci) red[tid] = 0.f;
-        __syncthreads();
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (lh == 0) {                                      // WR waves share a column: WR <= 2 adds per slot (order-free)
-            atomicAdd(&red[xcol], s1);
-            atomicAdd(&red[Ci + xcol], s2);
-        }
-        __syncthreads();
-        if (tid < Ci) {
-            double *o = a.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * Ci;
-            atomicAdd(&o[tid], (double)red[tid]);
-            atomicAdd(&o[Ci + tid], (double)red[Ci + tid]);
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------
-// Ping-pong variant (default): 512 threads = two half-workgroups of 4 waves that share W in LDS and own one tile
+// Ping-pong structure: 512 threads = two half-workgroups of 4 waves that share W in LDS and own one tile
 // buffer each.  A wave issues in order, so inside ONE wave the ~350 non-MFMA instructions of a tile (epilogue
 // stores, BN-backward sums, staging the next tile into LDS, issuing the prefetch) cannot hide behind its own
 // MFMAs; PMC on the single-group kernel shows MFMA busy 48 % + issue-active 29 % + parked 20 % with no overlap.
@@ -396,6 +231,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         const bool valid = k < nk;                 // uniform within the half
         const int m0 = tile_of(valid ? k : 0) * BM;
         // ================= MFMA phase =================
+        P2C_TR(0);
         if (valid) {
             {
                 float av[COT], bv[CIT], an[COT], bn[CIT];
@@ -410,6 +246,10 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                     for (int i = 0; i < COT; ++i) an[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + sn + lh];
 #pragma unroll
                     for (int j = 0; j < CIT; ++j) bn[j] = xr[(sn + lh) * LDX + wj * (CIT * 32) + j * 32 + l31];
+                    // pinned: the LDS reads of step s+1 are issued BEFORE the MFMAs of step s.  Left alone, the scheduler
+                    // sinks them next to their use and every group of MFMAs eats a full LDS round trip (phase trace:
+                    // 116 instead of 64 cycles per MFMA).
+                    __builtin_amdgcn_sched_barrier(0);
                     float bz[CIT];
 #pragma unroll
                     for (int j = 0; j < CIT; ++j) {
@@ -422,12 +262,14 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                     for (int i = 0; i < COT; ++i)
 #pragma unroll
                         for (int j = 0; j < CIT; ++j) accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bz[j], accW[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < COT; ++i) av[i] = an[i];
 #pragma unroll
                     for (int j = 0; j < CIT; ++j) bv[j] = bn[j];
                 }
             }
+            P2C_TR(1);
             if (GMODE == 0 && a.dbias && tid < Co) {
                 float sb = 0.f;
 #pragma unroll 8
@@ -446,15 +288,38 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
             if (NEED_DX) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accX[r] = 0.f;
-                float av = dy[lh * LDY + wr * 32 + l31], bv = Ws[lh * LDW + wc * 32 + l31];
-#pragma unroll 16
-                for (int kk = 0; kk < Co; kk += 2) {
-                    const int kn = (kk + 2 < Co) ? kk + 2 : kk;
-                    const float an = dy[(kn + lh) * LDY + wr * 32 + l31];
-                    const float bn = Ws[(kn + lh) * LDW + wc * 32 + l31];
-                    accX = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accX, 0, 0, 0);
-                    av = an;
-                    bv = bn;
+                // same pinning: groups of DXG k-steps, the reads of group g+1 in flight under the MFMAs of group g
+                constexpr int DXG = GMODE == 2 ? 2 : 4, NG = Co / (2 * DXG);    // the pooled variant carries the winner indices too: fewer registers to spare
+                float a0[DXG], b0[DXG], a1[DXG], b1[DXG];
+#pragma unroll
+                for (int u = 0; u < DXG; ++u) {
+                    a0[u] = dy[(2 * u + lh) * LDY + wr * 32 + l31];
+                    b0[u] = Ws[(2 * u + lh) * LDW + wc * 32 + l31];
+                }
+#pragma unroll
+                for (int g = 0; g < NG; g += 2) {
+#pragma unroll
+                    for (int u = 0; u < DXG; ++u) {
+                        const int kk = 2 * ((g + 1) * DXG + u);
+                        a1[u] = dy[(kk + lh) * LDY + wr * 32 + l31];
+                        b1[u] = Ws[(kk + lh) * LDW + wc * 32 + l31];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < DXG; ++u) accX = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], accX, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + 2 < NG) {
+#pragma unroll
+                        for (int u = 0; u < DXG; ++u) {
+                            const int kk = 2 * ((g + 2) * DXG + u);
+                            a0[u] = dy[(kk + lh) * LDY + wr * 32 + l31];
+                            b0[u] = Ws[(kk + lh) * LDW + wc * 32 + l31];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < DXG; ++u) accX = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], accX, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (HAS_STATS) {                    // the epilogue runs after the barrier, when xr may already be restaged
 #pragma unroll
@@ -462,11 +327,14 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                 }
             }
         }
+        P2C_TR(2);
         P2C_LDS_BARRIER();
+        P2C_TR(3);
         // ================= non-MFMA phase (the other half is in its MFMA phase) =================
         // The co-resident wave of the other half needs an issue slot only once per 64-cycle MFMA; give this phase's
         // VALU / LDS / VMEM instructions priority so it finishes inside the other half's MFMA phase.
         __builtin_amdgcn_s_setprio(1);
+#ifndef P2C_TRACE_NODATA
         if (valid && NEED_DX) {
             if (m0 + BM <= a.M) {
 #pragma unroll
@@ -489,9 +357,11 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                 }
             }
         }
+        P2C_TR(4);
         {
             const int k2 = k + 2, k4 = k + 4;
             if (k2 < nk) fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, tile_of(k2), dy, xr, rdz, ry, rarg, rx, cf);
+            P2C_TR(5);
             if (EX > 0 && tid < BM) *reinterpret_cast<v4f *>(&xe[tid * 4]) = rxe;
             fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
             if (EX > 0 && tid < BM) {
@@ -499,8 +369,11 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                 rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
             }
         }
+#endif
         __builtin_amdgcn_s_setprio(0);
+        P2C_TR(6);
         P2C_LDS_BARRIER();                         // the prefetch above stays in flight across this barrier
+        P2C_TR(7);
     }
     if (half == 0) P2C_LDS_BARRIER();
     // ---------------- flush: half 1 hands its dW accumulators to half 0 through LDS (the tile buffers and W are dead
@@ -592,18 +465,11 @@ static int launch_fused(const BwdFusedArgs &a, int extra, hipStream_t s)
             return P2C_EINVAL;
         }
     }
-    static const bool pingpong = !(getenv("P2C_FUSED_PP") && atoi(getenv("P2C_FUSED_PP")) == 0);
 #define P2C_FL(DX_, ST_)                                                                                                             \
     do {                                                                                                                             \
-        if (pingpong) {                                                                                                              \
-            (void)hipFuncSetAttribute((const void *)bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_, 0>,                           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
-            hipLaunchKernelGGL((bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_, 0>), dim3(grid), dim3(512), lds, s, a);             \
-        } else {                                                                                                                     \
-            (void)hipFuncSetAttribute((const void *)bwd_fused_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>,                              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                         \
-            hipLaunchKernelGGL((bwd_fused_kernel<COT, CIT, GMODE, IMODE, DX_, ST_>), dim3(grid), dim3(256), lds, s, a);                \
-        }                                                                                                                            \
+        (void)hipFuncSetAttribute((const void *)bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_, 0>,                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                             \
+        hipLaunchKernelGGL((bwd_fused_pp_kernel<COT, CIT, GMODE, IMODE, DX_, ST_, 0>), dim3(grid), dim3(512), lds, s, a);                 \
     } while (0)
     if (a.dx && a.pstat) P2C_FL(true, true);
     else if (a.dx) P2C_FL(true, false);

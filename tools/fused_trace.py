@@ -1,0 +1,49 @@
+"""Phase timeline of the ping-pong fused backward kernel (csrc/bwd_fused.hip built with -DP2C_TRACE into a throw-away
+library).  Build here:  python tools/fused_trace.py --build      Run on the GPU box:  python tools/fused_trace.py [M Co Ci]
+Stamps (shader clock) of workgroup 0, thread 0 of each half:
+  0 MFMA phase start | 1 end of dW MFMAs | 2 end of MFMA phase (before barrier) | 3 after barrier | 4 dX stored + sums
+  5 next tile transformed into LDS (waits for its global loads) | 6 prefetch issued | 7 after 2nd barrier"""
+import ctypes, os, subprocess, sys
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+NODATA = "--nodata" in sys.argv       # MFMA phases only: no global traffic, no LDS staging (isolates the MFMA loops)
+LIB = os.path.join(HERE, "libp2c_trace_nodata.so" if NODATA else "libp2c_trace.so")
+if "--build" in sys.argv:
+    for lib, extra in ((os.path.join(HERE, "libp2c_trace.so"), []), (os.path.join(HERE, "libp2c_trace_nodata.so"), ["-DP2C_TRACE_NODATA"])):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_TRACE"] + extra +
+                              ["-shared", "-o", lib, os.path.join(ROOT, "point2cyl_amd", "csrc", "bwd_fused.hip")])
+        print(lib)
+    sys.exit(0)
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+M, Co, Ci = (int(args[0]), int(args[1]), int(args[2])) if len(args) >= 3 else (262144, 128, 128)
+L = ctypes.CDLL(LIB)
+vp, ci = ctypes.c_void_p, ctypes.c_int
+L.p2c_linear_bwd_fused_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, vp, ci, vp, ci, ctypes.c_longlong, vp, vp, vp, ci, ci, ci, vp]
+dev = "cuda"
+dZ = torch.randn(M, Co, device=dev); Y = torch.randn(M, Co, device=dev); X = torch.randn(M, Ci, device=dev)
+coef = torch.randn(5, Co, device=dev); sc = torch.rand(Ci, device=dev) + .5; sh = torch.randn(Ci, device=dev) * .1
+W = torch.randn(Co, Ci, device=dev) * .1; dX = torch.empty(M, Ci, device=dev); dW8 = torch.zeros(8, Co, Ci, device=dev)
+pstat = torch.rand(4, Ci, device=dev); parts = torch.zeros(64, 2, Ci, device=dev, dtype=torch.float64)
+st = torch.cuda.current_stream().cuda_stream
+def run():
+    rc = L.p2c_linear_bwd_fused_f32(dZ.data_ptr(), Co, Y.data_ptr(), Co, 1, coef.data_ptr(), None, 0, X.data_ptr(), Ci, 1, sc.data_ptr(), sh.data_ptr(),
+                                    W.data_ptr(), Ci, dX.data_ptr(), Ci, dW8.data_ptr(), Ci, Co * Ci, None, pstat.data_ptr(), parts.data_ptr(), M, Co, Ci, st)
+    assert rc == 0, rc
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+print("kernel %.1f us" % (e0.elapsed_time(e1) * 1e3))
+buf = np.zeros((2, 12, 8), dtype=np.uint64)
+assert L.p2c_trace_read(buf.ctypes.data_as(vp)) == 0
+t0 = buf[0, 2, 0]
+names = ["mfma0", "dW_end", "mfma_end", "bar1", "dx+sums", "stage", "prefetch", "bar2"]
+for it in range(2, 10):
+    for h in range(2):
+        row = buf[h, it].astype(np.int64) - int(t0)
+        d = np.diff(row)
+        print("it %d half %d  start %8d | " % (it, h, row[0]) + "  ".join("%s %6d" % (n, v) for n, v in zip(names[1:], d)))

@@ -122,6 +122,9 @@ int p2c_linear_stat_tiles(int M);    /* ceil(M / p2c_linear_tile_m()) */
 int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
                        int K, int in_mode, const float *in_scale, const float *in_shift, const uint8_t *drop_mask,
                        int ldmask, float drop_scale, double *stat_slots, void *stream);
+/* 1 if p2c_linear_fwd_f32 runs this shape on the persistent weight-stationary kernel (fwd_pp.hip: M >= 8192, N <= 256,
+ * K <= 128 or the grouped K == 132, no byte mask); otherwise the tiled kernel is used.  Same results either way. */
+int p2c_linear_fwd_pp_supported(int M, int N, int K, int in_mode);
 
 /* BatchNorm batch statistics -> affine.  training != 0: mean/var from the slots (biased var for the
  * normalisation, unbiased for running_var, torch semantics), running stats updated in place with
@@ -192,7 +195,10 @@ int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int 
  * the two entry points above; dX may be NULL (then prev_stat/bwd_partials must be NULL too).
  * bwd_partials: the zeroed fp64 slots of the layer below (p2c_stat_slots_bytes(Ci)).
  * dW is accumulated into 8 copies (one per XCD, copy s at dW + s*dw_slot_stride elements, all zero-initialised by the
- * caller, who sums them); dw_slot_stride = 0 selects a single copy. */
+ * caller, who sums them); dw_slot_stride = 0 selects a single copy.
+ * p2c_linear_bwd_fused_supported: 0 = use the two generic entry points, 1 = supported, 2 = supported for the grouped
+ * layer [128 features | 4 trailing columns] (Ci = 132, in_mode 0): dW covers all 132 columns but dX[:, 128:132] is NOT
+ * written (the trailing columns are the relative coordinates, which receive no gradient). */
 int p2c_linear_bwd_fused_supported(int Co, int Ci, int in_mode);
 int p2c_linear_bwd_fused_parts(int M, int Ci);
 int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,

@@ -86,6 +86,8 @@ def lib():
     L.p2c_stat_slots_bytes.restype = ctypes.c_size_t
     L.p2c_linear_bwd_fused_supported.argtypes = [c_i, c_i, c_i]
     L.p2c_linear_bwd_fused_supported.restype = c_i
+    L.p2c_linear_fwd_pp_supported.argtypes = [c_i, c_i, c_i, c_i]
+    L.p2c_linear_fwd_pp_supported.restype = c_i
     L.p2c_linear_bwd_fused_parts.argtypes = [c_i, c_i]
     L.p2c_linear_bwd_fused_parts.restype = c_i
     L.p2c_linear_tile_m.restype = c_i

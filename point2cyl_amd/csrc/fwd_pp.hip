@@ -1,0 +1,309 @@
+// fwd_pp.hip -- forward of the narrow, long layers  Y = act_in(X) . W^T + b  (K <= 128 (+4), N <= 128 per workgroup,
+// M = 262144 .. 1048576 rows) as a persistent, weight-stationary, ping-pong kernel.
+//
+// Why not the tiled kernel of gemm.hip for these: its workgroups run load -> MFMA -> epilogue in sequence and the
+// two workgroups a CU holds start together, so the phases of the chip line up instead of overlapping (matrix pipes
+// busy ~50 %); and an fp32 MFMA loop on gfx950 is bounded by the OTHER instructions the wave issues (they do not
+// overlap its own MFMAs, tools/ubench/mfma_peak.hip), which its 4-byte operand reads make 1.5 per MFMA.
+//
+// Here (same skeleton as bwd_fused.hip):
+//  * one 512-thread workgroup per CU, W [N,K] in LDS once, row tiles of 64 streamed through;
+//  * two halves of 4 waves alternate: while one runs the MFMAs of its tile, the other - on the same SIMDs - does the
+//    epilogue of its previous tile (bias, BatchNorm sums, stores), copies its next tile to LDS (act_in applied once
+//    per element) and issues the global loads of the tile after that;
+//  * LDS tiles keep k contiguous ([row][KP+4]): a global float4 is one ds_write_b128, and ONE ds_read_b128 per lane
+//    feeds FOUR MFMAs of an operand block: lane (i = lane&31, h = lane>>5) holds k = 8q+4h .. +3 and MFMA e of group
+//    q multiplies the e-th components (k pair {8q+e, 8q+4+e}: A and B use the same pairing, the sum is the same);
+//  * everything outside the MFMA phase is WAVE-LOCAL (wave w owns rows 16w..16w+15 of the tile buffer: it parks its
+//    32 x 32NT output fragment there, writes it out as whole 128/256-byte row pieces, then fills the same rows with
+//    its share of the next tile), so the halves need no barrier of their own;
+//  * BatchNorm sums stay in registers for the whole kernel: one set of fp64 atomics per workgroup.
+#include "common.h"
+#include "fwd_pp.h"
+
+#define P2C_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+template <int KP, int NT, int MODE, int EX>
+__global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
+{
+    constexpr int LD = KP + 4, BM = 64, BN = 64 * NT;
+    constexpr int FR = 32 * 32 * NT;                         // floats of a wave's output fragment
+    constexpr int R = 16 * LD > FR ? 16 * LD : FR;           // floats of a wave's private region (16 tile rows or the fragment)
+    constexpr int HB = 4 * R;
+    constexpr int UPW = 16 * KP / 4 / 64;                    // float4 units a lane stages per tile
+    constexpr int QW = KP / 4;                               // float4 per tile row
+    constexpr int NQ = KP / 8;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Ws = smem;                                        // [BN][LD]
+    float *Hb = Ws + BN * LD;                                // [2 halves][HB]
+    float *red = Hb + 2 * HB;                                // [2 halves][2 row blocks][2][BN]
+    float *We = red + 8 * BN;                                // [BN][4]      (EX)
+    float *Xe = We + (EX ? BN * 4 : 0);                      // [2 halves][2 tile parities][BM][4]   (EX)
+
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int j0 = blockIdx.y * BN;                          // column block of this workgroup
+    const int ntiles = (a.M + BM - 1) / BM;
+    const int nk = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int niter = (nk + 1) / 2;
+    float *hb = Hb + half * HB;
+    float *mine = hb + wave * R;                             // this wave's region: tile rows 16*wave .. +15
+    float *xe2 = Xe + half * 2 * BM * 4;                     // parity-double-buffered: the partner wave restages while this one still reads
+    auto tile_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
+
+    // ---- W (and the EX trailing columns) -> LDS, zero-padded to [BN][KP]
+    for (int u = threadIdx.x; u < BN * QW; u += 512) {
+        const int n = u / QW, kq = u % QW;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (j0 + n < a.N && 4 * kq < a.K) v = *reinterpret_cast<const v4f *>(a.w + (size_t)(j0 + n) * a.ldw + 4 * kq);
+        *reinterpret_cast<v4f *>(&Ws[n * LD + 4 * kq]) = v;
+    }
+    if (EX) {
+        for (int n = threadIdx.x; n < BN; n += 512) {
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 + n < a.N) v = *reinterpret_cast<const v4f *>(a.w + (size_t)(j0 + n) * a.ldw + a.K);
+            *reinterpret_cast<v4f *>(&We[n * 4]) = v;
+        }
+    }
+
+    // ---- per-lane constants of the staging map: unit u = lane + 64 i -> row 16*wave + u / QW, float4 column u % QW
+    const int kq = lane % QW;                                // the same for every i (64 % QW == 0)
+    const bool kok = 4 * kq < a.K;
+    v4f isc = {1.f, 1.f, 1.f, 1.f}, ish = {0.f, 0.f, 0.f, 0.f};
+    if (MODE >= 1 && kok) {
+        isc = *reinterpret_cast<const v4f *>(a.in_scale + 4 * kq);
+        ish = *reinterpret_cast<const v4f *>(a.in_shift + 4 * kq);
+    }
+    uint32_t slo = 0, shi = 0;
+    if (MODE == 3) { slo = a.seed[0]; shi = a.seed[1]; }
+
+    v4f rx[UPW];
+    v4f rxe = {0.f, 0.f, 0.f, 0.f};
+    auto gload = [&](int t) {                                // raw rows of tile t (clamped; masked when staged)
+        const int m0 = t * BM + 16 * wave;
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int rl = (lane + 64 * i) / QW;
+            const int m = min(m0 + rl, a.M - 1);
+            rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + (kok ? 4 * kq : 0));
+        }
+        if (EX && lane < 16) rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)min(m0 + lane, a.M - 1) * a.ldx + a.K);
+    };
+    auto stage = [&](int t, int par) {                              // act_in, zero outside [M, K], 16-byte LDS writes into this wave's rows
+        const int m0 = t * BM + 16 * wave;
+#pragma unroll
+        for (int i = 0; i < UPW; ++i) {
+            const int rl = (lane + 64 * i) / QW;
+            const int m = m0 + rl;
+            v4f v = rx[i];
+            if (MODE >= 1) {
+                v.x = fmaxf(isc.x * v.x + ish.x, 0.f);
+                v.y = fmaxf(isc.y * v.y + ish.y, 0.f);
+                v.z = fmaxf(isc.z * v.z + ish.z, 0.f);
+                v.w = fmaxf(isc.w * v.w + ish.w, 0.f);
+            }
+            if (MODE == 3) {
+                const uint32_t e = (uint32_t)min(m, a.M - 1) * (uint32_t)a.Kfull + (uint32_t)(4 * kq);
+                v.x = p2c_hash32(slo, shi, e + 0) >= a.thr ? v.x * a.dscale : 0.f;
+                v.y = p2c_hash32(slo, shi, e + 1) >= a.thr ? v.y * a.dscale : 0.f;
+                v.z = p2c_hash32(slo, shi, e + 2) >= a.thr ? v.z * a.dscale : 0.f;
+                v.w = p2c_hash32(slo, shi, e + 3) >= a.thr ? v.w * a.dscale : 0.f;
+            }
+            if (!(m < a.M && kok)) v = v4f{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<v4f *>(&mine[rl * LD + 4 * kq]) = v;
+        }
+        if (EX && lane < 16) {
+            const bool ok = m0 + lane < a.M;
+            *reinterpret_cast<v4f *>(&xe2[par * BM * 4 + (16 * wave + lane) * 4]) = ok ? rxe : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    // ---- per-lane constants of the MFMA / epilogue maps
+    const int arow = wm * 32 + l31;
+    const float *Ap = hb + (arow >> 4) * R + (arow & 15) * LD + 4 * lh;
+    const float *Bp = Ws + (wn * (NT * 32) + l31) * LD + 4 * lh;
+    float bias[NT];
+    v4f we[NT];
+#pragma unroll
+    for (int y = 0; y < NT; ++y) {
+        const int col = j0 + wn * (NT * 32) + y * 32 + l31;
+        bias[y] = (a.bias && col < a.N) ? a.bias[col] : 0.f;
+        we[y] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int y = 0; y < NT; ++y) s1[y] = s2[y] = 0.f;
+    f32x16 acc[NT];
+
+    // ---- prologue: first tile of this half -> LDS, second -> registers
+    gload(tile_of(half < nk ? half : 0));
+    stage(half < nk ? tile_of(half) : ntiles, 0);            // tile index past the end: all rows masked to zero
+    gload(tile_of(half + 2 < nk ? half + 2 : 0));
+    __syncthreads();
+    if (EX) {
+#pragma unroll
+        for (int y = 0; y < NT; ++y) we[y] = *reinterpret_cast<const v4f *>(&We[(wn * (NT * 32) + y * 32 + l31) * 4]);
+    }
+    if (half == 1) P2C_LDS_BARRIER();                        // run one phase behind half 0
+    for (int it = 0; it < niter; ++it) {
+        const int k = 2 * it + half;
+        const bool valid = k < nk;                           // uniform within the half
+        const int m0 = tile_of(valid ? k : 0) * BM;
+        // ================= MFMA phase =================
+        if (valid) {
+#pragma unroll
+            for (int y = 0; y < NT; ++y)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[y][r] = 0.f;
+            v4f a0 = *reinterpret_cast<const v4f *>(Ap), a1;
+            v4f b0[NT], b1[NT];
+#pragma unroll
+            for (int y = 0; y < NT; ++y) b0[y] = *reinterpret_cast<const v4f *>(Bp + y * 32 * LD);
+#pragma unroll
+            for (int q = 0; q < NQ; q += 2) {
+                // the reads of group q+1 are issued before the MFMAs of group q (pinned: the scheduler would sink them)
+                a1 = *reinterpret_cast<const v4f *>(Ap + 8 * (q + 1));
+#pragma unroll
+                for (int y = 0; y < NT; ++y) b1[y] = *reinterpret_cast<const v4f *>(Bp + y * 32 * LD + 8 * (q + 1));
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int y = 0; y < NT; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[y][e], acc[y], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 2 < NQ) {
+                    a0 = *reinterpret_cast<const v4f *>(Ap + 8 * (q + 2));
+#pragma unroll
+                    for (int y = 0; y < NT; ++y) b0[y] = *reinterpret_cast<const v4f *>(Bp + y * 32 * LD + 8 * (q + 2));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int y = 0; y < NT; ++y) acc[y] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[y][e], acc[y], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        P2C_LDS_BARRIER();
+        // ================= wave-local phase (the other half is in its MFMA phase) =================
+        __builtin_amdgcn_s_setprio(1);
+        if (valid) {
+            // fragment (+ the EX trailing input columns, + bias) -> this wave's region; BatchNorm sums on the bias-free value
+            float *out = mine;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rf = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                v4f xv = {0.f, 0.f, 0.f, 0.f};
+                if (EX) xv = *reinterpret_cast<const v4f *>(&xe2[(it & 1) * BM * 4 + (wm * 32 + rf) * 4]);
+#pragma unroll
+                for (int y = 0; y < NT; ++y) {
+                    float v = acc[y][r];
+                    if (EX) v += (xv.x * we[y].x + xv.y * we[y].y) + (xv.z * we[y].z + xv.w * we[y].w);
+                    s1[y] += v;
+                    s2[y] += v * v;
+                    acc[y][r] = v + bias[y];
+                }
+            }
+            // (the region is also what the other wn-wave of this row block reads as its A operand: both finished before the barrier)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rf = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+                for (int y = 0; y < NT; ++y) out[rf * (32 * NT) + y * 32 + l31] = acc[y][r];
+            }
+            __builtin_amdgcn_wave_barrier();
+            constexpr int V = 8 * NT;                        // float4 per fragment row
+#pragma unroll
+            for (int i = 0; i < 4 * NT; ++i) {
+                const int u = lane + 64 * i, rf = u / V, c4 = u % V;
+                const int row = m0 + wm * 32 + rf, col = j0 + wn * (NT * 32) + 4 * c4;
+                const v4f v = *reinterpret_cast<const v4f *>(&out[rf * (32 * NT) + 4 * c4]);
+                if (row < a.M && col < a.N) *reinterpret_cast<v4f *>(a.y + (size_t)row * a.ldy + col) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        {
+            const int k2 = k + 2, k4 = k + 4;
+            if (k2 < nk) stage(tile_of(k2), (it + 1) & 1);
+            gload(tile_of(k4 < nk ? k4 : 0));                // unconditional: stays in registers
+        }
+        __builtin_amdgcn_s_setprio(0);
+        P2C_LDS_BARRIER();                                   // the prefetch stays in flight across this barrier
+    }
+    if (half == 0) P2C_LDS_BARRIER();
+    // ---- BatchNorm sums: every (half, row block) parks its column sums in its own LDS slot, summed in a fixed order
+    //      (bitwise reproducible), then one fp64 atomic per column into this workgroup's slot row
+    if (a.partials) {
+#pragma unroll
+        for (int y = 0; y < NT; ++y) {
+            const float t1 = s1[y] + __shfl_xor(s1[y], 32), t2 = s2[y] + __shfl_xor(s2[y], 32);
+            if (lh == 0) {
+                float *r = red + (half * 2 + wm) * 2 * BN;
+                r[wn * (NT * 32) + y * 32 + l31] = t1;
+                r[BN + wn * (NT * 32) + y * 32 + l31] = t2;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < BN && j0 + threadIdx.x < a.N) {
+            const int c = threadIdx.x;
+            const float q1 = (red[c] + red[2 * BN + c]) + (red[4 * BN + c] + red[6 * BN + c]);
+            const float q2 = (red[BN + c] + red[3 * BN + c]) + (red[5 * BN + c] + red[7 * BN + c]);
+            double *o = a.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * a.N;
+            atomicAdd(&o[j0 + c], (double)q1);
+            atomicAdd(&o[a.N + j0 + c], (double)q2);
+        }
+    }
+}
+
+template <int KP, int NT, int MODE, int EX>
+static int launch_pp(const FwdPPArgs &a, hipStream_t s)
+{
+    constexpr int LD = KP + 4, BN = 64 * NT, FR = 32 * 32 * NT, R = 16 * LD > FR ? 16 * LD : FR;
+    const size_t lds = (size_t)(BN * LD + 2 * 4 * R + 8 * BN + (EX ? BN * 4 + 4 * 64 * 4 : 0)) * sizeof(float);
+    const int gy = (a.N + BN - 1) / BN;
+    const int ntiles = (a.M + 63) / 64;
+    int gx = 256 / gy;
+    if (gx > ntiles) gx = ntiles;
+    (void)hipFuncSetAttribute((const void *)fwd_pp_kernel<KP, NT, MODE, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fwd_pp_kernel<KP, NT, MODE, EX>), dim3(gx, gy), dim3(512), lds, s, a);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// Which (M, N, K, in_mode) the persistent kernel takes; K == 132 is the grouped layer [128 features | xyz | pad].
+extern "C" int p2c_linear_fwd_pp_supported(int M, int N, int K, int in_mode)
+{
+    if (in_mode == 2 || M < 8192 || (K & 3) || (N & 3)) return 0;
+    if (K > 128 && K != 132) return 0;
+    if (N > 256) return 0;
+    if (in_mode == 3 && K > 128) return 0;
+    return 1;
+}
+
+int p2c_fwd_pp_launch(const FwdPPArgs &a, int in_mode, hipStream_t s)
+{
+    const int K = a.K;          // EX columns already split off by the caller
+    const bool ex = a.Kfull == 132 && in_mode != 3;
+    const int nt = a.N <= 64 ? 1 : 2;
+#define P2C_PP(KP_, NT_, MODE_, EX_) return launch_pp<KP_, NT_, MODE_, EX_>(a, s)
+#define P2C_PPK(NT_, MODE_)                          \
+    do {                                             \
+        if (ex) P2C_PP(128, NT_, MODE_, 4);          \
+        if (K <= 32) P2C_PP(32, NT_, MODE_, 0);      \
+        if (K <= 64) P2C_PP(64, NT_, MODE_, 0);      \
+        P2C_PP(128, NT_, MODE_, 0);                  \
+    } while (0)
+    if (in_mode == 0) { if (nt == 1) P2C_PPK(1, 0); P2C_PPK(2, 0); }
+    if (in_mode == 1) { if (nt == 1) P2C_PPK(1, 1); P2C_PPK(2, 1); }
+    if (in_mode == 3) {
+        if (nt == 1) { if (K <= 64) P2C_PP(64, 1, 3, 0); P2C_PP(128, 1, 3, 0); }
+        if (K <= 64) P2C_PP(64, 2, 3, 0);
+        P2C_PP(128, 2, 3, 0);
+    }
+#undef P2C_PPK
+#undef P2C_PP
+    return P2C_EINVAL;
+}

@@ -25,6 +25,7 @@
 // and out-of-range elements are zeroed by a select, all leading dimensions / channel counts are
 // multiples of 4 (the host pads), so the compiler can keep the 16-byte loads in flight across the MFMAs.
 #include "common.h"
+#include "fwd_pp.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -435,6 +436,12 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     P2C_REQ_ALIGNED(W, ldw);
     if (in_mode >= 1) { P2C_REQ_ALIGNED(in_scale, 0); P2C_REQ_ALIGNED(in_shift, 0); }
     hipStream_t s = (hipStream_t)stream;
+    static const bool use_pp = !(getenv("P2C_FWD_PP") && atoi(getenv("P2C_FWD_PP")) == 0);      // A/B switch for profiling
+    if (use_pp && p2c_linear_fwd_pp_supported(M, N, K, in_mode)) {
+        FwdPPArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K == 132 ? 128 : K, in_scale, in_shift, (const uint32_t *)drop_mask,
+                    (uint32_t)ldmask, drop_scale, K, stat_partials};
+        return p2c_fwd_pp_launch(a, in_mode, s);
+    }
     switch (in_mode) {
     case 0: return launch_fwd<0>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
     case 1: return launch_fwd<1>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);

@@ -430,7 +430,10 @@ class _MLPStack(torch.autograd.Function):
             need_dx = i > 0 or ctx.needs_input_grad[1]
             stats_below = i > 0                       # the layer below has a BatchNorm whose backward sums we produce here
             L_ = _lib.lib()
-            if USE_FUSED_BWD and mode <= 1 and M >= 4096 and L_.p2c_linear_bwd_fused_supported(Co, Ci, mode):
+            fused_kind = L_.p2c_linear_bwd_fused_supported(Co, Ci, mode) if (USE_FUSED_BWD and mode <= 1 and M >= 4096) else 0
+            if fused_kind == 2 and not (i == 0 and cfg.get("xyz_last")):
+                fused_kind = 0           # kind 2 yields no dX for the 4 trailing input columns: fine for [feats | xyz | pad] only
+            if fused_kind:
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev) if need_dx else None
                 part = arena.f64(STAT_SLOTS, 2, Ci) if stats_below else None
                 dW8 = arena.f32(8, Co, Ci)     # one copy per XCD, summed below

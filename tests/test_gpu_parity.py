@@ -153,6 +153,11 @@ def _ref_stack(X0, params, tail, G, ns, training, mask, momentum=0.1):
     ("bnrelu", 1000, 384, (256, 128), None, None),
     ("linear", 777, 128, (128, 96, 19), None, None),
     ("maxpool", 2 * 128, 259, (256, 512, 1024), 2, 128),
+    # >= 8192 rows: the persistent forward kernel (fwd_pp.hip) and the fused backward take the narrow layers
+    ("maxpool", 300 * 32, 3, (64, 64, 128), 300, 32),
+    ("maxpool", 141 * 64, 131, (128, 128, 256), 141, 64),
+    ("linear", 9001, 128, (128, 128, 19), None, None),
+    ("bnrelu", 8200, 64, (128, 64), None, None),
 ])
 def test_mlp_stack_forward_backward(tail, M, K0, widths, G, ns):
     g = torch.Generator().manual_seed(M + K0)
@@ -208,9 +213,18 @@ def test_mlp_stack_forward_backward(tail, M, K0, widths, G, ns):
             # conv bias in front of train-mode BN: gradient is analytically zero (ours is exactly 0)
             assert np.abs(got).max() == 0 and np.abs(ref).max() < 1e-3 * scale
             continue
+        if M >= 8192 and tail == "maxpool":
+            # tens of thousands of max-pool winners: a handful of near-ties (candidates within rounding of each other) resolve
+            # differently from the CPU reference and move single rows of gradient, so compare in norm
+            assert np.linalg.norm(got - ref) <= 3e-3 * np.linalg.norm(ref), (i, np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            continue
         np.testing.assert_allclose(got, ref, rtol=2e-3, atol=tol)
-    np.testing.assert_allclose(X0d.grad[:, :K0].cpu().numpy(), X0r.grad.numpy(), rtol=2e-3,
-                               atol=2e-4 * float(X0r.grad.abs().max()))
+    if M >= 8192 and tail == "maxpool":
+        gx, rx = X0d.grad[:, :K0].cpu().numpy(), X0r.grad.numpy()
+        assert np.linalg.norm(gx - rx) <= 3e-3 * np.linalg.norm(rx)
+    else:
+        np.testing.assert_allclose(X0d.grad[:, :K0].cpu().numpy(), X0r.grad.numpy(), rtol=2e-3,
+                                   atol=2e-4 * float(X0r.grad.abs().max()))
     for ly, (rm, rv) in zip(layers, rstats):
         np.testing.assert_allclose(ly["bn"].running_mean.cpu().numpy(), rm.numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(ly["bn"].running_var.cpu().numpy(), rv.numpy(), rtol=1e-4, atol=1e-5)
@@ -426,11 +440,13 @@ def test_train_step_golden():
             np.testing.assert_allclose(got[big][same], ref[big][same], rtol=0.05, atol=1e-5)
 
 
-def test_hashed_dropout_consistency_and_rate():
+@pytest.mark.parametrize("M", [1000, 9003])
+def test_hashed_dropout_consistency_and_rate(M):
     """in_mode 3: the keep-mask is regenerated from (seed, element) in forward, backward-weight and backward-data;
-    the gradients must agree with autograd on the mask the forward implied, and ~half the units are kept."""
+    the gradients must agree with autograd on the mask the forward implied, and ~half the units are kept.
+    (9003 rows: the persistent forward kernel; 1000: the tiled one.)"""
     g = torch.Generator().manual_seed(5)
-    M, C, Co = 1000, 128, 20
+    C, Co = 128, 20
     Y = torch.randn(M, C, generator=g).to(DEV)
     layers = [dict(W=(torch.randn(C, C, generator=g) / 11).to(DEV).requires_grad_(True), b=torch.zeros(C, device=DEV, requires_grad=True),
                    gamma=torch.ones(C, device=DEV, requires_grad=True), beta=torch.zeros(C, device=DEV, requires_grad=True),
@@ -463,7 +479,7 @@ def test_hashed_dropout_consistency_and_rate():
     np.testing.assert_allclose(out2.detach().cpu().numpy(), out.detach().cpu().numpy(), rtol=1e-5, atol=1e-6)
     out2.backward(go)
     for a, b in zip(g_hash, [layers[0]["W"].grad, layers[1]["W"].grad, layers[0]["gamma"].grad]):
-        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(b.abs().max()) + 1e-5)
 
 
 @pytest.mark.parametrize("full", [False, True])

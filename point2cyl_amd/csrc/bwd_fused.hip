@@ -26,24 +26,6 @@
 // the barrier into an exposed HBM round trip per phase.  LDS hand-offs only need lgkmcnt(0).
 #define P2C_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-// -DP2C_TRACE (tools/fused_trace.py builds that variant; never the product): workgroup 0 stamps the shader clock at
-// the phase boundaries of a few iterations so the overlap of the two halves can be read off directly.
-#ifdef P2C_TRACE
-#define P2C_TR_IT 12
-#define P2C_TR_PT 8
-__device__ unsigned long long p2c_trace_buf[2][P2C_TR_IT][P2C_TR_PT];
-#define P2C_TR(pt)                                                                                   \
-    do {                                                                                             \
-        if (blockIdx.x == 0 && tid == 0 && it < P2C_TR_IT) p2c_trace_buf[half][it][pt] = __builtin_readcyclecounter(); \
-    } while (0)
-extern "C" int p2c_trace_read(void *host_out)
-{
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(p2c_trace_buf), sizeof(unsigned long long) * 2 * P2C_TR_IT * P2C_TR_PT);
-}
-#else
-#define P2C_TR(pt) do { } while (0)
-#endif
-
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copy can pin an array in scratch)
 

@@ -74,3 +74,22 @@ static inline uint32_t p2c_drop_threshold(float scale)     // scale = 1/(1-p)  -
     if (p > 0.999999) p = 0.999999;
     return (uint32_t)(p * 4294967296.0);
 }
+
+// -DP2C_TRACE (tools/fused_trace.py builds one source file that way into a throw-away library; never the product):
+// workgroup 0 stamps the shader clock at the phase boundaries of a few iterations of a ping-pong kernel (variables
+// `tid`, `half`, `it` of the kernel), so the overlap of the two halves can be read off directly.
+#ifdef P2C_TRACE
+#define P2C_TR_IT 12
+#define P2C_TR_PT 8
+__device__ unsigned long long p2c_trace_buf[2][P2C_TR_IT][P2C_TR_PT];
+#define P2C_TR(pt)                                                                                   \
+    do {                                                                                             \
+        if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && it < P2C_TR_IT) p2c_trace_buf[half][it][pt] = __builtin_readcyclecounter(); \
+    } while (0)
+extern "C" int p2c_trace_read(void *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(p2c_trace_buf), sizeof(unsigned long long) * 2 * P2C_TR_IT * P2C_TR_PT);
+}
+#else
+#define P2C_TR(pt) do { } while (0)
+#endif

@@ -25,6 +25,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int KP, int NT, int MODE, int EX>
 __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
@@ -82,24 +83,35 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
 
     v4f rx[UPW];
     v4f rxe = {0.f, 0.f, 0.f, 0.f};
+    // row pointer of the lane's first unit in tile 0; unit i is (64 / QW) rows further down
+    const float *xlane = a.x + (size_t)(16 * wave + lane / QW) * a.ldx + (kok ? 4 * kq : 0);
+    const size_t xstep = (size_t)(64 / QW) * a.ldx;
     auto gload = [&](int t) {                                // raw rows of tile t (clamped; masked when staged)
         const int m0 = t * BM + 16 * wave;
+        if (t * BM + BM <= a.M) {                            // uniform: only the last tile can be ragged
+            const float *p = xlane + (size_t)t * BM * a.ldx;
 #pragma unroll
-        for (int i = 0; i < UPW; ++i) {
-            const int rl = (lane + 64 * i) / QW;
-            const int m = min(m0 + rl, a.M - 1);
-            rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + (kok ? 4 * kq : 0));
+            for (int i = 0; i < UPW; ++i) rx[i] = *reinterpret_cast<const v4f *>(p + i * xstep);
+        } else {
+#pragma unroll
+            for (int i = 0; i < UPW; ++i) {
+                const int rl = (lane + 64 * i) / QW;
+                const int m = min(m0 + rl, a.M - 1);
+                rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + (kok ? 4 * kq : 0));
+            }
         }
         if (EX && lane < 16) rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)min(m0 + lane, a.M - 1) * a.ldx + a.K);
     };
-    auto stage = [&](int t, int par) {                              // act_in, zero outside [M, K], 16-byte LDS writes into this wave's rows
+    auto stage = [&](int t, int par) {                       // act_in, zero outside [M, K], 16-byte LDS writes into this wave's rows
         const int m0 = t * BM + 16 * wave;
+        const bool full = t * BM + BM <= a.M && a.K >= KP;   // uniform: nothing to mask
 #pragma unroll
         for (int i = 0; i < UPW; ++i) {
             const int rl = (lane + 64 * i) / QW;
             const int m = m0 + rl;
             v4f v = rx[i];
-            if (MODE >= 1) {
+            if (MODE >= 1) {         // mul + add, NOT an fma: the backward kernels rebuild act_in(x) and its ReLU mask with the same
+                                     // two roundings; with an fma here the deep BatchNorm gradients drift 8x further from float64
                 v.x = fmaxf(isc.x * v.x + ish.x, 0.f);
                 v.y = fmaxf(isc.y * v.y + ish.y, 0.f);
                 v.z = fmaxf(isc.z * v.z + ish.z, 0.f);
@@ -112,7 +124,7 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
                 v.z = p2c_hash32(slo, shi, e + 2) >= a.thr ? v.z * a.dscale : 0.f;
                 v.w = p2c_hash32(slo, shi, e + 3) >= a.thr ? v.w * a.dscale : 0.f;
             }
-            if (!(m < a.M && kok)) v = v4f{0.f, 0.f, 0.f, 0.f};
+            if (!full) v *= (m < a.M && kok) ? 1.f : 0.f;    // branch-free (the clamped loads only ever return finite data)
             *reinterpret_cast<v4f *>(&mine[rl * LD + 4 * kq]) = v;
         }
         if (EX && lane < 16) {
@@ -133,9 +145,9 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
         bias[y] = (a.bias && col < a.N) ? a.bias[col] : 0.f;
         we[y] = v4f{0.f, 0.f, 0.f, 0.f};
     }
-    float s1[NT], s2[NT];
+    v2f s1v[NT], s2v[NT];
 #pragma unroll
-    for (int y = 0; y < NT; ++y) s1[y] = s2[y] = 0.f;
+    for (int y = 0; y < NT; ++y) s1v[y] = s2v[y] = v2f{0.f, 0.f};
     f32x16 acc[NT];
 
     // ---- prologue: first tile of this half -> LDS, second -> registers
@@ -153,6 +165,7 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
         const bool valid = k < nk;                           // uniform within the half
         const int m0 = tile_of(valid ? k : 0) * BM;
         // ================= MFMA phase =================
+        P2C_TR(0);
         if (valid) {
 #pragma unroll
             for (int y = 0; y < NT; ++y)
@@ -187,51 +200,77 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        P2C_TR(1);
         P2C_LDS_BARRIER();
+        P2C_TR(2);
         // ================= wave-local phase (the other half is in its MFMA phase) =================
+#if !(defined(P2C_DBG) && P2C_DBG == 2)
         __builtin_amdgcn_s_setprio(1);
+#endif
         if (valid) {
-            // fragment (+ the EX trailing input columns, + bias) -> this wave's region; BatchNorm sums on the bias-free value
+            // fragment (+ the EX trailing input columns, + bias) -> this wave's region; BatchNorm sums on the bias-free value.
+            // Register pairs along r are adjacent, so the sums run as packed-fp32 ops on (r, r+1) pairs.
             float *out = mine;
+            if (EX) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rf = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                v4f xv = {0.f, 0.f, 0.f, 0.f};
-                if (EX) xv = *reinterpret_cast<const v4f *>(&xe2[(it & 1) * BM * 4 + (wm * 32 + rf) * 4]);
+                for (int r = 0; r < 16; ++r) {
+                    const int rf = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const v4f xv = *reinterpret_cast<const v4f *>(&xe2[(it & 1) * BM * 4 + (wm * 32 + rf) * 4]);
 #pragma unroll
-                for (int y = 0; y < NT; ++y) {
-                    float v = acc[y][r];
-                    if (EX) v += (xv.x * we[y].x + xv.y * we[y].y) + (xv.z * we[y].z + xv.w * we[y].w);
-                    s1[y] += v;
-                    s2[y] += v * v;
-                    acc[y][r] = v + bias[y];
+                    for (int y = 0; y < NT; ++y)
+                        acc[y][r] += (xv.x * we[y].x + xv.y * we[y].y) + (xv.z * we[y].z + xv.w * we[y].w);
                 }
             }
-            // (the region is also what the other wn-wave of this row block reads as its A operand: both finished before the barrier)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rf = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            for (int y = 0; y < NT; ++y) {
 #pragma unroll
-                for (int y = 0; y < NT; ++y) out[rf * (32 * NT) + y * 32 + l31] = acc[y][r];
+                for (int r = 0; r < 16; r += 2) {
+                    const v2f v = {acc[y][r], acc[y][r + 1]};
+                    s1v[y] += v;
+                    s2v[y] += v * v;
+                    const v2f o = v + v2f{bias[y], bias[y]};
+                    const int rf = (r & 3) + 8 * (r >> 2) + 4 * lh;        // r even: rows rf and rf+1
+                    out[rf * (32 * NT) + y * 32 + l31] = o.x;
+                    out[(rf + 1) * (32 * NT) + y * 32 + l31] = o.y;
+                }
             }
+            P2C_TR(3);
             __builtin_amdgcn_wave_barrier();
-            constexpr int V = 8 * NT;                        // float4 per fragment row
+            // whole 128/256-byte row pieces, 16 bytes per lane: all reads first, then the stores (no round trip per store)
+            constexpr int V = 8 * NT, NS = 4 * NT;           // float4 per fragment row, stores per lane
+            const int c4 = lane % V, rf0 = lane / V;         // the lane's column is the same for all its stores (64 % V == 0)
+            const int col = j0 + wn * (NT * 32) + 4 * c4;
+            v4f o[NS];
 #pragma unroll
-            for (int i = 0; i < 4 * NT; ++i) {
-                const int u = lane + 64 * i, rf = u / V, c4 = u % V;
-                const int row = m0 + wm * 32 + rf, col = j0 + wn * (NT * 32) + 4 * c4;
-                const v4f v = *reinterpret_cast<const v4f *>(&out[rf * (32 * NT) + 4 * c4]);
-                if (row < a.M && col < a.N) *reinterpret_cast<v4f *>(a.y + (size_t)row * a.ldy + col) = v;
+            for (int i = 0; i < NS; ++i) o[i] = *reinterpret_cast<const v4f *>(&out[(rf0 + i * (64 / V)) * (32 * NT) + 4 * c4]);
+            P2C_TR(4);
+#if defined(P2C_DBG) && P2C_DBG == 1
+            if (col < a.N && o[0].x == 123456.f) {               // debug: no global stores
+#else
+            if (col < a.N) {
+#endif
+                float *yp = a.y + (size_t)(m0 + wm * 32 + rf0) * a.ldy + col;
+                if (m0 + BM <= a.M) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) *reinterpret_cast<v4f *>(yp + (size_t)(i * (64 / V)) * a.ldy) = o[i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+                        if (m0 + wm * 32 + rf0 + i * (64 / V) < a.M) *reinterpret_cast<v4f *>(yp + (size_t)(i * (64 / V)) * a.ldy) = o[i];
+                }
             }
             __builtin_amdgcn_wave_barrier();
         }
+        P2C_TR(5);
         {
             const int k2 = k + 2, k4 = k + 4;
             if (k2 < nk) stage(tile_of(k2), (it + 1) & 1);
+            P2C_TR(6);
             gload(tile_of(k4 < nk ? k4 : 0));                // unconditional: stays in registers
         }
         __builtin_amdgcn_s_setprio(0);
         P2C_LDS_BARRIER();                                   // the prefetch stays in flight across this barrier
+        P2C_TR(7);
     }
     if (half == 0) P2C_LDS_BARRIER();
     // ---- BatchNorm sums: every (half, row block) parks its column sums in its own LDS slot, summed in a fixed order
@@ -239,7 +278,8 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
     if (a.partials) {
 #pragma unroll
         for (int y = 0; y < NT; ++y) {
-            const float t1 = s1[y] + __shfl_xor(s1[y], 32), t2 = s2[y] + __shfl_xor(s2[y], 32);
+            const float u1 = s1v[y].x + s1v[y].y, u2 = s2v[y].x + s2v[y].y;
+            const float t1 = u1 + __shfl_xor(u1, 32), t2 = u2 + __shfl_xor(u2, 32);
             if (lh == 0) {
                 float *r = red + (half * 2 + wm) * 2 * BN;
                 r[wn * (NT * 32) + y * 32 + l31] = t1;

@@ -6,13 +6,19 @@ Stamps (shader clock) of workgroup 0, thread 0 of each half:
 import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
+FWD = "--fwd" in sys.argv             # trace fwd_pp.hip instead of bwd_fused.hip
 NODATA = "--nodata" in sys.argv       # MFMA phases only: no global traffic, no LDS staging (isolates the MFMA loops)
-LIB = os.path.join(HERE, "libp2c_trace_nodata.so" if NODATA else "libp2c_trace.so")
+DBG = [a for a in sys.argv if a.startswith("--dbg=")]
+LIB = os.path.join(HERE, ("libp2c_trace_fwd%s.so" % (DBG[0][6:] if DBG and DBG[0][6:] != "0" else "")) if FWD else "libp2c_trace_nodata.so" if NODATA else "libp2c_trace.so")
 if "--build" in sys.argv:
     for lib, extra in ((os.path.join(HERE, "libp2c_trace.so"), []), (os.path.join(HERE, "libp2c_trace_nodata.so"), ["-DP2C_TRACE_NODATA"])):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_TRACE"] + extra +
                               ["-shared", "-o", lib, os.path.join(ROOT, "point2cyl_amd", "csrc", "bwd_fused.hip")])
         print(lib)
+    for dbg in (0, 1, 2):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_TRACE",
+                               "-DP2C_DBG=%d" % dbg, "-shared", "-o", os.path.join(HERE, "libp2c_trace_fwd%s.so" % (dbg or "")),
+                               os.path.join(HERE, "fwd_trace_shim.hip")])
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -21,6 +27,30 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 M, Co, Ci = (int(args[0]), int(args[1]), int(args[2])) if len(args) >= 3 else (262144, 128, 128)
 L = ctypes.CDLL(LIB)
 vp, ci = ctypes.c_void_p, ctypes.c_int
+if FWD:
+    dev = "cuda"
+    X = torch.randn(M, Ci, device=dev); W = torch.randn(Co, Ci, device=dev) * .1; b = torch.randn(Co, device=dev); Y = torch.empty(M, Co, device=dev)
+    sc = torch.rand(Ci, device=dev) + .5; sh = torch.randn(Ci, device=dev) * .1; parts = torch.zeros(64, 2, Co, device=dev, dtype=torch.float64)
+    L.p2c_trace_fwd.argtypes = [vp, ci, vp, ci, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp]
+    st = torch.cuda.current_stream().cuda_stream
+    def runf():
+        assert L.p2c_trace_fwd(X.data_ptr(), Ci, W.data_ptr(), Ci, b.data_ptr(), Y.data_ptr(), Co, M, Co, Ci, sc.data_ptr(), sh.data_ptr(), parts.data_ptr(), st) == 0
+    for _ in range(3):
+        runf()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); runf(); e1.record(); torch.cuda.synchronize()
+    print("fwd_pp kernel %.1f us" % (e0.elapsed_time(e1) * 1e3))
+    buf = np.zeros((2, 12, 8), dtype=np.uint64)
+    assert L.p2c_trace_read(buf.ctypes.data_as(vp)) == 0
+    t0 = buf[0, 2, 0]
+    names = ["mfma0", "mfma", "bar1", "sums+frag", "readback", "stores", "stage", "prefetch+bar2"]
+    for it in range(2, 10):
+        for h in range(2):
+            row = buf[h, it].astype(np.int64) - int(t0)
+            d = np.diff(row)
+            print("it %d half %d  start %8d | " % (it, h, row[0]) + "  ".join("%s %6d" % (n, v) for n, v in zip(names[1:], d)))
+    sys.exit(0)
 L.p2c_linear_bwd_fused_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, vp, ci, vp, ci, ctypes.c_longlong, vp, vp, vp, ci, ci, ci, vp]
 dev = "cuda"
 dZ = torch.randn(M, Co, device=dev); Y = torch.randn(M, Co, device=dev); X = torch.randn(M, Ci, device=dev)

@@ -46,6 +46,33 @@ struct BwdFusedArgs {
     long long dw_slot_stride;        // elements between the 8 per-XCD copies of dW (0: a single copy)
 };
 
+// ------------------------------------------------------------------------------------------------
+// LDS layouts.  What bounds an fp32-MFMA loop on gfx950 is the number of OTHER instructions the SIMD has to issue: they
+// do not overlap the MFMAs - neither the wave's own nor, beyond one per MFMA, those of the second wave on the SIMD
+// (tools/ubench/mfma_peak.hip, coissue.hip).  So every operand tile keeps the REDUCTION index contiguous and one
+// ds_read_b128 per lane feeds four MFMAs: lane (i = lane&31, h = lane>>5) reads k = 8q+4h .. +3 and MFMA e of group q
+// multiplies the e-th components (k pair {8q+e, 8q+4+e}; A and B use the same pairing, so the sum is the same).
+//   dW = dY^T . act(X)   reduces over the rows m:  dYs[co][m], Xt[ci][m]   (both transposed on the way in)
+//   dX = dY . W          reduces over co:          Wt[ci][co] via 16-byte reads; dYs[co][m] (m across lanes) via ds_read2_b32
+// A transposing store of a float4 (4 channels of one row) is 4 scalar writes to 4 channel rows.  Row stride BM+4 alone
+// would put the 16 float4-columns a wave writes in one instruction on 2 banks; rotating channel row c by 4*((c>>3)&7)
+// positions (mod BM, so groups of 4 rows stay aligned for the 16-byte reads) spreads them over 8, and mapping a wave's
+// 64 lanes to 16 float4-columns x 4 rows covers the other 4: conflict-free.
+// ------------------------------------------------------------------------------------------------
+template <int C4>
+__device__ __forceinline__ void fused_unit(int u, int &m, int &c4)
+{
+    if (C4 == 32) {
+        c4 = (u & 15) | (((u >> 6) & 1) << 4);
+        m = ((u >> 4) & 3) | ((u >> 7) << 2);
+    } else {
+        c4 = u & 15;
+        m = u >> 4;
+    }
+}
+template <int BM>
+__device__ __forceinline__ int fused_pos(int c, int m) { return c * (BM + 4) + ((m + 4 * ((c >> 3) & 7)) & (BM - 1)); }
+
 // Raw tile fetch (no arithmetic: the values stay in flight during the MFMAs of the previous tile).
 template <int GMODE, int Co, int Ci, int BM, int UDY, int UX>
 __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, int t, float4 (&rdz)[UDY], float4 (&ry)[UDY],
@@ -54,7 +81,8 @@ __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, 
     const int m0 = t * BM;
 #pragma unroll
     for (int i = 0; i < UDY; ++i) {
-        const int u = tid + 256 * i, row = u / (Co / 4), c4 = u % (Co / 4);
+        int row, c4;
+        fused_unit<Co / 4>(tid + 256 * i, row, c4);
         const int r = min(m0 + row, a.M - 1);
         if (GMODE == 2) {
             const int grp = r / a.ns;
@@ -67,22 +95,24 @@ __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, 
     }
 #pragma unroll
     for (int i = 0; i < UX; ++i) {
-        const int u = tid + 256 * i, row = u / (Ci / 4), c4 = u % (Ci / 4);
+        int row, c4;
+        fused_unit<Ci / 4>(tid + 256 * i, row, c4);
         rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)min(m0 + row, a.M - 1) * a.ldx + c4 * 4);
     }
 }
 
-// dY = gs*(dZ*[scale*Y+shift>0]) + q*Y + p from the raw registers (cf[] = this thread's 4 channels of coef),
-// transposed into dYs[co][m]; raw X into Xr[m][ci].
-template <int GMODE, int Co, int Ci, int BM, int LDY, int LDX, int UDY, int UX>
-__device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid, int t, float *dy, float *xr, const float4 (&rdz)[UDY],
+// dY = gs*(dZ*[scale*Y+shift>0]) + q*Y + p from the raw registers (cf[] = this thread's 4 channels of coef) -> dYs[co][m];
+// raw X -> Xt[ci][m] (act_in is applied when the dW operand is read: the dX epilogue needs the raw values).
+template <int GMODE, int Co, int Ci, int BM, int UDY, int UX>
+__device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid, int t, float *dy, float *xt, const float4 (&rdz)[UDY],
                                                  const float4 (&ry)[UDY], const int4 (&rarg)[UDY], const v4f (&rx)[UX],
                                                  const float4 (&cf)[5])
 {
     const int m0 = t * BM;
 #pragma unroll
     for (int i = 0; i < UDY; ++i) {
-        const int u = tid + 256 * i, row = u / (Co / 4), c4 = u % (Co / 4);
+        int row, c4;
+        fused_unit<Co / 4>(tid + 256 * i, row, c4);
         const int m = m0 + row;
         float4 g = rdz[i];
         if (GMODE == 2) {
@@ -98,29 +128,34 @@ __device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid,
             o.z = cf[2].z * ((cf[0].z * yy.z + cf[1].z > 0.f) ? g.z : 0.f) + cf[3].z * yy.z + cf[4].z;
             o.w = cf[2].w * ((cf[0].w * yy.w + cf[1].w > 0.f) ? g.w : 0.f) + cf[3].w * yy.w + cf[4].w;
         }
-        const bool ok = m < a.M;
-        dy[(c4 * 4 + 0) * LDY + row] = ok ? o.x : 0.f;
-        dy[(c4 * 4 + 1) * LDY + row] = ok ? o.y : 0.f;
-        dy[(c4 * 4 + 2) * LDY + row] = ok ? o.z : 0.f;
-        dy[(c4 * 4 + 3) * LDY + row] = ok ? o.w : 0.f;
+        const float ok = m < a.M ? 1.f : 0.f;                       // rows past M contribute nothing to dW / dbias
+        float *d = dy + fused_pos<BM>(c4 * 4, row);                 // channels 4c4 .. 4c4+3 share (c >> 3): same rotation
+        d[0] = o.x * ok;
+        d[BM + 4] = o.y * ok;
+        d[2 * (BM + 4)] = o.z * ok;
+        d[3 * (BM + 4)] = o.w * ok;
     }
 #pragma unroll
     for (int i = 0; i < UX; ++i) {
-        const int u = tid + 256 * i, row = u / (Ci / 4), c4 = u % (Ci / 4);
-        *reinterpret_cast<v4f *>(&xr[row * LDX + c4 * 4]) = rx[i];
+        int row, c4;
+        fused_unit<Ci / 4>(tid + 256 * i, row, c4);
+        float *d = xt + fused_pos<BM>(c4 * 4, row);
+        d[0] = rx[i].x;
+        d[BM + 4] = rx[i].y;
+        d[2 * (BM + 4)] = rx[i].z;
+        d[3 * (BM + 4)] = rx[i].w;
     }
 }
 
 // COT = Co/64, CIT = Ci/64 (1 or 2).  Waves: for dW a 2x2 grid over Co x Ci (wave tile COT*32 x CIT*32);
 // for dX a WR x WC grid with WC = Ci/32 columns of 32, WR = 4/WC, so BM = 32*WR rows per tile.
 // ------------------------------------------------------------------------------------------------
-// Ping-pong structure: 512 threads = two half-workgroups of 4 waves that share W in LDS and own one tile
-// buffer each.  A wave issues in order, so inside ONE wave the ~350 non-MFMA instructions of a tile (epilogue
-// stores, BN-backward sums, staging the next tile into LDS, issuing the prefetch) cannot hide behind its own
-// MFMAs; PMC on the single-group kernel shows MFMA busy 48 % + issue-active 29 % + parked 20 % with no overlap.
-// Here the two halves run one phase apart (an extra barrier at the start of half 1 / end of half 0): while half A
-// streams its 128 MFMAs per wave, half B - resident on the same SIMDs - does its non-MFMA phase, then they swap.
-// Every barrier is workgroup-wide; both halves execute the same number of them.
+// Ping-pong structure: 512 threads = two half-workgroups of 4 waves that share W in LDS and own one tile buffer
+// each, one phase apart (an extra barrier at the start of half 1 / end of half 0): while half A streams the MFMAs of
+// its tile, half B - on the same SIMDs - stores its dX tile, reduces the BN-backward sums, copies its next tile to LDS
+// and issues the global loads of the one after.  The instruction streams of the two do not overlap (see above), but the
+// memory latencies of one hide behind the MFMAs of the other.  Every barrier is workgroup-wide; both halves execute the
+// same number of them.
 // ------------------------------------------------------------------------------------------------
 // EX: extra input columns [Ci, Ci+EX) of X (the 3 relative coordinates + pad of a grouped layer, laid out AFTER the
 // feature block): they only contribute EX more columns of dW (no dX, no act_in), accumulated on the VALU.
@@ -129,13 +164,13 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 {
     constexpr int Co = 64 * COT, Ci = 64 * CIT;
     constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
-    constexpr int LDW = Ci + 4, LDY = BM + 1, LDX = Ci + 4;
+    constexpr int LDT = Co + 4, LDM = BM + 4, NG = BM / 8, NQ = Co / 8;
     constexpr int UDY = BM * Co / 4 / 256, UX = BM * Ci / 4 / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Ws = smem;                              // [Co][LDW]          shared by both halves
-    float *dYs = Ws + Co * LDW;                    // [2 halves][Co][LDY]
-    float *Xr = dYs + 2 * Co * LDY;                // [2 halves][BM][LDX]
-    float *red = Xr + 2 * BM * LDX;                // [2][Ci]
+    float *Wt = smem;                              // [Ci][LDT]   W transposed: co contiguous      shared by both halves
+    float *dYs = Wt + Ci * LDT;                    // [2 halves][Co][LDM]
+    float *Xt = dYs + 2 * Co * LDM;                // [2 halves][Ci][LDM]
+    float *red = Xt + 2 * Ci * LDM;                // [2][Ci]
     float *Xe = red + 2 * Ci;                      // [2 halves][BM][4] extra input columns (EX > 0)
 
     const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
@@ -145,8 +180,8 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     const int ntiles = (a.M + BM - 1) / BM;
     const int nk = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles of this workgroup: blockIdx.x + k*gridDim.x
     const int niter = (nk + 1) / 2;                // per half
-    float *dy = dYs + half * Co * LDY;
-    float *xr = Xr + half * BM * LDX;
+    float *dy = dYs + half * Co * LDM;
+    float *xt = Xt + half * Ci * LDM;
     float *xe = Xe + half * BM * 4;
     constexpr int EPT = EX > 0 ? (EX * Co + 255) / 256 : 1;     // extra dW columns per thread (thread -> co = tid % Co)
     float acce[EPT];
@@ -154,10 +189,14 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     for (int i = 0; i < EPT; ++i) acce[i] = 0.f;
     v4f rxe = {0.f, 0.f, 0.f, 0.f};
 
-    if (NEED_DX) {
+    if (NEED_DX) {                                 // W [Co,Ci] -> Wt[ci][co]
         for (int u = threadIdx.x; u < Co * Ci / 4; u += 512) {
             const int r = u / (Ci / 4), c4 = u % (Ci / 4);
-            *reinterpret_cast<float4 *>(&Ws[r * LDW + c4 * 4]) = *reinterpret_cast<const float4 *>(a.w + (size_t)r * a.ldw + c4 * 4);
+            const float4 v = *reinterpret_cast<const float4 *>(a.w + (size_t)r * a.ldw + c4 * 4);
+            Wt[(c4 * 4 + 0) * LDT + r] = v.x;
+            Wt[(c4 * 4 + 1) * LDT + r] = v.y;
+            Wt[(c4 * 4 + 2) * LDT + r] = v.z;
+            Wt[(c4 * 4 + 3) * LDT + r] = v.w;
         }
     }
     float isc[CIT], ish[CIT];
@@ -171,9 +210,30 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     float psc = 0.f, psh = 0.f, pmu = 0.f, pis = 0.f;
     if (NEED_DX && HAS_STATS) { psc = a.pstat[xcol]; psh = a.pstat[Ci + xcol]; pmu = a.pstat[2 * Ci + xcol]; pis = a.pstat[3 * Ci + xcol]; }
     float4 cf[5];
+    {
+        int row0, c40;
+        fused_unit<Co / 4>(tid, row0, c40);        // the float4 column of a thread's units does not depend on i
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
-        cf[i] = GMODE >= 1 ? *reinterpret_cast<const float4 *>(a.coef + i * Co + (tid % (Co / 4)) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 5; ++i)
+            cf[i] = GMODE >= 1 ? *reinterpret_cast<const float4 *>(a.coef + i * Co + c40 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // per-lane LDS offsets (floats) of the operand reads; they are the same for every tile
+    int adw[COT][NG], bdw[CIT][NG];                // dW: group q of block i / j  (16-byte reads over m)
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+#pragma unroll
+        for (int i = 0; i < COT; ++i) adw[i][q] = fused_pos<BM>(wi * (COT * 32) + i * 32 + l31, 8 * q + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < CIT; ++j) bdw[j][q] = fused_pos<BM>(wj * (CIT * 32) + j * 32 + l31, 8 * q + 4 * lh);
+    }
+    int adx[8];                                    // dX: A element (co = 8q+4h+e, m = wr*32+l31): rotation class q & 7
+#pragma unroll
+    for (int r = 0; r < 8; ++r) adx[r] = 4 * lh * LDM + ((wr * 32 + l31 + 4 * r) & (BM - 1));
+    const int bdx = xcol * LDT + 4 * lh;           // dX: B = Wt[ci][8q + 4h .. +3]
+    int ayp[4];                                    // raw x of the lane's output column at its 16 rows (4 groups of 4)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) ayp[g] = fused_pos<BM>(xcol, wr * 32 + 8 * g + 4 * lh);
+
     float s1 = 0.f, s2 = 0.f, dbacc = 0.f;
     f32x16 accW[COT][CIT];
 #pragma unroll
@@ -195,7 +255,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     {
         const int k0 = half, k1 = half + 2;
         fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
-        fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xr, rdz, ry, rarg, rx, cf);
+        fused_store_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xt, rdz, ry, rarg, rx, cf);
         if (EX > 0 && tid < BM) {
             const int m = min(tile_of(k0 < nk ? k0 : 0) * BM + tid, a.M - 1);
             *reinterpret_cast<v4f *>(&xe[tid * 4]) = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
@@ -215,97 +275,81 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         // ================= MFMA phase =================
         P2C_TR(0);
         if (valid) {
-            {
-                float av[COT], bv[CIT], an[COT], bn[CIT];
+            // ---- dW += dY^T . act(X): per group of 8 rows, COT + CIT 16-byte reads feed 4*COT*CIT MFMAs
 #pragma unroll
-                for (int i = 0; i < COT; ++i) av[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + lh];
+            for (int q = 0; q < NG; ++q) {
+                v4f av[COT], bv[CIT];
 #pragma unroll
-                for (int j = 0; j < CIT; ++j) bv[j] = xr[lh * LDX + wj * (CIT * 32) + j * 32 + l31];
-#pragma unroll 8
-                for (int s = 0; s < BM; s += 2) {
-                    const int sn = (s + 2 < BM) ? s + 2 : s;
+                for (int i = 0; i < COT; ++i) av[i] = *reinterpret_cast<const v4f *>(dy + adw[i][q]);
 #pragma unroll
-                    for (int i = 0; i < COT; ++i) an[i] = dy[(wi * (COT * 32) + i * 32 + l31) * LDY + sn + lh];
-#pragma unroll
-                    for (int j = 0; j < CIT; ++j) bn[j] = xr[(sn + lh) * LDX + wj * (CIT * 32) + j * 32 + l31];
-                    // pinned: the LDS reads of step s+1 are issued BEFORE the MFMAs of step s.  Left alone, the scheduler
-                    // sinks them next to their use and every group of MFMAs eats a full LDS round trip (phase trace:
-                    // 116 instead of 64 cycles per MFMA).
-                    __builtin_amdgcn_sched_barrier(0);
-                    float bz[CIT];
-#pragma unroll
-                    for (int j = 0; j < CIT; ++j) {
-                        float v = bv[j];
-                        if (IMODE == 1) v = fmaxf(isc[j] * v + ish[j], 0.f);
-                        if (m0 + s + lh >= a.M) v = 0.f;
-                        bz[j] = v;
+                for (int j = 0; j < CIT; ++j) {
+                    v4f v = *reinterpret_cast<const v4f *>(xt + bdw[j][q]);
+                    if (IMODE == 1) {
+                        v.x = fmaxf(isc[j] * v.x + ish[j], 0.f);
+                        v.y = fmaxf(isc[j] * v.y + ish[j], 0.f);
+                        v.z = fmaxf(isc[j] * v.z + ish[j], 0.f);
+                        v.w = fmaxf(isc[j] * v.w + ish[j], 0.f);
                     }
+                    bv[j] = v;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
                     for (int i = 0; i < COT; ++i)
 #pragma unroll
-                        for (int j = 0; j < CIT; ++j) accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bz[j], accW[i][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < COT; ++i) av[i] = an[i];
-#pragma unroll
-                    for (int j = 0; j < CIT; ++j) bv[j] = bn[j];
-                }
+                        for (int j = 0; j < CIT; ++j) accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], accW[i][j], 0, 0, 0);
             }
             P2C_TR(1);
             if (GMODE == 0 && a.dbias && tid < Co) {
                 float sb = 0.f;
 #pragma unroll 8
-                for (int s = 0; s < BM; ++s) sb += dy[tid * LDY + s];
+                for (int s = 0; s < BM; ++s) sb += dy[tid * LDM + s];      // the BM row entries in their rotated order
                 dbacc += sb;
             }
             if (EX > 0) {                               // dW[co, Ci + e] += sum_m dY[m,co] * x[m, Ci + e]   (rows past M have dY == 0)
                 const int co = tid % Co, e0 = (tid / Co) * EPT;
 #pragma unroll 8
                 for (int s = 0; s < BM; ++s) {
-                    const float d = dy[co * LDY + s];
+                    const float d = dy[fused_pos<BM>(co, s)];
 #pragma unroll
                     for (int i = 0; i < EPT; ++i) acce[i] += d * xe[s * 4 + e0 + i];
                 }
             }
             if (NEED_DX) {
+                // ---- dX = dY . W: per group of 8 output channels co, one 16-byte read of Wt and two ds_read2_b32 of dYs
+                //      (rows co, co+1 / co+2, co+3 at this lane's m) feed 4 MFMAs; group q+1 is fetched under the MFMAs of q
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accX[r] = 0.f;
-                // same pinning: groups of DXG k-steps, the reads of group g+1 in flight under the MFMAs of group g
-                constexpr int DXG = GMODE == 2 ? 2 : 4, NG = Co / (2 * DXG);    // the pooled variant carries the winner indices too: fewer registers to spare
-                float a0[DXG], b0[DXG], a1[DXG], b1[DXG];
+                const float *ap = dy, *bp = Wt + bdx;
+                float a0[4], a1[4];
+                v4f b0, b1;
+#define P2C_DXLOAD(A_, B_, Q_)                                            \
+    do {                                                                  \
+        const float *p_ = ap + adx[(Q_) & 7] + 8 * (Q_) * LDM;            \
+        A_[0] = p_[0]; A_[1] = p_[LDM]; A_[2] = p_[2 * LDM]; A_[3] = p_[3 * LDM]; \
+        B_ = *reinterpret_cast<const v4f *>(bp + 8 * (Q_));               \
+    } while (0)
+                P2C_DXLOAD(a0, b0, 0);
 #pragma unroll
-                for (int u = 0; u < DXG; ++u) {
-                    a0[u] = dy[(2 * u + lh) * LDY + wr * 32 + l31];
-                    b0[u] = Ws[(2 * u + lh) * LDW + wc * 32 + l31];
-                }
-#pragma unroll
-                for (int g = 0; g < NG; g += 2) {
-#pragma unroll
-                    for (int u = 0; u < DXG; ++u) {
-                        const int kk = 2 * ((g + 1) * DXG + u);
-                        a1[u] = dy[(kk + lh) * LDY + wr * 32 + l31];
-                        b1[u] = Ws[(kk + lh) * LDW + wc * 32 + l31];
-                    }
+                for (int q = 0; q < NQ; q += 2) {
+                    P2C_DXLOAD(a1, b1, q + 1);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < DXG; ++u) accX = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], accX, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) accX = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], accX, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (g + 2 < NG) {
-#pragma unroll
-                        for (int u = 0; u < DXG; ++u) {
-                            const int kk = 2 * ((g + 2) * DXG + u);
-                            a0[u] = dy[(kk + lh) * LDY + wr * 32 + l31];
-                            b0[u] = Ws[(kk + lh) * LDW + wc * 32 + l31];
-                        }
-                    }
+                    if (q + 2 < NQ) P2C_DXLOAD(a0, b0, q + 2);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int u = 0; u < DXG; ++u) accX = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], accX, 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) accX = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], accX, 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if (HAS_STATS) {                    // the epilogue runs after the barrier, when xr may already be restaged
+#undef P2C_DXLOAD
+                if (HAS_STATS) {                    // the epilogue runs after the barrier, when Xt may already be restaged
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) yp[r] = xr[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDX + xcol];
+                    for (int g = 0; g < 4; ++g) {
+                        const v4f v = *reinterpret_cast<const v4f *>(xt + ayp[g]);
+                        yp[4 * g] = v.x; yp[4 * g + 1] = v.y; yp[4 * g + 2] = v.z; yp[4 * g + 3] = v.w;
+                    }
                 }
             }
         }
@@ -313,8 +357,6 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         P2C_LDS_BARRIER();
         P2C_TR(3);
         // ================= non-MFMA phase (the other half is in its MFMA phase) =================
-        // The co-resident wave of the other half needs an issue slot only once per 64-cycle MFMA; give this phase's
-        // VALU / LDS / VMEM instructions priority so it finishes inside the other half's MFMA phase.
         __builtin_amdgcn_s_setprio(1);
 #ifndef P2C_TRACE_NODATA
         if (valid && NEED_DX) {
@@ -342,7 +384,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         P2C_TR(4);
         {
             const int k2 = k + 2, k4 = k + 4;
-            if (k2 < nk) fused_store_tile<GMODE, Co, Ci, BM, LDY, LDX, UDY, UX>(a, tid, tile_of(k2), dy, xr, rdz, ry, rarg, rx, cf);
+            if (k2 < nk) fused_store_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k2), dy, xt, rdz, ry, rarg, rx, cf);
             P2C_TR(5);
             if (EX > 0 && tid < BM) *reinterpret_cast<v4f *>(&xe[tid * 4]) = rxe;
             fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
@@ -433,7 +475,7 @@ static int launch_fused(const BwdFusedArgs &a, int extra, hipStream_t s)
 {
     constexpr int Co = 64 * COT, Ci = 64 * CIT;
     constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
-    const size_t lds = (size_t)(Co * (Ci + 4) + 2 * Co * (BM + 1) + 2 * BM * (Ci + 4) + 2 * Ci + 2 * BM * 4) * sizeof(float);
+    const size_t lds = (size_t)(Ci * (Co + 4) + 2 * Co * (BM + 4) + 2 * Ci * (BM + 4) + 2 * Ci + 2 * BM * 4) * sizeof(float);
     const int grid = fused_grid(a.M, Ci);
     if (extra) {      // grouped first layer: [feats(128) | xyz(3) | pad] -> 4 extra dW columns (only this shape needs it)
         if constexpr (COT == 2 && CIT == 2 && GMODE == 1 && IMODE == 0) {

@@ -195,7 +195,7 @@ int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int 
  * the two entry points above; dX may be NULL (then prev_stat/bwd_partials must be NULL too).
  * bwd_partials: the zeroed fp64 slots of the layer below (p2c_stat_slots_bytes(Ci)).
  * dW is accumulated into 8 copies (one per XCD, copy s at dW + s*dw_slot_stride elements, all zero-initialised by the
- * caller, who sums them); dw_slot_stride = 0 selects a single copy.
+ * caller, who sums them); dw_slot_stride = 0 selects a single copy.  grad_mode 2 needs pool_ns >= 32, pool_ns % 16 == 0.
  * p2c_linear_bwd_fused_supported: 0 = use the two generic entry points, 1 = supported, 2 = supported for the grouped
  * layer [128 features | 4 trailing columns] (Ci = 132, in_mode 0): dW covers all 132 columns but dX[:, 128:132] is NOT
  * written (the trailing columns are the relative coordinates, which receive no gradient). */

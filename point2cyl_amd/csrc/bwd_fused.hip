@@ -21,6 +21,7 @@
 #include "common.h"
 #include <stdlib.h>
 
+
 // Workgroup barrier that only drains the LDS queue.  __syncthreads() also waits for every outstanding global
 // load/store of the wave (vmcnt(0)), which would turn the register prefetch that is meant to stay in flight across
 // the barrier into an exposed HBM round trip per phase.  LDS hand-offs only need lgkmcnt(0).
@@ -74,23 +75,31 @@ template <int BM>
 __device__ __forceinline__ int fused_pos(int c, int m) { return c * (BM + 4) + ((m + 4 * ((c >> 3) & 7)) & (BM - 1)); }
 
 // Raw tile fetch (no arithmetic: the values stay in flight during the MFMAs of the previous tile).
-template <int GMODE, int Co, int Ci, int BM, int UDY, int UX>
-__device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, int t, float4 (&rdz)[UDY], float4 (&ry)[UDY],
-                                                int4 (&rarg)[UDY], v4f (&rx)[UX])
+// GMODE 2 (the layer feeds the max-pool): the gradient and the winner index are per GROUP of ns rows, and a tile spans at
+// most two groups (host-checked: ns % 16 == 0, 2 ns >= BM), so a thread fetches its float4 column of those two group rows
+// once instead of once per row unit: UDZ = 2 register sets instead of UDY.
+template <int GMODE, int Co, int Ci, int BM, int UDY, int UDZ, int UX>
+__device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, int t, float4 (&rdz)[UDZ], float4 (&ry)[UDY],
+                                                int4 (&rarg)[UDZ], v4f (&rx)[UX])
 {
     const int m0 = t * BM;
+    if (GMODE == 2) {
+        int row, c4;
+        fused_unit<Co / 4>(tid, row, c4);
+        const int g0 = m0 / a.ns, glast = (a.M - 1) / a.ns;
+#pragma unroll
+        for (int sI = 0; sI < UDZ; ++sI) {
+            const int grp = min(g0 + sI, glast);
+            rdz[sI] = *reinterpret_cast<const float4 *>(a.dz + (size_t)grp * a.lddz + c4 * 4);
+            rarg[sI] = *reinterpret_cast<const int4 *>(a.arg + (size_t)grp * Co + c4 * 4);
+        }
+    }
 #pragma unroll
     for (int i = 0; i < UDY; ++i) {
         int row, c4;
         fused_unit<Co / 4>(tid + 256 * i, row, c4);
         const int r = min(m0 + row, a.M - 1);
-        if (GMODE == 2) {
-            const int grp = r / a.ns;
-            rdz[i] = *reinterpret_cast<const float4 *>(a.dz + (size_t)grp * a.lddz + c4 * 4);
-            rarg[i] = *reinterpret_cast<const int4 *>(a.arg + (size_t)grp * Co + c4 * 4);
-        } else {
-            rdz[i] = *reinterpret_cast<const float4 *>(a.dz + (size_t)r * a.lddz + c4 * 4);
-        }
+        if (GMODE != 2) rdz[i] = *reinterpret_cast<const float4 *>(a.dz + (size_t)r * a.lddz + c4 * 4);
         if (GMODE >= 1) ry[i] = *reinterpret_cast<const float4 *>(a.y + (size_t)r * a.ldy + c4 * 4);
     }
 #pragma unroll
@@ -103,30 +112,37 @@ __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, 
 
 // dY = gs*(dZ*[scale*Y+shift>0]) + q*Y + p from the raw registers (cf[] = this thread's 4 channels of coef) -> dYs[co][m];
 // raw X -> Xt[ci][m] (act_in is applied when the dW operand is read: the dX epilogue needs the raw values).
-template <int GMODE, int Co, int Ci, int BM, int UDY, int UX>
-__device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid, int t, float *dy, float *xt, const float4 (&rdz)[UDY],
-                                                 const float4 (&ry)[UDY], const int4 (&rarg)[UDY], const v4f (&rx)[UX],
+template <int GMODE, int Co, int Ci, int BM, int UDY, int UDZ, int UX>
+__device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid, int t, float *dy, float *xt, const float4 (&rdz)[UDZ],
+                                                 const float4 (&ry)[UDY], const int4 (&rarg)[UDZ], const v4f (&rx)[UX],
                                                  const float4 (&cf)[5])
 {
     const int m0 = t * BM;
+    constexpr int RS = 1024 / Co;                  // rows a unit index spans: unit i holds rows [RS*i, RS*i + RS) of the tile
 #pragma unroll
     for (int i = 0; i < UDY; ++i) {
         int row, c4;
         fused_unit<Co / 4>(tid + 256 * i, row, c4);
         const int m = m0 + row;
-        float4 g = rdz[i];
+        float4 g;
         if (GMODE == 2) {
-            const int r = min(m, a.M - 1);
-            const int j = r - (r / a.ns) * a.ns;
-            g = make_float4(rarg[i].x == j ? g.x : 0.f, rarg[i].y == j ? g.y : 0.f, rarg[i].z == j ? g.z : 0.f, rarg[i].w == j ? g.w : 0.f);
+            const int gi = (m0 + RS * i) / a.ns;   // uniform: the group of every row of this unit
+            const int j = m - gi * a.ns;           // the row's index inside its group
+            const bool second = gi != m0 / a.ns;
+            const float4 d = second ? rdz[UDZ - 1] : rdz[0];
+            const int4 w = second ? rarg[UDZ - 1] : rarg[0];
+            g = make_float4(w.x == j ? d.x : 0.f, w.y == j ? d.y : 0.f, w.z == j ? d.z : 0.f, w.w == j ? d.w : 0.f);
+        } else {
+            g = rdz[i];
         }
         float4 o = g;
         if (GMODE >= 1) {
             const float4 yy = ry[i];
-            o.x = cf[2].x * ((cf[0].x * yy.x + cf[1].x > 0.f) ? g.x : 0.f) + cf[3].x * yy.x + cf[4].x;
-            o.y = cf[2].y * ((cf[0].y * yy.y + cf[1].y > 0.f) ? g.y : 0.f) + cf[3].y * yy.y + cf[4].y;
-            o.z = cf[2].z * ((cf[0].z * yy.z + cf[1].z > 0.f) ? g.z : 0.f) + cf[3].z * yy.z + cf[4].z;
-            o.w = cf[2].w * ((cf[0].w * yy.w + cf[1].w > 0.f) ? g.w : 0.f) + cf[3].w * yy.w + cf[4].w;
+            // the ReLU mask with the forward's own two roundings (mul, add); the affine rest as fmas
+            o.x = __builtin_fmaf(cf[2].x, (cf[0].x * yy.x + cf[1].x > 0.f) ? g.x : 0.f, __builtin_fmaf(cf[3].x, yy.x, cf[4].x));
+            o.y = __builtin_fmaf(cf[2].y, (cf[0].y * yy.y + cf[1].y > 0.f) ? g.y : 0.f, __builtin_fmaf(cf[3].y, yy.y, cf[4].y));
+            o.z = __builtin_fmaf(cf[2].z, (cf[0].z * yy.z + cf[1].z > 0.f) ? g.z : 0.f, __builtin_fmaf(cf[3].z, yy.z, cf[4].z));
+            o.w = __builtin_fmaf(cf[2].w, (cf[0].w * yy.w + cf[1].w > 0.f) ? g.w : 0.f, __builtin_fmaf(cf[3].w, yy.w, cf[4].w));
         }
         const float ok = m < a.M ? 1.f : 0.f;                       // rows past M contribute nothing to dW / dbias
         float *d = dy + fused_pos<BM>(c4 * 4, row);                 // channels 4c4 .. 4c4+3 share (c >> 3): same rotation
@@ -209,14 +225,17 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     const int xcol = wc * 32 + l31;
     float psc = 0.f, psh = 0.f, pmu = 0.f, pis = 0.f;
     if (NEED_DX && HAS_STATS) { psc = a.pstat[xcol]; psh = a.pstat[Ci + xcol]; pmu = a.pstat[2 * Ci + xcol]; pis = a.pstat[3 * Ci + xcol]; }
+    const float npm = -pmu * pis;
+    // coef of the thread's float4 column (it does not depend on the unit index i)
     float4 cf[5];
-    {
-        int row0, c40;
-        fused_unit<Co / 4>(tid, row0, c40);        // the float4 column of a thread's units does not depend on i
+    int row0_, c40;
+    fused_unit<Co / 4>(tid, row0_, c40);
+    auto load_cf = [&]() {
 #pragma unroll
         for (int i = 0; i < 5; ++i)
             cf[i] = GMODE >= 1 ? *reinterpret_cast<const float4 *>(a.coef + i * Co + c40 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    };
+    load_cf();
     // per-lane LDS offsets (floats) of the operand reads; they are the same for every tile
     int adw[COT][NG], bdw[CIT][NG];                // dW: group q of block i / j  (16-byte reads over m)
 #pragma unroll
@@ -247,20 +266,21 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accX[r] = 0.f; yp[r] = 0.f; }
 
-    float4 rdz[UDY], ry[UDY];
+    constexpr int UDZ = GMODE == 2 ? 2 : UDY;
+    float4 rdz[UDZ], ry[UDY];
     v4f rx[UX];
-    int4 rarg[UDY];
+    int4 rarg[UDZ];
     auto tile_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
     // prologue: this half's first tile -> its LDS buffer; its second tile -> registers (in flight)
     {
         const int k0 = half, k1 = half + 2;
-        fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
-        fused_store_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xt, rdz, ry, rarg, rx, cf);
+        fused_load_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
+        fused_store_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xt, rdz, ry, rarg, rx, cf);
         if (EX > 0 && tid < BM) {
             const int m = min(tile_of(k0 < nk ? k0 : 0) * BM + tid, a.M - 1);
             *reinterpret_cast<v4f *>(&xe[tid * 4]) = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
         }
-        fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k1 < nk ? k1 : 0), rdz, ry, rarg, rx);
+        fused_load_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k1 < nk ? k1 : 0), rdz, ry, rarg, rx);
         if (EX > 0 && tid < BM) {
             const int m = min(tile_of(k1 < nk ? k1 : 0) * BM + tid, a.M - 1);
             rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
@@ -275,22 +295,30 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         // ================= MFMA phase =================
         P2C_TR(0);
         if (valid) {
-            // ---- dW += dY^T . act(X): per group of 8 rows, COT + CIT 16-byte reads feed 4*COT*CIT MFMAs
+            // ---- dW += dY^T . act(X): per group of 8 rows, COT + CIT 16-byte reads feed 4*COT*CIT MFMAs; the reads of group
+            //      q+1 are issued before the MFMAs of group q (pinned: the scheduler would sink them next to their use)
+            v4f av[COT], bv[CIT], an[COT], bn[CIT];
+#pragma unroll
+            for (int i = 0; i < COT; ++i) av[i] = *reinterpret_cast<const v4f *>(dy + adw[i][0]);
+#pragma unroll
+            for (int j = 0; j < CIT; ++j) bv[j] = *reinterpret_cast<const v4f *>(xt + bdw[j][0]);
 #pragma unroll
             for (int q = 0; q < NG; ++q) {
-                v4f av[COT], bv[CIT];
+                if (q + 1 < NG) {
 #pragma unroll
-                for (int i = 0; i < COT; ++i) av[i] = *reinterpret_cast<const v4f *>(dy + adw[i][q]);
+                    for (int i = 0; i < COT; ++i) an[i] = *reinterpret_cast<const v4f *>(dy + adw[i][q + 1]);
 #pragma unroll
-                for (int j = 0; j < CIT; ++j) {
-                    v4f v = *reinterpret_cast<const v4f *>(xt + bdw[j][q]);
-                    if (IMODE == 1) {
-                        v.x = fmaxf(isc[j] * v.x + ish[j], 0.f);
-                        v.y = fmaxf(isc[j] * v.y + ish[j], 0.f);
-                        v.z = fmaxf(isc[j] * v.z + ish[j], 0.f);
-                        v.w = fmaxf(isc[j] * v.w + ish[j], 0.f);
+                    for (int j = 0; j < CIT; ++j) bn[j] = *reinterpret_cast<const v4f *>(xt + bdw[j][q + 1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (IMODE == 1) {
+#pragma unroll
+                    for (int j = 0; j < CIT; ++j) {
+                        bv[j].x = fmaxf(isc[j] * bv[j].x + ish[j], 0.f);
+                        bv[j].y = fmaxf(isc[j] * bv[j].y + ish[j], 0.f);
+                        bv[j].z = fmaxf(isc[j] * bv[j].z + ish[j], 0.f);
+                        bv[j].w = fmaxf(isc[j] * bv[j].w + ish[j], 0.f);
                     }
-                    bv[j] = v;
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -298,6 +326,11 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                     for (int i = 0; i < COT; ++i)
 #pragma unroll
                         for (int j = 0; j < CIT; ++j) accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], accW[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < COT; ++i) av[i] = an[i];
+#pragma unroll
+                for (int j = 0; j < CIT; ++j) bv[j] = bn[j];
             }
             P2C_TR(1);
             if (GMODE == 0 && a.dbias && tid < Co) {
@@ -375,19 +408,19 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = accX[r];
-                    const float g = (psc * yp[r] + psh > 0.f) ? v : 0.f;
+                    const float g = (psc * yp[r] + psh > 0.f) ? v : 0.f;          // mask: the forward's two roundings
                     s1 += g;
-                    s2 += g * ((yp[r] - pmu) * pis);
+                    s2 = __builtin_fmaf(g, __builtin_fmaf(yp[r], pis, npm), s2);    // g * (y - mean) * invstd
                 }
             }
         }
         P2C_TR(4);
         {
             const int k2 = k + 2, k4 = k + 4;
-            if (k2 < nk) fused_store_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k2), dy, xt, rdz, ry, rarg, rx, cf);
+            if (k2 < nk) fused_store_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k2), dy, xt, rdz, ry, rarg, rx, cf);
             P2C_TR(5);
             if (EX > 0 && tid < BM) *reinterpret_cast<v4f *>(&xe[tid * 4]) = rxe;
-            fused_load_tile<GMODE, Co, Ci, BM, UDY, UX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
+            fused_load_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
             if (EX > 0 && tid < BM) {
                 const int m = min(tile_of(k4 < nk ? k4 : 0) * BM + tid, a.M - 1);
                 rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
@@ -524,7 +557,7 @@ extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *
     const int extra = sup == 2 ? 4 : 0;
     if (extra) Ci -= extra;
     if (grad_mode >= 1 && (!Yfwd || !coef)) return P2C_EINVAL;
-    if (grad_mode == 2 && (!pool_arg || pool_ns <= 0)) return P2C_EINVAL;
+    if (grad_mode == 2 && (!pool_arg || pool_ns < 32 || (pool_ns & 15))) return P2C_EINVAL;    // a 64-row tile spans <= 2 groups
     if (in_mode == 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
     if (prev_stat && (!bwd_partials || !dX)) return P2C_EINVAL;
     if ((lddz & 3) || (ldx & 3) || (ldw & 3) || (grad_mode >= 1 && (ldy & 3)) || ((uintptr_t)dZ & 15) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))

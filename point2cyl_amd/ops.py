@@ -431,6 +431,8 @@ class _MLPStack(torch.autograd.Function):
             stats_below = i > 0                       # the layer below has a BatchNorm whose backward sums we produce here
             L_ = _lib.lib()
             fused_kind = L_.p2c_linear_bwd_fused_supported(Co, Ci, mode) if (USE_FUSED_BWD and mode <= 1 and M >= 4096) else 0
+            if grad_mode == 2 and (pool_ns < 32 or pool_ns % 16):
+                fused_kind = 0           # the pooled variant wants a row tile to span at most two groups
             if fused_kind == 2 and not (i == 0 and cfg.get("xyz_last")):
                 fused_kind = 0           # kind 2 yields no dX for the 4 trailing input columns: fine for [feats | xyz | pad] only
             if fused_kind:

@@ -10,11 +10,13 @@
 
 #define HM_MAXK 15
 
+// Called by ONE thread of a workgroup.  The solver's state is indexed dynamically, which in private arrays means scratch
+// memory (a ~1 us round trip per access: the 8x8 solve took 90 us); it lives in LDS instead.  col4row: LDS, >= nr ints.
 __device__ void p2c_lsa_min(const double *cost, int nr, int nc, int *col4row)
 {
-    double u[HM_MAXK + 1], v[HM_MAXK + 1], spc[HM_MAXK + 1];
-    int path[HM_MAXK + 1], row4col[HM_MAXK + 1], remaining[HM_MAXK + 1];
-    bool SR[HM_MAXK + 1], SC[HM_MAXK + 1];
+    __shared__ double u[HM_MAXK + 1], v[HM_MAXK + 1], spc[HM_MAXK + 1];
+    __shared__ int path[HM_MAXK + 1], row4col[HM_MAXK + 1], remaining[HM_MAXK + 1];
+    __shared__ bool SR[HM_MAXK + 1], SC[HM_MAXK + 1];
     for (int i = 0; i < nr; ++i) { u[i] = 0.0; col4row[i] = -1; }
     for (int j = 0; j < nc; ++j) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
     for (int cur = 0; cur < nr; ++cur) {
@@ -71,6 +73,7 @@ __global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__re
     extern __shared__ float sacc[];                 // [HM_THREADS][2K+1] private rows: K label sums | column sum | K label counts
     __shared__ int smax[HM_THREADS / 64];
     __shared__ double cost[HM_MAXK * HM_MAXK];
+    __shared__ int col4row[HM_MAXK + 1];
     __shared__ float tot[(HM_MAXK + 1) * HM_MAXK], cnt[HM_MAXK];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t *lab = I_gt + (size_t)b * N;
@@ -129,7 +132,6 @@ __global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__re
                 const float iou = dot / fmaxf(den, 1e-10f);               // :41
                 cost[r * K + q] = -(double)iou;                           // :43 maximise
             }
-        int col4row[HM_MAXK + 1];
         if (nr > 0) p2c_lsa_min(cost, nr, K, col4row);
         for (int q = 0; q < K; ++q) {
             match_out[(size_t)b * K + q] = q < nr ? (int64_t)col4row[q] : 0;   // rest stays 0 (:30)
@@ -208,6 +210,7 @@ __global__ void __launch_bounds__(128) hungarian_finish8_kernel(const float *__r
 {
     constexpr int K = 8, NA = (K + 1) * K + K, NP = NA + 1;
     __shared__ double cost[HM_MAXK * HM_MAXK];
+    __shared__ int col4row[HM_MAXK + 1];
     __shared__ float tot[NP];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (tid < NP) {
@@ -228,7 +231,6 @@ __global__ void __launch_bounds__(128) hungarian_finish8_kernel(const float *__r
                 const float den = (rc + col) - dot;
                 cost[r * K + q] = -(double)(dot / fmaxf(den, 1e-10f));
             }
-        int col4row[HM_MAXK + 1];
         if (nr > 0) p2c_lsa_min(cost, nr, K, col4row);
         for (int q = 0; q < K; ++q) {
             match_out[(size_t)b * K + q] = q < nr ? (int64_t)col4row[q] : 0;

@@ -20,6 +20,27 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 PEAK_HBM_GBS = 8000.0
 
 
+# HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE and
+# WRITE_SIZE need separate passes, so they cannot be read inside the timed run); launch-weighted over the family's kernels.
+_PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_pmc_hbm_traffic.json")
+_PMC_NAME = {"p2c_linear_bwd_fused_f32": "bwd_fused_pp_kernel", "p2c_linear_fwd_f32": "fwd_pp_kernel"}
+
+
+def _pmc_traffic(entry):
+    try:
+        with open(_PMC_FILE) as f:
+            ks = json.load(f)["kernels"]
+        sub = _PMC_NAME.get(entry)
+        sel = [v for k, v in ks.items() if sub and sub in k]
+        n = sum(v["launches"] for v in sel)
+        if not n:
+            return None, None
+        tot = sum(v["launches"] * (v.get("fetch_bytes_per_launch", 0.0) + v.get("write_bytes_per_launch", 0.0)) for v in sel)
+        return round(tot / n), "profiles/" + os.path.basename(_PMC_FILE)
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,8 +153,10 @@ def main():
         d = dom[1]
         if d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            traffic, tsrc = _pmc_traffic(dom[0])
             roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (HBM read+write, PMC)",
+                            traffic_source=tsrc, algorithmic_bytes_per_launch=round(d["bytes"] / max(1, d["launches"])),
                             launches_per_step=d["launches"] / prof_steps, avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
                             share_of_step=round(d["ms"] / prof_steps / ms, 3))
         else:

@@ -442,7 +442,8 @@ class _MLPStack(torch.autograd.Function):
                 call("p2c_linear_bwd_fused_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(arg) if grad_mode == 2 else None,
                      pool_ns, ptr(Xin), ldxin, mode, ptr(sc), ptr(sh), ptr(W2), Ci, ptr(dX), Ci, ptr(dW8), Ci, Co * Ci,
                      ptr(db) if grad_mode == 0 else None, ptr(aff[i - 1]) if stats_below else None, ptr(part), M, Co, Ci, stream(),
-                     flops=(4.0 if need_dx else 2.0) * M * Co * Ci)
+                     flops=(4.0 if need_dx else 2.0) * M * Co * Ci,
+                     nbytes=4.0 * M * ((1 if grad_mode == 2 else 2) * Co + (2 if need_dx else 1) * Ci))   # dZ (unless pooled), Y, X read once; dX written once
                 dW_final = dW8.sum(0)
             else:
                 use_slots = M >= 65536       # many split-k workgroups: spread the atomics over 8 copies of dW

@@ -6,6 +6,7 @@
 // -ffp-contract=off and fused multiply-adds are spelled __builtin_fmaf() where the reference's CPU
 // BLAS uses them.
 #include "common.h"
+#include <stdlib.h>
 
 // squared distance exactly as square_distance() rounds it (pointnet_util.py:37-39):
 //   ((-2*dot + |s|^2) + |d|^2),  dot = fma(sz,dz, fma(sy,dy, sx*dx)),  |v|^2 = (x*x + y*y) + z*z
@@ -115,7 +116,11 @@ extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start,
     int threads = ((N + ppt - 1) / ppt + 63) & ~63;
     if (threads > 1024) return P2C_EINVAL;
     const int Npad = (N + 3) & ~3;
-    const bool in_lds = (size_t)(3 * Npad + 64) * sizeof(float) <= 160 * 1024;
+    // Clouds whose SoA copy is larger than 24 KB read the centroid from global memory (an L1/L2 hit, measured equally
+    // fast) instead: FPS runs on a side stream under the persistent GEMM kernels, whose 135 KB workgroups cannot share a
+    // CU with a 96 KB copy (N = 8192) and would queue behind the 32 FPS workgroups.  P2C_FPS_LDS_KB overrides.
+    static const size_t lds_cap = (getenv("P2C_FPS_LDS_KB") ? (size_t)atoi(getenv("P2C_FPS_LDS_KB")) : 24) * 1024;
+    const bool in_lds = (size_t)(3 * Npad + 64) * sizeof(float) <= lds_cap;
     const size_t lds = in_lds ? (size_t)(3 * Npad + 64) * sizeof(float) : 64 * sizeof(float);
 #define P2C_FPS_LAUNCH(P, L)                                                                                              \
     (void)hipFuncSetAttribute((const void *)fps_kernel<P, L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \

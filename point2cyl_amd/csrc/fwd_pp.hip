@@ -204,9 +204,7 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
         P2C_LDS_BARRIER();
         P2C_TR(2);
         // ================= wave-local phase (the other half is in its MFMA phase) =================
-#if !(defined(P2C_DBG) && P2C_DBG == 2)
         __builtin_amdgcn_s_setprio(1);
-#endif
         if (valid) {
             // fragment (+ the EX trailing input columns, + bias) -> this wave's region; BatchNorm sums on the bias-free value.
             // Register pairs along r are adjacent, so the sums run as packed-fp32 ops on (r, r+1) pairs.
@@ -244,11 +242,7 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
 #pragma unroll
             for (int i = 0; i < NS; ++i) o[i] = *reinterpret_cast<const v4f *>(&out[(rf0 + i * (64 / V)) * (32 * NT) + 4 * c4]);
             P2C_TR(4);
-#if defined(P2C_DBG) && P2C_DBG == 1
-            if (col < a.N && o[0].x == 123456.f) {               // debug: no global stores
-#else
             if (col < a.N) {
-#endif
                 float *yp = a.y + (size_t)(m0 + wm * 32 + rf0) * a.ldy + col;
                 if (m0 + BM <= a.M) {
 #pragma unroll

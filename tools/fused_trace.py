@@ -8,17 +8,14 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 FWD = "--fwd" in sys.argv             # trace fwd_pp.hip instead of bwd_fused.hip
 NODATA = "--nodata" in sys.argv       # MFMA phases only: no global traffic, no LDS staging (isolates the MFMA loops)
-DBG = [a for a in sys.argv if a.startswith("--dbg=")]
-LIB = os.path.join(HERE, ("libp2c_trace_fwd%s.so" % (DBG[0][6:] if DBG and DBG[0][6:] != "0" else "")) if FWD else "libp2c_trace_nodata.so" if NODATA else "libp2c_trace.so")
+LIB = os.path.join(HERE, "libp2c_trace_fwd.so" if FWD else "libp2c_trace_nodata.so" if NODATA else "libp2c_trace.so")
 if "--build" in sys.argv:
     for lib, extra in ((os.path.join(HERE, "libp2c_trace.so"), []), (os.path.join(HERE, "libp2c_trace_nodata.so"), ["-DP2C_TRACE_NODATA"])):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_TRACE"] + extra +
                               ["-shared", "-o", lib, os.path.join(ROOT, "point2cyl_amd", "csrc", "bwd_fused.hip")])
         print(lib)
-    for dbg in (0, 1, 2):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_TRACE",
-                               "-DP2C_DBG=%d" % dbg, "-shared", "-o", os.path.join(HERE, "libp2c_trace_fwd%s.so" % (dbg or "")),
-                               os.path.join(HERE, "fwd_trace_shim.hip")])
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_TRACE",
+                           "-shared", "-o", os.path.join(HERE, "libp2c_trace_fwd.so"), os.path.join(HERE, "fwd_trace_shim.hip")])
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import numpy as np

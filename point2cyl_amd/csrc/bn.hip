@@ -176,13 +176,13 @@ extern "C" int p2c_maxpool_bwd_f32(const float *dout, int ldo, const int32_t *ar
 __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(const float *__restrict__ dZ, int lddz, const float *__restrict__ Y, int ldy,
                                                              const float *__restrict__ scale, const float *__restrict__ shift,
                                                              const float *__restrict__ mean, const float *__restrict__ invstd,
-                                                             long long M, int C, double *__restrict__ ws)
+                                                             long long M, int C, int rows_per_chunk, double *__restrict__ ws)
 {
     __shared__ float red[2][4][64];
     const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + cx;
-    const long long r0 = (long long)blockIdx.x * BWD_ROWS;
-    const long long r1 = min(M, r0 + BWD_ROWS);
+    const long long r0 = (long long)blockIdx.x * rows_per_chunk;
+    const long long r1 = min(M, r0 + rows_per_chunk);
     float s1 = 0.f, s2 = 0.f;
     if (c < C) {
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
@@ -290,9 +290,13 @@ extern "C" int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float 
 {
     if (!dZ || !Y || !scale || !shift || !mean || !invstd || !gamma || !coef_out || !slots || M <= 0 || C <= 0) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    const int chunks = p2c_cdiv(M, BWD_ROWS);
+    // rows per workgroup: 512 for the long layers, down to 32 for the deep small-M ones (4096 rows in 512-row chunks are
+    // 8 x C/64 workgroups, each a 128-step serial loop: 65 us for a 4 MB reduction)
+    int rows = BWD_ROWS;
+    while (rows > 32 && (long long)p2c_cdiv(M, rows) * p2c_cdiv(C, 64) < 1024) rows >>= 1;
+    const int chunks = p2c_cdiv(M, rows);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dZ, lddz, Y, ldy, scale, shift, mean, invstd,
-                       (long long)M, C, slots);
+                       (long long)M, C, rows, slots);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, (const double *)slots, P2C_STAT_SLOTS, C, (long long)M, scale, shift,
                        mean, invstd, gamma, dgamma, dbeta, coef_out);
     P2C_LAUNCH_CHECK();

@@ -219,20 +219,23 @@ __global__ void __launch_bounds__(256) csr_gather_kernel(const float *__restrict
 #pragma unroll
     for (int i = 0; i < CPL; ++i) acc[i] = 0.f;
     int k = k0;
-    for (; k + 4 <= k1; k += 4) {                // four independent row reads in flight
-        int e[4]; float we[4]; const float *row[4];
+    constexpr int UB = 8;                        // independent row reads in flight per lane
+    for (; k + UB <= k1; k += UB) {
+        float we[UB]; const float *row[UB];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            e[u] = eb[k + u];
+        for (int u = 0; u < UB; ++u) {
             we[u] = wb ? wb[k + u] : 1.f;
-            row[u] = src + ((size_t)b * rows_b + e[u]) * lds_ + coff;
+            row[u] = src + ((size_t)b * rows_b + eb[k + u]) * lds_ + coff;
         }
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = lane + 64 * i;
             if (c < C) {
-                const float v0 = row[0][c], v1 = row[1][c], v2 = row[2][c], v3 = row[3][c];
-                acc[i] += we[0] * v0; acc[i] += we[1] * v1; acc[i] += we[2] * v2; acc[i] += we[3] * v3;
+                float v[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) v[u] = row[u][c];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) acc[i] += we[u] * v[u];
             }
         }
     }

@@ -22,7 +22,7 @@ PEAK_HBM_GBS = 8000.0
 
 # HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE and
 # WRITE_SIZE need separate passes, so they cannot be read inside the timed run); launch-weighted over the family's kernels.
-_PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01d_pmc_hbm_traffic.json")
+_PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01e_pmc_hbm_traffic.json")
 _PMC_NAME = {"p2c_linear_bwd_fused_f32": "bwd_fused_pp_kernel", "p2c_linear_fwd_f32": "fwd_pp_kernel"}
 
 
@@ -50,7 +50,7 @@ def main():
     ap.add_argument("--num_point", type=int, default=8192)
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_batch", type=int, default=2)
+    ap.add_argument("--cpu_batch", type=int, default=4)
     ap.add_argument("--full_losses", action="store_true", help="configs[2]: + --pred_extrusion --pred_center")
     ap.add_argument("--torch_losses", action="store_true", help="evaluate the losses with torch ops instead of csrc/loss.hip")
     ap.add_argument("--no_prefetch", action="store_true", help="compute FPS/ball-query/3-NN inline instead of one step ahead on a side stream")
@@ -170,10 +170,10 @@ def main():
         from oracle import ref_step
         cb = args.cpu_batch
         sample = tuple(x[:cb].contiguous() for x in (pcs, normals, seg, bb))
-        pps, sec, thr = ref_step.time_cpu_baseline(sample, steps=1, threads=min(32, os.cpu_count() or 1))
+        pps, sec, thr, nst = ref_step.time_cpu_baseline(sample, threads=min(32, os.cpu_count() or 1), budget_s=12.0)
         cpu = dict(value=round(pps, 1), unit="points/s", cores=thr, kind="port",
-                   sample="1 full training step (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
-                          "points (same generator as the GPU batch), %.1f s" % (cb, N, sec))
+                   sample="%d full training steps (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
+                          "points (same generator as the GPU batch), %.1f s of CPU work" % (nst, cb, N, sec * nst))
     line = dict(metric="training-step points/sec (BxN) at N=8192", value=round(value, 1), unit="points/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                 vs_baseline=None, dtype="f32", data="synthetic",

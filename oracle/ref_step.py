@@ -35,14 +35,20 @@ class CpuStepper:
         return float(total)
 
 
-def time_cpu_baseline(batch, steps=1, threads=None):
-    """Returns (points_per_second, seconds_per_step, threads)."""
+def time_cpu_baseline(batch, steps=1, threads=None, budget_s=None):
+    """Returns (points_per_second, seconds_per_step, threads, steps_run).  With budget_s the first step sizes the sample:
+    further steps run until about budget_s seconds of CPU work are spent (at most 12 steps)."""
     if threads:
         torch.set_num_threads(threads)
     pcs, normals, seg, bb = batch
     st = CpuStepper()
     t0 = time.perf_counter()
-    for _ in range(steps):
+    st.step(pcs, normals, seg, bb)
+    first = time.perf_counter() - t0
+    n = steps
+    if budget_s:
+        n = max(1, min(12, int(budget_s / max(first, 1e-3))))
+    for _ in range(n - 1):
         st.step(pcs, normals, seg, bb)
-    dt = (time.perf_counter() - t0) / steps
-    return pcs.shape[0] * pcs.shape[1] / dt, dt, torch.get_num_threads()
+    dt = (time.perf_counter() - t0) / n
+    return pcs.shape[0] * pcs.shape[1] / dt, dt, torch.get_num_threads(), n

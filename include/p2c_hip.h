@@ -122,6 +122,34 @@ int p2c_linear_stat_tiles(int M);    /* ceil(M / p2c_linear_tile_m()) */
 int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
                        int K, int in_mode, const float *in_scale, const float *in_shift, const uint8_t *drop_mask,
                        int ldmask, float drop_scale, double *stat_slots, void *stream);
+/* ---- Folded first layer.  A stack whose first 1x1-conv layer has <= 4 input channels (the grouped relative coordinates of
+ * SA1, rows [dx,dy,dz,0]: models/pointnet_util.py:136 with no point features) never writes that layer's output: its
+ * train-mode BatchNorm statistics follow from the moments of the input, and the consumers rebuild
+ * Y0 = X0 W0^T + b0 from the 16-byte input row while they stage their operand tiles (268 MB less written and three
+ * times less read at config 1).
+ * p2c_input_moments_f32: moments[0:4] += sum_m x, moments[4:14] += upper triangle of sum_m x x^T (fp64; zero it first).
+ * p2c_bn_finalize_affine_f32: stat = [scale|shift|mean|invstd] x C of that layer (and its running statistics, momentum
+ *   as in p2c_bn_finalize_f32) from the moments; W0 [C,4] row-major (4th column multiplies the zero pad), b0 [C] or NULL.
+ * p2c_linear_fwd_fold0_f32: Y = relu(scale0*(X0 W0^T + b0) + shift0) . W^T + bias for the NEXT layer (C0 == 64, N <= 256,
+ *   M >= 8192), stat_partials as in p2c_linear_fwd_f32. */
+int p2c_input_moments_f32(const float *X0, int ldx0, long long M, double *moments, void *stream);
+int p2c_bn_finalize_affine_f32(const double *moments, long long M, const float *W0, const float *b0, const float *gamma,
+                               const float *beta, float eps, float momentum, float *running_mean, float *running_var, int C,
+                               float *stat, void *stream);
+int p2c_linear_fwd_fold0_f32(const float *X0, int ldx0, const float *W0, const float *b0, const float *scale0, const float *shift0,
+                             int C0, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
+                             double *stat_partials, void *stream);
+
+/* Backward of the pair (folded layer, next layer): p2c_linear_bwd_fused_fold0_f32 is the fused backward of the NEXT layer
+ * (grad_mode 1 arguments of p2c_linear_bwd_fused_f32; Co in {64,128}, C0 == 64) with its X operand rebuilt from X0; it
+ * stores no dX and leaves 5 sums per column of the folded layer in partials5 [P2C_STAT_SLOTS][5][C0] (fp64, zeroed by the
+ * caller).  p2c_fold0_bwd_finalize_f32 turns them and the moments into dgamma0, dbeta0 and dW0 [C0,4]. */
+int p2c_linear_bwd_fused_fold0_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, const float *coef, const float *X0, int ldx0,
+                                   const float *W0, const float *b0, const float *stat0, const float *W, int ldw, float *dW, int lddw,
+                                   long long dw_slot_stride, double *partials5, int M, int Co, int C0, void *stream);
+int p2c_fold0_bwd_finalize_f32(const double *partials5, const double *moments, long long M, const float *W0, const float *b0,
+                               const float *stat0, const float *gamma0, int C0, float *dgamma0, float *dbeta0, float *dW0, void *stream);
+
 /* 1 if p2c_linear_fwd_f32 runs this shape on the persistent weight-stationary kernel (fwd_pp.hip: M >= 8192, N <= 256,
  * K <= 128 or the grouped K == 132, no byte mask); otherwise the tiled kernel is used.  Same results either way. */
 int p2c_linear_fwd_pp_supported(int M, int N, int K, int in_mode);

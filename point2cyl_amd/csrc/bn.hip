@@ -270,6 +270,140 @@ extern "C" int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const fl
     return P2C_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Folded first layer.  A stack whose first layer has <= 4 input channels (the grouped relative coordinates of SA1:
+// [dx, dy, dz, 0], 1 M rows at config 1) never materialises that layer's output Y0 = X0 W0^T + b0 (268 MB written once and
+// read three times): its train-mode BatchNorm statistics follow from the input moments,
+//     mean0 = W0 mu + b0,   var0[c] = w_c^T Cov(x) w_c,
+// and the layers that consume Y0 rebuild it from the 16-byte input row while they stage their operand tiles.
+// p2c_input_moments_f32: out[0:4] = sum_m x, out[4:14] = upper triangle of sum_m x x^T (00 01 02 03 11 12 13 22 23 33), fp64,
+// ACCUMULATED into out (zero it first).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) input_moments_kernel(const float *__restrict__ X, int ld, long long M, double *__restrict__ out)
+{
+    __shared__ double red[4][14];
+    double a[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) a[i] = 0.0;
+    for (long long m = (long long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long long)gridDim.x * 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(X + m * ld);
+        const double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+        a[0] += x0; a[1] += x1; a[2] += x2; a[3] += x3;
+        a[4] += x0 * x0; a[5] += x0 * x1; a[6] += x0 * x2; a[7] += x0 * x3;
+        a[8] += x1 * x1; a[9] += x1 * x2; a[10] += x1 * x3;
+        a[11] += x2 * x2; a[12] += x2 * x3; a[13] += x3 * x3;
+    }
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+        const double v = p2c_wave_sum_f64(a[i]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 14) atomicAdd(&out[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+extern "C" int p2c_input_moments_f32(const float *X, int ld, long long M, double *out, void *stream)
+{
+    if (!X || !out || M <= 0 || ld < 4 || (ld & 3) || ((uintptr_t)X & 15)) return P2C_EINVAL;
+    const int blocks = (int)min((long long)p2c_cdiv(M, 256 * 8), 1024LL);
+    hipLaunchKernelGGL(input_moments_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, X, ld, M, out);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// scale / shift / mean / invstd (and the running statistics) of the folded layer from the input moments; W0 is [C,4] row-major.
+__global__ void bn_finalize_affine_kernel(const double *__restrict__ mom, long long M, const float *__restrict__ W0, const float *__restrict__ b0,
+                                          const float *__restrict__ gamma, const float *__restrict__ beta, float eps, float momentum,
+                                          float *__restrict__ running_mean, float *__restrict__ running_var, int C, float *__restrict__ st)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double inv = 1.0 / (double)M;
+    double mu[4], cov[4][4];
+    for (int i = 0; i < 4; ++i) mu[i] = mom[i] * inv;
+    int t = 4;
+    for (int i = 0; i < 4; ++i)
+        for (int j = i; j < 4; ++j) {
+            const double v = mom[t++] * inv - mu[i] * mu[j];
+            cov[i][j] = v;
+            cov[j][i] = v;
+        }
+    double w[4];
+    for (int i = 0; i < 4; ++i) w[i] = (double)W0[c * 4 + i];
+    double m = b0 ? (double)b0[c] : 0.0, var = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        m += w[i] * mu[i];
+        for (int j = 0; j < 4; ++j) var += w[i] * w[j] * cov[i][j];
+    }
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+        running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+    }
+    const float sc = gamma[c] * invstd;
+    st[c] = sc;
+    st[C + c] = beta[c] - mean * sc;
+    st[2 * C + c] = mean;
+    st[3 * C + c] = invstd;
+}
+
+extern "C" int p2c_bn_finalize_affine_f32(const double *moments, long long M, const float *W0, const float *b0, const float *gamma,
+                                          const float *beta, float eps, float momentum, float *running_mean, float *running_var, int C,
+                                          float *stat, void *stream)
+{
+    if (!moments || !W0 || !gamma || !beta || !stat || M <= 0 || C <= 0) return P2C_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_affine_kernel, dim3(p2c_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, moments, M, W0, b0, gamma, beta, eps,
+                       momentum, running_mean, running_var, C, stat);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// Backward of the folded layer from the 5 column sums the consumer's fused backward left in partials5 [slots][5][C]:
+//   dgamma = s2, dbeta = s1, and with dY0 = gs*g + q*Y0 + p (gs, q, p as in bn_bwd_finalize):
+//   dW0[c, e] = sum_m dY0[m,c] x0[m,e] = gs*G[c,e] + q*(sum_e' W0[c,e'] S2[e',e] + b0[c] S1[e]) + p*S1[e]
+// (S1, S2 = the input moments).  The bias in front of a train-mode BatchNorm has an exactly zero gradient.
+__global__ void fold0_bwd_finalize_kernel(const double *__restrict__ part, const double *__restrict__ mom, long long M,
+                                          const float *__restrict__ W0, const float *__restrict__ b0, const float *__restrict__ stat,
+                                          const float *__restrict__ gamma, int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                          float *__restrict__ dW0)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double sv[5] = {0, 0, 0, 0, 0};
+    for (int t = 0; t < P2C_STAT_SLOTS; ++t)
+        for (int q = 0; q < 5; ++q) sv[q] += part[((size_t)t * 5 + q) * C + c];
+    const double s1 = sv[0], s2 = sv[1];
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+    const double mean = (double)stat[2 * C + c], is = (double)stat[3 * C + c], gs = (double)gamma[c] * is;
+    const double q = -gs * is * s2 / (double)M;
+    const double p = -gs * s1 / (double)M - q * mean;
+    double S2[4][4];
+    int t = 4;
+    for (int i = 0; i < 4; ++i)
+        for (int j = i; j < 4; ++j) { S2[i][j] = mom[t]; S2[j][i] = mom[t]; ++t; }
+    const double bb = b0 ? (double)b0[c] : 0.0;
+    for (int e = 0; e < 4; ++e) {
+        double yx = bb * mom[e];
+        for (int k = 0; k < 4; ++k) yx += (double)W0[c * 4 + k] * S2[k][e];
+        const double G = e < 3 ? sv[2 + e] : 0.0;
+        dW0[c * 4 + e] = (float)(gs * G + q * yx + p * mom[e]);
+    }
+}
+
+extern "C" int p2c_fold0_bwd_finalize_f32(const double *partials5, const double *moments, long long M, const float *W0, const float *b0,
+                                          const float *stat0, const float *gamma0, int C0, float *dgamma0, float *dbeta0, float *dW0,
+                                          void *stream)
+{
+    if (!partials5 || !moments || !W0 || !stat0 || !gamma0 || !dgamma0 || !dbeta0 || !dW0 || C0 <= 0 || M <= 0) return P2C_EINVAL;
+    hipLaunchKernelGGL(fold0_bwd_finalize_kernel, dim3(p2c_cdiv(C0, 64)), dim3(64), 0, (hipStream_t)stream, partials5, moments, M, W0, b0, stat0,
+                       gamma0, C0, dgamma0, dbeta0, dW0);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
 extern "C" size_t p2c_stat_slots_bytes(int C) { return (size_t)P2C_STAT_SLOTS * 2 * (size_t)C * sizeof(double); }
 
 // finalize from per-tile partials produced elsewhere (the fused backward-data epilogue): stat = [scale|shift|mean|invstd] x C

@@ -45,6 +45,7 @@ struct BwdFusedArgs {
     double *partials;                     // [P2C_STAT_SLOTS][2][Ci] fp64 accumulators (atomic)
     int M;
     long long dw_slot_stride;        // elements between the 8 per-XCD copies of dW (0: a single copy)
+    const float *w0, *b0;            // IMODE 2 (folded first layer below, bn.hip): x = its input [M,4], w0 [Ci,4], b0 [Ci] or NULL
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -78,7 +79,7 @@ __device__ __forceinline__ int fused_pos(int c, int m) { return c * (BM + 4) + (
 // GMODE 2 (the layer feeds the max-pool): the gradient and the winner index are per GROUP of ns rows, and a tile spans at
 // most two groups (host-checked: ns % 16 == 0, 2 ns >= BM), so a thread fetches its float4 column of those two group rows
 // once instead of once per row unit: UDZ = 2 register sets instead of UDY.
-template <int GMODE, int Co, int Ci, int BM, int UDY, int UDZ, int UX>
+template <int GMODE, int IMODE, int Co, int Ci, int BM, int UDY, int UDZ, int UX>
 __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, int t, float4 (&rdz)[UDZ], float4 (&ry)[UDY],
                                                 int4 (&rarg)[UDZ], v4f (&rx)[UX])
 {
@@ -106,16 +107,19 @@ __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, 
     for (int i = 0; i < UX; ++i) {
         int row, c4;
         fused_unit<Ci / 4>(tid + 256 * i, row, c4);
-        rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)min(m0 + row, a.M - 1) * a.ldx + c4 * 4);
+        rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)min(m0 + row, a.M - 1) * a.ldx + (IMODE == 2 ? 0 : c4 * 4));
     }
 }
 
 // dY = gs*(dZ*[scale*Y+shift>0]) + q*Y + p from the raw registers (cf[] = this thread's 4 channels of coef) -> dYs[co][m];
 // raw X -> Xt[ci][m] (act_in is applied when the dW operand is read: the dX epilogue needs the raw values).
-template <int GMODE, int Co, int Ci, int BM, int UDY, int UDZ, int UX>
+// IMODE 2: rx[] holds the 16-byte INPUT rows of a folded first layer; the pre-BN values y0 = W0 x + b0 of the thread's four
+// channels are rebuilt here (w0r/b0r = its rows of W0, b0) and the input row itself is parked in x0s[row][4] for the
+// weight-gradient sums of that layer (see the epilogue).
+template <int GMODE, int IMODE, int Co, int Ci, int BM, int UDY, int UDZ, int UX>
 __device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid, int t, float *dy, float *xt, const float4 (&rdz)[UDZ],
                                                  const float4 (&ry)[UDY], const int4 (&rarg)[UDZ], const v4f (&rx)[UX],
-                                                 const float4 (&cf)[5])
+                                                 const float4 (&cf)[5], const v4f (&w0r)[4], const v4f &b0r, float *x0s)
 {
     const int m0 = t * BM;
     constexpr int RS = 1024 / Co;                  // rows a unit index spans: unit i holds rows [RS*i, RS*i + RS) of the tile
@@ -156,10 +160,19 @@ __device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid,
         int row, c4;
         fused_unit<Ci / 4>(tid + 256 * i, row, c4);
         float *d = xt + fused_pos<BM>(c4 * 4, row);
-        d[0] = rx[i].x;
-        d[BM + 4] = rx[i].y;
-        d[2 * (BM + 4)] = rx[i].z;
-        d[3 * (BM + 4)] = rx[i].w;
+        v4f v = rx[i];
+        if (IMODE == 2) {
+            const v4f x = rx[i];
+            v.x = p2c_l0_preact(w0r[0].x, w0r[0].y, w0r[0].z, b0r.x, x.x, x.y, x.z);
+            v.y = p2c_l0_preact(w0r[1].x, w0r[1].y, w0r[1].z, b0r.y, x.x, x.y, x.z);
+            v.z = p2c_l0_preact(w0r[2].x, w0r[2].y, w0r[2].z, b0r.z, x.x, x.y, x.z);
+            v.w = p2c_l0_preact(w0r[3].x, w0r[3].y, w0r[3].z, b0r.w, x.x, x.y, x.z);
+            if (c4 == 0) *reinterpret_cast<v4f *>(&x0s[row * 4]) = (m0 + row < a.M) ? x : v4f{0.f, 0.f, 0.f, 0.f};
+        }
+        d[0] = v.x;
+        d[BM + 4] = v.y;
+        d[2 * (BM + 4)] = v.z;
+        d[3 * (BM + 4)] = v.w;
     }
 }
 
@@ -187,7 +200,8 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     float *dYs = Wt + Ci * LDT;                    // [2 halves][Co][LDM]
     float *Xt = dYs + 2 * Co * LDM;                // [2 halves][Ci][LDM]
     float *red = Xt + 2 * Ci * LDM;                // [2][Ci]
-    float *Xe = red + 2 * Ci;                      // [2 halves][BM][4] extra input columns (EX > 0)
+    float *Xe = red + 6 * Ci;                      // [2 halves][BM][4] extra input columns (EX > 0); IMODE 2: [2 halves][2 parities][BM][4] input rows
+    static_assert(!(EX > 0 && IMODE == 2), "");
 
     const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -219,8 +233,8 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 #pragma unroll
     for (int t = 0; t < CIT; ++t) {
         const int ci = wj * (CIT * 32) + t * 32 + l31;
-        isc[t] = IMODE == 1 ? a.in_scale[ci] : 1.f;
-        ish[t] = IMODE == 1 ? a.in_shift[ci] : 0.f;
+        isc[t] = IMODE >= 1 ? a.in_scale[ci] : 1.f;
+        ish[t] = IMODE >= 1 ? a.in_shift[ci] : 0.f;
     }
     const int xcol = wc * 32 + l31;
     float psc = 0.f, psh = 0.f, pmu = 0.f, pis = 0.f;
@@ -236,6 +250,17 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
             cf[i] = GMODE >= 1 ? *reinterpret_cast<const float4 *>(a.coef + i * Co + c40 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     load_cf();
+    v4f w0r[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    v4f b0r = {0.f, 0.f, 0.f, 0.f};
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;            // IMODE 2: sum_m g[m, xcol] * x0[m, 0..2] (weight gradient of the folded layer)
+    if (IMODE == 2) {
+        int rowx_, c4x;
+        fused_unit<Ci / 4>(tid, rowx_, c4x);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w0r[e] = *reinterpret_cast<const v4f *>(a.w0 + (size_t)(4 * c4x + e) * 4);
+        if (a.b0) b0r = *reinterpret_cast<const v4f *>(a.b0 + 4 * c4x);
+    }
+    float *x0h = Xe + half * 2 * BM * 4;
     // per-lane LDS offsets (floats) of the operand reads; they are the same for every tile
     int adw[COT][NG], bdw[CIT][NG];                // dW: group q of block i / j  (16-byte reads over m)
 #pragma unroll
@@ -274,13 +299,13 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     // prologue: this half's first tile -> its LDS buffer; its second tile -> registers (in flight)
     {
         const int k0 = half, k1 = half + 2;
-        fused_load_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
-        fused_store_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xt, rdz, ry, rarg, rx, cf);
+        fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
+        fused_store_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xt, rdz, ry, rarg, rx, cf, w0r, b0r, x0h);
         if (EX > 0 && tid < BM) {
             const int m = min(tile_of(k0 < nk ? k0 : 0) * BM + tid, a.M - 1);
             *reinterpret_cast<v4f *>(&xe[tid * 4]) = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
         }
-        fused_load_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k1 < nk ? k1 : 0), rdz, ry, rarg, rx);
+        fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k1 < nk ? k1 : 0), rdz, ry, rarg, rx);
         if (EX > 0 && tid < BM) {
             const int m = min(tile_of(k1 < nk ? k1 : 0) * BM + tid, a.M - 1);
             rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
@@ -311,7 +336,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                     for (int j = 0; j < CIT; ++j) bn[j] = *reinterpret_cast<const v4f *>(xt + bdw[j][q + 1]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                if (IMODE == 1) {
+                if (IMODE >= 1) {
 #pragma unroll
                     for (int j = 0; j < CIT; ++j) {
                         bv[j].x = fmaxf(isc[j] * bv[j].x + ish[j], 0.f);
@@ -393,7 +418,10 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         __builtin_amdgcn_s_setprio(1);
 #ifndef P2C_TRACE_NODATA
         if (valid && NEED_DX) {
-            if (m0 + BM <= a.M) {
+            if (IMODE == 2) {
+                // the layer below is folded: nobody reads dX; what its backward needs from it are the BatchNorm sums (below) and
+                // G[c, :] = sum_m g[m, c] x0[m, :], from which its weight gradient is assembled (p2c_fold0_bwd_finalize_f32)
+            } else if (m0 + BM <= a.M) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     a.dx[(size_t)(m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * a.lddx + xcol] = accX[r];
@@ -405,22 +433,29 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                 }
             }
             if (HAS_STATS) {
+                const float *x0t = x0h + (it & 1) * BM * 4;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = accX[r];
                     const float g = (psc * yp[r] + psh > 0.f) ? v : 0.f;          // mask: the forward's two roundings
                     s1 += g;
                     s2 = __builtin_fmaf(g, __builtin_fmaf(yp[r], pis, npm), s2);    // g * (y - mean) * invstd
+                    if (IMODE == 2) {
+                        const v4f x = *reinterpret_cast<const v4f *>(&x0t[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4]);   // zero past M
+                        g0 = __builtin_fmaf(g, x.x, g0);
+                        g1 = __builtin_fmaf(g, x.y, g1);
+                        g2 = __builtin_fmaf(g, x.z, g2);
+                    }
                 }
             }
         }
         P2C_TR(4);
         {
             const int k2 = k + 2, k4 = k + 4;
-            if (k2 < nk) fused_store_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k2), dy, xt, rdz, ry, rarg, rx, cf);
+            if (k2 < nk) fused_store_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k2), dy, xt, rdz, ry, rarg, rx, cf, w0r, b0r, x0h + ((it + 1) & 1) * BM * 4);
             P2C_TR(5);
             if (EX > 0 && tid < BM) *reinterpret_cast<v4f *>(&xe[tid * 4]) = rxe;
-            fused_load_tile<GMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
+            fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
             if (EX > 0 && tid < BM) {
                 const int m = min(tile_of(k4 < nk ? k4 : 0) * BM + tid, a.M - 1);
                 rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
@@ -472,19 +507,19 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     }
     if (GMODE == 0 && a.dbias && tid < Co) atomicAdd(&a.dbias[tid], dbacc);
     if (NEED_DX && HAS_STATS) {
-        if (threadIdx.x < 2 * Ci) red[threadIdx.x] = 0.f;
+        constexpr int NS_ = IMODE == 2 ? 5 : 2;         // sums per column: s1, s2 (+ G[.,0..2] for a folded layer below)
+        for (int u = threadIdx.x; u < NS_ * Ci; u += 512) red[u] = 0.f;
         __syncthreads();
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (lh == 0) {
-            atomicAdd(&red[xcol], s1);
-            atomicAdd(&red[Ci + xcol], s2);
+        float sv[5] = {s1, s2, g0, g1, g2};
+#pragma unroll
+        for (int q = 0; q < NS_; ++q) {
+            const float t = sv[q] + __shfl_xor(sv[q], 32);
+            if (lh == 0) atomicAdd(&red[q * Ci + xcol], t);
         }
         __syncthreads();
-        if (threadIdx.x < Ci) {
-            double *o = a.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * Ci;
-            atomicAdd(&o[threadIdx.x], (double)red[threadIdx.x]);
-            atomicAdd(&o[Ci + threadIdx.x], (double)red[Ci + threadIdx.x]);
+        for (int u = threadIdx.x; u < NS_ * Ci; u += 512) {
+            double *o = a.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * NS_ * Ci;
+            atomicAdd(&o[u], (double)red[u]);
         }
     }
 }
@@ -508,7 +543,7 @@ static int launch_fused(const BwdFusedArgs &a, int extra, hipStream_t s)
 {
     constexpr int Co = 64 * COT, Ci = 64 * CIT;
     constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
-    const size_t lds = (size_t)(Ci * (Co + 4) + 2 * Co * (BM + 4) + 2 * Ci * (BM + 4) + 2 * Ci + 2 * BM * 4) * sizeof(float);
+    const size_t lds = (size_t)(Ci * (Co + 4) + 2 * Co * (BM + 4) + 2 * Ci * (BM + 4) + 6 * Ci + 4 * BM * 4) * sizeof(float);
     const int grid = fused_grid(a.M, Ci);
     if (extra) {      // grouped first layer: [feats(128) | xyz(3) | pad] -> 4 extra dW columns (only this shape needs it)
         if constexpr (COT == 2 && CIT == 2 && GMODE == 1 && IMODE == 0) {
@@ -563,7 +598,7 @@ extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *
     if ((lddz & 3) || (ldx & 3) || (ldw & 3) || (grad_mode >= 1 && (ldy & 3)) || ((uintptr_t)dZ & 15) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return P2C_EALIGN;
     BwdFusedArgs a{dZ, lddz, Yfwd, ldy, coef, pool_arg, pool_ns, X, ldx, in_scale, in_shift, W, ldw, dX, lddx, dW, lddw, dbias, prev_stat,
-                   bwd_partials, M, dw_slot_stride};
+                   bwd_partials, M, dw_slot_stride, nullptr, nullptr};
     hipStream_t s = (hipStream_t)stream;
 #define P2C_F(G_, I_) return dispatch_shape<G_, I_>(Co, Ci, extra, a, s)
     if (grad_mode == 0) { if (in_mode == 0) P2C_F(0, 0); P2C_F(0, 1); }
@@ -571,4 +606,34 @@ extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *
     if (in_mode == 0) P2C_F(2, 0);
     P2C_F(2, 1);
 #undef P2C_F
+}
+
+// Backward of the layer that FOLLOWS a folded first layer (bn.hip): same kernel, IMODE 2.  The X operand (that layer's
+// pre-BN output) is rebuilt from its 16-byte input rows, dX is not stored, and per column c of the folded layer the kernel
+// accumulates 5 sums into partials5 [P2C_STAT_SLOTS][5][C0] (zeroed by the caller): s1 = sum g, s2 = sum g*xhat (its
+// BatchNorm backward) and G[c, 0..2] = sum_m g[m,c] x0[m, 0..2] (its weight gradient, finished by p2c_fold0_bwd_finalize_f32).
+extern "C" int p2c_linear_bwd_fused_fold0_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, const float *coef, const float *X0, int ldx0,
+                                              const float *W0, const float *b0, const float *stat0, const float *W, int ldw, float *dW, int lddw,
+                                              long long dw_slot_stride, double *partials5, int M, int Co, int C0, void *stream)
+{
+    if (!dZ || !Yfwd || !coef || !X0 || !W0 || !stat0 || !W || !dW || !partials5 || M <= 0 || C0 != 64 || (Co != 64 && Co != 128) || ldx0 != 4)
+        return P2C_EINVAL;
+    if ((lddz & 3) || (ldy & 3) || (ldw & 3) || ((uintptr_t)dZ & 15) || ((uintptr_t)X0 & 15) || ((uintptr_t)W & 15) || ((uintptr_t)W0 & 15))
+        return P2C_EALIGN;
+    BwdFusedArgs a{dZ, lddz, Yfwd, ldy, coef, nullptr, 0, X0, ldx0, stat0, stat0 + C0, W, ldw, nullptr, 0, dW, lddw, nullptr, stat0,
+                   partials5, M, dw_slot_stride, W0, b0};
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int Ci = 64, BM = 64;
+    const int grid = fused_grid(M, Ci);
+#define P2C_F0(COT_)                                                                                                                 \
+    do {                                                                                                                             \
+        const size_t lds = (size_t)(Ci * (64 * COT_ + 4) + 2 * 64 * COT_ * (BM + 4) + 2 * Ci * (BM + 4) + 6 * Ci + 4 * BM * 4) * sizeof(float); \
+        (void)hipFuncSetAttribute((const void *)bwd_fused_pp_kernel<COT_, 1, 1, 2, true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                                         \
+        hipLaunchKernelGGL((bwd_fused_pp_kernel<COT_, 1, 1, 2, true, true, 0>), dim3(grid), dim3(512), lds, s, a);                       \
+    } while (0)
+    if (Co == 128) P2C_F0(2); else P2C_F0(1);
+#undef P2C_F0
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
 }

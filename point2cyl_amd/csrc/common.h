@@ -55,6 +55,13 @@ __device__ __forceinline__ double p2c_wave_sum_f64(double v)
     return v;
 }
 
+// Pre-activation of a folded first layer (3 input channels + zero pad, see bn.hip p2c_input_moments_f32): the SAME
+// expression wherever it is recomputed (forward staging, backward staging), so the ReLU decisions agree everywhere.
+__device__ __forceinline__ float p2c_l0_preact(float wx, float wy, float wz, float b, float x, float y, float z)
+{
+    return __builtin_fmaf(wz, z, __builtin_fmaf(wy, y, wx * x)) + b;
+}
+
 // Counter-based dropout bits: keep(row, col) = hash(seed, row*C + col) >= threshold.  Stateless, so the forward
 // and the two backward kernels regenerate the same mask from (seed, element index) instead of storing M x C bytes.
 __device__ __forceinline__ uint32_t p2c_hash32(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx)

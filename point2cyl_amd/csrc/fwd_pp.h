@@ -13,6 +13,7 @@ struct FwdPPArgs {
     const uint32_t *seed; uint32_t thr; float dscale;   // MODE == 3 (hashed dropout, same stream as gemm.hip OpActIn<3>)
     int Kfull;                            // width used in the dropout element index (row * Kfull + col)
     double *partials;                     // [P2C_STAT_SLOTS][2][N] or NULL
+    const float *w0, *b0;                 // MODE == 4: x is the folded first layer's INPUT [M,4]; w0 [K,4], b0 [K]; in_scale/in_shift = its BN
 };
 
 

@@ -80,11 +80,20 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
     }
     uint32_t slo = 0, shi = 0;
     if (MODE == 3) { slo = a.seed[0]; shi = a.seed[1]; }
+    // MODE 4: the A operand is act(bn(W0 x + b0)) of a folded first layer, rebuilt from its 16-byte input row
+    v4f w0r[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    v4f b0r = {0.f, 0.f, 0.f, 0.f};
+    if (MODE == 4 && kok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w0r[e] = *reinterpret_cast<const v4f *>(a.w0 + (size_t)(4 * kq + e) * 4);
+        if (a.b0) b0r = *reinterpret_cast<const v4f *>(a.b0 + 4 * kq);
+    }
+    const int xcoloff = MODE == 4 ? 0 : (kok ? 4 * kq : 0);
 
     v4f rx[UPW];
     v4f rxe = {0.f, 0.f, 0.f, 0.f};
     // row pointer of the lane's first unit in tile 0; unit i is (64 / QW) rows further down
-    const float *xlane = a.x + (size_t)(16 * wave + lane / QW) * a.ldx + (kok ? 4 * kq : 0);
+    const float *xlane = a.x + (size_t)(16 * wave + lane / QW) * a.ldx + xcoloff;
     const size_t xstep = (size_t)(64 / QW) * a.ldx;
     auto gload = [&](int t) {                                // raw rows of tile t (clamped; masked when staged)
         const int m0 = t * BM + 16 * wave;
@@ -97,7 +106,7 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
             for (int i = 0; i < UPW; ++i) {
                 const int rl = (lane + 64 * i) / QW;
                 const int m = min(m0 + rl, a.M - 1);
-                rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + (kok ? 4 * kq : 0));
+                rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + xcoloff);
             }
         }
         if (EX && lane < 16) rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)min(m0 + lane, a.M - 1) * a.ldx + a.K);
@@ -110,6 +119,13 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
             const int rl = (lane + 64 * i) / QW;
             const int m = m0 + rl;
             v4f v = rx[i];
+            if (MODE == 4) {
+                const v4f x = rx[i];
+                v.x = p2c_l0_preact(w0r[0].x, w0r[0].y, w0r[0].z, b0r.x, x.x, x.y, x.z);
+                v.y = p2c_l0_preact(w0r[1].x, w0r[1].y, w0r[1].z, b0r.y, x.x, x.y, x.z);
+                v.z = p2c_l0_preact(w0r[2].x, w0r[2].y, w0r[2].z, b0r.z, x.x, x.y, x.z);
+                v.w = p2c_l0_preact(w0r[3].x, w0r[3].y, w0r[3].z, b0r.w, x.x, x.y, x.z);
+            }
             if (MODE >= 1) {         // mul + add, NOT an fma: the backward kernels rebuild act_in(x) and its ReLU mask with the same
                                      // two roundings; with an fma here the deep BatchNorm gradients drift 8x further from float64
                 v.x = fmaxf(isc.x * v.x + ish.x, 0.f);
@@ -332,6 +348,11 @@ int p2c_fwd_pp_launch(const FwdPPArgs &a, int in_mode, hipStream_t s)
     } while (0)
     if (in_mode == 0) { if (nt == 1) P2C_PPK(1, 0); P2C_PPK(2, 0); }
     if (in_mode == 1) { if (nt == 1) P2C_PPK(1, 1); P2C_PPK(2, 1); }
+    if (in_mode == 4) {                  // folded first layer of 64 channels
+        if (K != 64) return P2C_EINVAL;
+        if (nt == 1) P2C_PP(64, 1, 4, 0);
+        P2C_PP(64, 2, 4, 0);
+    }
     if (in_mode == 3) {
         if (nt == 1) { if (K <= 64) P2C_PP(64, 1, 3, 0); P2C_PP(128, 1, 3, 0); }
         if (K <= 64) P2C_PP(64, 2, 3, 0);

@@ -439,7 +439,7 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     static const bool use_pp = !(getenv("P2C_FWD_PP") && atoi(getenv("P2C_FWD_PP")) == 0);      // A/B switch for profiling
     if (use_pp && p2c_linear_fwd_pp_supported(M, N, K, in_mode)) {
         FwdPPArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K == 132 ? 128 : K, in_scale, in_shift, (const uint32_t *)drop_mask,
-                    (uint32_t)ldmask, drop_scale, K, stat_partials};
+                    (uint32_t)ldmask, drop_scale, K, stat_partials, nullptr, nullptr};
         return p2c_fwd_pp_launch(a, in_mode, s);
     }
     switch (in_mode) {
@@ -448,6 +448,19 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     case 2: return launch_fwd<2>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
     default: return launch_fwd<3>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
     }
+}
+
+// ---- forward of the layer that FOLLOWS a folded first layer (see bn.hip): A = relu(bn0(X0 W0^T + b0)) rebuilt from X0 [M,4]
+extern "C" int p2c_linear_fwd_fold0_f32(const float *X0, int ldx0, const float *W0, const float *b0, const float *scale0, const float *shift0,
+                                        int C0, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
+                                        double *stat_partials, void *stream)
+{
+    if (!X0 || !W0 || !scale0 || !shift0 || !W || !Y || M < 8192 || N <= 0 || N > 256 || (N & 3) || C0 != 64 || ldx0 != 4) return P2C_EINVAL;
+    P2C_REQ_ALIGNED(X0, ldx0);
+    P2C_REQ_ALIGNED(W, ldw);
+    P2C_REQ_ALIGNED(W0, 0);
+    FwdPPArgs a{X0, ldx0, W, ldw, bias, Y, ldy, M, N, C0, scale0, shift0, nullptr, 0u, 1.f, C0, stat_partials, W0, b0};
+    return p2c_fwd_pp_launch(a, 4, (hipStream_t)stream);
 }
 
 // ---- backward data ----------------------------------------------------------------------------------

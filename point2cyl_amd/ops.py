@@ -14,6 +14,7 @@ from ._lib import PROFILE, call, ptr, stream  # noqa: F401
 I32 = torch.int32
 PENDING_NBT = []      # num_batches_tracked counters to bump with ONE foreach add per forward (see backbone.forward)
 USE_FUSED_BWD = os.environ.get("P2C_FUSED_BWD", "1") != "0"
+USE_FOLD0 = os.environ.get("P2C_FOLD0", "1") != "0"         # first layer with <= 4 input channels never materialised (bn.hip)
 USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated backward of the gathers (no atomics)
 
 
@@ -280,12 +281,19 @@ class _MLPStack(torch.autograd.Function):
         seed = cfg.get("drop_seed")       # device int64 scalar: counter-hash dropout (no mask tensor)
         dscale = cfg.get("drop_scale", 1.0)
         Ys, aff, Ws = [], [], []
+        fold_b0 = None
         X, ldx, in_mode, sc, sh = X0, ldx0, 0, None, None
         pi = 0
         arena = None
         if training:
             widths = [_pad4(params[j].shape[0]) for j in _weight_slots(L, tail)]
-            arena = _ZeroArena(sum(STAT_SLOTS * 2 * c for c in widths), dev)
+            arena = _ZeroArena(sum(STAT_SLOTS * 2 * c for c in widths) + 16, dev)
+        # Folded first layer (csrc/bn.hip): 3 input channels (+pad), 64 outputs, train mode, no gradient wanted for the input,
+        # a BatchNorm'ed middle layer of 64/128 channels next: Y_0 is never written; layer 1 rebuilds it from the input rows.
+        fold0 = (USE_FOLD0 and training and K == 4 and ldx0 == 4 and M >= 8192 and not X0.requires_grad and mask is None and seed is None
+                 and (L >= 3 or (L == 2 and tail == "bnrelu")) and params[0].shape[0] == 64 and params[4].shape[0] in (64, 128)
+                 and bns[0] is not None and bns[1] is not None)
+        mom = None
         for i in range(L):
             has_bn = not (tail == "linear" and i == L - 1)
             W, b = params[pi], params[pi + 1]
@@ -299,7 +307,44 @@ class _MLPStack(torch.autograd.Function):
                 W2 = torch.nn.functional.pad(W2, (0, K - W2.shape[1], 0, Co - Co_true))
                 b = torch.nn.functional.pad(b, (0, Co - Co_true))
             W2 = W2.contiguous()
+            if fold0 and i == 0:
+                gamma, beta = params[pi], params[pi + 1]
+                pi += 2
+                bn = bns[0]
+                mom = arena.f64(16)
+                call("p2c_input_moments_f32", ptr(X0), ldx0, M, ptr(mom), stream())
+                st = torch.empty(4, Co, dtype=torch.float32, device=dev)
+                call("p2c_bn_finalize_affine_f32", ptr(mom), M, ptr(W2), ptr(b), ptr(gamma), ptr(beta), float(bn.eps), float(bn.momentum),
+                     ptr(bn.running_mean), ptr(bn.running_var), Co, ptr(st), stream())
+                if bn.nbt is not None:
+                    PENDING_NBT.append(bn.nbt)
+                Ys.append(None)
+                Ws.append(W2)
+                aff.append(st)
+                fold_b0 = b
+                sc, sh, in_mode = st[0], st[1], 1
+                K = Co
+                continue
             Y = torch.empty(M, Co, dtype=torch.float32, device=dev)
+            if fold0 and i == 1:
+                partials = arena.f64(STAT_SLOTS, 2, Co)
+                call("p2c_linear_fwd_fold0_f32", ptr(X0), ldx0, ptr(Ws[0]), ptr(fold_b0), ptr(sc), ptr(sh), K, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co,
+                     ptr(partials), stream(), flops=2.0 * M * Co * K)
+                Ys.append(Y)
+                Ws.append(W2)
+                gamma, beta = params[pi], params[pi + 1]
+                pi += 2
+                bn = bns[1]
+                st = torch.empty(4, Co, dtype=torch.float32, device=dev)
+                call("p2c_bn_finalize_f32", ptr(partials), Co, M, ptr(b), ptr(gamma),
+                     ptr(beta), float(bn.eps), float(bn.momentum), 1, ptr(bn.running_mean), ptr(bn.running_var),
+                     ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
+                if bn.nbt is not None:
+                    PENDING_NBT.append(bn.nbt)
+                aff.append(st)
+                sc, sh, in_mode = st[0], st[1], 1
+                X, ldx, K = Y, Co, Co
+                continue
             mode, mptr, mld = in_mode, None, 0
             if (not has_bn) and in_mode == 1:
                 if mask is not None:
@@ -342,6 +387,7 @@ class _MLPStack(torch.autograd.Function):
             out = Ys[-1]
         ctx.cfg = cfg
         ctx.saved = (X0, Ys, aff, Ws, arg, params)
+        ctx.fold = (mom, fold_b0) if fold0 else None
         return out
 
     @staticmethod
@@ -360,7 +406,7 @@ class _MLPStack(torch.autograd.Function):
         grads = [None] * len(params)
         n64 = 0
         for W2 in Ws:       # per layer: 8 dW copies + dW + dbias (fp32) and two sets of fp64 stat slots (own top-of-stack + layer below)
-            n64 += (9 * W2.shape[0] * W2.shape[1] + W2.shape[0]) // 2 + 8 + STAT_SLOTS * 2 * (W2.shape[0] + W2.shape[1])
+            n64 += (9 * W2.shape[0] * W2.shape[1] + W2.shape[0]) // 2 + 8 + STAT_SLOTS * 5 * (W2.shape[0] + W2.shape[1])
         arena = _ZeroArena(n64, dev)
         slots, pi = [], 0
         for i in range(L):
@@ -399,10 +445,36 @@ class _MLPStack(torch.autograd.Function):
             dZ, grad_mode, coef = dout, 0, None
             if dZ.shape[1] != Cl:
                 dZ = torch.nn.functional.pad(dZ, (0, Cl - dZ.shape[1]))
+        fold = ctx.fold
         for i in range(L - 1, -1, -1):
             p0, has_bn = slots[i]
             Y, W2 = Ys[i], Ws[i]
             Co, Ci = W2.shape
+            if fold is not None and i == 0:
+                break                         # handled together with layer 1 below
+            if fold is not None and i == 1:
+                # fused backward of layer 1 with its X operand rebuilt from the stack input; no dX, 5 sums per column for layer 0
+                mom, b0 = fold
+                q0, _ = slots[0]
+                W0p, st0, C0 = Ws[0], aff[0], Ws[0].shape[0]
+                dW8 = arena.f32(8, Co, Ci)
+                part5 = arena.f64(STAT_SLOTS, 5, C0)
+                call("p2c_linear_bwd_fused_fold0_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(coef), ptr(X0), X0.stride(0), ptr(W0p), ptr(b0),
+                     ptr(st0), ptr(W2), Ci, ptr(dW8), Ci, Co * Ci, ptr(part5), M, Co, C0, stream(), flops=4.0 * M * Co * Ci,
+                     nbytes=4.0 * M * (2 * Co + 4))
+                Wp = params[p0]
+                grads[p0] = dW8.sum(0)[:Wp.shape[0], :Wp.numel() // Wp.shape[0]].reshape(Wp.shape)
+                grads[p0 + 1] = arena.f32(Co)[:Wp.shape[0]]
+                dW0 = torch.empty(C0, 4, dtype=torch.float32, device=dev)
+                dgamma0 = torch.empty(C0, dtype=torch.float32, device=dev)
+                dbeta0 = torch.empty(C0, dtype=torch.float32, device=dev)
+                call("p2c_fold0_bwd_finalize_f32", ptr(part5), ptr(mom), M, ptr(W0p), ptr(b0), ptr(st0), ptr(params[q0 + 2]), C0, ptr(dgamma0),
+                     ptr(dbeta0), ptr(dW0), stream())
+                W0param = params[q0]
+                grads[q0] = dW0[:, :W0param.numel() // W0param.shape[0]].reshape(W0param.shape)
+                grads[q0 + 1] = arena.f32(C0)
+                grads[q0 + 2], grads[q0 + 3] = dgamma0, dbeta0
+                continue
             if i == 0:
                 Xin, ldxin, in_mode, sc, sh = X0, X0.stride(0), 0, None, None
             else:

@@ -160,6 +160,21 @@ def _ref_stack(X0, params, tail, G, ns, training, mask, momentum=0.1):
     ("bnrelu", 8200, 64, (128, 64), None, None),
 ])
 def test_mlp_stack_forward_backward(tail, M, K0, widths, G, ns):
+    _check_mlp_stack(tail, M, K0, widths, G, ns, True)
+
+
+@pytest.mark.parametrize("tail,M,K0,widths,G,ns", [
+    ("maxpool", 300 * 32, 3, (64, 64, 128), 300, 32),
+    ("maxpool", 130 * 64 + 0, 3, (64, 128, 128), 130, 64),
+    ("bnrelu", 8200 + 13, 3, (64, 64), None, None),
+])
+def test_mlp_stack_folded_first_layer(tail, M, K0, widths, G, ns):
+    """No gradient wanted for the 3-channel input: the first layer's output is never materialised (csrc/bn.hip); forward
+    values, running statistics and every parameter gradient must still match the plain reference."""
+    _check_mlp_stack(tail, M, K0, widths, G, ns, False)
+
+
+def _check_mlp_stack(tail, M, K0, widths, G, ns, xgrad):
     g = torch.Generator().manual_seed(M + K0)
     ld = (K0 + 3) // 4 * 4
     X0 = torch.zeros(M, ld)
@@ -197,7 +212,7 @@ def test_mlp_stack_forward_backward(tail, M, K0, widths, G, ns):
         else:
             ly.update(gamma=None, beta=None, bn=None)
         layers.append(ly)
-    X0d = X0.to(DEV).requires_grad_(True)
+    X0d = X0.to(DEV).requires_grad_(xgrad)
     y = ops.mlp_stack(X0d, K0, layers, tail, True, G=G, ns=ns, drop_mask=None if mask is None else mask.to(DEV).to(torch.uint8),
                       drop_scale=2.0)
     scale = max(1.0, float(yref.abs().max()))
@@ -219,7 +234,9 @@ def test_mlp_stack_forward_backward(tail, M, K0, widths, G, ns):
             assert np.linalg.norm(got - ref) <= 3e-3 * np.linalg.norm(ref), (i, np.linalg.norm(got - ref) / np.linalg.norm(ref))
             continue
         np.testing.assert_allclose(got, ref, rtol=2e-3, atol=tol)
-    if M >= 8192 and tail == "maxpool":
+    if not xgrad:
+        assert X0d.grad is None
+    elif M >= 8192 and tail == "maxpool":
         gx, rx = X0d.grad[:, :K0].cpu().numpy(), X0r.grad.numpy()
         assert np.linalg.norm(gx - rx) <= 3e-3 * np.linalg.norm(rx)
     else:

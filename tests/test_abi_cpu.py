@@ -37,6 +37,23 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_fps_f32(None, 1, 16, None, 4, None, None, None) == -1
     assert L.p2c_ball_query_f32(None, None, 1, 1, 1, 0.04, 64, None, None) == -1
     assert L.p2c_hungarian_f32(None, None, 1, 1, 8, None, None, None) == -1
+    assert L.p2c_build_csr_i32(None, None, 1, 8, 1, 4, None, None, None, None) == -1
+    assert L.p2c_input_moments_f32(None, 4, 10, None, None) == -1
+    assert L.p2c_linear_fwd_fold0_f32(None, 4, None, None, None, None, 64, None, 64, None, None, 64, 9000, 64, None, None) == -1
+    assert L.p2c_fold0_bwd_finalize_f32(None, None, 10, None, None, None, None, 64, None, None, None, None) == -1
+
+
+def test_shape_queries_describe_the_kernel_coverage():
+    L = _lib.lib()
+    # persistent forward: long narrow layers only; the grouped 128+4 layer included, byte masks and deep layers excluded
+    assert L.p2c_linear_fwd_pp_supported(262144, 128, 128, 1) == 1
+    assert L.p2c_linear_fwd_pp_supported(262144, 128, 132, 0) == 1
+    assert L.p2c_linear_fwd_pp_supported(262144, 128, 128, 2) == 0
+    assert L.p2c_linear_fwd_pp_supported(4096, 1024, 512, 1) == 0
+    # fused backward: Co, Ci in {64,128}; 2 = the grouped layer (no dX for the 4 trailing columns)
+    assert L.p2c_linear_bwd_fused_supported(128, 128, 1) == 1
+    assert L.p2c_linear_bwd_fused_supported(128, 132, 0) == 2
+    assert L.p2c_linear_bwd_fused_supported(256, 128, 1) == 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -94,6 +94,18 @@ int p2c_build_csr_i32(const int32_t *idx, const float *w, int B, int E, int ediv
 int p2c_csr_gather_f32(const float *src, int ld_src, int coff, const int32_t *offsets, const int32_t *rows, const float *wsorted,
                        int B, int E, int rows_b, int T, int C, float *out, int ldo, void *stream);
 
+/* "Linear before the gather": a 1x1-conv applied to gathered rows commutes with the gather, so the first layer of FP1 (and
+ * of SA2, round 2) runs on the sparse set and the dense pre-BN tensor is produced by the gather itself.
+ * p2c_three_interp_bias_stats_f32: out = interp(feats) + bias, BatchNorm sums of the bias-free value into stat_slots
+ *   (p2c_stat_slots_bytes(C), zeroed by the caller; NULL = no sums).  C <= 256.
+ * p2c_csr_gather_bn_f32: p2c_csr_gather_f32 of dY = gs*(dZ*[scale*Y+shift>0]) + q*Y + p (coef [5][C] as produced by the
+ *   *_bwd_stats / bwd_finalize entry points), rebuilt per element from the stored dZ and Y. */
+int p2c_three_interp_bias_stats_f32(const float *feats, int ldf, const int32_t *idx, const float *weight, int B, int N, int S, int C,
+                                    const float *bias, float *out, int ldo, double *stat_slots, void *stream);
+int p2c_csr_gather_bn_f32(const float *dz, int lddz, const float *y, int ldy, const float *coef, const int32_t *offsets,
+                          const int32_t *rows, const float *wsorted, int B, int E, int rows_b, int T, int C, float *out, int ldo,
+                          void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Shared per-point MLP: 1x1 conv (+ train-mode BatchNorm + ReLU) as fp32 MFMA GEMMs
  * (models/pointnet_util.py:201-205, :317-319; models/pointnet_extrusion.py:58-65)

@@ -124,8 +124,22 @@ class PointNetFeaturePropagation(nn.Module):
                    keep_padding=False, nn_=None):
         """xyz1 (B,N,3) dense, xyz2 (B,S,3) sparse, feats1 (B,N,D1)|None, feats2 (B,S,D2) -> (B,N,C')."""
         B, N, _ = xyz1.shape
-        X0 = self._input_pm(xyz1, xyz2, feats1, feats2, nn_)
+        S = xyz2.shape[1]
         layers = _layers(self.mlp_convs, self.mlp_bns) + list(extra_layers)
+        if feats1 is None and S > 1 and ops.USE_PRE_LINEAR and feats2.shape[-1] % 4 == 0:
+            # no skip features: the first conv commutes with the interpolation, so it runs on the S sparse points and the
+            # interpolation produces its dense pre-BN output (ops.mlp_stack(pre=...), csrc/gather.hip)
+            if nn_ is None:
+                idx, w = ops.three_nn(xyz1, xyz2)
+                nn_ = (idx, w, ops.build_csr(idx, S, w, 3))
+            idx, w, csr = nn_
+            self.last_aux = dict(nn_idx=idx, nn_w=w)
+            pre = dict(kind="interp", idx=idx, w=w, csr=csr, B=B, N=N, S=S, rows=B * N)
+            F2 = feats2.reshape(B * S, -1)
+            out = ops.mlp_stack(F2, F2.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
+                                keep_padding=keep_padding, pre=pre)
+            return out.view(B, N, -1)
+        X0 = self._input_pm(xyz1, xyz2, feats1, feats2, nn_)
         out = ops.mlp_stack(X0, X0.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
                             keep_padding=keep_padding)
         return out.view(B, N, -1)

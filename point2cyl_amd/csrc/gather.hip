@@ -273,3 +273,159 @@ extern "C" int p2c_csr_gather_f32(const float *src, int ld_src, int coff, const 
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// "Linear before the gather".  A 1x1-conv layer applied to gathered rows commutes with the gather (both are linear):
+//     interp(F) . W^T = interp(F . W^T),      [F[idx] | dxyz] . [Wf | Wx]^T = (F . Wf^T)[idx] + dxyz . Wx^T
+// so the GEMM runs on the SPARSE set (FP1: 512 instead of 8192 rows per cloud, SA2: 512 points instead of 128 x 64 grouped
+// rows: 16x fewer FLOPs) and the dense pre-BN tensor Y0 is produced by a gather that also adds the bias and the BatchNorm
+// sums.  Backward: dY0 (the ReLU+BN backward of the stored gradient, rebuilt per element) is reduced to the sparse rows by
+// the CSR gather, then two small GEMMs give dW and dF.
+// ------------------------------------------------------------------------------------------------
+template <int CPL>
+__global__ void __launch_bounds__(256) three_interp_stats_kernel(const float *__restrict__ feats, int ldf, const int32_t *__restrict__ idx,
+                                                                 const float *__restrict__ w, int N, int S, int C, long long rows,
+                                                                 const float *__restrict__ bias, float *__restrict__ out, int ldo,
+                                                                 double *__restrict__ slots)
+{
+    constexpr int RPW = 16;                       // rows per wave
+    __shared__ float red[2][4][64 * CPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * RPW;
+    float bv[CPL], s1[CPL], s2[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        bv[i] = (bias && c < C) ? bias[c] : 0.f;
+        s1[i] = s2[i] = 0.f;
+    }
+    for (int rr = 0; rr < RPW; ++rr) {
+        const long long r = r0 + rr;
+        if (r >= rows) break;
+        const int b = (int)(r / N);
+        const int i0 = idx[r * 3 + 0], i1 = idx[r * 3 + 1], i2 = idx[r * 3 + 2];
+        const float w0 = w[r * 3 + 0], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
+        const float *f0 = feats + ((size_t)b * S + i0) * ldf, *f1 = feats + ((size_t)b * S + i1) * ldf,
+                    *f2 = feats + ((size_t)b * S + i2) * ldf;
+        float *o = out + (size_t)r * ldo;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                const float v = (f0[c] * w0 + f1[c] * w1) + f2[c] * w2;
+                s1[i] += v;
+                s2[i] += v * v;
+                o[c] = v + bv[i];
+            }
+        }
+    }
+    if (!slots) return;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { red[0][wave][lane + 64 * i] = s1[i]; red[1][wave][lane + 64 * i] = s2[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double *o = slots + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * C;
+        atomicAdd(&o[c], (double)((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])));
+        atomicAdd(&o[C + c], (double)((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])));
+    }
+}
+
+// out[b,n,:] = interp(feats)[b,n,:] + bias; BatchNorm sums of the bias-free value into stat_slots (NULL: none)
+extern "C" int p2c_three_interp_bias_stats_f32(const float *feats, int ldf, const int32_t *idx, const float *weight, int B, int N, int S, int C,
+                                               const float *bias, float *out, int ldo, double *stat_slots, void *stream)
+{
+    if (!feats || !idx || !weight || !out || C <= 0 || C > 256) return P2C_EINVAL;
+    const long long rows = (long long)B * N;
+    const int blocks = p2c_cdiv(rows, 64);
+    hipStream_t s = (hipStream_t)stream;
+#define P2C_TI(CPL_) hipLaunchKernelGGL(three_interp_stats_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, feats, ldf, idx, weight, N, S, C, rows, bias, out, ldo, stat_slots)
+    if (C <= 64) P2C_TI(1);
+    else if (C <= 128) P2C_TI(2);
+    else P2C_TI(4);
+#undef P2C_TI
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// CSR gather of dY = gs*(dZ*[scale*Y+shift > 0]) + q*Y + p (coef = [scale|shift|gs|q|p] x C, as everywhere): the ReLU +
+// train-BatchNorm backward of a stored gradient, rebuilt per element and reduced to the target rows in one pass.
+template <int CPL>
+__global__ void __launch_bounds__(256) csr_gather_bn_kernel(const float *__restrict__ dz, int lddz, const float *__restrict__ y, int ldy,
+                                                            const float *__restrict__ coef, const int32_t *__restrict__ offsets,
+                                                            const int32_t *__restrict__ entries, const float *__restrict__ w, int E, int rows_b,
+                                                            int T, int C, long long total, float *__restrict__ out, int ldo)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv >= total) return;
+    const int b = (int)(wv / T), t = (int)(wv - (long long)b * T);
+    const int k0 = offsets[(size_t)b * (T + 1) + t], k1 = offsets[(size_t)b * (T + 1) + t + 1];
+    const int32_t *eb = entries + (size_t)b * E;
+    const float *wb = w ? w + (size_t)b * E : nullptr;
+    float acc[CPL], csc[CPL], csh[CPL], cgs[CPL], cq[CPL], cp[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = min(lane + 64 * i, C - 1);
+        acc[i] = 0.f;
+        csc[i] = coef[c]; csh[i] = coef[C + c]; cgs[i] = coef[2 * C + c]; cq[i] = coef[3 * C + c]; cp[i] = coef[4 * C + c];
+    }
+    constexpr int UB = 4;
+    int k = k0;
+    for (; k + UB <= k1; k += UB) {
+        float we[UB]; size_t ro[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            we[u] = wb ? wb[k + u] : 1.f;
+            ro[u] = (size_t)b * rows_b + eb[k + u];
+        }
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                float g[UB], yy[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) { g[u] = dz[ro[u] * lddz + c]; yy[u] = y[ro[u] * ldy + c]; }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const float d = __builtin_fmaf(cgs[i], (csc[i] * yy[u] + csh[i] > 0.f) ? g[u] : 0.f, __builtin_fmaf(cq[i], yy[u], cp[i]));
+                    acc[i] += we[u] * d;
+                }
+            }
+        }
+    }
+    for (; k < k1; ++k) {
+        const float we = wb ? wb[k] : 1.f;
+        const size_t ro = (size_t)b * rows_b + eb[k];
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                const float g = dz[ro * lddz + c], yy = y[ro * ldy + c];
+                acc[i] += we * __builtin_fmaf(cgs[i], (csc[i] * yy + csh[i] > 0.f) ? g : 0.f, __builtin_fmaf(cq[i], yy, cp[i]));
+            }
+        }
+    }
+    float *o = out + ((size_t)b * T + t) * ldo;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) o[c] = acc[i];
+    }
+}
+
+extern "C" int p2c_csr_gather_bn_f32(const float *dz, int lddz, const float *y, int ldy, const float *coef, const int32_t *offsets,
+                                     const int32_t *rows, const float *wsorted, int B, int E, int rows_b, int T, int C, float *out, int ldo,
+                                     void *stream)
+{
+    if (!dz || !y || !coef || !offsets || !rows || !out || B <= 0 || E <= 0 || T <= 0 || C <= 0 || C > 256) return P2C_EINVAL;
+    const long long total = (long long)B * T;
+    dim3 grid(p2c_cdiv(total, 4));
+    hipStream_t s = (hipStream_t)stream;
+#define P2C_CGB(CPL_) hipLaunchKernelGGL(csr_gather_bn_kernel<CPL_>, grid, dim3(256), 0, s, dz, lddz, y, ldy, coef, offsets, rows, wsorted, E, rows_b, T, C, total, out, ldo)
+    if (C <= 64) P2C_CGB(1);
+    else if (C <= 128) P2C_CGB(2);
+    else P2C_CGB(4);
+#undef P2C_CGB
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

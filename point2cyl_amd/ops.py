@@ -14,6 +14,7 @@ from ._lib import PROFILE, call, ptr, stream  # noqa: F401
 I32 = torch.int32
 PENDING_NBT = []      # num_batches_tracked counters to bump with ONE foreach add per forward (see backbone.forward)
 USE_FUSED_BWD = os.environ.get("P2C_FUSED_BWD", "1") != "0"
+USE_PRE_LINEAR = os.environ.get("P2C_PRE_LINEAR", "1") != "0"   # first conv of a gather-fed stack on the sparse rows (gather.hip)
 USE_FOLD0 = os.environ.get("P2C_FOLD0", "1") != "0"         # first layer with <= 4 input channels never materialised (bn.hip)
 USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated backward of the gathers (no atomics)
 
@@ -270,7 +271,11 @@ class _MLPStack(torch.autograd.Function):
     @staticmethod
     def forward(ctx, cfg, X0, *params):
         dev = X0.device
-        M, ldx0 = X0.shape[0], X0.stride(0)
+        # pre = "linear before the gather" (csrc/gather.hip): X0 holds the SPARSE rows; layer 0 runs on them and its dense pre-BN
+        # output (pre["rows"] rows) is produced by the gather itself
+        pre = cfg.get("pre")
+        Ms, ldx0 = X0.shape[0], X0.stride(0)
+        M = pre["rows"] if pre is not None else Ms
         K = _pad4(cfg["in_channels"])
         assert X0.shape[1] >= K and ldx0 % 4 == 0, (X0.shape, K)
         training = cfg["training"]
@@ -290,7 +295,7 @@ class _MLPStack(torch.autograd.Function):
             arena = _ZeroArena(sum(STAT_SLOTS * 2 * c for c in widths) + 16, dev)
         # Folded first layer (csrc/bn.hip): 3 input channels (+pad), 64 outputs, train mode, no gradient wanted for the input,
         # a BatchNorm'ed middle layer of 64/128 channels next: Y_0 is never written; layer 1 rebuilds it from the input rows.
-        fold0 = (USE_FOLD0 and training and K == 4 and ldx0 == 4 and M >= 8192 and not X0.requires_grad and mask is None and seed is None
+        fold0 = (USE_FOLD0 and pre is None and training and K == 4 and ldx0 == 4 and M >= 8192 and not X0.requires_grad and mask is None and seed is None
                  and (L >= 3 or (L == 2 and tail == "bnrelu")) and params[0].shape[0] == 64 and params[4].shape[0] in (64, 128)
                  and bns[0] is not None and bns[1] is not None)
         mom = None
@@ -352,8 +357,16 @@ class _MLPStack(torch.autograd.Function):
                 elif seed is not None:
                     mode, mptr, mld = 3, ptr(seed), 0
             partials = arena.f64(STAT_SLOTS, 2, Co) if (has_bn and training) else None
-            call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
-                 mptr, mld, float(dscale), ptr(partials), stream(), flops=2.0 * M * Co * K)
+            if pre is not None and i == 0:
+                assert has_bn and pre["kind"] == "interp"
+                Gs = torch.empty(Ms, Co, dtype=torch.float32, device=dev)
+                call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, None, ptr(Gs), Co, Ms, Co, K, 0, None, None, None, 0, 1.0, None, stream(),
+                     flops=2.0 * Ms * Co * K)
+                call("p2c_three_interp_bias_stats_f32", ptr(Gs), Co, ptr(pre["idx"]), ptr(pre["w"]), pre["B"], pre["N"], pre["S"], Co, ptr(b),
+                     ptr(Y), Co, ptr(partials), stream())
+            else:
+                call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
+                     mptr, mld, float(dscale), ptr(partials), stream(), flops=2.0 * M * Co * K)
             Ys.append(Y)
             Ws.append(W2)
             if has_bn:
@@ -398,7 +411,9 @@ class _MLPStack(torch.autograd.Function):
         if not cfg["training"]:
             raise RuntimeError("point2cyl_amd: backward through an eval-mode (running-stats) stack is not implemented")
         dev = X0.device
-        M = X0.shape[0]
+        pre = cfg.get("pre")
+        Ms = X0.shape[0]
+        M = pre["rows"] if pre is not None else Ms
         L, tail = cfg["n_layers"], cfg["tail"]
         mask, seed, dscale = cfg.get("drop_mask"), cfg.get("drop_seed"), cfg.get("drop_scale", 1.0)
         dout = _f32c(dout)
@@ -452,6 +467,25 @@ class _MLPStack(torch.autograd.Function):
             Co, Ci = W2.shape
             if fold is not None and i == 0:
                 break                         # handled together with layer 1 below
+            if pre is not None and i == 0:
+                # dY0 -> sparse rows (CSR gather with the ReLU+BN backward rebuilt per element), then two small GEMMs
+                assert grad_mode == 1
+                offsets, rows_, ws_ = pre["csr"]
+                dG = torch.empty(Ms, Co, dtype=torch.float32, device=dev)
+                call("p2c_csr_gather_bn_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(coef), ptr(offsets), ptr(rows_), ptr(ws_), pre["B"],
+                     pre["N"] * 3, pre["N"], pre["S"], Co, ptr(dG), Co, stream())
+                dW = arena.f32(Co, Ci)
+                call("p2c_linear_bwd_weight_f32", ptr(dG), Co, None, 0, 0, None, ptr(X0), X0.stride(0), 0, None, None, None, 0, 1.0, ptr(dW), Ci, 0,
+                     None, Ms, Co, Ci, None, 0, stream(), flops=2.0 * Ms * Co * Ci)
+                Wp = params[p0]
+                grads[p0] = dW[:Wp.shape[0], :Wp.numel() // Wp.shape[0]].reshape(Wp.shape)
+                grads[p0 + 1] = arena.f32(Co)[:Wp.shape[0]]          # bias in front of a train-mode BatchNorm: exactly zero
+                dZ = None
+                if ctx.needs_input_grad[1]:
+                    dZ = torch.empty(Ms, Ci, dtype=torch.float32, device=dev)
+                    call("p2c_linear_bwd_data_f32", ptr(dG), Co, None, 0, 0, None, ptr(W2), Ci, ptr(dZ), Ci, Ms, Co, Ci, None, 0, 1.0, None, 0,
+                         None, None, None, 0, stream(), flops=2.0 * Ms * Co * Ci)
+                break
             if fold is not None and i == 1:
                 # fused backward of layer 1 with its X operand rebuilt from the stack input; no dX, 5 sums per column for layer 0
                 mom, b0 = fold
@@ -556,7 +590,7 @@ class _MLPStack(torch.autograd.Function):
 
 
 def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mask=None, drop_scale=1.0, drop_seed=None,
-              keep_padding=False, xyz_last=False):
+              keep_padding=False, xyz_last=False, pre=None):
     """layers: list of dicts {W, b, gamma, beta, bn: BNState} (gamma/beta/bn None for a BN-less last layer)."""
     params, bns = [], []
     for ly in layers:
@@ -565,7 +599,7 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
             params += [ly["gamma"], ly["beta"]]
         bns.append(ly.get("bn"))
     cfg = dict(in_channels=in_channels, n_layers=len(layers), tail=tail, training=training, bns=bns, G=G, ns=ns,
-               drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed, xyz_last=xyz_last)
+               drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed, xyz_last=xyz_last, pre=pre)
     out = _MLPStack.apply(cfg, X0, *params)
     if not _DEFER_NBT[0]:
         flush_nbt()

@@ -95,7 +95,7 @@ int p2c_csr_gather_f32(const float *src, int ld_src, int coff, const int32_t *of
                        int B, int E, int rows_b, int T, int C, float *out, int ldo, void *stream);
 
 /* "Linear before the gather": a 1x1-conv applied to gathered rows commutes with the gather, so the first layer of FP1 (and
- * of SA2, round 2) runs on the sparse set and the dense pre-BN tensor is produced by the gather itself.
+ * of SA2) runs on the sparse set and the dense pre-BN tensor is produced by the gather itself.
  * p2c_three_interp_bias_stats_f32: out = interp(feats) + bias, BatchNorm sums of the bias-free value into stat_slots
  *   (p2c_stat_slots_bytes(C), zeroed by the caller; NULL = no sums).  C <= 256.
  * p2c_csr_gather_bn_f32: p2c_csr_gather_f32 of dY = gs*(dZ*[scale*Y+shift>0]) + q*Y + p (coef [5][C] as produced by the
@@ -105,6 +105,20 @@ int p2c_three_interp_bias_stats_f32(const float *feats, int ldf, const int32_t *
 int p2c_csr_gather_bn_f32(const float *dz, int lddz, const float *y, int ldy, const float *coef, const int32_t *offsets,
                           const int32_t *rows, const float *wsorted, int B, int E, int rows_b, int T, int C, float *out, int ldo,
                           void *stream);
+/* Grouped layer with point features (SA2; pointnet_util.py:128-139 + the first conv of :201): with W = [Wx | Wf] in the
+ * reference's [xyz | features] order and G = F . Wf^T computed on the N points,
+ *   out[(b,s,j), :] = G[b, idx[b,s,j], :] + Wx . (xyz[b, idx] - new_xyz[b, s]) + bias      (Wx [C,4] row-major, 4th column unused)
+ * and the BatchNorm sums of the bias-free value go to stat_slots (NULL: none).  The grouped input tensor is never built.
+ * p2c_group_linear_bwd_f32: dG[b,p,:] = sum over the grouped rows reading point p of dY (dY rebuilt from dz, y, coef as in
+ *   p2c_csr_gather_bn_f32; offsets/rows = p2c_build_csr_i32 of idx with T = N; dG is ACCUMULATED with atomics: zero it first),
+ *   and dWx accumulated into
+ *   dwx_slots [P2C_STAT_SLOTS][3][C] (fp64, zeroed by the caller; the caller sums the slots). */
+int p2c_group_linear_bias_stats_f32(const float *G, int ldg, const float *xyz, const float *new_xyz, const int32_t *idx, const float *Wx,
+                                    const float *bias, int B, int N, int S, int nsample, int C, float *out, int ldo,
+                                    double *stat_slots, void *stream);
+int p2c_group_linear_bwd_f32(const float *dz, int lddz, const float *y, int ldy, const float *coef, const int32_t *offsets,
+                             const int32_t *rows, const float *xyz, const float *new_xyz, int B, int N, int S, int nsample, int C,
+                             float *dG, int ldo, double *dwx_slots, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Shared per-point MLP: 1x1 conv (+ train-mode BatchNorm + ReLU) as fp32 MFMA GEMMs

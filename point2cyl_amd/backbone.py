@@ -78,9 +78,18 @@ class PointNetSetAbstraction(nn.Module):
             if geom is None:
                 geom = self.geometry(xyz)
             fps_idx, new_xyz, gidx = geom["fps_idx"], geom["new_xyz"], geom["group_idx"]
-            X0 = geom["X0"] if (feats is None and "X0" in geom) else ops.group_gather(xyz, feats, new_xyz, gidx, geom.get("csr"))
             G, ns = B * self.npoint, self.nsample
             self.last_aux = dict(fps_idx=fps_idx, group_idx=gidx)
+            if feats is not None and ops.USE_PRE_LINEAR and feats.shape[-1] % 4 == 0 and self.mlp_convs[0].weight.shape[0] <= 256:
+                # the first conv commutes with the grouping gather: it runs on the N points, the gather adds the coordinate part,
+                # the bias and the BatchNorm sums (ops.mlp_stack(pre=...), csrc/gather.hip); the grouped input is never built
+                csr = geom.get("csr") or ops.build_csr(gidx, N)
+                pre = dict(kind="group", xyz=xyz.contiguous(), new_xyz=new_xyz.contiguous(), idx=gidx, csr=csr, B=B, N=N, S=self.npoint,
+                           ns=ns, rows=G * ns)
+                F2 = feats.reshape(B * N, -1)
+                out = ops.mlp_stack(F2, F2.shape[1], layers, "maxpool", self.training, G=G, ns=ns, pre=pre)
+                return new_xyz, out.view(B, -1, out.shape[-1])
+            X0 = geom["X0"] if (feats is None and "X0" in geom) else ops.group_gather(xyz, feats, new_xyz, gidx, geom.get("csr"))
         out = ops.mlp_stack(X0, cin, layers, "maxpool", self.training, G=G, ns=ns, xyz_last=True)
         return new_xyz, out.view(B, -1, out.shape[-1])
 

@@ -429,3 +429,186 @@ extern "C" int p2c_csr_gather_bn_f32(const float *dz, int lddz, const float *y, 
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
+
+// Grouped layer with point features (SA2): Y0[(b,s,j), :] = G[b, idx[b,s,j], :] + Wx . (xyz[b,idx] - new_xyz[b,s]) + bias, where
+// G = F . Wf^T was computed on the N points (W = [Wx | Wf] in the reference's [xyz | features] column order).
+// Wx: [C,4] row-major (4th column unused).  BatchNorm sums of the bias-free value into stat_slots (NULL: none).
+template <int CPL>
+__global__ void __launch_bounds__(256) group_linear_stats_kernel(const float *__restrict__ Gf, int ldg, const float *__restrict__ xyz,
+                                                                 const float *__restrict__ new_xyz, const int32_t *__restrict__ idx,
+                                                                 const float *__restrict__ Wx, const float *__restrict__ bias, int N, int S, int ns,
+                                                                 int C, long long rows, float *__restrict__ out, int ldo,
+                                                                 double *__restrict__ slots)
+{
+    constexpr int RPW = 16;
+    __shared__ float red[2][4][64 * CPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r0 = ((long long)blockIdx.x * 4 + wave) * RPW;
+    float bv[CPL], s1[CPL], s2[CPL], wx0[CPL], wx1[CPL], wx2[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = min(lane + 64 * i, C - 1);
+        bv[i] = bias ? bias[c] : 0.f;
+        wx0[i] = Wx[c * 4 + 0]; wx1[i] = Wx[c * 4 + 1]; wx2[i] = Wx[c * 4 + 2];
+        s1[i] = s2[i] = 0.f;
+    }
+    for (int rr = 0; rr < RPW; ++rr) {
+        const long long r = r0 + rr;
+        if (r >= rows) break;
+        const long long grp = r / ns;                     // (b, s)
+        const int b = (int)(grp / S);
+        const int p = idx[r];
+        const float *pp = xyz + ((size_t)b * N + p) * 3, *cc = new_xyz + (size_t)grp * 3;
+        const float dx = pp[0] - cc[0], dy = pp[1] - cc[1], dz = pp[2] - cc[2];
+        const float *g = Gf + ((size_t)b * N + p) * ldg;
+        float *o = out + (size_t)r * ldo;
+#pragma unroll
+        for (int i = 0; i < CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                const float v = g[c] + __builtin_fmaf(wx2[i], dz, __builtin_fmaf(wx1[i], dy, wx0[i] * dx));
+                s1[i] += v;
+                s2[i] += v * v;
+                o[c] = v + bv[i];
+            }
+        }
+    }
+    if (!slots) return;
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { red[0][wave][lane + 64 * i] = s1[i]; red[1][wave][lane + 64 * i] = s2[i]; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double *o = slots + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * C;
+        atomicAdd(&o[c], (double)((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])));
+        atomicAdd(&o[C + c], (double)((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])));
+    }
+}
+
+extern "C" int p2c_group_linear_bias_stats_f32(const float *G, int ldg, const float *xyz, const float *new_xyz, const int32_t *idx, const float *Wx,
+                                               const float *bias, int B, int N, int S, int nsample, int C, float *out, int ldo,
+                                               double *stat_slots, void *stream)
+{
+    if (!G || !xyz || !new_xyz || !idx || !Wx || !out || B <= 0 || N <= 0 || S <= 0 || nsample <= 0 || C <= 0 || C > 256) return P2C_EINVAL;
+    const long long rows = (long long)B * S * nsample;
+    const int blocks = p2c_cdiv(rows, 64);
+    hipStream_t s = (hipStream_t)stream;
+#define P2C_GL(CPL_) hipLaunchKernelGGL(group_linear_stats_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, G, ldg, xyz, new_xyz, idx, Wx, bias, N, S, nsample, C, rows, out, ldo, stat_slots)
+    if (C <= 64) P2C_GL(1);
+    else if (C <= 128) P2C_GL(2);
+    else P2C_GL(4);
+#undef P2C_GL
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// Backward of the above: dG[b,p,:] = sum of dY0 over the grouped rows that read point p (CSR, unit weights), and
+// dWx[c, 0..2] = sum over ALL rows of dY0[row,c] * (xyz[b,p] - new_xyz[b,row/ns]) accumulated on the way (every grouped row
+// belongs to exactly one point) into dwx_slots [P2C_STAT_SLOTS][3][C] (fp64, zeroed by the caller).
+// Balanced over ENTRIES, not points: ball-query padding repeats the first neighbour, so a few points are read by hundreds of
+// grouped rows (one wave - or one workgroup - per point left a 0.3 - 1 ms tail).  Every wave takes EPW consecutive entries of
+// the point-sorted list, runs a segmented sum (the point changes where k reaches offsets[t+1]) and flushes each segment with
+// one atomicAdd per channel into dG (zeroed by the caller): ~2 segments per wave instead of one atomic per entry.
+template <int CPL>
+__global__ void __launch_bounds__(256) group_linear_bwd_kernel(const float *__restrict__ dz, int lddz, const float *__restrict__ y, int ldy,
+                                                               const float *__restrict__ coef, const int32_t *__restrict__ offsets,
+                                                               const int32_t *__restrict__ entries, const float *__restrict__ xyz,
+                                                               const float *__restrict__ new_xyz, int B, int N, int S, int ns, int C, int wpc,
+                                                               float *__restrict__ dG, int ldo, double *__restrict__ dwx_slots)
+{
+    constexpr int EPW = 16, UB = 4;
+    __shared__ float red[3][4][64 * CPL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int E = S * ns;
+    float csc[CPL], csh[CPL], cgs[CPL], cq[CPL], cp[CPL], a0[CPL], a1[CPL], a2[CPL], acc[CPL];
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) {
+        const int c = min(lane + 64 * i, C - 1);
+        csc[i] = coef[c]; csh[i] = coef[C + c]; cgs[i] = coef[2 * C + c]; cq[i] = coef[3 * C + c]; cp[i] = coef[4 * C + c];
+        a0[i] = a1[i] = a2[i] = acc[i] = 0.f;
+    }
+    const long long gw = (long long)blockIdx.x * 4 + wave;      // global wave id: cloud b, entry range [kb, kend)
+    const int b = (int)(gw / wpc);
+    if (b < B) {
+        const int32_t *off = offsets + (size_t)b * (N + 1);
+        const int32_t *eb = entries + (size_t)b * E;
+        const int kb = (int)(gw - (long long)b * wpc) * EPW, kend = min(min(E, kb + EPW), off[N]);     // off[N] = number of valid entries
+        if (kb < kend) {
+            int lo = 0, hi = N;                                 // point t with off[t] <= kb < off[t+1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= kb) lo = mid; else hi = mid; }
+            int t = lo, seg_end = off[t + 1];
+            int cur = -1;                                       // owner of acc[] (wave-uniform)
+            auto flush = [&]() {
+                float *o = dG + ((size_t)b * N + cur) * ldo;
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) { const int c = lane + 64 * i; if (c < C) atomicAdd(o + c, acc[i]); acc[i] = 0.f; }
+            };
+            for (int k = kb; k < kend; k += UB) {
+                size_t ro[UB]; float dx[UB], dy[UB], dzz[UB]; int tt[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int kk = min(k + u, kend - 1);
+                    while (kk >= seg_end) { ++t; seg_end = off[t + 1]; }
+                    tt[u] = t;
+                    const int e = eb[kk];
+                    ro[u] = (size_t)b * E + e;
+                    const float *pp = xyz + ((size_t)b * N + t) * 3, *cc = new_xyz + ((size_t)b * S + e / ns) * 3;
+                    dx[u] = pp[0] - cc[0]; dy[u] = pp[1] - cc[1]; dzz[u] = pp[2] - cc[2];
+                }
+                float d[UB][CPL];
+#pragma unroll
+                for (int i = 0; i < CPL; ++i) {
+                    const int c = min(lane + 64 * i, C - 1);
+#pragma unroll
+                    for (int u = 0; u < UB; ++u) {
+                        const float g = dz[ro[u] * lddz + c], yy = y[ro[u] * ldy + c];
+                        d[u][i] = __builtin_fmaf(cgs[i], (csc[i] * yy + csh[i] > 0.f) ? g : 0.f, __builtin_fmaf(cq[i], yy, cp[i]));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    if (k + u < kend) {                         // uniform
+                        if (tt[u] != cur) {
+                            if (cur >= 0) flush();
+                            cur = tt[u];
+                        }
+#pragma unroll
+                        for (int i = 0; i < CPL; ++i) {
+                            acc[i] += d[u][i];
+                            a0[i] = __builtin_fmaf(d[u][i], dx[u], a0[i]);
+                            a1[i] = __builtin_fmaf(d[u][i], dy[u], a1[i]);
+                            a2[i] = __builtin_fmaf(d[u][i], dzz[u], a2[i]);
+                        }
+                    }
+                }
+            }
+            if (cur >= 0) flush();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPL; ++i) { red[0][wave][lane + 64 * i] = a0[i]; red[1][wave][lane + 64 * i] = a1[i]; red[2][wave][lane + 64 * i] = a2[i]; }
+    __syncthreads();
+    for (int u = threadIdx.x; u < 3 * C; u += 256) {
+        const int e = u / C, c = u - e * C;
+        double *o = dwx_slots + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 3 * C;
+        atomicAdd(&o[u], (double)((red[e][0][c] + red[e][1][c]) + (red[e][2][c] + red[e][3][c])));
+    }
+}
+
+extern "C" int p2c_group_linear_bwd_f32(const float *dz, int lddz, const float *y, int ldy, const float *coef, const int32_t *offsets,
+                                        const int32_t *rows, const float *xyz, const float *new_xyz, int B, int N, int S, int nsample, int C,
+                                        float *dG, int ldo, double *dwx_slots, void *stream)
+{
+    if (!dz || !y || !coef || !offsets || !rows || !xyz || !new_xyz || !dG || !dwx_slots || B <= 0 || N <= 0 || S <= 0 || nsample <= 0 ||
+        C <= 0 || C > 256)
+        return P2C_EINVAL;
+    const int wpc = p2c_cdiv((long long)S * nsample, 16);             // waves per cloud, 16 entries each
+    const int blocks = p2c_cdiv((long long)B * wpc, 4);
+    hipStream_t s = (hipStream_t)stream;
+#define P2C_GLB(CPL_) hipLaunchKernelGGL(group_linear_bwd_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, dz, lddz, y, ldy, coef, offsets, rows, xyz, new_xyz, B, N, S, nsample, C, wpc, dG, ldo, dwx_slots)
+    if (C <= 64) P2C_GLB(1);
+    else if (C <= 128) P2C_GLB(2);
+    else P2C_GLB(4);
+#undef P2C_GLB
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

@@ -286,7 +286,7 @@ class _MLPStack(torch.autograd.Function):
         seed = cfg.get("drop_seed")       # device int64 scalar: counter-hash dropout (no mask tensor)
         dscale = cfg.get("drop_scale", 1.0)
         Ys, aff, Ws = [], [], []
-        fold_b0 = None
+        fold_b0 = pre_wx = None
         X, ldx, in_mode, sc, sh = X0, ldx0, 0, None, None
         pi = 0
         arena = None
@@ -305,6 +305,10 @@ class _MLPStack(torch.autograd.Function):
             pi += 2
             Co_true = W.shape[0]
             W2 = W.reshape(Co_true, -1)
+            if i == 0 and pre is not None and pre["kind"] == "group":
+                # reference column order [xyz(3) | features]: the coordinate part goes to the gather, the feature part to the GEMM
+                pre_wx = torch.nn.functional.pad(W2[:, :3], (0, 1, 0, _pad4(Co_true) - Co_true)).contiguous()
+                W2 = W2[:, 3:]
             if i == 0 and cfg.get("xyz_last") and W2.shape[1] > 3:
                 W2 = torch.cat([W2[:, 3:], W2[:, :3]], 1)          # reference order [xyz(3) | feats] -> [feats | xyz(3)]
             Co = _pad4(Co_true)
@@ -358,12 +362,16 @@ class _MLPStack(torch.autograd.Function):
                     mode, mptr, mld = 3, ptr(seed), 0
             partials = arena.f64(STAT_SLOTS, 2, Co) if (has_bn and training) else None
             if pre is not None and i == 0:
-                assert has_bn and pre["kind"] == "interp"
+                assert has_bn
                 Gs = torch.empty(Ms, Co, dtype=torch.float32, device=dev)
                 call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, None, ptr(Gs), Co, Ms, Co, K, 0, None, None, None, 0, 1.0, None, stream(),
                      flops=2.0 * Ms * Co * K)
-                call("p2c_three_interp_bias_stats_f32", ptr(Gs), Co, ptr(pre["idx"]), ptr(pre["w"]), pre["B"], pre["N"], pre["S"], Co, ptr(b),
-                     ptr(Y), Co, ptr(partials), stream())
+                if pre["kind"] == "interp":
+                    call("p2c_three_interp_bias_stats_f32", ptr(Gs), Co, ptr(pre["idx"]), ptr(pre["w"]), pre["B"], pre["N"], pre["S"], Co, ptr(b),
+                         ptr(Y), Co, ptr(partials), stream())
+                else:
+                    call("p2c_group_linear_bias_stats_f32", ptr(Gs), Co, ptr(pre["xyz"]), ptr(pre["new_xyz"]), ptr(pre["idx"]), ptr(pre_wx),
+                         ptr(b), pre["B"], pre["N"], pre["S"], pre["ns"], Co, ptr(Y), Co, ptr(partials), stream())
             else:
                 call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
                      mptr, mld, float(dscale), ptr(partials), stream(), flops=2.0 * M * Co * K)
@@ -401,6 +409,7 @@ class _MLPStack(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.saved = (X0, Ys, aff, Ws, arg, params)
         ctx.fold = (mom, fold_b0) if fold0 else None
+        ctx.pre_wx = pre_wx
         return out
 
     @staticmethod
@@ -471,14 +480,24 @@ class _MLPStack(torch.autograd.Function):
                 # dY0 -> sparse rows (CSR gather with the ReLU+BN backward rebuilt per element), then two small GEMMs
                 assert grad_mode == 1
                 offsets, rows_, ws_ = pre["csr"]
-                dG = torch.empty(Ms, Co, dtype=torch.float32, device=dev)
-                call("p2c_csr_gather_bn_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(coef), ptr(offsets), ptr(rows_), ptr(ws_), pre["B"],
-                     pre["N"] * 3, pre["N"], pre["S"], Co, ptr(dG), Co, stream())
+                dG = (torch.empty if pre["kind"] == "interp" else torch.zeros)(Ms, Co, dtype=torch.float32, device=dev)
+                dwx = None
+                if pre["kind"] == "interp":
+                    call("p2c_csr_gather_bn_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(coef), ptr(offsets), ptr(rows_), ptr(ws_), pre["B"],
+                         pre["N"] * 3, pre["N"], pre["S"], Co, ptr(dG), Co, stream())
+                else:
+                    dwx = arena.f64(STAT_SLOTS, 3, Co)
+                    call("p2c_group_linear_bwd_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(coef), ptr(offsets), ptr(rows_), ptr(pre["xyz"]),
+                         ptr(pre["new_xyz"]), pre["B"], pre["N"], pre["S"], pre["ns"], Co, ptr(dG), Co, ptr(dwx), stream())
                 dW = arena.f32(Co, Ci)
                 call("p2c_linear_bwd_weight_f32", ptr(dG), Co, None, 0, 0, None, ptr(X0), X0.stride(0), 0, None, None, None, 0, 1.0, ptr(dW), Ci, 0,
                      None, Ms, Co, Ci, None, 0, stream(), flops=2.0 * Ms * Co * Ci)
                 Wp = params[p0]
-                grads[p0] = dW[:Wp.shape[0], :Wp.numel() // Wp.shape[0]].reshape(Wp.shape)
+                if dwx is not None:
+                    dWx = dwx.sum(0).t().to(torch.float32)                                         # (Co, 3)
+                    grads[p0] = torch.cat([dWx[:Wp.shape[0]], dW[:Wp.shape[0], :Wp.numel() // Wp.shape[0] - 3]], 1).reshape(Wp.shape)
+                else:
+                    grads[p0] = dW[:Wp.shape[0], :Wp.numel() // Wp.shape[0]].reshape(Wp.shape)
                 grads[p0 + 1] = arena.f32(Co)[:Wp.shape[0]]          # bias in front of a train-mode BatchNorm: exactly zero
                 dZ = None
                 if ctx.needs_input_grad[1]:

@@ -176,6 +176,18 @@ int p2c_linear_bwd_fused_fold0_f32(const float *dZ, int lddz, const float *Yfwd,
 int p2c_fold0_bwd_finalize_f32(const double *partials5, const double *moments, long long M, const float *W0, const float *b0,
                                const float *stat0, const float *gamma0, int C0, float *dgamma0, float *dbeta0, float *dW0, void *stream);
 
+/* Layer fed by [X | one vector per row group repeated over the group's rows] (FP3: the global feature repeated over the 128
+ * points of a cloud, pointnet_util.py:298-299, :312).  The repeated part's product G = V . Wb^T is computed once per group by the
+ * caller (a tiny p2c_linear_fwd_f32) and enters as a per-group additive term:
+ *   p2c_linear_fwd_gbias_f32: Y[m,:] = act_in(X)[m,:] . Wa^T + gbias[m / rows_per_group, :] + bias   (rows_per_group % 64 == 0,
+ *     M % rows_per_group == 0, in_mode 0/1; the BatchNorm sums include the per-group term);
+ *   p2c_group_colsum_bn_f32: out[g,:] = sum over the group's rows of dY (rebuilt from dz, y, coef): the gradient of gbias. */
+int p2c_linear_fwd_gbias_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, const float *gbias, int ldgb,
+                             int rows_per_group, float *Y, int ldy, int M, int N, int K, int in_mode, const float *in_scale,
+                             const float *in_shift, double *stat_partials, void *stream);
+int p2c_group_colsum_bn_f32(const float *dz, int lddz, const float *y, int ldy, const float *coef, int G, int rows_per_group, int C,
+                            float *out, int ldo, void *stream);
+
 /* 1 if p2c_linear_fwd_f32 runs this shape on the persistent weight-stationary kernel (fwd_pp.hip: M >= 8192, N <= 256,
  * K <= 128 or the grouped K == 132, no byte mask); otherwise the tiled kernel is used.  Same results either way. */
 int p2c_linear_fwd_pp_supported(int M, int N, int K, int in_mode);

@@ -40,6 +40,8 @@ _SIGS = {
     "p2c_csr_gather_bn_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_group_linear_bias_stats_f32": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
     "p2c_group_linear_bwd_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p],
+    "p2c_linear_fwd_gbias_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+    "p2c_group_colsum_bn_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_linear_fwd_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p],
     "p2c_bn_finalize_f32": [c_p, c_i, c_ll, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_bn_bwd_finalize_f32": [c_p, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p],

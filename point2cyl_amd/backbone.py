@@ -148,6 +148,15 @@ class PointNetFeaturePropagation(nn.Module):
             out = ops.mlp_stack(F2, F2.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
                                 keep_padding=keep_padding, pre=pre)
             return out.view(B, N, -1)
+        if (S == 1 and feats1 is not None and ops.USE_PRE_LINEAR and N % 64 == 0 and feats1.shape[-1] % 4 == 0 and feats2.shape[-1] % 4 == 0
+                and self.training and self.mlp_convs[0].weight.shape[0] % 4 == 0):
+            # one sparse point: its features are REPEATED over the N rows (:298-299), so their product with the weight columns they
+            # meet is computed once per cloud and enters the GEMM over the skip features as a per-cloud additive term
+            pre = dict(kind="repeat", V=feats2.reshape(B, -1), rpg=N, rows=B * N)
+            F1 = feats1.reshape(B * N, -1)
+            out = ops.mlp_stack(F1, F1.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
+                                keep_padding=keep_padding, pre=pre)
+            return out.view(B, N, -1)
         X0 = self._input_pm(xyz1, xyz2, feats1, feats2, nn_)
         out = ops.mlp_stack(X0, X0.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
                             keep_padding=keep_padding)

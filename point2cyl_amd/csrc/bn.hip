@@ -404,6 +404,38 @@ extern "C" int p2c_fold0_bwd_finalize_f32(const double *partials5, const double 
     return P2C_OK;
 }
 
+// out[g, c] = sum over the rpg rows of group g of dY[m, c],  dY = gs*(dZ*[scale*Y+shift>0]) + q*Y + p  (coef [5][C]):
+// the gradient of a per-group additive term (p2c_linear_fwd_gbias_f32).  One workgroup per (group, 64 channels).
+__global__ void __launch_bounds__(256) group_colsum_bn_kernel(const float *__restrict__ dz, int lddz, const float *__restrict__ y, int ldy,
+                                                              const float *__restrict__ coef, int rpg, int C, float *__restrict__ out, int ldo)
+{
+    __shared__ float red[4][64];
+    const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + cx, g = blockIdx.x;
+    float s = 0.f;
+    if (c < C) {
+        const float sc = coef[c], sh = coef[C + c], gs = coef[2 * C + c], q = coef[3 * C + c], p = coef[4 * C + c];
+        for (int r = ty; r < rpg; r += 4) {
+            const size_t m = (size_t)g * rpg + r;
+            const float yy = y[m * ldy + c], gg = dz[m * lddz + c];
+            s += __builtin_fmaf(gs, (sc * yy + sh > 0.f) ? gg : 0.f, __builtin_fmaf(q, yy, p));
+        }
+    }
+    red[ty][cx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) out[(size_t)g * ldo + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+}
+
+extern "C" int p2c_group_colsum_bn_f32(const float *dz, int lddz, const float *y, int ldy, const float *coef, int G, int rows_per_group, int C,
+                                       float *out, int ldo, void *stream)
+{
+    if (!dz || !y || !coef || !out || G <= 0 || rows_per_group <= 0 || C <= 0) return P2C_EINVAL;
+    hipLaunchKernelGGL(group_colsum_bn_kernel, dim3(G, p2c_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, dz, lddz, y, ldy, coef, rows_per_group,
+                       C, out, ldo);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
 extern "C" size_t p2c_stat_slots_bytes(int C) { return (size_t)P2C_STAT_SLOTS * 2 * (size_t)C * sizeof(double); }
 
 // finalize from per-tile partials produced elsewhere (the fused backward-data epilogue): stat = [scale|shift|mean|invstd] x C

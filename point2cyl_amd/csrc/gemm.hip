@@ -169,6 +169,9 @@ struct Tile {
 // ------------------------------------------------------------------------------------------------
 struct EpiFwd {
     float *Y; int ldy; const float *bias; double *partials;  // [P2C_STAT_SLOTS][2][N] fp64 accumulators (atomic) or NULL
+    // optional per-row-group term gbias[row / rpg, col] (rpg a multiple of the row tile): it is part of the value whose
+    // BatchNorm sums are taken (a layer fed by [features | one vector repeated over the rows of a group], see FP3)
+    const float *gbias; int ldgb; int rpg;
 };
 struct EpiBwdData {
     float *dX; int lddx; const uint8_t *mask; int ldmask; float mscale;   // ldmask < 0: hashed mask, mask -> seed[2], thr below
@@ -260,13 +263,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
             const int col = j0 + cl;
             const bool cok = col < J;
             const float bv = (epi.bias && cok) ? epi.bias[col] : 0.f;
+            const float gbv = (epi.gbias && cok) ? epi.gbias[(size_t)(i0 / epi.rpg) * epi.ldgb + col] : 0.f;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int ta = 0; ta < TM; ++ta)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int rl = wm * (TM * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * rquad;
-                    const float v = acc[ta][tb][r];
+                    const float v = acc[ta][tb][r] + gbv;
                     smem[rl * LDO + cl] = v + bv;
                     if (i0 + rl < I && cok) {
                         s1 += v;
@@ -407,11 +411,11 @@ extern "C" int p2c_linear_stat_tiles(int M) { return (M + tile_m() - 1) / tile_m
 template <int MODE>
 static int launch_fwd(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
                       const float *in_scale, const float *in_shift, const uint8_t *drop_mask, int ldmask, float drop_scale,
-                      double *stat_partials, hipStream_t s)
+                      double *stat_partials, hipStream_t s, const float *gbias = nullptr, int ldgb = 0, int rpg = 1)
 {
     OpActIn<MODE> a{X, ldx, in_scale, in_shift, drop_mask, ldmask, drop_scale};
     OpPlain b{W, ldw};
-    EpiFwd e{Y, ldy, bias, stat_partials};
+    EpiFwd e{Y, ldy, bias, stat_partials, gbias, ldgb, rpg};
     const int kps = (K + GK - 1) / GK * GK;
 #define P2C_FW(TM_, TN_)                                                                                                          \
     hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, true, OpActIn<MODE>, OpPlain, EpiFwd>), dim3(p2c_cdiv(M, 64 * TM_), p2c_cdiv(N, 64 * TN_), 1), \
@@ -448,6 +452,26 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     case 2: return launch_fwd<2>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
     default: return launch_fwd<3>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
     }
+}
+
+// ---- forward with a per-row-group additive term: Y[m,:] = act_in(X)[m,:] . W^T + gbias[m / rows_per_group, :] + bias.
+// The layer's input is [X | one vector per group repeated over its rows] (FP3: the global feature repeated over the 128 points,
+// pointnet_util.py:298-299, :312); the repeated part's product is computed once per group by the caller.  rows_per_group must
+// be a multiple of 64 and divide M.  in_mode 0 or 1.
+extern "C" int p2c_linear_fwd_gbias_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, const float *gbias, int ldgb,
+                                        int rows_per_group, float *Y, int ldy, int M, int N, int K, int in_mode, const float *in_scale,
+                                        const float *in_shift, double *stat_partials, void *stream)
+{
+    if (!X || !W || !Y || !gbias || M <= 0 || N <= 0 || K <= 0 || in_mode < 0 || in_mode > 1 || rows_per_group <= 0 ||
+        (rows_per_group % 64) || (M % rows_per_group) || tile_m() != 64)
+        return P2C_EINVAL;
+    if (in_mode == 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
+    if (K & 3) return P2C_EALIGN;
+    P2C_REQ_ALIGNED(X, ldx);
+    P2C_REQ_ALIGNED(W, ldw);
+    hipStream_t s = (hipStream_t)stream;
+    if (in_mode == 0) return launch_fwd<0>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, nullptr, 0, 1.f, stat_partials, s, gbias, ldgb, rows_per_group);
+    return launch_fwd<1>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, nullptr, 0, 1.f, stat_partials, s, gbias, ldgb, rows_per_group);
 }
 
 // ---- forward of the layer that FOLLOWS a folded first layer (see bn.hip): A = relu(bn0(X0 W0^T + b0)) rebuilt from X0 [M,4]

@@ -274,6 +274,9 @@ class _MLPStack(torch.autograd.Function):
         # pre = "linear before the gather" (csrc/gather.hip): X0 holds the SPARSE rows; layer 0 runs on them and its dense pre-BN
         # output (pre["rows"] rows) is produced by the gather itself
         pre = cfg.get("pre")
+        rep_v = None
+        if pre is not None and pre["kind"] == "repeat":       # params[0] is the per-group vector V (G, D2), a differentiable input
+            rep_v, params = params[0], params[1:]
         Ms, ldx0 = X0.shape[0], X0.stride(0)
         M = pre["rows"] if pre is not None else Ms
         K = _pad4(cfg["in_channels"])
@@ -286,7 +289,7 @@ class _MLPStack(torch.autograd.Function):
         seed = cfg.get("drop_seed")       # device int64 scalar: counter-hash dropout (no mask tensor)
         dscale = cfg.get("drop_scale", 1.0)
         Ys, aff, Ws = [], [], []
-        fold_b0 = pre_wx = None
+        fold_b0 = pre_wx = pre_wb = None
         X, ldx, in_mode, sc, sh = X0, ldx0, 0, None, None
         pi = 0
         arena = None
@@ -305,6 +308,11 @@ class _MLPStack(torch.autograd.Function):
             pi += 2
             Co_true = W.shape[0]
             W2 = W.reshape(Co_true, -1)
+            if i == 0 and rep_v is not None:
+                # input = [X | V repeated over the rows of a group] (reference column order [points1 | interpolated]): V's product once
+                # per group, as a per-group additive term of the GEMM over X
+                pre_wb = W2[:, K:].contiguous()
+                W2 = W2[:, :K]
             if i == 0 and pre is not None and pre["kind"] == "group":
                 # reference column order [xyz(3) | features]: the coordinate part goes to the gather, the feature part to the GEMM
                 pre_wx = torch.nn.functional.pad(W2[:, :3], (0, 1, 0, _pad4(Co_true) - Co_true)).contiguous()
@@ -361,7 +369,15 @@ class _MLPStack(torch.autograd.Function):
                 elif seed is not None:
                     mode, mptr, mld = 3, ptr(seed), 0
             partials = arena.f64(STAT_SLOTS, 2, Co) if (has_bn and training) else None
-            if pre is not None and i == 0:
+            if rep_v is not None and i == 0:
+                assert has_bn and Co == Co_true
+                D2 = pre_wb.shape[1]
+                Gb = torch.empty(rep_v.shape[0], Co, dtype=torch.float32, device=dev)
+                call("p2c_linear_fwd_f32", ptr(rep_v), rep_v.stride(0), ptr(pre_wb), D2, None, ptr(Gb), Co, rep_v.shape[0], Co, D2, 0, None, None,
+                     None, 0, 1.0, None, stream(), flops=2.0 * rep_v.shape[0] * Co * D2)
+                call("p2c_linear_fwd_gbias_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Gb), Co, pre["rpg"], ptr(Y), Co, M, Co, K, 0, None, None,
+                     ptr(partials), stream(), flops=2.0 * M * Co * K)
+            elif pre is not None and i == 0:
                 assert has_bn
                 Gs = torch.empty(Ms, Co, dtype=torch.float32, device=dev)
                 call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, None, ptr(Gs), Co, Ms, Co, K, 0, None, None, None, 0, 1.0, None, stream(),
@@ -407,15 +423,17 @@ class _MLPStack(torch.autograd.Function):
         else:
             out = Ys[-1]
         ctx.cfg = cfg
-        ctx.saved = (X0, Ys, aff, Ws, arg, params)
+        ctx.saved = (X0, Ys, aff, Ws, arg, params)      # params: the layer parameters (without a leading repeat vector)
         ctx.fold = (mom, fold_b0) if fold0 else None
         ctx.pre_wx = pre_wx
+        ctx.rep = (rep_v, pre_wb) if rep_v is not None else None
         return out
 
     @staticmethod
     def backward(ctx, dout):
         cfg = ctx.cfg
         X0, Ys, aff, Ws, arg, params = ctx.saved
+        rep_grad = None
         arg, ywin = arg if isinstance(arg, tuple) else (arg, None)
         if not cfg["training"]:
             raise RuntimeError("point2cyl_amd: backward through an eval-mode (running-stats) stack is not implemented")
@@ -476,6 +494,32 @@ class _MLPStack(torch.autograd.Function):
             Co, Ci = W2.shape
             if fold is not None and i == 0:
                 break                         # handled together with layer 1 below
+            if ctx.rep is not None and i == 0:
+                assert grad_mode == 1
+                V, Wb = ctx.rep
+                G_, D2 = V.shape[0], Wb.shape[1]
+                dGb = torch.empty(G_, Co, dtype=torch.float32, device=dev)
+                call("p2c_group_colsum_bn_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(coef), G_, pre["rpg"], Co, ptr(dGb), Co, stream())
+                dWb = arena.f32(Co, D2)
+                call("p2c_linear_bwd_weight_f32", ptr(dGb), Co, None, 0, 0, None, ptr(V), V.stride(0), 0, None, None, None, 0, 1.0, ptr(dWb), D2, 0,
+                     None, G_, Co, D2, None, 0, stream(), flops=2.0 * G_ * Co * D2)
+                dV = torch.empty(G_, D2, dtype=torch.float32, device=dev)
+                call("p2c_linear_bwd_data_f32", ptr(dGb), Co, None, 0, 0, None, ptr(Wb), D2, ptr(dV), D2, G_, Co, D2, None, 0, 1.0, None, 0,
+                     None, None, None, 0, stream(), flops=2.0 * G_ * Co * D2)
+                dWa = arena.f32(Co, Ci)
+                call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, 1, ptr(coef), ptr(X0), X0.stride(0), 0, None, None, None, 0, 1.0,
+                     ptr(dWa), Ci, 0, None, M, Co, Ci, None, 0, stream(), flops=2.0 * M * Co * Ci)
+                Wp = params[p0]
+                grads[p0] = torch.cat([dWa[:, :Ci], dWb], 1).reshape(Wp.shape)
+                grads[p0 + 1] = arena.f32(Co)
+                rep_grad = dV
+                dX = None
+                if ctx.needs_input_grad[1]:
+                    dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
+                    call("p2c_linear_bwd_data_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, 1, ptr(coef), ptr(W2), Ci, ptr(dX), Ci, M, Co, Ci, None, 0,
+                         1.0, None, 0, None, None, None, 0, stream(), flops=2.0 * M * Co * Ci)
+                dZ = dX
+                break
             if pre is not None and i == 0:
                 # dY0 -> sparse rows (CSR gather with the ReLU+BN backward rebuilt per element), then two small GEMMs
                 assert grad_mode == 1
@@ -605,6 +649,8 @@ class _MLPStack(torch.autograd.Function):
                 dX0 = dX0[:, : X0.shape[1]]
             elif dX0.shape[1] < X0.shape[1]:
                 dX0 = torch.nn.functional.pad(dX0, (0, X0.shape[1] - dX0.shape[1]))
+        if ctx.rep is not None:
+            return (None, dX0, rep_grad) + tuple(grads)
         return (None, dX0) + tuple(grads)
 
 
@@ -619,6 +665,8 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
         bns.append(ly.get("bn"))
     cfg = dict(in_channels=in_channels, n_layers=len(layers), tail=tail, training=training, bns=bns, G=G, ns=ns,
                drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed, xyz_last=xyz_last, pre=pre)
+    if pre is not None and pre["kind"] == "repeat":
+        params = [pre.pop("V")] + params
     out = _MLPStack.apply(cfg, X0, *params)
     if not _DEFER_NBT[0]:
         flush_nbt()

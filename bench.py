@@ -8,6 +8,7 @@ B=32 clouds x 8192 points per GPU, already resident in HBM.  Prints ONE JSON lin
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -22,7 +23,7 @@ PEAK_HBM_GBS = 8000.0
 
 # HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE and
 # WRITE_SIZE need separate passes, so they cannot be read inside the timed run); launch-weighted over the family's kernels.
-_PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01f_pmc_hbm_traffic.json")
+_PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01g_pmc_hbm_traffic.json")
 _PMC_NAME = {"p2c_linear_bwd_fused_f32": "bwd_fused_pp_kernel", "p2c_linear_fwd_f32": "fwd_pp_kernel"}
 
 
@@ -31,7 +32,8 @@ def _pmc_traffic(entry):
         with open(_PMC_FILE) as f:
             ks = json.load(f)["kernels"]
         sub = _PMC_NAME.get(entry)
-        sel = [v for k, v in ks.items() if sub and sub in k]
+        # (the IMODE-2 instantiation "<.., .., .., 2, ...>" belongs to p2c_linear_bwd_fused_fold0_f32, a different entry point)
+        sel = [v for k, v in ks.items() if sub and sub in k and not re.search(r"bwd_fused_pp_kernel<\d+, \d+, \d+, 2,", k)]
         n = sum(v["launches"] for v in sel)
         if not n:
             return None, None

@@ -299,23 +299,43 @@ __global__ void __launch_bounds__(256) three_interp_stats_kernel(const float *__
         bv[i] = (bias && c < C) ? bias[c] : 0.f;
         s1[i] = s2[i] = 0.f;
     }
-    for (int rr = 0; rr < RPW; ++rr) {
-        const long long r = r0 + rr;
-        if (r >= rows) break;
-        const int b = (int)(r / N);
-        const int i0 = idx[r * 3 + 0], i1 = idx[r * 3 + 1], i2 = idx[r * 3 + 2];
-        const float w0 = w[r * 3 + 0], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
-        const float *f0 = feats + ((size_t)b * S + i0) * ldf, *f1 = feats + ((size_t)b * S + i1) * ldf,
-                    *f2 = feats + ((size_t)b * S + i2) * ldf;
-        float *o = out + (size_t)r * ldo;
+    // the 16 rows' neighbour indices and weights in one shot (lane l < 48 holds entry l of the 48), so the row loop below has no
+    // dependent index -> feature load chain and two rows are in flight
+    const long long nleft = rows - r0;
+    int myi = 0; float myw = 0.f;
+    if (lane < 3 * RPW && lane < 3 * nleft) { myi = idx[r0 * 3 + lane]; myw = w[r0 * 3 + lane]; }
+    for (int rr = 0; rr < RPW; rr += 2) {
+        if (r0 + rr >= rows) break;
+        const bool two = r0 + rr + 1 < rows;
+        const float *f[2][3]; float ww[2][3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const long long r = r0 + rr + (two ? u : 0);
+            const int b = (int)(r / N);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int src = 3 * (rr + (two ? u : 0)) + j;
+                f[u][j] = feats + ((size_t)b * S + __shfl(myi, src)) * ldf;
+                ww[u][j] = __shfl(myw, src);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = lane + 64 * i;
             if (c < C) {
-                const float v = (f0[c] * w0 + f1[c] * w1) + f2[c] * w2;
-                s1[i] += v;
-                s2[i] += v * v;
-                o[c] = v + bv[i];
+                float a[2][3];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) a[u][j] = f[u][j][c];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !two) break;
+                    const float v = (a[u][0] * ww[u][0] + a[u][1] * ww[u][1]) + a[u][2] * ww[u][2];
+                    s1[i] += v;
+                    s2[i] += v * v;
+                    out[(size_t)(r0 + rr + u) * ldo + c] = v + bv[i];
+                }
             }
         }
     }
@@ -452,24 +472,40 @@ __global__ void __launch_bounds__(256) group_linear_stats_kernel(const float *__
         wx0[i] = Wx[c * 4 + 0]; wx1[i] = Wx[c * 4 + 1]; wx2[i] = Wx[c * 4 + 2];
         s1[i] = s2[i] = 0.f;
     }
-    for (int rr = 0; rr < RPW; ++rr) {
-        const long long r = r0 + rr;
-        if (r >= rows) break;
-        const long long grp = r / ns;                     // (b, s)
-        const int b = (int)(grp / S);
-        const int p = idx[r];
+    // lane l < 16 resolves row r0 + l (source point, relative coordinates) so the row loop has no dependent load chain
+    long long myrow = 0; float mdx = 0.f, mdy = 0.f, mdz = 0.f;
+    if (lane < RPW && r0 + lane < rows) {
+        const long long r = r0 + lane, grp = r / ns;
+        const int b = (int)(grp / S), p = idx[r];
         const float *pp = xyz + ((size_t)b * N + p) * 3, *cc = new_xyz + (size_t)grp * 3;
-        const float dx = pp[0] - cc[0], dy = pp[1] - cc[1], dz = pp[2] - cc[2];
-        const float *g = Gf + ((size_t)b * N + p) * ldg;
-        float *o = out + (size_t)r * ldo;
+        mdx = pp[0] - cc[0]; mdy = pp[1] - cc[1]; mdz = pp[2] - cc[2];
+        myrow = (long long)b * N + p;
+    }
+    for (int rr = 0; rr < RPW; rr += 2) {
+        if (r0 + rr >= rows) break;
+        const bool two = r0 + rr + 1 < rows;
+        const float *g[2]; float dx[2], dy[2], dz[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int src = rr + (two ? u : 0);
+            g[u] = Gf + (size_t)__shfl(myrow, src) * ldg;
+            dx[u] = __shfl(mdx, src); dy[u] = __shfl(mdy, src); dz[u] = __shfl(mdz, src);
+        }
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = lane + 64 * i;
             if (c < C) {
-                const float v = g[c] + __builtin_fmaf(wx2[i], dz, __builtin_fmaf(wx1[i], dy, wx0[i] * dx));
-                s1[i] += v;
-                s2[i] += v * v;
-                o[c] = v + bv[i];
+                float gv[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) gv[u] = g[u][c];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !two) break;
+                    const float v = gv[u] + __builtin_fmaf(wx2[i], dz[u], __builtin_fmaf(wx1[i], dy[u], wx0[i] * dx[u]));
+                    s1[i] += v;
+                    s2[i] += v * v;
+                    out[(size_t)(r0 + rr + u) * ldo + c] = v + bv[i];
+                }
             }
         }
     }

@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(256) csr_gather_bn_kernel(const float *__restr
         acc[i] = 0.f;
         csc[i] = coef[c]; csh[i] = coef[C + c]; cgs[i] = coef[2 * C + c]; cq[i] = coef[3 * C + c]; cp[i] = coef[4 * C + c];
     }
-    constexpr int UB = 4;
+    constexpr int UB = 8;                         // (dz, y) row pairs in flight per lane
     int k = k0;
     for (; k + UB <= k1; k += UB) {
         float we[UB]; size_t ro[UB];

@@ -405,6 +405,14 @@ static int tile_m()
     return v;
 }
 extern "C" int p2c_linear_tile_m(void) { return tile_m(); }
+// Small problems (the SA3 / FP3 / FP2 layers: 4 k - 16 k rows): with 64 x 128 tiles the grid has fewer workgroups than the chip has
+// CUs, one workgroup per CU cannot hide the operand latency behind its own MFMAs, and the kernel runs at 15-40 TFLOP/s.  64 x 64
+// tiles double the number of workgroups (twice the loads in flight per CU) at the price of one more LDS read per MFMA.
+static bool narrow_tiles(int rows, int cols)
+{
+    static const int thr = getenv("P2C_GEMM_NARROW") ? atoi(getenv("P2C_GEMM_NARROW")) : 512;
+    return (long long)p2c_cdiv(rows, 64) * p2c_cdiv(cols, 128) < thr;
+}
 extern "C" int p2c_linear_stat_tiles(int M) { return (M + tile_m() - 1) / tile_m(); }
 
 // ---- forward --------------------------------------------------------------------------------------
@@ -421,7 +429,7 @@ static int launch_fwd(const float *X, int ldx, const float *W, int ldw, const fl
     hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, true, OpActIn<MODE>, OpPlain, EpiFwd>), dim3(p2c_cdiv(M, 64 * TM_), p2c_cdiv(N, 64 * TN_), 1), \
                        dim3(256), 0, s, a, b, e, M, N, K, kps)
     if (tile_m() == 128) { if (N > 64) P2C_FW(2, 2); else P2C_FW(2, 1); }
-    else { if (N > 64) P2C_FW(1, 2); else P2C_FW(1, 1); }
+    else { if (N > 64 && !narrow_tiles(M, N)) P2C_FW(1, 2); else P2C_FW(1, 1); }
 #undef P2C_FW
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -502,7 +510,7 @@ static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy
     hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, false, OpGrad<GMODE>, OpPlain, EpiBwdData>),                                    \
                        dim3(p2c_cdiv(M, 64 * TM_), p2c_cdiv(K, 64 * TN_), 1), dim3(256), 0, s, a, b, e, M, K, N, kps)
     if (tile_m() == 128) { if (K > 64) P2C_BDL(2, 2); else P2C_BDL(2, 1); }
-    else { if (K > 64) P2C_BDL(1, 2); else P2C_BDL(1, 1); }
+    else { if (K > 64 && !narrow_tiles(M, K)) P2C_BDL(1, 2); else P2C_BDL(1, 1); }
 #undef P2C_BDL
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -544,9 +552,14 @@ static int launch_bwd_weight(const float *dZ, int lddz, const float *Yfwd, int l
     EpiAtomic e{dW, lddw, dbias, slot_stride};
     const int ti = N > 64 ? p2c_cdiv(N, 128) : 1, tj = K > 64 ? p2c_cdiv(K, 128) : 1;
     const int ktiles = (M + GK - 1) / GK;
-    int splits = 2048 / (ti * tj);
+    // workgroups = tiles x splits.  Long reductions (the 262 k / 1 M-row layers): ~2048 workgroups of >= 8 k-tiles.  Short ones
+    // (4 k - 16 k rows): the atomic epilogue (one 128 x 128 tile per workgroup) is no longer small against the main loop, so aim at
+    // ~512 workgroups, but of >= 4 k-tiles only (measured on the SA3 / FP3 / FP2 shapes, tools/gemm_bench.py).
+    const bool longk = ktiles >= 2048;
+    int splits = (longk ? 2048 : 512) / (ti * tj);
     if (splits < 1) splits = 1;
-    if (splits > (ktiles + 7) / 8) splits = (ktiles + 7) / 8;
+    const int mink = longk ? 8 : 4;
+    if (splits > (ktiles + mink - 1) / mink) splits = (ktiles + mink - 1) / mink;
     const int kps = (ktiles + splits - 1) / splits * GK;
     splits = (M + kps - 1) / kps;
     dim3 grid(ti, tj, (unsigned)splits);

@@ -12,6 +12,10 @@ SHAPES = [  # name, M, K, N
     ("sa3.2", 4096, 512, 1024), ("fp3.0", 4096, 1280, 256), ("fp2.0", 16384, 384, 256),
     ("fp1.x", 262144, 128, 128), ("heads", 262144, 128, 20),
 ]
+SMALL = [("sa3.0", 4096, 260, 256), ("sa3.1", 4096, 256, 512), ("sa3.2", 4096, 512, 1024), ("fp3.v", 32, 1024, 256), ("fp3.1", 4096, 256, 256),
+         ("fp2.0", 16384, 384, 256), ("fp2.1", 16384, 256, 128), ("fp1.p", 16384, 128, 128)]
+if os.environ.get("GEMM_BENCH_SMALL"):
+    SHAPES = SMALL
 
 
 def timeit(fn, n=10):

@@ -307,6 +307,17 @@ int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, const int64_t 
                               const int64_t *rand_idx, int B, int N, int K, int S, float *extents_out, float *found_out,
                               void *ws, void *stream);
 
+/* sketch_implicit_projection / sketch_implicit_projection2 (data_utils.py:1014-1146, :1149-1282) and, with all_points = 1
+ * (S == N, seg / bb / rand_idx unused), sketch_implicit_projection3 (:1284-1417): the S sampled barrel points and normals
+ * of every segment, turned by the matrix that takes the segment's axis onto z (the reference's construction through
+ * torchgeometry's angle_axis_to_rotation_matrix, restated), x and y kept, points centred on the turned centre.
+ * rand_idx [B,K,S] int64 = the reference's torch.randint(0, n_barrel(b,k), (S,)) draws (:1064), made by the caller.
+ * P_proj, X_proj [K,B,S,2] (8-byte aligned), scales_out [K,B] (largest radius; 1 where not found), found_out [B,K].
+ * ws: p2c_extents_ws_bytes(B,K) bytes. */
+int p2c_sketch_projection_f32(const float *P, const float *X, const int64_t *seg, const int64_t *bb, const float *axes,
+                              const float *centers, const int64_t *rand_idx, int B, int N, int K, int S, int all_points,
+                              float *P_proj, float *X_proj, float *scales_out, float *found_out, void *ws, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Hungarian matching on the device (losses.py:22-52; scipy.optimize.linear_sum_assignment restated)
  * W [B,N,K] soft or hard segmentation, I_gt [B,N] int64 (may contain -1).  match_out [B,K] int64,

@@ -407,3 +407,89 @@ def get_extrusion_extents(P, seg, bb, axes, centers, rand_idx):
             t = ((pts - centers[b, k]) * axes[b, k]).sum(-1)   # bmm (1x3)(3x1) :1712
             ext[k, b, 0], ext[k, b, 1] = t.min(), t.max()
     return ext, found
+
+
+# --------------------------------------------------------------------------- sketch branch
+def angle_axis_to_rotation_matrix(angle_axis, eps=1e-6):
+    """torchgeometry==0.1.2 `angle_axis_to_rotation_matrix` (requirements.txt; call site data_utils.py:1101), which is NOT
+    installed here and not vendored in the reference: PARITY UNPINNED at this boundary.  This restates its published
+    algorithm: Rodrigues' formula with the axis normalised as aa / (theta + eps) where theta^2 = aa.aa > eps, and the
+    first-order form I + [aa]x otherwise.  (N,3) -> (N,3,3) (the 3x3 block the reference keeps of the 4x4 result)."""
+    aa = angle_axis
+    theta2 = (aa * aa).sum(-1, keepdim=True)
+    theta = torch.sqrt(theta2)
+    w = aa / (theta + eps)
+    wx, wy, wz = w[:, 0:1], w[:, 1:2], w[:, 2:3]
+    c, s = torch.cos(theta), torch.sin(theta)
+    one = 1.0
+    R = torch.cat([c + wx * wx * (one - c), wx * wy * (one - c) - wz * s, wy * s + wx * wz * (one - c),
+                   wz * s + wx * wy * (one - c), c + wy * wy * (one - c), -wx * s + wy * wz * (one - c),
+                   -wy * s + wx * wz * (one - c), wx * s + wy * wz * (one - c), c + wz * wz * (one - c)], 1).view(-1, 3, 3)
+    rx, ry, rz = aa[:, 0:1], aa[:, 1:2], aa[:, 2:3]
+    k1 = torch.ones_like(rx)
+    T = torch.cat([k1, -rz, ry, rz, k1, -rx, -ry, rx, k1], 1).view(-1, 3, 3)
+    return torch.where((theta2 > eps).view(-1, 1, 1), R, T)
+
+
+def axis_to_z_rotation(ax):
+    """data_utils.py:1086-1103: the matrix the reference builds to turn axis `ax` (B,3) onto z.  The rotation vector is
+    cross(ax, z) * acos(ax.z) with the cross product NOT normalised (so its length is angle*sin(angle), not angle) - kept."""
+    B = ax.shape[0]
+    z = torch.tensor([0.0, 0.0, 1.0]).expand(B, 3)
+    ang = torch.acos((ax * z).sum(-1))
+    R = torch.eye(3).repeat(B, 1, 1)
+    for a in range(B):
+        if ang[a] > G_ZERO_TOL:                                   # NaN (|ax.z| > 1) compares False: identity
+            R[a] = angle_axis_to_rotation_matrix((torch.linalg.cross(ax[a], z[a]) * ang[a]).unsqueeze(0))[0]
+    return R
+
+
+def sketch_implicit_projection(P, X, seg, bb, axes, centers, rand_idx, S, all_points=False):
+    """data_utils.py:1014-1146 (and :1149 = the same + the found mask, :1284 = all points of the cloud for every segment,
+    no sampling).  rand_idx[(k,b)] is the torch.randint draw of :1064 (indices into the ascending list of barrel points of
+    segment k in cloud b).  -> P_projected (K,B,S,2), X_projected (K,B,S,2), scales (K,B), found (B,K).
+    Kept quirks: a segment with <= 1 barrel point in the WHOLE batch is skipped (outputs zero, scale 1) :1043; a cloud with
+    <= 1 barrel point of the segment keeps zero samples, which still go through the projection and the centring (so its
+    rows are -centroid_projected) and get scale 1 :1054, :1131, :1143."""
+    B, K, _ = axes.shape
+    Pp, Xp = torch.zeros(K, B, S, 2), torch.zeros(K, B, S, 2)
+    found, scales = torch.zeros(B, K), torch.ones(K, B)
+    member = torch.ones(B, P.shape[1], K, dtype=torch.bool) if all_points else (F.one_hot(seg, K).bool() & (bb == 0).unsqueeze(-1))
+    for k in range(K):
+        if int(member[:, :, k].sum()) <= 1:
+            continue
+        pts, nrm = torch.zeros(B, S, 3), torch.zeros(B, S, 3)
+        for b in range(B):
+            ids = member[b, :, k].nonzero().flatten()
+            if ids.numel() <= 1:
+                continue
+            sel = ids if all_points else ids[rand_idx[(k, b)]]
+            pts[b], nrm[b] = P[b][sel], X[b][sel]
+            found[b, k] = 1.0
+        R = axis_to_z_rotation(axes[:, k])
+        q = torch.bmm(pts, R)[:, :, :2]                           # row vector times matrix :1110
+        xq = torch.bmm(nrm, R)[:, :, :2]
+        q = q - torch.bmm(centers[:, k].unsqueeze(1), R)[:, :, :2]
+        scales[k] = (q.abs() ** 2).sum(-1).sqrt().max(-1)[0]
+        Pp[k], Xp[k] = q, xq
+    scales = torch.where(found.T == 1, scales, torch.ones(()))
+    return Pp, Xp, scales, found
+
+
+PN_ENCODER_LAYERS = (("mlp1.0", "mlp1.1"), ("mlp1.3", "mlp1.4"), ("mlp2.0", "mlp2.1"), ("mlp2.3", "mlp2.4"), ("mlp2.6", "mlp2.7"))
+
+
+def pointnet_encoder_forward(sd, x, training=True, momentum=0.1):
+    """IGR/network.py:132-174: x (B', S, C>=input_channels) -> unit-norm latent codes (B', E).  sd = its state_dict
+    (mlp1.{0,3} / mlp2.{0,3,6} Conv1d, the BatchNorm1d after each, fc); running stats are updated in place when training."""
+    cin = sd["mlp1.0.weight"].shape[1]
+    h = x[:, :, :cin].transpose(2, 1)
+    for c, b in PN_ENCODER_LAYERS:
+        h = F.conv1d(h, sd[c + ".weight"], sd[c + ".bias"])
+        h = F.batch_norm(h, sd[b + ".running_mean"], sd[b + ".running_var"], sd[b + ".weight"], sd[b + ".bias"], training, momentum, 1e-5)
+        if training:
+            sd[b + ".num_batches_tracked"] += 1
+        h = F.relu(h)
+    h = h.max(dim=2)[0]                                           # F.max_pool1d over all points :170
+    h = F.linear(h, sd["fc.weight"], sd["fc.bias"])
+    return F.normalize(h)

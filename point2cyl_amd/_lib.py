@@ -62,6 +62,7 @@ _SIGS = {
     "p2c_extrusion_centers_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "p2c_segment_centroids_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "p2c_extrusion_extents_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+    "p2c_sketch_projection_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_hungarian_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "p2c_hungarian_logits_f32": [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_seg_losses_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],

@@ -306,19 +306,13 @@ extern "C" int p2c_extrusion_centers_bwd_f32(const float *dcenters, const float 
 #define EXT_WAVES (EXT_THREADS / 64)
 #define EXT_MAXCH 8                       // 64-point chunks a wave keeps in registers per sweep: N <= EXT_WAVES*64*EXT_MAXCH per sweep
 
-__global__ void __launch_bounds__(EXT_THREADS) extents_kernel(const float *__restrict__ P, const int64_t *__restrict__ seg,
-                                                              const int64_t *__restrict__ bb, const float *__restrict__ axes,
-                                                              const float *__restrict__ centers, const int64_t *__restrict__ rand_idx, int N, int K,
-                                                              int S, float *__restrict__ ext_tmp, int *__restrict__ counts)
+// passes 1-2 of both kernels below: the K ascending lists of barrel points of cloud b -> list[start[k] .. start[k+1])
+__device__ __forceinline__ void ext_build_lists(const int64_t *__restrict__ sg, const int64_t *__restrict__ bl, int N, int K, int *list,
+                                                int (*wcnt)[FIT_MAXK], int *start)
 {
-    extern __shared__ int list[];                       // N ints, partitioned by segment
-    __shared__ int wcnt[EXT_WAVES][FIT_MAXK];           // barrel points of segment k in wave w's range
-    __shared__ int start[FIT_MAXK + 1];
-    __shared__ float rmin[EXT_WAVES], rmax[EXT_WAVES];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = ((N + EXT_WAVES - 1) / EXT_WAVES + 63) / 64 * 64;     // points per wave, a multiple of 64
     const int n_begin = wave * per, n_end = min(N, n_begin + per);
-    const int64_t *sg = seg + (size_t)b * N, *bl = bb + (size_t)b * N;
     // pass 1: key of every point of this wave's range (-1 = not a barrel point of any segment); per-segment counts
     int key[EXT_MAXCH];
     int cntk[FIT_MAXK];
@@ -388,6 +382,19 @@ __global__ void __launch_bounds__(EXT_THREADS) extents_kernel(const float *__res
         }
     }
     __syncthreads();
+}
+
+__global__ void __launch_bounds__(EXT_THREADS) extents_kernel(const float *__restrict__ P, const int64_t *__restrict__ seg,
+                                                              const int64_t *__restrict__ bb, const float *__restrict__ axes,
+                                                              const float *__restrict__ centers, const int64_t *__restrict__ rand_idx, int N, int K,
+                                                              int S, float *__restrict__ ext_tmp, int *__restrict__ counts)
+{
+    extern __shared__ int list[];                       // N ints, partitioned by segment
+    __shared__ int wcnt[EXT_WAVES][FIT_MAXK];           // barrel points of segment k in wave w's range
+    __shared__ int start[FIT_MAXK + 1];
+    __shared__ float rmin[EXT_WAVES], rmax[EXT_WAVES];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ext_build_lists(seg + (size_t)b * N, bb + (size_t)b * N, N, K, list, wcnt, start);
     // pass 3: project the samples of every segment
     for (int k = 0; k < K; ++k) {
         const int cnt = start[k + 1] - start[k];
@@ -455,6 +462,133 @@ extern "C" int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, con
     (void)hipFuncSetAttribute((const void *)extents_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(extents_kernel, dim3(B), dim3(EXT_THREADS), lds, s, P, seg, bb, axes, centers, rand_idx, N, K, S, ext_tmp, counts);
     hipLaunchKernelGGL(extents_finish_kernel, dim3(K), dim3(256), 0, s, ext_tmp, counts, B, K, extents_out, found_out);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sketch projection (data_utils.py:1014-1146; :1149 = the same + found mask; :1284 = every point of the cloud for every
+// segment, no sampling -> all_points).  Same structure as the extents: one workgroup per cloud builds the barrel lists,
+// then per segment turns the S sampled points AND normals by the matrix that takes the segment's axis onto z, keeps x, y,
+// subtracts the turned centre from the points and takes the largest radius (the sketch's scale).
+//   * the matrix is the reference's: rotation vector cross(axis, z) * acos(axis.z) - the cross product is NOT normalised
+//     there, so its length is angle*sin(angle); kept - through torchgeometry 0.1.2's angle_axis_to_rotation_matrix
+//     (not installed anywhere here: its published algorithm is restated, Rodrigues with axis aa/(|aa| + 1e-6), first-order
+//     form for |aa|^2 <= 1e-6; parity unpinned at that boundary, see oracle/ref_torch.py);
+//   * points are ROW vectors times the matrix (:1110);
+//   * a cloud with <= 1 barrel point of the segment keeps zero samples that still go through the centring (rows =
+//     -centre_turned, :1054 + :1131) and gets scale 1 (:1143); a segment with <= 1 barrel point in the whole batch is
+//     skipped: zeros, scale 1 (:1043) - applied by the finish kernel.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sketch_axis_rotation(float ax, float ay, float az, float (&R)[3][3])
+{
+    R[0][0] = 1.f; R[0][1] = 0.f; R[0][2] = 0.f; R[1][0] = 0.f; R[1][1] = 1.f; R[1][2] = 0.f; R[2][0] = 0.f; R[2][1] = 0.f; R[2][2] = 1.f;
+    const float ang = acosf(az);
+    if (!(ang > 1.0e-6f)) return;                      // g_zero_tol; NaN compares false: identity
+    const float rx = ay * ang, ry = -ax * ang, rz = 0.f;       // cross((ax,ay,az), (0,0,1)) * angle
+    const float th2 = rx * rx + ry * ry + rz * rz;
+    if (th2 > 1.0e-6f) {
+        const float th = sqrtf(th2), inv = 1.f / (th + 1.0e-6f);
+        const float wx = rx * inv, wy = ry * inv, wz = rz * inv, c = cosf(th), s = sinf(th), oc = 1.f - c;
+        R[0][0] = c + wx * wx * oc;      R[0][1] = wx * wy * oc - wz * s; R[0][2] = wy * s + wx * wz * oc;
+        R[1][0] = wz * s + wx * wy * oc; R[1][1] = c + wy * wy * oc;      R[1][2] = -wx * s + wy * wz * oc;
+        R[2][0] = -wy * s + wx * wz * oc; R[2][1] = wx * s + wy * wz * oc; R[2][2] = c + wz * wz * oc;
+    } else {
+        R[0][1] = -rz; R[0][2] = ry; R[1][0] = rz; R[1][2] = -rx; R[2][0] = -ry; R[2][1] = rx;
+    }
+}
+
+__global__ void __launch_bounds__(EXT_THREADS) sketch_project_kernel(const float *__restrict__ P, const float *__restrict__ X,
+                                                                     const int64_t *__restrict__ seg, const int64_t *__restrict__ bb,
+                                                                     const float *__restrict__ axes, const float *__restrict__ centers,
+                                                                     const int64_t *__restrict__ rand_idx, int B, int N, int K, int S, int all_points,
+                                                                     float *__restrict__ Pp, float *__restrict__ Xp, float *__restrict__ scale_tmp,
+                                                                     int *__restrict__ counts)
+{
+    extern __shared__ int list[];                       // N ints, partitioned by segment
+    __shared__ int wcnt[EXT_WAVES][FIT_MAXK];
+    __shared__ int start[FIT_MAXK + 1];
+    __shared__ float rmax[EXT_WAVES];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!all_points) ext_build_lists(seg + (size_t)b * N, bb + (size_t)b * N, N, K, list, wcnt, start);
+    for (int k = 0; k < K; ++k) {
+        const int cnt = all_points ? N : start[k + 1] - start[k];
+        const float *a = axes + ((size_t)b * K + k) * 3, *c = centers + ((size_t)b * K + k) * 3;
+        float R[3][3];
+        sketch_axis_rotation(a[0], a[1], a[2], R);
+        const float c0 = c[0], c1 = c[1], c2 = c[2];
+        const float cqx = c0 * R[0][0] + c1 * R[1][0] + c2 * R[2][0], cqy = c0 * R[0][1] + c1 * R[1][1] + c2 * R[2][1];
+        const int64_t *ri = rand_idx ? rand_idx + ((size_t)b * K + k) * S : nullptr;
+        const int *lk = list + (all_points ? 0 : start[k]);
+        float2 *po = reinterpret_cast<float2 *>(Pp) + ((size_t)k * B + b) * S, *xo = reinterpret_cast<float2 *>(Xp) + ((size_t)k * B + b) * S;
+        float r2max = 0.f;
+        for (int s = tid; s < S; s += EXT_THREADS) {
+            float px = 0.f, py = 0.f, pz = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+            if (cnt > 1) {
+                const int n = all_points ? s : lk[(int)ri[s]];
+                const float *pp = P + ((size_t)b * N + n) * 3, *xx = X + ((size_t)b * N + n) * 3;
+                px = pp[0]; py = pp[1]; pz = pp[2];
+                nx = xx[0]; ny = xx[1]; nz = xx[2];
+            }
+            const float qx = (px * R[0][0] + py * R[1][0] + pz * R[2][0]) - cqx, qy = (px * R[0][1] + py * R[1][1] + pz * R[2][1]) - cqy;
+            po[s] = make_float2(qx, qy);
+            xo[s] = make_float2(nx * R[0][0] + ny * R[1][0] + nz * R[2][0], nx * R[0][1] + ny * R[1][1] + nz * R[2][1]);
+            r2max = fmaxf(r2max, qx * qx + qy * qy);
+        }
+        for (int o = 32; o > 0; o >>= 1) r2max = fmaxf(r2max, __shfl_xor(r2max, o));
+        if (lane == 0) rmax[wave] = r2max;
+        __syncthreads();
+        if (tid == 0) {
+            float m = rmax[0];
+            for (int w = 1; w < EXT_WAVES; ++w) m = fmaxf(m, rmax[w]);
+            scale_tmp[(size_t)b * K + k] = sqrtf(m);
+            counts[b * K + k] = cnt;
+        }
+        __syncthreads();
+    }
+}
+
+// one workgroup per segment k: the batch-wide rule (:1043) and the scale / found conventions (:1143)
+__global__ void __launch_bounds__(256) sketch_finish_kernel(const float *__restrict__ scale_tmp, const int *__restrict__ counts, int B, int K, int S,
+                                                            float *__restrict__ Pp, float *__restrict__ Xp, float *__restrict__ scales,
+                                                            float *__restrict__ found)
+{
+    __shared__ long long part[4];
+    const int k = blockIdx.x, tid = threadIdx.x;
+    long long t = 0;
+    for (int b = tid; b < B; b += 256) t += counts[b * K + k];
+    for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+    if ((tid & 63) == 0) part[tid >> 6] = t;
+    __syncthreads();
+    const bool seg_ok = part[0] + part[1] + part[2] + part[3] > 1;
+    for (int b = tid; b < B; b += 256) {
+        const bool f = seg_ok && counts[b * K + k] > 1;
+        scales[(size_t)k * B + b] = f ? scale_tmp[(size_t)b * K + k] : 1.f;
+        found[(size_t)b * K + k] = f ? 1.f : 0.f;
+    }
+    if (!seg_ok) {
+        const size_t n = (size_t)B * S * 2, o = (size_t)k * n;
+        for (size_t i = tid; i < n; i += 256) { Pp[o + i] = 0.f; Xp[o + i] = 0.f; }
+    }
+}
+
+extern "C" int p2c_sketch_projection_f32(const float *P, const float *X, const int64_t *seg, const int64_t *bb, const float *axes,
+                                         const float *centers, const int64_t *rand_idx, int B, int N, int K, int S, int all_points,
+                                         float *P_proj, float *X_proj, float *scales_out, float *found_out, void *ws, void *stream)
+{
+    if (!P || !X || !axes || !centers || !P_proj || !X_proj || !scales_out || !found_out || !ws || B <= 0 || N <= 0 || N > EXT_MAXN || K <= 0 ||
+        K > FIT_MAXK || S <= 0)
+        return P2C_EINVAL;
+    if (all_points ? S != N : (!seg || !bb || !rand_idx)) return P2C_EINVAL;
+    if (((uintptr_t)P_proj & 7) || ((uintptr_t)X_proj & 7)) return P2C_EALIGN;
+    float *scale_tmp = (float *)ws;
+    int *counts = (int *)(scale_tmp + (size_t)B * K * 2);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)N * sizeof(int);
+    (void)hipFuncSetAttribute((const void *)sketch_project_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(sketch_project_kernel, dim3(B), dim3(EXT_THREADS), lds, s, P, X, seg, bb, axes, centers, rand_idx, B, N, K, S, all_points,
+                       P_proj, X_proj, scale_tmp, counts);
+    hipLaunchKernelGGL(sketch_finish_kernel, dim3(K), dim3(256), 0, s, scale_tmp, counts, B, K, S, P_proj, X_proj, scales_out, found_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

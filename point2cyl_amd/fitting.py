@@ -46,14 +46,44 @@ def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_cen
     B, K, _ = extrusion_axes.shape
     S = num_points_to_sample
     if rand_idx is None:
-        barrel = (seg_label.unsqueeze(-1) == torch.arange(K, device=seg_label.device)) & (bb_labels == 0).unsqueeze(-1)
-        counts = barrel.sum(dim=1).cpu()                 # (B,K): the reference syncs K*B times here
-        rand_idx = torch.zeros(B, K, S, dtype=torch.int64)
-        for k in range(K):
-            if int(counts[:, k].sum()) <= 1:
-                continue
-            for b in range(B):
-                if int(counts[b, k]) <= 1:
-                    continue
-                rand_idx[b, k] = torch.randint(0, int(counts[b, k]), (S,))
+        rand_idx = _barrel_draws(seg_label, bb_labels, K, S)
     return ops.extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, rand_idx.to(P.device))
+
+
+def _barrel_draws(seg_label, bb_labels, K, S):
+    """The reference's torch.randint draws for its K x B sampling loops (data_utils.py:1064, :1696): k outer, b inner, only
+    where the segment has > 1 barrel point in the batch and in the cloud, on the CPU generator."""
+    B = seg_label.shape[0]
+    barrel = (seg_label.unsqueeze(-1) == torch.arange(K, device=seg_label.device)) & (bb_labels == 0).unsqueeze(-1)
+    counts = barrel.sum(dim=1).cpu()                     # (B,K): ONE sync; the reference syncs K*B times here
+    rand_idx = torch.zeros(B, K, S, dtype=torch.int64)
+    for k in range(K):
+        if int(counts[:, k].sum()) <= 1:
+            continue
+        for b in range(B):
+            if int(counts[b, k]) <= 1:
+                continue
+            rand_idx[b, k] = torch.randint(0, int(counts[b, k]), (S,))
+    return rand_idx
+
+
+def sketch_implicit_projection(P, X, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample=1024, rand_idx=None):
+    """data_utils.py:1014-1146 -> P_projected (K,B,S,2), X_projected (K,B,S,2), scales (K,B).  The barrel samples are drawn
+    like the reference draws them (same generator, same order) unless `rand_idx` (B,K,S) is given."""
+    return sketch_implicit_projection2(P, X, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample, rand_idx)[:3]
+
+
+def sketch_implicit_projection2(P, X, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample=1024, rand_idx=None):
+    """data_utils.py:1149-1282: the same + found_centers_mask (B,K)."""
+    K, S = extrusion_axes.shape[1], num_points_to_sample
+    if rand_idx is None:
+        rand_idx = _barrel_draws(seg_label, bb_labels, K, S)
+    return ops.sketch_projection(P, X, seg_label, bb_labels, extrusion_axes, extrusion_centers, rand_idx.to(P.device), S)
+
+
+def sketch_implicit_projection3(P, X, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample=8192):
+    """data_utils.py:1284-1417: every point of the cloud for every segment (labels unused there as well: its mask is all ones,
+    :1294), no sampling; num_points_to_sample must equal N as in the reference (its buffers are that size)."""
+    if num_points_to_sample != P.shape[1]:
+        raise ValueError("sketch_implicit_projection3 takes all N points: num_points_to_sample must be N (data_utils.py:1306-1336)")
+    return ops.sketch_projection(P, X, None, None, extrusion_axes, extrusion_centers, None, P.shape[1], all_points=True)

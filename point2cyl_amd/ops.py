@@ -298,7 +298,7 @@ class _MLPStack(torch.autograd.Function):
             arena = _ZeroArena(sum(STAT_SLOTS * 2 * c for c in widths) + 16, dev)
         # Folded first layer (csrc/bn.hip): 3 input channels (+pad), 64 outputs, train mode, no gradient wanted for the input,
         # a BatchNorm'ed middle layer of 64/128 channels next: Y_0 is never written; layer 1 rebuilds it from the input rows.
-        fold0 = (USE_FOLD0 and pre is None and training and K == 4 and ldx0 == 4 and M >= 8192 and not X0.requires_grad and mask is None and seed is None
+        fold0 = (USE_FOLD0 and pre is None and training and K == 4 and cfg["in_channels"] <= 3 and ldx0 == 4 and M >= 8192 and not X0.requires_grad and mask is None and seed is None
                  and (L >= 3 or (L == 2 and tail == "bnrelu")) and params[0].shape[0] == 64 and params[4].shape[0] in (64, 128)
                  and bns[0] is not None and bns[1] is not None)
         mom = None
@@ -759,6 +759,30 @@ def extrusion_extents(P, seg, bb, axes, centers, rand_idx):
     call("p2c_extrusion_extents_f32", ptr(P), ptr(seg), ptr(bb), ptr(axes), ptr(centers), ptr(rand_idx), B, N, K, S, ptr(ext),
          ptr(found), ptr(ws), stream())
     return ext, found
+
+
+def sketch_projection(P, X, seg, bb, axes, centers, rand_idx, S, all_points=False):
+    """data_utils.py:1014-1417 (csrc/fit.hip).  rand_idx (B,K,S) int64 or None with all_points ->
+    P_projected (K,B,S,2), X_projected (K,B,S,2), scales (K,B), found (B,K).  No gradient (the reference's projection is built
+    from index gathers of detached samples as well: its callers only backpropagate through what consumes the sketch)."""
+    _lib.require_device(P, X, axes, centers)
+    P, X, axes, centers = _f32c(P.detach()), _f32c(X.detach()), _f32c(axes.detach()), _f32c(centers.detach())
+    B, N, _ = P.shape
+    K = axes.shape[1]
+    if all_points:
+        S, seg_, bb_, ri = N, None, None, None
+    else:
+        _lib.require_device(seg, bb, rand_idx)
+        seg_, bb_, ri = seg.to(torch.int64).contiguous(), bb.to(torch.int64).contiguous(), rand_idx.to(torch.int64).contiguous()
+        assert tuple(ri.shape) == (B, K, S)
+    Pp = torch.empty(K, B, S, 2, dtype=torch.float32, device=P.device)
+    Xp = torch.empty(K, B, S, 2, dtype=torch.float32, device=P.device)
+    scales = torch.empty(K, B, dtype=torch.float32, device=P.device)
+    found = torch.empty(B, K, dtype=torch.float32, device=P.device)
+    ws = torch.empty(_lib.lib().p2c_extents_ws_bytes(B, K) // 4 + 4, dtype=torch.float32, device=P.device)
+    call("p2c_sketch_projection_f32", ptr(P), ptr(X), ptr(seg_), ptr(bb_), ptr(axes), ptr(centers), ptr(ri), B, N, K, S, int(all_points),
+         ptr(Pp), ptr(Xp), ptr(scales), ptr(found), ptr(ws), stream(), nbytes=float(B * K * S * (24 + 16)))
+    return Pp, Xp, scales, found
 
 
 def hungarian(W, I_gt):

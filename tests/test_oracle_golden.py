@@ -182,3 +182,45 @@ def test_train_step_forward_losses():
     assert np.array_equal(W.argmax(-1).numpy(), g["label"])
     np.testing.assert_allclose([(total + bbl).item(), nl.item(), ml.item(), bbl.item()],
                                [g["total"], g["normal_loss"], g["miou_loss"], g["bb_loss"]], rtol=2e-5)
+
+
+def _sketch_draws(g):
+    return {tuple(k): t(r) for k, r in zip(g["rand_keys"].tolist(), g["rand_idx"])}
+
+
+def test_sketch_projection():
+    """G10: sketch_implicit_projection / 2 / 3 (data_utils.py:1014-1417) with the captured randint draws."""
+    g = load_golden("g10_sketch")
+    args = [t(g[k]) for k in ("pcs", "normals", "seg", "bb", "axes", "centers")]
+    Pp, Xp, sc, found = R.sketch_implicit_projection(*args, _sketch_draws(g), int(g["S"]))
+    assert np.array_equal(found.numpy(), g["found"])
+    assert (g["found"] == 0).any(), "not-found path not exercised"
+    np.testing.assert_allclose(Pp.numpy(), g["P_proj"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(Xp.numpy(), g["X_proj"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sc.numpy(), g["scales"], rtol=1e-5, atol=1e-6)
+    P3, X3, sc3, found3 = R.sketch_implicit_projection(*args, None, args[0].shape[1], all_points=True)
+    assert np.array_equal(found3.numpy(), g["found3"])
+    np.testing.assert_allclose(P3.numpy(), g["P_proj3"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(X3.numpy(), g["X_proj3"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sc3.numpy(), g["scales3"], rtol=1e-5, atol=1e-6)
+
+
+def test_pointnet_encoder():
+    """G10: PointNetEncoder (IGR/network.py:132-174) forward, input / parameter gradients, BatchNorm running stats."""
+    g = load_golden("g10_sketch")
+    sd = {str(n): t(g["enc_sd:" + str(n)]).clone() for n in g["enc_names"]}
+    for k in sd:
+        if sd[k].dtype == torch.float32 and not k.endswith(("running_mean", "running_var")):
+            sd[k].requires_grad_(True)
+    x = t(g["enc_x"]).clone().requires_grad_(True)
+    z = R.pointnet_encoder_forward(sd, x, training=True)
+    np.testing.assert_allclose(z.detach().numpy(), g["enc_z"], rtol=1e-4, atol=1e-6)
+    loss = ((z - t(g["enc_tgt"])) ** 2).sum()
+    loss.backward()
+    np.testing.assert_allclose(loss.item(), g["enc_loss"], rtol=1e-5)
+    np.testing.assert_allclose(x.grad.numpy(), g["enc_gx"], rtol=1e-3, atol=1e-6 * np.abs(g["enc_gx"]).max() + 1e-9)
+    for k in ("mlp1.0.weight", "mlp2.6.weight", "mlp2.7.bias", "fc.weight"):
+        ref = g["enc_grad:" + k]
+        np.testing.assert_allclose(sd[k].grad.numpy(), ref, rtol=1e-3, atol=1e-5 * np.abs(ref).max() + 1e-9)
+    for k in ("mlp1.1.running_mean", "mlp2.7.running_var", "mlp2.7.num_batches_tracked"):
+        np.testing.assert_allclose(sd[k].detach().numpy(), g["enc_after:" + k], rtol=1e-5, atol=1e-7)

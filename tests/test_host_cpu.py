@@ -59,7 +59,7 @@ def test_dropin_import_names():
             "m=importlib.import_module('pointnet_extrusion');"
             "from models.pointnet_util import PointNetSetAbstractionMsg,PointNetSetAbstraction,PointNetFeaturePropagation;"
             "from losses import *;from data_utils import *;from global_variables import *;"
-            "assert callable(m.backbone) and callable(compute_all_losses) and callable(estimate_extrusion_axis) and g_zero_tol==1e-6;"
+            "assert callable(m.backbone) and callable(compute_all_losses) and callable(estimate_extrusion_axis) and callable(sketch_implicit_projection3) and g_zero_tol==1e-6;"
             "print('ok')")
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "point2cyl_amd", "dropin"),
                                                        os.path.join(ROOT, "point2cyl_amd", "dropin", "models"), ROOT]))

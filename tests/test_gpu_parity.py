@@ -685,3 +685,55 @@ def test_pointnet_encoder_vs_oracle_large():
         ze = enc(x.to(DEV))
     zre = R.pointnet_encoder_forward(sd, x, training=False)
     np.testing.assert_allclose(ze.cpu().numpy(), zre.numpy(), rtol=1e-3, atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------- full size (BASELINE configs[1])
+def test_full_size_properties_b32_n8192():
+    """At B=32, N=8192 the oracle is too slow to be the checker; size-independent properties of the path instead:
+    (i) FPS: 512 distinct in-range indices per cloud, the first is the start index, and the k-th pick is the arg-max (lowest
+        index) of the min-distance to the first k picks - verified for every pick of a few clouds with torch ops;
+    (ii) ball query: each row is strictly ascending up to its in-ball count, then padded with its first entry, and every
+        listed point is inside the ball while no skipped lower index is;
+    (iii) the network is equivariant to the ORDER of the clouds in the batch (train-mode BatchNorm statistics are sums over the
+        batch): permuting the clouds permutes the FPS / ball-query indices exactly and the head outputs to rounding."""
+    from point2cyl_amd import synth
+    B, N = 32, 8192
+    pcs = synth.make_batch(B, N, 8, seed=4242)[0].float()
+    x = pcs.to(DEV)
+    m = _model(11, [3, 16]).train()
+    m.dropout_mask = "off"
+    g = torch.Generator().manual_seed(1)
+    s1, s2 = torch.randint(0, N, (B,), generator=g), torch.randint(0, 512, (B,), generator=g)
+    m.sa1.fps_start, m.sa2.fps_start = s1, s2
+    with torch.no_grad():
+        h1, _ = m.forward_heads(x)
+    fps = m.sa1.last_aux["fps_idx"].long().cpu()
+    gi = m.sa1.last_aux["group_idx"].long().cpu()
+    assert fps.shape == (B, 512) and gi.shape == (B, 512, 64)
+    assert int(fps.min()) >= 0 and int(fps.max()) < N and torch.equal(fps[:, 0], s1)
+    assert all(len(set(fps[b].tolist())) == 512 for b in range(B))
+    for b in (0, 17, 31):                                            # (i) the greedy rule, pick by pick
+        p = pcs[b]
+        dist = torch.full((N,), 1e10)
+        for k in range(511):
+            d = p - p[fps[b, k]]
+            d = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+            dist = torch.minimum(dist, d)
+            assert int(torch.argmax(dist)) == int(fps[b, k + 1]), (b, k)
+    for b in (0, 31):                                                # (ii)
+        p, c = pcs[b], pcs[b][fps[b]]
+        d2 = R.square_distance(c.unsqueeze(0), p.unsqueeze(0))[0]     # the reference's expression (pointnet_util.py:37-39)
+        inside = ~(d2 > 0.2 ** 2)
+        for s in range(0, 512, 37):
+            ids = inside[s].nonzero().flatten()[:64]
+            exp = torch.cat([ids, ids[:1].expand(64 - ids.numel())])
+            assert torch.equal(gi[b, s], exp), (b, s)
+    perm = torch.randperm(B, generator=g)                            # (iii)
+    m.sa1.fps_start, m.sa2.fps_start = s1[perm], s2[perm]
+    with torch.no_grad():
+        h2, _ = m.forward_heads(x[perm.to(DEV)])
+    assert torch.equal(m.sa1.last_aux["fps_idx"].long().cpu(), fps[perm])
+    assert torch.equal(m.sa1.last_aux["group_idx"].long().cpu(), gi[perm])
+    h1p = h1.view(B, N, -1)[perm.to(DEV)].reshape(B * N, -1)
+    err = float((h2 - h1p).abs().max()) / float(h1.abs().max())
+    assert err < 1e-4, err

@@ -493,3 +493,37 @@ def pointnet_encoder_forward(sd, x, training=True, momentum=0.1):
     h = h.max(dim=2)[0]                                           # F.max_pool1d over all points :170
     h = F.linear(h, sd["fc.weight"], sd["fc.bias"])
     return F.normalize(h)
+
+
+def implicit_net_forward(sd, inp, skip_in=(4,), beta=100):
+    """IGR/network.py:67-92 with its state_dict (lin0..lin<L-1>): softplus(beta) between the layers, input re-injected at skip_in."""
+    L = len([k for k in sd if k.endswith(".weight")])
+    x = inp
+    for layer in range(L):
+        if layer in skip_in:
+            x = torch.cat([x, inp], -1) / math.sqrt(2)
+        x = F.linear(x, sd["lin%d.weight" % layer], sd["lin%d.bias" % layer])
+        if layer < L - 1:
+            x = F.softplus(x, beta=beta)
+    return x
+
+
+def implicit_losses(sd, sk_pnts, sk_normals, nonmnfld_pnts, latent, mask_gt, B, K, skip_in=(4,), beta=100):
+    """train_Point2Cyl.py:611-648: manifold |f|, eikonal (|grad f| - 1)^2 on the off-surface samples, SALD normal term
+    min(|grad f - n|, |grad f + n|) on the surface samples, masked means over the K segments -> (im_loss, mnfld, eikonal, normal)."""
+    def add_latent(points, codes):
+        b, n, d = points.shape
+        return torch.cat([codes.unsqueeze(1).repeat(1, n, 1).reshape(b * n, -1), points.reshape(b * n, d)], 1)
+
+    def grad(inputs, outputs):
+        return torch.autograd.grad(outputs, inputs, torch.ones_like(outputs), create_graph=True, retain_graph=True)[0][:, -2:]
+    a = add_latent(sk_pnts, latent).requires_grad_()
+    n = add_latent(nonmnfld_pnts, latent).requires_grad_()
+    fa, fn = implicit_net_forward(sd, a, skip_in, beta), implicit_net_forward(sd, n, skip_in, beta)
+    ga, gn = grad(a, fa).reshape(B, K, -1, 2), grad(n, fn).reshape(B, K, -1, 2)
+    mn = reduce_mean_masked_instance(fa.reshape(B, K, -1, 1).abs().mean(-1).mean(-1), mask_gt).mean()
+    ek = reduce_mean_masked_instance(((gn.norm(2, dim=-1) - 1) ** 2).mean(-1), mask_gt).mean()
+    nr = sk_normals.reshape(B, K, -1, 2)
+    nl = torch.minimum((ga - nr).norm(2, dim=-1), (ga + nr).norm(2, dim=-1)).mean(-1)
+    nl = reduce_mean_masked_instance(nl, mask_gt).mean()
+    return mn + 0.1 * ek + 1.0 * nl, mn, ek, nl

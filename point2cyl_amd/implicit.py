@@ -1,0 +1,162 @@
+"""The sketch branch's implicit decoder: drop-in for the reference's IGR/network.py `ImplicitNet`
+(:20-92), `gradient` (:8-17) and `add_latent` (:200-206).
+
+The with-sketch trainer differentiates the decoder TWICE: the eikonal / normal losses are functions of d(output)/d(point)
+(`gradient`, torch.autograd.grad with create_graph=True), and the optimiser step needs their derivative w.r.t. the weights
+(train_Point2Cyl.py:608-648).  Every matrix product of all three passes runs on this package's GEMM kernels (csrc/gemm.hip through
+the C ABI): the three product shapes
+
+    NT(X, W) = X W^T        NN(A, W) = A W        TN(A, X) = A^T X
+
+are closed under differentiation (d NT = {NN, TN}, d NN = {NT, TN}, d TN = {NT, NN}), so three autograd Functions whose backward
+passes call each other give derivatives of any order with nothing but those kernels.  Channel counts are zero-padded to multiples of
+4 on the way in (258 -> 260 inputs, 254 -> 256 outputs of the skip layer, 1 -> 4 outputs of the last) and sliced on the way out;
+parameters keep the reference's shapes and names (lin0 .. lin8).  The softplus and the bias adds between the products are torch
+elementwise ops for now (memory-bound; fusing them into the GEMM prologues / epilogues is the next step for this row).
+There is no CPU path."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+
+def _c(t):
+    t = t if t.dtype == torch.float32 else t.float()
+    return t if (t.is_contiguous() and t.data_ptr() % 16 == 0) else t.contiguous()
+
+
+def _check(*ts):
+    _lib.require_device(*ts)
+    for t in ts:
+        if t.shape[-1] % 4:
+            raise ValueError("implicit GEMMs need channel counts that are multiples of 4 (got %s)" % (tuple(t.shape),))
+
+
+class _NT(torch.autograd.Function):
+    """X [M,K], W [N,K] -> X W^T [M,N]  (p2c_linear_fwd_f32, no bias, no statistics)."""
+
+    @staticmethod
+    def forward(ctx, X, W):
+        X, W = _c(X), _c(W)
+        _check(X, W)
+        M, K = X.shape
+        N = W.shape[0]
+        Y = torch.empty(M, N, dtype=torch.float32, device=X.device)
+        call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, None, ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(),
+             flops=2.0 * M * N * K)
+        ctx.save_for_backward(X, W)
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        X, W = ctx.saved_tensors
+        return (_NN.apply(dY, W) if ctx.needs_input_grad[0] else None, _TN.apply(dY, X) if ctx.needs_input_grad[1] else None)
+
+
+class _NN(torch.autograd.Function):
+    """A [M,N], W [N,K] -> A W [M,K]  (p2c_linear_bwd_data_f32, plain gradient mode)."""
+
+    @staticmethod
+    def forward(ctx, A, W):
+        A, W = _c(A), _c(W)
+        _check(A, W)
+        M, N = A.shape
+        K = W.shape[1]
+        O = torch.empty(M, K, dtype=torch.float32, device=A.device)
+        call("p2c_linear_bwd_data_f32", ptr(A), N, None, 0, 0, None, ptr(W), K, ptr(O), K, M, N, K, None, 0, 1.0, None, 0, None, None, None, 0,
+             stream(), flops=2.0 * M * N * K)
+        ctx.save_for_backward(A, W)
+        return O
+
+    @staticmethod
+    def backward(ctx, dO):
+        A, W = ctx.saved_tensors
+        return (_NT.apply(dO, W) if ctx.needs_input_grad[0] else None, _TN.apply(A, dO) if ctx.needs_input_grad[1] else None)
+
+
+class _TN(torch.autograd.Function):
+    """A [M,N], X [M,K] -> A^T X [N,K]  (p2c_linear_bwd_weight_f32: split over the M rows, fp32 atomics into a zeroed result)."""
+
+    @staticmethod
+    def forward(ctx, A, X):
+        A, X = _c(A), _c(X)
+        _check(A, X)
+        M, N = A.shape
+        K = X.shape[1]
+        G = torch.zeros(N, K, dtype=torch.float32, device=A.device)
+        call("p2c_linear_bwd_weight_f32", ptr(A), N, None, 0, 0, None, ptr(X), K, 0, None, None, None, 0, 1.0, ptr(G), K, 0, None, M, N, K, None, 0,
+             stream(), flops=2.0 * M * N * K)
+        ctx.save_for_backward(A, X)
+        return G
+
+    @staticmethod
+    def backward(ctx, dG):
+        A, X = ctx.saved_tensors
+        return (_NT.apply(X, dG) if ctx.needs_input_grad[0] else None, _NN.apply(A, dG) if ctx.needs_input_grad[1] else None)
+
+
+def linear(x, weight, bias):
+    """F.linear(x, weight, bias) for x [M,K] on the GEMM kernels, differentiable to any order."""
+    N, K = weight.shape
+    kp, np_ = (-K) % 4, (-N) % 4
+    if kp:
+        x = F.pad(x, (0, kp))
+    w = F.pad(weight, (0, kp, 0, np_)) if (kp or np_) else weight
+    y = _NT.apply(x, w)
+    if np_:
+        y = y[:, :N]
+    return y + bias if bias is not None else y
+
+
+def gradient(inputs, outputs):
+    """IGR/network.py:8-17: d(outputs)/d(inputs) with the graph kept, last two columns (the sketch point)."""
+    d_points = torch.ones_like(outputs, requires_grad=False, device=outputs.device)
+    return torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=d_points, create_graph=True, retain_graph=True,
+                               only_inputs=True)[0][:, -2:]
+
+
+def add_latent(points, latent_codes):
+    """IGR/network.py:200-206: [latent code of the sketch | point] rows, (B'*S, L+dim)."""
+    batch_size, num_of_points, dim = points.shape
+    points = points.reshape(batch_size * num_of_points, dim)
+    latent_codes = latent_codes.unsqueeze(1).repeat(1, num_of_points, 1).reshape(batch_size * num_of_points, -1)
+    return torch.cat([latent_codes, points], 1)
+
+
+class ImplicitNet(nn.Module):
+    """IGR/network.py:20-92: d_in -> dims... -> 1 with softplus(beta) between the layers, the input re-injected (concat, / sqrt 2)
+    at the layers in `skip_in`, IGR's geometric initialisation.  Same constructor, same parameter names (lin<i>.weight / .bias)."""
+
+    def __init__(self, d_in, dims, skip_in=(), geometric_init=True, radius_init=1, beta=100):
+        super().__init__()
+        dims = [d_in] + dims + [1]
+        self.num_layers = len(dims)
+        self.skip_in = skip_in
+        self.beta = beta
+        for layer in range(0, self.num_layers - 1):
+            out_dim = dims[layer + 1] - d_in if layer + 1 in skip_in else dims[layer + 1]
+            lin = nn.Linear(dims[layer], out_dim)
+            if geometric_init:                                         # network.py:46-56
+                if layer == self.num_layers - 2:
+                    torch.nn.init.normal_(lin.weight, mean=np.sqrt(np.pi) / np.sqrt(dims[layer]), std=0.00001)
+                    torch.nn.init.constant_(lin.bias, -radius_init)
+                else:
+                    torch.nn.init.constant_(lin.bias, 0.0)
+                    torch.nn.init.normal_(lin.weight, 0.0, np.sqrt(2) / np.sqrt(out_dim))
+            setattr(self, "lin" + str(layer), lin)
+
+    def forward(self, input):
+        if not input.is_cuda:
+            raise RuntimeError("point2cyl_amd.implicit.ImplicitNet runs on the HIP device only (got %s); there is no CPU path" % input.device)
+        x = input
+        for layer in range(0, self.num_layers - 1):
+            lin = getattr(self, "lin" + str(layer))
+            if layer in self.skip_in:
+                x = torch.cat([x, input], -1) / np.sqrt(2)
+            x = linear(x, lin.weight, lin.bias)
+            if layer < self.num_layers - 2:
+                x = F.softplus(x, beta=self.beta) if self.beta > 0 else F.relu(x)
+        return x

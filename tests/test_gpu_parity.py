@@ -737,3 +737,75 @@ def test_full_size_properties_b32_n8192():
     h1p = h1.view(B, N, -1)[perm.to(DEV)].reshape(B * N, -1)
     err = float((h2 - h1p).abs().max()) / float(h1.abs().max())
     assert err < 1e-4, err
+
+
+# ---------------------------------------------------------------------------------------------- implicit decoder
+def _implicit_from_golden(g, dims=50, L=13):
+    from point2cyl_amd.implicit import ImplicitNet
+    dec = ImplicitNet(d_in=2 + L, dims=[dims] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100)
+    assert list(dec.state_dict().keys()) == [str(n) for n in g["names"]]
+    dec.load_state_dict({str(n): t(g["sd:" + str(n)]) for n in g["names"]})
+    return dec.to(DEV)
+
+
+def _im_losses(dec, sk, nrm, non, lat, mask_gt, B, K):
+    """train_Point2Cyl.py:610-648 with this package's ImplicitNet / gradient / add_latent."""
+    from point2cyl_amd.implicit import add_latent, gradient
+    a = add_latent(sk, lat).requires_grad_()
+    n = add_latent(non, lat).requires_grad_()
+    fa, fn = dec(a), dec(n)
+    ga, gn = gradient(a, fa).reshape(B, K, -1, 2), gradient(n, fn).reshape(B, K, -1, 2)
+    mn = losses.reduce_mean_masked_instance(fa.reshape(B, K, -1, 1).abs().mean(-1).mean(-1), mask_gt).mean()
+    ek = losses.reduce_mean_masked_instance(((gn.norm(2, dim=-1) - 1) ** 2).mean(-1), mask_gt).mean()
+    nr = nrm.reshape(B, K, -1, 2)
+    nl = torch.minimum((ga - nr).norm(2, dim=-1), (ga + nr).norm(2, dim=-1)).mean(-1)
+    nl = losses.reduce_mean_masked_instance(nl, mask_gt).mean()
+    return mn + 0.1 * ek + 1.0 * nl, mn, ek, nl, fa, ga
+
+
+def test_implicit_decoder_golden():
+    """ImplicitNet forward, d f / d point, the three loss terms and - through the DOUBLE backward - the gradients of their sum w.r.t.
+    every decoder parameter and the latent codes, against the reference's own run (G11).  Widths 15 / 35 / 1 exercise the
+    zero-padding to multiples of 4."""
+    g = load_golden("g11_implicit")
+    dec = _implicit_from_golden(g)
+    B, K = int(g["B"]), int(g["K"])
+    lat = cu(g["latent"]).requires_grad_(True)
+    im, mn, ek, nl, fa, ga = _im_losses(dec, cu(g["sk_pnts"]), cu(g["sk_normals"]), cu(g["nonmnfld_pnts"]), lat, cu(g["mask_gt"]), B, K)
+    np.testing.assert_allclose(fa.detach().cpu().numpy().reshape(g["sk_pred"].shape), g["sk_pred"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(ga.detach().cpu().numpy(), g["mnfld_grad"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose([im.item(), mn.item(), ek.item(), nl.item()], [g["im_loss"], g["mnfld_loss"], g["grad_loss"], g["normals_loss"]], rtol=1e-4)
+    im.backward()
+    ref = g["lat_grad"]
+    assert np.linalg.norm(lat.grad.cpu().numpy() - ref) <= 1e-3 * np.linalg.norm(ref)
+    for n, p in dec.named_parameters():
+        ref = g["grad:" + n]
+        assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 1e-3 * np.linalg.norm(ref) + 1e-9, n
+
+
+def test_implicit_decoder_vs_oracle_trainer_shapes():
+    """The trainer's widths (d_in = 2 + 256, eight 512-wide layers, skip at 4) on 4 x 2 sketches of 256 points: losses and the
+    double-backward gradients against the oracle's plain-torch restatement."""
+    from point2cyl_amd.implicit import ImplicitNet
+    torch.manual_seed(9)
+    dec = ImplicitNet(d_in=258, dims=[512] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    dec = dec.to(DEV)
+    B, K, S = 4, 2, 256
+    gen = torch.Generator().manual_seed(2)
+    sk = torch.randn(B * K, S, 2, generator=gen) * 0.4
+    nrm = F.normalize(torch.randn(B * K, S, 2, generator=gen), dim=-1)
+    non = torch.cat([sk + 0.05 * torch.randn(B * K, S, 2, generator=gen), torch.rand(B * K, S // 8, 2, generator=gen) * 2 - 1], 1)
+    lat0 = F.normalize(torch.randn(B * K, 256, generator=gen))
+    mask = torch.tensor([[True, True], [True, False], [True, True], [False, False]])
+    lat = lat0.to(DEV).requires_grad_(True)
+    im, mn, ek, nl, _, _ = _im_losses(dec, sk.to(DEV), nrm.to(DEV), non.to(DEV), lat, mask.to(DEV), B, K)
+    im.backward()
+    latr = lat0.clone().requires_grad_(True)
+    imr, mnr, ekr, nlr = R.implicit_losses(sd, sk, nrm, non, latr, mask, B, K)
+    imr.backward()
+    np.testing.assert_allclose([im.item(), mn.item(), ek.item(), nl.item()], [imr.item(), mnr.item(), ekr.item(), nlr.item()], rtol=1e-4)
+    assert np.linalg.norm(lat.grad.cpu().numpy() - latr.grad.numpy()) <= 2e-3 * np.linalg.norm(latr.grad.numpy())
+    for n, p in dec.named_parameters():
+        ref = sd[n].grad.numpy()
+        assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 2e-3 * np.linalg.norm(ref) + 1e-9, n

@@ -224,3 +224,17 @@ def test_pointnet_encoder():
         np.testing.assert_allclose(sd[k].grad.numpy(), ref, rtol=1e-3, atol=1e-5 * np.abs(ref).max() + 1e-9)
     for k in ("mlp1.1.running_mean", "mlp2.7.running_var", "mlp2.7.num_batches_tracked"):
         np.testing.assert_allclose(sd[k].detach().numpy(), g["enc_after:" + k], rtol=1e-5, atol=1e-7)
+
+
+def test_implicit_decoder_losses_and_double_backward():
+    """G11: ImplicitNet + gradient + the with-sketch trainer's loss block (IGR/network.py:8-92; train_Point2Cyl.py:610-648)."""
+    g = load_golden("g11_implicit")
+    sd = {str(n): t(g["sd:" + str(n)]).clone().requires_grad_(True) for n in g["names"]}
+    lat = t(g["latent"]).clone().requires_grad_(True)
+    im, mn, ek, nl = R.implicit_losses(sd, t(g["sk_pnts"]), t(g["sk_normals"]), t(g["nonmnfld_pnts"]), lat, t(g["mask_gt"]), int(g["B"]), int(g["K"]))
+    np.testing.assert_allclose([im.item(), mn.item(), ek.item(), nl.item()], [g["im_loss"], g["mnfld_loss"], g["grad_loss"], g["normals_loss"]], rtol=1e-5)
+    im.backward()
+    np.testing.assert_allclose(lat.grad.numpy(), g["lat_grad"], rtol=1e-3, atol=1e-6 * np.abs(g["lat_grad"]).max())
+    for n in sd:
+        ref = g["grad:" + n]
+        np.testing.assert_allclose(sd[n].grad.numpy(), ref, rtol=1e-3, atol=1e-5 * np.abs(ref).max() + 1e-9)

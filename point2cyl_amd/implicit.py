@@ -11,8 +11,8 @@ the C ABI): the three product shapes
 are closed under differentiation (d NT = {NN, TN}, d NN = {NT, TN}, d TN = {NT, NN}), so three autograd Functions whose backward
 passes call each other give derivatives of any order with nothing but those kernels.  Channel counts are zero-padded to multiples of
 4 on the way in (258 -> 260 inputs, 254 -> 256 outputs of the skip layer, 1 -> 4 outputs of the last) and sliced on the way out;
-parameters keep the reference's shapes and names (lin0 .. lin8).  The softplus and the bias adds between the products are torch
-elementwise ops for now (memory-bound; fusing them into the GEMM prologues / epilogues is the next step for this row).
+parameters keep the reference's shapes and names (lin0 .. lin8).  The bias is added in the GEMM epilogue; the softplus between the products is a torch
+elementwise op for now (memory-bound; fusing them into the GEMM prologues / epilogues is the next step for this row).
 There is no CPU path."""
 import numpy as np
 import torch
@@ -36,16 +36,17 @@ def _check(*ts):
 
 
 class _NT(torch.autograd.Function):
-    """X [M,K], W [N,K] -> X W^T [M,N]  (p2c_linear_fwd_f32, no bias, no statistics)."""
+    """X [M,K], W [N,K], bias [N] or None -> X W^T + bias [M,N]  (p2c_linear_fwd_f32: the bias is added in the GEMM epilogue)."""
 
     @staticmethod
-    def forward(ctx, X, W):
+    def forward(ctx, X, W, bias):
         X, W = _c(X), _c(W)
         _check(X, W)
         M, K = X.shape
         N = W.shape[0]
         Y = torch.empty(M, N, dtype=torch.float32, device=X.device)
-        call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, None, ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(),
+        b = None if bias is None else _c(bias)
+        call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, ptr(b), ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(),
              flops=2.0 * M * N * K)
         ctx.save_for_backward(X, W)
         return Y
@@ -53,7 +54,8 @@ class _NT(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         X, W = ctx.saved_tensors
-        return (_NN.apply(dY, W) if ctx.needs_input_grad[0] else None, _TN.apply(dY, X) if ctx.needs_input_grad[1] else None)
+        return (_NN.apply(dY, W) if ctx.needs_input_grad[0] else None, _TN.apply(dY, X) if ctx.needs_input_grad[1] else None,
+                dY.sum(0) if ctx.needs_input_grad[2] else None)
 
 
 class _NN(torch.autograd.Function):
@@ -74,7 +76,7 @@ class _NN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dO):
         A, W = ctx.saved_tensors
-        return (_NT.apply(dO, W) if ctx.needs_input_grad[0] else None, _TN.apply(A, dO) if ctx.needs_input_grad[1] else None)
+        return (_NT.apply(dO, W, None) if ctx.needs_input_grad[0] else None, _TN.apply(A, dO) if ctx.needs_input_grad[1] else None)
 
 
 class _TN(torch.autograd.Function):
@@ -95,7 +97,7 @@ class _TN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dG):
         A, X = ctx.saved_tensors
-        return (_NT.apply(X, dG) if ctx.needs_input_grad[0] else None, _NN.apply(A, dG) if ctx.needs_input_grad[1] else None)
+        return (_NT.apply(X, dG, None) if ctx.needs_input_grad[0] else None, _NN.apply(A, dG) if ctx.needs_input_grad[1] else None)
 
 
 def linear(x, weight, bias):
@@ -105,10 +107,9 @@ def linear(x, weight, bias):
     if kp:
         x = F.pad(x, (0, kp))
     w = F.pad(weight, (0, kp, 0, np_)) if (kp or np_) else weight
-    y = _NT.apply(x, w)
-    if np_:
-        y = y[:, :N]
-    return y + bias if bias is not None else y
+    b = F.pad(bias, (0, np_)) if (bias is not None and np_) else bias
+    y = _NT.apply(x, w, b)
+    return y[:, :N] if np_ else y
 
 
 def gradient(inputs, outputs):
@@ -160,3 +161,21 @@ class ImplicitNet(nn.Module):
             if layer < self.num_layers - 2:
                 x = F.softplus(x, beta=self.beta) if self.beta > 0 else F.relu(x)
         return x
+
+
+class NormalPerPoint:
+    """IGR/sampler.py:18-40: off-surface samples = every sketch point + N(0, local_sigma) and S/8 uniform points in
+    [-global_sigma, global_sigma]^dim per sketch (drawn on the input's device, like the reference)."""
+
+    def __init__(self, global_sigma, local_sigma=0.01):
+        self.global_sigma = global_sigma
+        self.local_sigma = local_sigma
+
+    def get_points(self, pc_input, local_sigma=None):
+        batch_size, sample_size, dim = pc_input.shape
+        if local_sigma is not None:
+            sample_local = pc_input + (torch.randn_like(pc_input) * local_sigma.unsqueeze(-1))
+        else:
+            sample_local = pc_input + (torch.randn_like(pc_input) * self.local_sigma)
+        sample_global = (torch.rand(batch_size, sample_size // 8, dim, device=pc_input.device) * (self.global_sigma * 2)) - self.global_sigma
+        return torch.cat([sample_local, sample_global], dim=1)

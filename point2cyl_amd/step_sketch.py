@@ -1,0 +1,65 @@
+"""The implicit-sketch part of one step of the with-sketch trainer (train_Point2Cyl.py:519-672), default path: predicted labels
+(not --use_gt_im, not --use_whole_pc), angle or L2 latent loss, --with_im_loss.  Composition only - every piece is a kernel path of
+this package: fitting.sketch_implicit_projection (csrc/fit.hip), sketch.PointNetEncoder (MLP-stack kernels), implicit.ImplicitNet and
+its double backward (csrc/gemm.hip)."""
+import torch
+
+from . import fitting, losses
+from .implicit import add_latent, gradient
+
+
+def implicit_losses(implicit_net, sk_pnts, sk_normals, nonmnfld_pnts, latent_codes, mask_gt, batch_size, K):
+    """train_Point2Cyl.py:610-648 -> (im_loss, mnfld_loss, grad_loss, normals_loss)."""
+    a = add_latent(sk_pnts, latent_codes).requires_grad_()
+    n = add_latent(nonmnfld_pnts, latent_codes).requires_grad_()
+    sk_pred, nonmnfld_pred = implicit_net(a), implicit_net(n)
+    mnfld_grad = gradient(a, sk_pred).reshape(batch_size, K, -1, 2)
+    nonmnfld_grad = gradient(n, nonmnfld_pred).reshape(batch_size, K, -1, 2)
+    sk_normals = sk_normals.reshape(batch_size, K, -1, 2)
+    mnfld_loss = losses.reduce_mean_masked_instance(sk_pred.reshape(batch_size, K, -1, 1).abs().mean(dim=-1).mean(dim=-1), mask_gt).mean()
+    grad_loss = losses.reduce_mean_masked_instance(((nonmnfld_grad.norm(2, dim=-1) - 1) ** 2).mean(dim=-1), mask_gt).mean()
+    normals_loss = torch.minimum((mnfld_grad - sk_normals).norm(2, dim=-1), (mnfld_grad + sk_normals).norm(2, dim=-1)).mean(dim=-1)   # SALD :639-645
+    normals_loss = losses.reduce_mean_masked_instance(normals_loss, mask_gt).mean()
+    return mnfld_loss + 0.1 * grad_loss + 1.0 * normals_loss, mnfld_loss, grad_loss, normals_loss
+
+
+def sketch_branch_losses(pcs, X, W, W_2K, matching_indices, mask, gt_normals, gt_extrusion_instances, gt_bb_labels, gt_extrusion_axes,
+                         gt_extrusion_centers, gt_sketches, pn_encoder, loaded_pn_encoder, implicit_net, sampler, K, num_sk_point,
+                         with_im_loss=True, is_l2=False, rand_idx_pred=None, rand_idx_gt=None, nonmnfld_pnts=None):
+    """train_Point2Cyl.py:519-672.  pcs (B,N,3); X (B,N,3) predicted normals; W (B,N,K) and W_2K (B,N,2K) the softmaxed segmentation;
+    matching_indices / mask from hungarian_matching; gt_sketches (B,K,S,4) = [point | normal] of the ground-truth profiles.
+    -> dict(im_loss, latent_loss, mnfld_loss, grad_loss, normals_loss, latent_codes)."""
+    B, N, _ = pcs.shape
+    S = num_sk_point
+    mask_gt = losses.get_mask_gt(gt_extrusion_instances, K)
+    with torch.no_grad():                                                              # labels: no gradient through the arg-max / sampling
+        W_reordered = torch.gather(W, 2, matching_indices.unsqueeze(1).expand(B, N, K))                                   # :521
+        W_reordered = torch.where(mask.unsqueeze(1).expand(B, N, K) == 1, W_reordered, torch.zeros_like(W_reordered))   # :522
+        label = torch.argmax(W_reordered, dim=-1)                                                                        # :541
+        BB = torch.stack([W_2K[:, :, 0::2].sum(-1), W_2K[:, :, 1::2].sum(-1)], -1)                                       # :544-547
+        pred_bb_label = torch.argmax(BB, dim=-1)
+        pred_pc, pred_nrm, _ = fitting.sketch_implicit_projection(pcs, X, label, pred_bb_label, gt_extrusion_axes, gt_extrusion_centers, S,
+                                                                  rand_idx=rand_idx_pred)                                # :549
+        _, _, gt_scales = fitting.sketch_implicit_projection(pcs, gt_normals, gt_extrusion_instances, gt_bb_labels, gt_extrusion_axes,
+                                                             gt_extrusion_centers, S, rand_idx=rand_idx_gt)             # :550
+        pred_pc = pred_pc / gt_scales.unsqueeze(-1).unsqueeze(-1)                                                        # :552-553
+        global_pc = torch.cat((pred_pc.reshape(B * K, S, 2), pred_nrm.reshape(B * K, S, 2)), dim=-1)                     # :555-558 (the reference's own
+        #                                                                                   (K,B,..) -> (B*K,..) reshape, kept as it is)
+        sk_pnts = gt_sketches[:, :, :, :2].reshape(B * K, S, 2)                                                          # :602-604
+        sk_normals = gt_sketches[:, :, :, -2:].reshape(B * K, S, 2)
+        latent_codes_gt = loaded_pn_encoder(torch.cat((sk_pnts, sk_normals), dim=-1))                                    # :605 (its parameters are frozen)
+    latent_codes = pn_encoder(global_pc)                                                                                 # :559
+    zero = torch.zeros((), device=pcs.device)
+    if with_im_loss:
+        if nonmnfld_pnts is None:
+            nonmnfld_pnts = sampler.get_points(sk_pnts)                                                                  # :609
+        im_loss, mnfld_loss, grad_loss, normals_loss = implicit_losses(implicit_net, sk_pnts, sk_normals, nonmnfld_pnts, latent_codes, mask_gt, B, K)
+    else:
+        im_loss, mnfld_loss, grad_loss, normals_loss = zero, zero, zero, zero                                            # :650-654
+    lc, lg = latent_codes.reshape(B, K, -1), latent_codes_gt.reshape(B, K, -1)
+    if is_l2:
+        latent_loss = losses.reduce_mean_masked_instance(torch.square(lc - lg).sum(dim=-1), mask_gt).mean()            # :662-663
+    else:
+        latent_loss = losses.reduce_mean_masked_instance(1.0 - torch.sum(lc * lg, dim=-1), mask_gt).mean()             # :667-669
+    return dict(im_loss=im_loss + latent_loss, latent_loss=latent_loss, mnfld_loss=mnfld_loss, grad_loss=grad_loss, normals_loss=normals_loss,
+                latent_codes=latent_codes)

@@ -809,3 +809,59 @@ def test_implicit_decoder_vs_oracle_trainer_shapes():
     for n, p in dec.named_parameters():
         ref = sd[n].grad.numpy()
         assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 2e-3 * np.linalg.norm(ref) + 1e-9, n
+
+
+def test_sketch_branch_step_vs_oracle():
+    """The composed implicit-sketch losses of one with-sketch training step (train_Point2Cyl.py:519-672: projection of the predicted
+    and the ground-truth segmentation, encoder, frozen ground-truth encoder, decoder losses, latent loss) and the gradients they
+    send into the trainable encoder, against the same composition of the oracle's restatements on the same draws."""
+    from point2cyl_amd import synth, step_sketch
+    from point2cyl_amd.sketch import PointNetEncoder
+    from point2cyl_amd.implicit import ImplicitNet
+    B, N, K, S, E = 3, 1024, 8, 64, 24
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=77)
+    pcs, nrm, axes, cen = pcs.float(), nrm.float(), axes.float(), cen.float()
+    gen = torch.Generator().manual_seed(6)
+    X = F.normalize(nrm + 0.1 * torch.randn(B, N, 3, generator=gen), dim=-1)
+    W2K = torch.softmax(torch.randn(B, N, 2 * K, generator=gen) + 5 * F.one_hot(seg * 2 + bb, 2 * K), -1)
+    W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
+    match, mask = R.hungarian_matching(W, seg)
+    torch.manual_seed(12)
+    enc, enc_gt = PointNetEncoder(E, 2, with_normals=True), PointNetEncoder(E, 2, with_normals=True).eval()
+    dec = ImplicitNet(d_in=2 + E, dims=[64] * 8, skip_in=[4])
+    sd_e = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    sd_g = {k: v.detach().clone() for k, v in enc_gt.state_dict().items()}
+    sd_d = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    gt_sk = torch.cat([torch.randn(B, K, S, 2, generator=gen) * 0.4, F.normalize(torch.randn(B, K, S, 2, generator=gen), dim=-1)], -1)
+    non = torch.cat([gt_sk[..., :2].reshape(B * K, S, 2) + 0.02 * torch.randn(B * K, S, 2, generator=gen), torch.rand(B * K, S // 8, 2, generator=gen) * 2 - 1], 1)
+    Wre = torch.gather(W, 2, match.unsqueeze(1).expand(B, N, K))
+    Wre = torch.where(mask.unsqueeze(1).expand(B, N, K), Wre, torch.zeros_like(Wre))
+    label, pbb = Wre.argmax(-1), torch.stack([W2K[:, :, 0::2].sum(-1), W2K[:, :, 1::2].sum(-1)], -1).argmax(-1)
+    torch.manual_seed(1); r_pred = fitting._barrel_draws(label, pbb, K, S)
+    torch.manual_seed(2); r_gt = fitting._barrel_draws(seg, bb, K, S)
+    d = lambda x: x.to(DEV)
+    enc, enc_gt, dec = enc.to(DEV).train(), enc_gt.to(DEV), dec.to(DEV)
+    out = step_sketch.sketch_branch_losses(d(pcs), d(X), d(W), d(W2K), d(match), d(mask), d(nrm), d(seg), d(bb), d(axes), d(cen), d(gt_sk), enc, enc_gt, dec,
+                                           None, K, S, rand_idx_pred=r_pred, rand_idx_gt=r_gt, nonmnfld_pnts=d(non))
+    out["im_loss"].backward()
+    # the oracle's composition
+    dk = lambda r: {(k, b): r[b, k] for k in range(K) for b in range(B)}
+    pP, pX, _, _ = R.sketch_implicit_projection(pcs, X, label, pbb, axes, cen, dk(r_pred), S)
+    _, _, gsc, _ = R.sketch_implicit_projection(pcs, nrm, seg, bb, axes, cen, dk(r_gt), S)
+    gpc = torch.cat(((pP / gsc.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2), pX.reshape(B * K, S, 2)), -1)
+    for k in sd_e:
+        if sd_e[k].dtype == torch.float32 and "running" not in k:
+            sd_e[k].requires_grad_(True)
+    lat = R.pointnet_encoder_forward(sd_e, gpc, training=True)
+    skp, skn = gt_sk[..., :2].reshape(B * K, S, 2), gt_sk[..., -2:].reshape(B * K, S, 2)
+    lat_gt = R.pointnet_encoder_forward(sd_g, torch.cat((skp, skn), -1), training=False)
+    mask_gt = R.get_mask_gt(seg, K)
+    im, mn, ek, nl = R.implicit_losses(sd_d, skp, skn, non, lat, mask_gt, B, K)
+    ll = R.reduce_mean_masked_instance(1.0 - (lat.reshape(B, K, -1) * lat_gt.reshape(B, K, -1)).sum(-1), mask_gt).mean()
+    (im + ll).backward()
+    got = [out[k].item() for k in ("im_loss", "latent_loss", "mnfld_loss", "grad_loss", "normals_loss")]
+    np.testing.assert_allclose(got, [(im + ll).item(), ll.item(), mn.item(), ek.item(), nl.item()], rtol=2e-4)
+    gmax = max(float(sd_e[n].grad.norm()) for n, _ in enc.named_parameters())
+    for n, p in enc.named_parameters():
+        ref = sd_e[n].grad.numpy()
+        assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 5e-3 * np.linalg.norm(ref) + 1e-5 * gmax, n

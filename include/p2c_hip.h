@@ -318,6 +318,17 @@ int p2c_sketch_projection_f32(const float *P, const float *X, const int64_t *seg
                               const float *centers, const int64_t *rand_idx, int B, int N, int K, int S, int all_points,
                               float *P_proj, float *X_proj, float *scales_out, float *found_out, void *ws, void *stream);
 
+/* nn.Softplus(beta) of the sketch branch's implicit decoder (IGR/network.py:58-59, :80-82) and the derivatives its double backward
+ * needs (train_Point2Cyl.py:619-646 differentiate the decoder w.r.t. its input with create_graph), one pass each over n elements
+ * (n % 4 == 0, 16-byte aligned).  s = sigmoid(beta z); beta z > threshold is the linear region as in torch (threshold 20).
+ *   fwd:      h  = softplus(z)
+ *   bwd:      out = u * s(z)
+ *   bwd_bwd:  du = g * s(z),  dz = g * u * beta * s(z) (1 - s(z)) */
+int p2c_softplus_fwd_f32(const float *z, float *h, long long n, float beta, float threshold, void *stream);
+int p2c_softplus_bwd_f32(const float *u, const float *z, float *out, long long n, float beta, float threshold, void *stream);
+int p2c_softplus_bwd_bwd_f32(const float *g, const float *u, const float *z, float *du, float *dz, long long n, float beta, float threshold,
+                             void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Hungarian matching on the device (losses.py:22-52; scipy.optimize.linear_sum_assignment restated)
  * W [B,N,K] soft or hard segmentation, I_gt [B,N] int64 (may contain -1).  match_out [B,K] int64,

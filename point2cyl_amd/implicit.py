@@ -11,8 +11,9 @@ the C ABI): the three product shapes
 are closed under differentiation (d NT = {NN, TN}, d NN = {NT, TN}, d TN = {NT, NN}), so three autograd Functions whose backward
 passes call each other give derivatives of any order with nothing but those kernels.  Channel counts are zero-padded to multiples of
 4 on the way in (258 -> 260 inputs, 254 -> 256 outputs of the skip layer, 1 -> 4 outputs of the last) and sliced on the way out;
-parameters keep the reference's shapes and names (lin0 .. lin8).  The bias is added in the GEMM epilogue; the softplus between the products is a torch
-elementwise op for now (memory-bound; fusing them into the GEMM prologues / epilogues is the next step for this row).
+parameters keep the reference's shapes and names (lin0 .. lin8).  The bias is added in the GEMM epilogue; the softplus between the products and the two derivatives of it that
+the double backward evaluates are one pass each (csrc/softplus.hip); moving them into the GEMM prologues / epilogues is the next
+step for this row.
 There is no CPU path."""
 import numpy as np
 import torch
@@ -24,8 +25,26 @@ from ._lib import call, ptr, stream
 
 
 def _c(t):
+    """fp32, contiguous, 16-byte aligned - as a DIFFERENTIABLE op applied before a Function sees the tensor: a Function must save
+    its own inputs (not a private copy made inside forward), or the second derivative through the saved tensor is cut."""
+    if t is None:
+        return None
     t = t if t.dtype == torch.float32 else t.float()
-    return t if (t.is_contiguous() and t.data_ptr() % 16 == 0) else t.contiguous()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t if t.data_ptr() % 16 == 0 else t.clone()
+
+
+def _nt(X, W, b=None):
+    return _NT.apply(_c(X), _c(W), _c(b))
+
+
+def _nn(A, W):
+    return _NN.apply(_c(A), _c(W))
+
+
+def _tn(A, X):
+    return _TN.apply(_c(A), _c(X))
 
 
 def _check(*ts):
@@ -40,13 +59,11 @@ class _NT(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, X, W, bias):
-        X, W = _c(X), _c(W)
         _check(X, W)
         M, K = X.shape
         N = W.shape[0]
         Y = torch.empty(M, N, dtype=torch.float32, device=X.device)
-        b = None if bias is None else _c(bias)
-        call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, ptr(b), ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(),
+        call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(),
              flops=2.0 * M * N * K)
         ctx.save_for_backward(X, W)
         return Y
@@ -54,7 +71,7 @@ class _NT(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dY):
         X, W = ctx.saved_tensors
-        return (_NN.apply(dY, W) if ctx.needs_input_grad[0] else None, _TN.apply(dY, X) if ctx.needs_input_grad[1] else None,
+        return (_nn(dY, W) if ctx.needs_input_grad[0] else None, _tn(dY, X) if ctx.needs_input_grad[1] else None,
                 dY.sum(0) if ctx.needs_input_grad[2] else None)
 
 
@@ -63,7 +80,6 @@ class _NN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, W):
-        A, W = _c(A), _c(W)
         _check(A, W)
         M, N = A.shape
         K = W.shape[1]
@@ -76,7 +92,7 @@ class _NN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dO):
         A, W = ctx.saved_tensors
-        return (_NT.apply(dO, W, None) if ctx.needs_input_grad[0] else None, _TN.apply(A, dO) if ctx.needs_input_grad[1] else None)
+        return (_nt(dO, W) if ctx.needs_input_grad[0] else None, _tn(A, dO) if ctx.needs_input_grad[1] else None)
 
 
 class _TN(torch.autograd.Function):
@@ -84,7 +100,6 @@ class _TN(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, A, X):
-        A, X = _c(A), _c(X)
         _check(A, X)
         M, N = A.shape
         K = X.shape[1]
@@ -97,7 +112,51 @@ class _TN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dG):
         A, X = ctx.saved_tensors
-        return (_NT.apply(X, dG, None) if ctx.needs_input_grad[0] else None, _NN.apply(A, dG) if ctx.needs_input_grad[1] else None)
+        return (_nt(X, dG) if ctx.needs_input_grad[0] else None, _nn(A, dG) if ctx.needs_input_grad[1] else None)
+
+
+class _Softplus(torch.autograd.Function):
+    """h = softplus(z) (csrc/softplus.hip); backward = u * sigmoid(beta z), itself differentiable (below)."""
+
+    @staticmethod
+    def forward(ctx, z, beta, thr):
+        _lib.require_device(z)
+        h = torch.empty_like(z)
+        call("p2c_softplus_fwd_f32", ptr(z), ptr(h), z.numel(), beta, thr, stream(), nbytes=8.0 * z.numel())
+        ctx.save_for_backward(z)
+        ctx.bt = (beta, thr)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        (z,) = ctx.saved_tensors
+        return _SoftplusBwd.apply(_c(dh), z, *ctx.bt), None, None
+
+
+class _SoftplusBwd(torch.autograd.Function):
+    """o = u * s(z), s = sigmoid(beta z); backward (one pass for both): du = g * s(z), dz = g * u * beta * s (1 - s)."""
+
+    @staticmethod
+    def forward(ctx, u, z, beta, thr):
+        o = torch.empty_like(z)
+        call("p2c_softplus_bwd_f32", ptr(u), ptr(z), ptr(o), z.numel(), beta, thr, stream(), nbytes=12.0 * z.numel())
+        ctx.save_for_backward(u, z)
+        ctx.bt = (beta, thr)
+        return o
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        u, z = ctx.saved_tensors
+        g = _c(g)
+        du, dz = torch.empty_like(z), torch.empty_like(z)
+        call("p2c_softplus_bwd_bwd_f32", ptr(g), ptr(u), ptr(z), ptr(du), ptr(dz), z.numel(), *ctx.bt, stream(), nbytes=20.0 * z.numel())
+        return du, dz, None, None
+
+
+def softplus(z, beta=100.0, threshold=20.0):
+    """F.softplus(z, beta, threshold) on the device kernels, twice differentiable (what a training step of the decoder needs)."""
+    return _Softplus.apply(_c(z), float(beta), float(threshold)) if z.numel() % 4 == 0 else F.softplus(z, beta=beta, threshold=threshold)
 
 
 def linear(x, weight, bias):
@@ -108,7 +167,7 @@ def linear(x, weight, bias):
         x = F.pad(x, (0, kp))
     w = F.pad(weight, (0, kp, 0, np_)) if (kp or np_) else weight
     b = F.pad(bias, (0, np_)) if (bias is not None and np_) else bias
-    y = _NT.apply(x, w, b)
+    y = _nt(x, w, b)
     return y[:, :N] if np_ else y
 
 
@@ -159,7 +218,7 @@ class ImplicitNet(nn.Module):
                 x = torch.cat([x, input], -1) / np.sqrt(2)
             x = linear(x, lin.weight, lin.bias)
             if layer < self.num_layers - 2:
-                x = F.softplus(x, beta=self.beta) if self.beta > 0 else F.relu(x)
+                x = softplus(x, self.beta) if self.beta > 0 else F.relu(x)
         return x
 
 

@@ -1,0 +1,84 @@
+"""BASELINE configs[4] on ONE GPU: a step of the with-sketch trainer (train_Point2Cyl.py:376-700 with --pred_seg --pred_normal
+--pred_bb --is_pc_train --is_im_train --with_im_loss) at B=16 clouds x N=8192 points, K=8, NUM_SK_POINT=2048:
+
+    backbone forward + segmentation / normal / base-barrel losses  (the step bench.py measures, at half its batch)
+  + projection of the predicted and the ground-truth segmentation, sketch encoder (trainable) + frozen ground-truth encoder,
+    implicit decoder losses with their double backward, latent loss       (point2cyl_amd/step_sketch.py)
+  + backward of everything + Adam over backbone and encoder parameters.
+
+    python tools/bench_config5.py [--steps 5] [--train_decoder]
+
+The implicit decoder is frozen by default like in the reference's optimiser (train_Point2Cyl.py:298-321: only `model` and `pn_encoder`
+parameters are optimised); --train_decoder also asks for its weight gradients.  One JSON line; the matrix products of the decoder
+dominate (>95 % of the step), so the roofline object prices them against the fp32 MFMA peak."""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+
+PEAK_MFMA = 157.3e12
+
+
+def main():
+    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16); ap.add_argument("--train_decoder", action="store_true"); a = ap.parse_args()
+    from point2cyl_amd import fitting, ops, step, step_sketch, synth
+    from point2cyl_amd.backbone import backbone
+    from point2cyl_amd.implicit import ImplicitNet, NormalPerPoint
+    from point2cyl_amd.sketch import PointNetEncoder
+    dev = torch.device("cuda:0"); B, N, K, S = a.batch, 8192, 8, 2048
+    fl = step.StepFlags(K=K)
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=1234)
+    batch = tuple(x.to(dev) for x in (pcs.float(), nrm.float(), seg, bb, axes.float(), cen.float()))
+    torch.manual_seed(0)
+    model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
+    enc, enc_gt = PointNetEncoder(256, 2, with_normals=True).to(dev).train(), PointNetEncoder(256, 2, with_normals=True).to(dev).eval()
+    dec = ImplicitNet(d_in=258, dims=[512] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100).to(dev)
+    for p in enc_gt.parameters(): p.requires_grad_(False)
+    for p in dec.parameters(): p.requires_grad_(a.train_decoder)
+    sampler = NormalPerPoint(1.0, 0.01)
+    # synthetic ground-truth sketches (dataloader.py's sampled_sketch, (B,K,S,4) = [point | normal]): the ground-truth projection itself
+    torch.manual_seed(5)
+    P0, X0, s0, _ = fitting.sketch_implicit_projection2(*batch[:1], batch[1], batch[2], batch[3], batch[4], batch[5], S)
+    gt_sk = torch.cat([(P0 / s0.unsqueeze(-1).unsqueeze(-1)), F.normalize(X0 + 1e-6, dim=-1)], -1).permute(1, 0, 2, 3).contiguous()
+    params = list(model.parameters()) + list(enc.parameters()) + (list(dec.parameters()) if a.train_decoder else [])
+    opt = torch.optim.Adam(params, lr=1e-3, fused=True)
+
+    def one_step():
+        with ops.step_arena(dev):
+            out = step.compute_losses_fused(model, *batch, fl)
+            h = out["heads"].view(B, N, -1)
+            with torch.no_grad():
+                X = F.normalize(h[:, :, 0:3], p=2, dim=2, eps=1e-12)
+                W2K = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2)
+                W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
+            sk = step_sketch.sketch_branch_losses(batch[0], X, W, W2K, out["match"], out["mask"], batch[1], batch[2], batch[3], batch[4], batch[5], gt_sk,
+                                                  enc, enc_gt, dec, sampler, K, S)
+            total = out["total"] + sk["im_loss"]
+            opt.zero_grad(set_to_none=True)
+            total.backward()
+        opt.step()
+        return total, sk
+
+    for _ in range(a.warmup): one_step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(a.steps): total, sk = one_step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
+    ops.PROFILE.reset(enabled=True); one_step(); prof = ops.PROFILE.summary(); ops.PROFILE.enabled = False
+    gemm = {k: v for k, v in prof.items() if v["flops"] > 0}
+    fl_all, ms_all = sum(v["flops"] for v in gemm.values()), sum(v["ms"] for v in gemm.values())
+    print(json.dumps(dict(
+        metric="with-sketch training-step points/sec (BxN) at N=8192", value=round(B * N / dt, 1), unit="points/s", n_gpus=1, steps=a.steps, warmup=a.warmup,
+        ms_per_step=round(dt * 1e3, 2), higher_is_better=True, dtype="f32", data="synthetic",
+        config=dict(workload="configs[4] on 1 GPU: B=%d clouds x N=%d, K=%d, %d points per sketch; backbone + seg/normal/bb losses + projection + sketch encoder "
+                             "+ implicit decoder losses (decoder %s) + latent loss; fwd + bwd (double backward through the decoder) + Adam"
+                             % (B, N, K, S, "trainable" if a.train_decoder else "frozen, as in the reference's optimiser"),
+                    loss=round(float(total), 5), im_loss=round(float(sk["im_loss"]), 5)),
+        roofline=dict(bound="mfma", kernel="gemm_kernel family (all matrix products of the step)", achieved=round(fl_all / ms_all / 1e9, 2), peak=157.3,
+                      unit="TFLOP/s", frac=round(fl_all / ms_all / 1e9 / 157.3, 4), gflop_per_step=round(fl_all / 1e9, 1), gemm_ms_per_step=round(ms_all, 2),
+                      share_of_step=round(ms_all / (dt * 1e3), 3), traffic=None),
+        kernels={k: dict(ms_per_step=round(v["ms"], 3), launches=v["launches"]) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]})))
+
+
+if __name__ == "__main__":
+    main()

@@ -79,7 +79,8 @@ def main():
     rows_dec = B * K * (S + S + S // 8)
     w_flops = 2.0 * (260 * 512 + 3 * 512 * 512 + 512 * 256 + 3 * 512 * 512 + 512 * 4)        # per row, padded widths as executed
     dec_gemm_flops = sum(v["flops"] for v in prof_dec.values()) / 2
-    dec_gemm_ms = sum(v["ms"] for v in prof_dec.values()) / 2
+    dec_gemm_ms = sum(v["ms"] for v in prof_dec.values() if v["flops"] > 0) / 2
+    dec_act_ms = sum(v["ms"] for v in prof_dec.values() if v["flops"] == 0) / 2
     M = B * K * S
     fl_fwd = 2.0 * M * (4 * 64 + 64 * 64 + 64 * 64 + 64 * 128 + 128 * 1024)
     proj_bytes = B * N * 16 + B * K * S * (8 + 24 + 16)          # labels once; per sample its draw, point + normal, two float2 out
@@ -102,8 +103,8 @@ def main():
         decoder=dict(ms=round(t_dec * 1e3, 2), rows=rows_dec, gemm_gflop=round(dec_gemm_flops / 1e9, 1), gemm_ms=round(dec_gemm_ms, 2),
                      gemm_tflops=round(dec_gemm_flops / dec_gemm_ms / 1e9, 2), frac_mfma_gemm=round(dec_gemm_flops / dec_gemm_ms / 1e9 / (PEAK_MFMA / 1e12), 4),
                      tflops_whole=round(dec_gemm_flops / t_dec / 1e12, 2), frac_mfma_whole=round(dec_gemm_flops / t_dec / PEAK_MFMA, 4),
-                     gemm_launches=int(sum(v["launches"] for v in prof_dec.values()) / 2),
-                     note="fwd + d f/d point (create_graph) + losses + double backward; matrix products on csrc/gemm.hip, softplus / bias adds torch elementwise"),
+                     gemm_launches=int(sum(v["launches"] for v in prof_dec.values() if v["flops"] > 0) / 2), softplus_ms=round(dec_act_ms, 2),
+                     note="fwd + d f/d point (create_graph) + losses + double backward; matrix products on csrc/gemm.hip, softplus and its derivatives on csrc/softplus.hip"),
         cpu_baseline=dict(kind="port", cores=torch.get_num_threads(), encoder_sketches_per_s=round(c / cpu_enc, 2),
                           projection_clouds_per_s=round(2 / cpu_proj, 2),
                           sample="oracle encoder fwd+bwd on %d sketches (%.1f s), oracle projection on 2 clouds (%.1f s)" % (c, cpu_enc, cpu_proj)),

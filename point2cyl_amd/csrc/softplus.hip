@@ -27,7 +27,10 @@ __global__ void __launch_bounds__(256) softplus_kernel(const float *__restrict__
             const bool lin = bz > thr;
             if (MODE == 0) {
                 // log1p(exp(bz)) / beta, evaluated as max(bz, 0) + log1p(exp(-|bz|)) (same value, no overflow)
-                a[c] = lin ? zz[c] : (fmaxf(bz, 0.f) + log1pf(__expf(-fabsf(bz)))) * inv_beta;
+                const float e = __expf(-fabsf(bz));          // in (0, 1]
+                // log1p(e): three terms of the series below 2^-7 (error < e^4/4 < 1e-9 relative), the hardware log above it
+                const float l1p = e < 0.0078125f ? e * (1.f - e * (0.5f - e * 0.33333334f)) : __logf(1.f + e);
+                a[c] = lin ? zz[c] : (fmaxf(bz, 0.f) + l1p) * inv_beta;
             } else {
                 const float s = lin ? 1.f : sp_sigmoid(bz);
                 if (MODE == 1) {

@@ -328,6 +328,13 @@ int p2c_softplus_fwd_f32(const float *z, float *h, long long n, float beta, floa
 int p2c_softplus_bwd_f32(const float *u, const float *z, float *out, long long n, float beta, float threshold, void *stream);
 int p2c_softplus_bwd_bwd_f32(const float *g, const float *u, const float *z, float *du, float *dz, long long n, float beta, float threshold,
                              void *stream);
+/* The same derivative fused into the product it follows: dX[M,K] = (dZ[M,N] . W[N,K]) * s(Z[M,K]) (the data gradient of a linear
+ * layer fed by softplus(Z); IGR/network.py:80-82 under autograd), and the backward of THAT from its own output a:
+ * t = g * s(z), dz = g * a * beta * (1 - s(z)). */
+int p2c_linear_bwd_data_sig_f32(const float *dZ, int lddz, const float *W, int ldw, const float *Z, int ldz, float beta, float threshold,
+                                float *dX, int lddx, int M, int N, int K, void *stream);
+int p2c_softplus_sig_bwd_f32(const float *g, const float *a, const float *z, float *t, float *dz, long long n, float beta, float threshold,
+                             void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian matching on the device (losses.py:22-52; scipy.optimize.linear_sum_assignment restated)

@@ -179,6 +179,9 @@ struct EpiBwdData {
     // fused ReLU+BN-backward reduction of the layer BELOW (whose pre-BN output is Yp, same shape as dX):
     const float *Yp; int ldyp; const float *pstat;   // pstat [4][J]: scale, shift, mean, invstd
     double *partials;                                // [P2C_STAT_SLOTS][2][J] fp64 accumulators (atomic) or NULL
+    // optional: dX *= sigmoid(beta * Z) (Z the pre-activation the product is the gradient of, same shape as dX): the derivative of the
+    // softplus that precedes the layer, applied where the product leaves the registers (the implicit decoder, IGR/network.py:80-82)
+    const float *spz; int ldspz; float sp_beta, sp_thr;
 };
 struct EpiAtomic {
     float *dW; int lddw; float *dbias;
@@ -315,6 +318,42 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
             }
         }
     } else if constexpr (std::is_same<Epi, EpiBwdData>::value) {
+        if (!epi.mask && !epi.partials && (epi.lddx & 3) == 0 && (((uintptr_t)epi.dX) & 15) == 0 && (J & 3) == 0 &&
+            (!epi.spz || ((epi.ldspz & 3) == 0 && (((uintptr_t)epi.spz) & 15) == 0))) {
+            // plain / softplus-derivative gradient (the implicit decoder's 512-wide layers): like the forward, stage the tile in LDS and
+            // move whole rows - dX out and, for the sigmoid factor, Z in - as 16-byte pieces instead of two 128-byte pieces per instruction
+            constexpr int LDO = BN + 4, V = BN / 4;
+            __syncthreads();
+#pragma unroll
+            for (int tb = 0; tb < TN; ++tb)
+#pragma unroll
+                for (int ta = 0; ta < TM; ++ta)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        smem[(wm * (TM * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * rquad) * LDO + wn * (TN * 32) + tb * 32 + col_l] = acc[ta][tb][r];
+            __syncthreads();
+            for (int u = tid; u < BM * V; u += 256) {
+                const int rl = u / V, c4 = (u % V) * 4;
+                const int row = i0 + rl, col = j0 + c4;
+                if (row >= I || col >= J) continue;
+                float4 v = *reinterpret_cast<const float4 *>(&smem[rl * LDO + c4]);
+                if (epi.spz) {
+                    const float4 z = *reinterpret_cast<const float4 *>(epi.spz + (size_t)row * epi.ldspz + col);
+                    float *vv = reinterpret_cast<float *>(&v);
+                    const float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float bz = zz[c] * epi.sp_beta;
+                        if (!(bz > epi.sp_thr)) {                           // linear region of softplus: derivative 1
+                            const float e = __expf(-fabsf(bz)), sg = 1.f / (1.f + e);
+                            vv[c] *= bz >= 0.f ? sg : 1.f - sg;
+                        }
+                    }
+                }
+                *reinterpret_cast<float4 *>(epi.dX + (size_t)row * epi.lddx + col) = v;
+            }
+            return;
+        }
         if (epi.partials) {
             __syncthreads();
             if (tid < 2 * BN) sstat[tid] = 0.f;
@@ -345,6 +384,13 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
                                 keep = epi.mask[(size_t)row * epi.ldmask + col] != 0;
                             }
                             v = keep ? v * epi.mscale : 0.f;
+                        }
+                        if (epi.spz) {
+                            const float bz = epi.spz[(size_t)row * epi.ldspz + col] * epi.sp_beta;
+                            if (!(bz > epi.sp_thr)) {                       // linear region of softplus: derivative 1
+                                const float e = __expf(-fabsf(bz)), sg = 1.f / (1.f + e);
+                                v *= bz >= 0.f ? sg : 1.f - sg;
+                            }
                         }
                         epi.dX[(size_t)row * epi.lddx + col] = v;
                         if (epi.partials) {
@@ -499,12 +545,13 @@ extern "C" int p2c_linear_fwd_fold0_f32(const float *X0, int ldx0, const float *
 template <int GMODE>
 static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy, const float *coef, const float *W, int ldw, float *dX,
                            int lddx, int M, int N, int K, const uint8_t *out_mask, int ldmask, float out_mask_scale, const float *Yprev,
-                           int ldyp, const float *prev_stat, double *bwd_partials, const int32_t *pool_arg, int pool_ns, hipStream_t s)
+                           int ldyp, const float *prev_stat, double *bwd_partials, const int32_t *pool_arg, int pool_ns, hipStream_t s,
+                           const float *spz = nullptr, int ldspz = 0, float sp_beta = 0.f, float sp_thr = 0.f)
 {
     // layer: Y[M,N] = in[M,K] . W[N,K]^T ; here the GEMM is dX[M,K] = dY[M,N] . W[N,K]
     OpGrad<GMODE> a{dZ, lddz, Yfwd, ldy, coef, N, pool_arg, pool_ns};
     OpPlain b{W, ldw};
-    EpiBwdData e{dX, lddx, out_mask, ldmask, out_mask_scale, p2c_drop_threshold(out_mask_scale), Yprev, ldyp, prev_stat, bwd_partials};
+    EpiBwdData e{dX, lddx, out_mask, ldmask, out_mask_scale, p2c_drop_threshold(out_mask_scale), Yprev, ldyp, prev_stat, bwd_partials, spz, ldspz, sp_beta, sp_thr};
     const int kps = (N + GK - 1) / GK * GK;
 #define P2C_BDL(TM_, TN_)                                                                                                          \
     hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, false, OpGrad<GMODE>, OpPlain, EpiBwdData>),                                    \
@@ -537,6 +584,19 @@ extern "C" int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Y
     if (grad_mode == 1) P2C_BD(1);
     P2C_BD(2);
 #undef P2C_BD
+}
+
+// dX[M,K] = (dZ[M,N] . W[N,K]) * sigmoid(beta * Z[M,K])  (1 where beta*Z > threshold): the data gradient of a linear layer whose
+// input is softplus(Z) (nn.Softplus(beta), IGR/network.py:58-59, :80-82), with the activation's derivative in the epilogue.
+extern "C" int p2c_linear_bwd_data_sig_f32(const float *dZ, int lddz, const float *W, int ldw, const float *Z, int ldz, float beta, float threshold,
+                                           float *dX, int lddx, int M, int N, int K, void *stream)
+{
+    if (!dZ || !W || !Z || !dX || M <= 0 || N <= 0 || K <= 0 || beta <= 0.f) return P2C_EINVAL;
+    if ((N & 3) || (K & 3)) return P2C_EALIGN;
+    P2C_REQ_ALIGNED(dZ, lddz);
+    P2C_REQ_ALIGNED(W, ldw);
+    return launch_bwd_data<0>(dZ, lddz, nullptr, 0, nullptr, W, ldw, dX, lddx, M, N, K, nullptr, 0, 1.f, nullptr, 0, nullptr, nullptr, nullptr, 0,
+                              (hipStream_t)stream, Z, ldz, beta, threshold);
 }
 
 // ---- backward weight --------------------------------------------------------------------------------

@@ -12,6 +12,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float sp_sigmoid(float bz) { const float e = __expf(-fabsf(bz)); const float s = 1.f / (1.f + e); return bz >= 0.f ? s : 1.f - s; }
 
 template <int MODE>       // 0: h = softplus(z)   1: o = u * s(z)   2: du = g * s(z), dz = g * u * beta * s (1 - s)
+                          // 3: du = g * s(z), dz = g * a * beta * (1 - s)  with a = P * s(z) given instead of P (u carries a)
 __global__ void __launch_bounds__(256) softplus_kernel(const float *__restrict__ z, const float *__restrict__ u, const float *__restrict__ g,
                                                        float *__restrict__ o0, float *__restrict__ o1, size_t n4, float beta, float thr)
 {
@@ -20,7 +21,7 @@ __global__ void __launch_bounds__(256) softplus_kernel(const float *__restrict__
         const v4f zz = reinterpret_cast<const v4f *>(z)[i];
         v4f a = {0.f, 0.f, 0.f, 0.f}, b = a, uu = a, gg = a;
         if (MODE >= 1) uu = reinterpret_cast<const v4f *>(u)[i];
-        if (MODE == 2) gg = reinterpret_cast<const v4f *>(g)[i];
+        if (MODE >= 2) gg = reinterpret_cast<const v4f *>(g)[i];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const float bz = zz[c] * beta;
@@ -35,27 +36,28 @@ __global__ void __launch_bounds__(256) softplus_kernel(const float *__restrict__
                 const float s = lin ? 1.f : sp_sigmoid(bz);
                 if (MODE == 1) {
                     a[c] = uu[c] * s;
-                } else {
+                } else {        // MODE 2, 3
                     a[c] = gg[c] * s;
-                    b[c] = lin ? 0.f : gg[c] * uu[c] * beta * s * (1.f - s);
+                    b[c] = lin ? 0.f : gg[c] * uu[c] * beta * (MODE == 3 ? 1.f : s) * (1.f - s);
                 }
             }
         }
         reinterpret_cast<v4f *>(o0)[i] = a;
-        if (MODE == 2) reinterpret_cast<v4f *>(o1)[i] = b;
+        if (MODE >= 2) reinterpret_cast<v4f *>(o1)[i] = b;
     }
 }
 
 static int softplus_launch(int mode, const float *z, const float *u, const float *g, float *o0, float *o1, long long n, float beta, float thr, void *stream)
 {
-    if (!z || !o0 || n <= 0 || (n & 3) || beta <= 0.f || (mode >= 1 && !u) || (mode == 2 && (!g || !o1))) return P2C_EINVAL;
+    if (!z || !o0 || n <= 0 || (n & 3) || beta <= 0.f || (mode >= 1 && !u) || (mode >= 2 && (!g || !o1))) return P2C_EINVAL;
     if (((uintptr_t)z | (uintptr_t)o0 | (uintptr_t)u | (uintptr_t)g | (uintptr_t)o1) & 15) return P2C_EALIGN;
     const size_t n4 = (size_t)n / 4;
     const int grid = (int)(n4 < (size_t)256 * 2048 ? (n4 + 255) / 256 : 2048);
     hipStream_t s = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL(softplus_kernel<0>, dim3(grid), dim3(256), 0, s, z, u, g, o0, o1, n4, beta, thr);
     else if (mode == 1) hipLaunchKernelGGL(softplus_kernel<1>, dim3(grid), dim3(256), 0, s, z, u, g, o0, o1, n4, beta, thr);
-    else hipLaunchKernelGGL(softplus_kernel<2>, dim3(grid), dim3(256), 0, s, z, u, g, o0, o1, n4, beta, thr);
+    else if (mode == 2) hipLaunchKernelGGL(softplus_kernel<2>, dim3(grid), dim3(256), 0, s, z, u, g, o0, o1, n4, beta, thr);
+    else hipLaunchKernelGGL(softplus_kernel<3>, dim3(grid), dim3(256), 0, s, z, u, g, o0, o1, n4, beta, thr);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -72,4 +74,11 @@ extern "C" int p2c_softplus_bwd_bwd_f32(const float *g, const float *u, const fl
                                         void *stream)
 {
     return softplus_launch(2, z, u, g, du, dz, n, beta, threshold, stream);
+}
+// backward of a = (A W) * s(z) (p2c_linear_bwd_data_sig_f32) w.r.t. the product and z, from a itself: t = g * s(z) (what goes back
+// through the product) and dz = g * a * beta * (1 - s(z))
+extern "C" int p2c_softplus_sig_bwd_f32(const float *g, const float *a, const float *z, float *t, float *dz, long long n, float beta, float threshold,
+                                        void *stream)
+{
+    return softplus_launch(3, z, a, g, t, dz, n, beta, threshold, stream);
 }

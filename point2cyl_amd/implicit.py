@@ -159,6 +159,67 @@ def softplus(z, beta=100.0, threshold=20.0):
     return _Softplus.apply(_c(z), float(beta), float(threshold)) if z.numel() % 4 == 0 else F.softplus(z, beta=beta, threshold=threshold)
 
 
+class _NNSig(torch.autograd.Function):
+    """A [M,N], W [N,K], z [M,K] -> (A W) * s(z), s = sigmoid(beta z): the gradient that a layer fed by softplus(z) sends to z, with the
+    activation's derivative in the GEMM epilogue (p2c_linear_bwd_data_sig_f32).  Its own backward needs only its output a:
+    d/d(A W) = g * s(z) and d/dz = g * a * beta * (1 - s(z)), one pass (p2c_softplus_sig_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, A, W, z, beta, thr):
+        _check(A, W, z)
+        M, N = A.shape
+        K = W.shape[1]
+        a = torch.empty(M, K, dtype=torch.float32, device=A.device)
+        call("p2c_linear_bwd_data_sig_f32", ptr(A), N, ptr(W), K, ptr(z), K, beta, thr, ptr(a), K, M, N, K, stream(), flops=2.0 * M * N * K)
+        ctx.save_for_backward(A, W, z, a)
+        ctx.bt = (beta, thr)
+        return a
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        A, W, z, a = ctx.saved_tensors
+        g = _c(g)
+        t, dz = torch.empty_like(z), torch.empty_like(z)
+        call("p2c_softplus_sig_bwd_f32", ptr(g), ptr(a), ptr(z), ptr(t), ptr(dz), z.numel(), *ctx.bt, stream(), nbytes=20.0 * z.numel())
+        dA = _nt(t, W) if ctx.needs_input_grad[0] else None
+        dW = _tn(A, t) if ctx.needs_input_grad[1] else None
+        return dA, dW, (dz if ctx.needs_input_grad[2] else None), None, None
+
+
+class _SpLinear(torch.autograd.Function):
+    """z [M,K], W [N,K], bias -> softplus(z) W^T + bias: one decoder layer on the PRE-activations.  Its backward is differentiable
+    (the trainer differentiates the decoder w.r.t. its input with the graph kept): dz = NNSig(dY, W, z)."""
+
+    @staticmethod
+    def forward(ctx, z, W, bias, beta, thr):
+        _check(z, W)
+        M, K = z.shape
+        N = W.shape[0]
+        h = torch.empty_like(z)
+        call("p2c_softplus_fwd_f32", ptr(z), ptr(h), z.numel(), beta, thr, stream(), nbytes=8.0 * z.numel())
+        Y = torch.empty(M, N, dtype=torch.float32, device=z.device)
+        call("p2c_linear_fwd_f32", ptr(h), K, ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(), flops=2.0 * M * N * K)
+        ctx.save_for_backward(z, W)
+        ctx.bt = (beta, thr)
+        ctx.has_bias = bias is not None
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        z, W = ctx.saved_tensors
+        dY = _c(dY)
+        dz = _NNSig.apply(dY, W, z, *ctx.bt) if ctx.needs_input_grad[0] else None
+        dW = _tn(dY, softplus(z, *ctx.bt)) if ctx.needs_input_grad[1] else None          # h is recomputed: only a trainable decoder needs it
+        db = dY.sum(0) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dz, dW, db, None, None
+
+
+def sp_linear(z, weight, bias, beta=100.0, threshold=20.0):
+    """F.linear(F.softplus(z, beta, threshold), weight, bias), twice differentiable; widths that are multiples of 4 only."""
+    return _SpLinear.apply(_c(z), _c(weight), _c(bias), float(beta), float(threshold))
+
+
 def linear(x, weight, bias):
     """F.linear(x, weight, bias) for x [M,K] on the GEMM kernels, differentiable to any order."""
     N, K = weight.shape
@@ -211,14 +272,31 @@ class ImplicitNet(nn.Module):
     def forward(self, input):
         if not input.is_cuda:
             raise RuntimeError("point2cyl_amd.implicit.ImplicitNet runs on the HIP device only (got %s); there is no CPU path" % input.device)
-        x = input
+        # x is kept as the PRE-activation of the previous layer where the next layer can take it that way (_SpLinear: softplus and its
+        # derivative ride on the GEMMs); the skip layer (needs the activation itself for the concat), odd widths and ReLU take the
+        # plain route
+        x, pending = input, False                       # pending: x still needs its softplus
         for layer in range(0, self.num_layers - 1):
             lin = getattr(self, "lin" + str(layer))
+            N, K = lin.weight.shape
+            fused = pending and layer not in self.skip_in and K % 4 == 0 and x.shape[1] == K
+            if pending and not fused:
+                x, pending = softplus(x, self.beta), False
             if layer in self.skip_in:
                 x = torch.cat([x, input], -1) / np.sqrt(2)
-            x = linear(x, lin.weight, lin.bias)
+            if fused:
+                npad = (-N) % 4
+                w = F.pad(lin.weight, (0, 0, 0, npad)) if npad else lin.weight
+                b = F.pad(lin.bias, (0, npad)) if npad else lin.bias
+                x = sp_linear(x, w, b, self.beta)
+                x = x[:, :N] if npad else x
+            else:
+                x = linear(x, lin.weight, lin.bias)
             if layer < self.num_layers - 2:
-                x = softplus(x, self.beta) if self.beta > 0 else F.relu(x)
+                if self.beta > 0:
+                    pending = True
+                else:
+                    x = F.relu(x)
         return x
 
 

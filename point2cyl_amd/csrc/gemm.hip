@@ -318,12 +318,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
             }
         }
     } else if constexpr (std::is_same<Epi, EpiBwdData>::value) {
-        if (!epi.mask && !epi.partials && (epi.lddx & 3) == 0 && (((uintptr_t)epi.dX) & 15) == 0 && (J & 3) == 0 &&
-            (!epi.spz || ((epi.ldspz & 3) == 0 && (((uintptr_t)epi.spz) & 15) == 0))) {
-            // plain / softplus-derivative gradient (the implicit decoder's 512-wide layers): like the forward, stage the tile in LDS and
-            // move whole rows - dX out and, for the sigmoid factor, Z in - as 16-byte pieces instead of two 128-byte pieces per instruction
+        if ((epi.lddx & 3) == 0 && (((uintptr_t)epi.dX) & 15) == 0 && (J & 3) == 0 &&
+            (!epi.spz || ((epi.ldspz & 3) == 0 && (((uintptr_t)epi.spz) & 15) == 0)) &&
+            (!epi.partials || ((epi.ldyp & 3) == 0 && (((uintptr_t)epi.Yp) & 15) == 0)) && !(epi.mask && epi.ldmask >= 0)) {
+            // Like the forward: stage the tile in LDS (the operand tiles are dead) and move whole rows - dX out, and the pre-activations
+            // the epilogue reads (Yp for the ReLU + BatchNorm-backward sums of the layer below, Z for the softplus derivative) in - as
+            // 16-byte pieces per lane instead of two 128-byte pieces per wave instruction.  A thread keeps the same four columns over all
+            // its rows, so the column sums stay in registers until one LDS add per thread.
             constexpr int LDO = BN + 4, V = BN / 4;
             __syncthreads();
+            if (epi.partials && tid < 2 * BN) sstat[tid] = 0.f;
 #pragma unroll
             for (int tb = 0; tb < TN; ++tb)
 #pragma unroll
@@ -332,14 +336,27 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
                     for (int r = 0; r < 16; ++r)
                         smem[(wm * (TM * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * rquad) * LDO + wn * (TN * 32) + tb * 32 + col_l] = acc[ta][tb][r];
             __syncthreads();
-            for (int u = tid; u < BM * V; u += 256) {
-                const int rl = u / V, c4 = (u % V) * 4;
-                const int row = i0 + rl, col = j0 + c4;
+            static_assert(256 % V == 0, "");
+            const int c4 = (tid % V) * 4, col = j0 + c4;
+            float psc[4] = {0.f, 0.f, 0.f, 0.f}, psh[4] = {0.f, 0.f, 0.f, 0.f}, pmu[4] = {0.f, 0.f, 0.f, 0.f}, pis[4] = {0.f, 0.f, 0.f, 0.f};
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+            if (epi.partials && col < J) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { psc[c] = epi.pstat[col + c]; psh[c] = epi.pstat[J + col + c]; pmu[c] = epi.pstat[2 * J + col + c]; pis[c] = epi.pstat[3 * J + col + c]; }
+            }
+            for (int rl = tid / V; rl < BM; rl += 256 / V) {
+                const int row = i0 + rl;
                 if (row >= I || col >= J) continue;
-                float4 v = *reinterpret_cast<const float4 *>(&smem[rl * LDO + c4]);
+                float4 v4 = *reinterpret_cast<const float4 *>(&smem[rl * LDO + c4]);
+                float *vv = reinterpret_cast<float *>(&v4);
+                if (epi.mask) {                                             // hashed keep-mask (ldmask < 0)
+                    const uint32_t *sd = reinterpret_cast<const uint32_t *>(epi.mask);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        vv[c] = p2c_hash32(sd[0], sd[1], (uint32_t)row * (uint32_t)J + (uint32_t)(col + c)) >= epi.thr ? vv[c] * epi.mscale : 0.f;
+                }
                 if (epi.spz) {
                     const float4 z = *reinterpret_cast<const float4 *>(epi.spz + (size_t)row * epi.ldspz + col);
-                    float *vv = reinterpret_cast<float *>(&v);
                     const float zz[4] = {z.x, z.y, z.z, z.w};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -350,7 +367,27 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
                         }
                     }
                 }
-                *reinterpret_cast<float4 *>(epi.dX + (size_t)row * epi.lddx + col) = v;
+                *reinterpret_cast<float4 *>(epi.dX + (size_t)row * epi.lddx + col) = v4;
+                if (epi.partials) {
+                    const float4 y = *reinterpret_cast<const float4 *>(epi.Yp + (size_t)row * epi.ldyp + col);
+                    const float yy[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float g = (psc[c] * yy[c] + psh[c] > 0.f) ? vv[c] : 0.f;
+                        s1[c] += g;
+                        s2[c] += g * ((yy[c] - pmu[c]) * pis[c]);
+                    }
+                }
+            }
+            if (epi.partials) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { atomicAdd(&sstat[c4 + c], s1[c]); atomicAdd(&sstat[BN + c4 + c], s2[c]); }
+                __syncthreads();
+                if (tid < BN && j0 + tid < J) {        // one fp64 atomic per column and workgroup into its slot
+                    double *o = epi.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * J;
+                    atomicAdd(&o[j0 + tid], (double)sstat[tid]);
+                    atomicAdd(&o[J + j0 + tid], (double)sstat[BN + tid]);
+                }
             }
             return;
         }

@@ -113,3 +113,29 @@ def test_grad_sync_two_ranks_gloo(tmp_path):
                           "--master-port", "29517", str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ok") == 2
+
+
+def test_checkpoint_abi_matches_the_reference_module(tmp_path):
+    """SURVEY 8(b) checkpoint ABI: the drop-in backbone registers the reference's 123 state_dict keys in the reference's order, with
+    the reference's shapes and - same torch seed, same construction order - the reference's initial values (G5 holds the key list and
+    per-tensor checksums of the upstream module); `{"model": state_dict}` (train...:408) round-trips through torch.save / load; the
+    trainer's update_momentum name matching (train...:153-156) reaches 23 modules."""
+    from tests.conftest import load_golden
+    from point2cyl_amd.backbone import backbone
+    g = load_golden("g5_backbone_train")
+    torch.manual_seed(int(g["seed"]))
+    m = backbone(output_sizes=[3, 16])
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]] and len(sd) == 123
+    ck = np.stack([[v.double().sum().item(), v.double().abs().sum().item(), (v.double() ** 2).sum().item()] for v in sd.values()])
+    np.testing.assert_allclose(ck, g["init_ck"], rtol=2e-5, atol=1e-6)
+    assert tuple(sd["sa1.mlp_convs.0.weight"].shape) == (64, 3, 1, 1) and tuple(sd["fp3.mlp_convs.0.weight"].shape) == (256, 1280, 1)
+    assert tuple(sd["fc1.weight"].shape) == (128, 128, 1) and tuple(sd["fc2.1.weight"].shape) == (16, 128, 1)
+    path = os.path.join(tmp_path, "model.pth")
+    torch.save({"model": sd}, path)
+    m2 = backbone(output_sizes=[3, 16])
+    m2.load_state_dict(torch.load(path)["model"])
+    assert all(torch.equal(a, b) for a, b in zip(m2.state_dict().values(), sd.values()))
+    step.update_momentum(m2, 0.25)
+    hit = [n for n, mod in m2.named_modules() if "bn" in n]
+    assert len(hit) == 23 and all(mod.momentum == 0.25 for n, mod in m2.named_modules() if "bn" in n)

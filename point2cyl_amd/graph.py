@@ -107,8 +107,14 @@ class GraphedForwardBackward:
         with torch.cuda.graph(self.graph):
             self.out = body()
         self.starts.refresh()
+        # the gradient tensors the graph writes (static addresses).  A data-parallel exchange re-points .grad at views of its flat
+        # buffer after every step (ddp.FlatGradSync.allreduce); the next replay still writes HERE, so .grad is pointed back first
+        self._grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]
 
     def __call__(self):
         self.graph.replay()
+        if self._grads and self._grads[0][0].grad is not self._grads[0][1]:
+            for p, g in self._grads:
+                p.grad = g
         self.starts.refresh()      # host work for the NEXT step overlaps this step's GPU time
         return self.out

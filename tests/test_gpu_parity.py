@@ -584,6 +584,49 @@ def test_hip_graph_replay_trains():
     assert losses_[-1] < losses_[0] + 0.05
 
 
+def test_hip_graph_replay_feeds_the_gradient_exchange():
+    """Data-parallel runs re-point every .grad at a view of the all-reduced flat buffer after each step (ddp.FlatGradSync); the
+    graph keeps writing its own static gradient tensors.  Replays must hand the exchange the FRESH gradients: simulated here on
+    one GPU by re-pointing .grad at scaled copies (what the all-reduce's averaging does) between replays with different inputs."""
+    from point2cyl_amd import synth
+    from point2cyl_amd.graph import GraphedForwardBackward
+    B, N, K = 2, 1024, 8
+    mk = lambda seed: tuple(v.to(DEV) for v in [synth.make_batch(B, N, K, seed=seed)[i] for i in (0, 1, 2, 3, 6, 8)])
+    batch, other = mk(3), mk(4)
+    torch.manual_seed(0)
+    fl = step.StepFlags(K=K)
+    m = backbone(output_sizes=fl.pred_sizes()).to(DEV).train()
+    m.dropout_mask = "off"
+    g = torch.Generator().manual_seed(1)
+    s1, s2 = torch.randint(0, N, (B,), generator=g).to(DEV), torch.randint(0, 512, (B,), generator=g).to(DEV)
+    m.sa1.fps_start, m.sa2.fps_start = (lambda N_, B_: s1), (lambda N_, B_: s2)        # device-resident: nothing to copy inside the capture
+
+    def fwd_bwd(geom=None):
+        out = step.compute_losses_fused(m, *batch, fl, geom=geom)
+        for p in m.parameters():
+            p.grad = None
+        out["total"].backward()
+        return {"total": out["total"].detach()}
+
+    gr = GraphedForwardBackward(m, fwd_bwd)
+    gr()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    for p in m.parameters():                       # what FlatGradSync.allreduce leaves behind: .grad = view of another buffer
+        p.grad = p.grad.clone() * 0.5
+    for dst, src in zip(batch, other):             # next batch into the static input tensors
+        dst.copy_(src)
+    gr()
+    g2 = {n: p.grad.clone() for n, p in m.named_parameters()}
+    fwd_bwd()                                      # eager reference on the same (new) inputs
+    torch.cuda.synchronize()
+    big = "fp1.mlp_convs.0.weight"
+    assert float((g2[big] - g1[big]).abs().max()) > 1e-6 * float(g1[big].abs().max())           # not the stale (halved) ones
+    gmax = max(float(p.grad.norm()) for p in m.parameters())
+    for n, p in m.named_parameters():              # (atomics order differs between runs: compare to rounding, on the scale of the step's gradients)
+        ref = p.grad
+        assert float((g2[n] - ref).norm()) <= 1e-4 * float(ref.norm()) + 1e-6 * gmax, n
+
+
 # ---------------------------------------------------------------------------------------------- sketch branch (SURVEY 8(f) rank 1)
 def _sketch_ridx(g):
     B, K = g["found"].shape

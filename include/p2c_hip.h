@@ -318,6 +318,11 @@ int p2c_sketch_projection_f32(const float *P, const float *X, const int64_t *seg
                               const float *centers, const int64_t *rand_idx, int B, int N, int K, int S, int all_points,
                               float *P_proj, float *X_proj, float *scales_out, float *found_out, void *ws, void *stream);
 
+/* scipy.optimize.linear_sum_assignment (minimising; the reference's call site is losses.py:43) for a batch of small dense problems:
+ * cost [n_problems, nr, nc] fp64 (device), nr <= nc <= 15 -> col4row_out [n_problems, nr] int32.  solver 1: one wave per problem
+ * (the solver inside the matching kernels); solver 0: the single-lane restatement of the same algorithm (cross-check). */
+int p2c_linear_sum_assignment_f64(const double *cost, int n_problems, int nr, int nc, int32_t *col4row_out, int solver, void *stream);
+
 /* nn.Softplus(beta) of the sketch branch's implicit decoder (IGR/network.py:58-59, :80-82) and the derivatives its double backward
  * needs (train_Point2Cyl.py:619-646 differentiate the decoder w.r.t. its input with create_graph), one pass each over n elements
  * (n % 4 == 0, 16-byte aligned).  s = sigmoid(beta z); beta z > threshold is the linear region as in torch (threshold 20).

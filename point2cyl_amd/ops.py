@@ -785,6 +785,16 @@ def sketch_projection(P, X, seg, bb, axes, centers, rand_idx, S, all_points=Fals
     return Pp, Xp, scales, found
 
 
+def linear_sum_assignment(cost, solver=1):
+    """scipy.optimize.linear_sum_assignment(cost)[1] for a batch: cost (P, nr, nc) fp64 on the device, nr <= nc <= 15 -> (P, nr) int32."""
+    _lib.require_device(cost)
+    cost = cost.to(torch.float64).contiguous()
+    P, nr, nc = cost.shape
+    out = torch.empty(P, nr, dtype=torch.int32, device=cost.device)
+    call("p2c_linear_sum_assignment_f64", ptr(cost), P, nr, nc, ptr(out), int(solver), stream())
+    return out
+
+
 def hungarian(W, I_gt):
     """losses.py:22-52 on the device -> matching_indices (B,K) int64, mask (B,K) bool.  No gradient."""
     _lib.require_device(W, I_gt)

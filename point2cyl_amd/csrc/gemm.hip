@@ -498,6 +498,41 @@ static bool narrow_tiles(int rows, int cols)
 }
 extern "C" int p2c_linear_stat_tiles(int M) { return (M + tile_m() - 1) / tile_m(); }
 
+// ---- forward, very few rows ------------------------------------------------------------------------
+// Y[M,N] = X[M,K] . W[N,K]^T + bias for M <= 32 (FP3's global feature: one 1024-vector per cloud against 256 weight rows).  The tiled
+// kernel gives such a problem one row of tiles - N/64 workgroups walking K sequentially, 33 us for 17 MFLOP.  Here one WAVE owns one
+// output column: its lanes stride over K in 16-byte pieces (the weight row is read once, the <= 32 input rows come from L2), 32
+// accumulators per lane, one DPP reduction per row at the end.
+#define SKINNY_MAXM 32
+__global__ void __launch_bounds__(256) skinny_fwd_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W, int ldw,
+                                                         const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K)
+{
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[SKINNY_MAXM];
+#pragma unroll
+    for (int m = 0; m < SKINNY_MAXM; ++m) acc[m] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const float4 w = *reinterpret_cast<const float4 *>(W + (size_t)n * ldw + k);
+#pragma unroll
+        for (int m = 0; m < SKINNY_MAXM; ++m) {
+            if (m < M) {
+                const float4 x = *reinterpret_cast<const float4 *>(X + (size_t)m * ldx + k);
+                acc[m] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
+            }
+        }
+    }
+    const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int m = 0; m < SKINNY_MAXM; ++m) {
+        if (m < M) {
+            float v = acc[m];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) Y[(size_t)m * ldy + n] = v + b;
+        }
+    }
+}
+
 // ---- forward --------------------------------------------------------------------------------------
 template <int MODE>
 static int launch_fwd(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
@@ -531,6 +566,11 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     P2C_REQ_ALIGNED(W, ldw);
     if (in_mode >= 1) { P2C_REQ_ALIGNED(in_scale, 0); P2C_REQ_ALIGNED(in_shift, 0); }
     hipStream_t s = (hipStream_t)stream;
+    if (M <= SKINNY_MAXM && in_mode == 0 && !stat_partials && K >= 256) {
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(p2c_cdiv(N, 4)), dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, M, N, K);
+        P2C_LAUNCH_CHECK();
+        return P2C_OK;
+    }
     static const bool use_pp = !(getenv("P2C_FWD_PP") && atoi(getenv("P2C_FWD_PP")) == 0);      // A/B switch for profiling
     if (use_pp && p2c_linear_fwd_pp_supported(M, N, K, in_mode)) {
         FwdPPArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K == 132 ? 128 : K, in_scale, in_shift, (const uint32_t *)drop_mask,

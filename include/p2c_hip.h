@@ -325,7 +325,7 @@ int p2c_linear_sum_assignment_f64(const double *cost, int n_problems, int nr, in
 
 /* nn.Softplus(beta) of the sketch branch's implicit decoder (IGR/network.py:58-59, :80-82) and the derivatives its double backward
  * needs (train_Point2Cyl.py:619-646 differentiate the decoder w.r.t. its input with create_graph), one pass each over n elements
- * (n % 4 == 0, 16-byte aligned).  s = sigmoid(beta z); beta z > threshold is the linear region as in torch (threshold 20).
+ * (16-byte aligned).  s = sigmoid(beta z); beta z > threshold is the linear region as in torch (threshold 20).
  *   fwd:      h  = softplus(z)
  *   bwd:      out = u * s(z)
  *   bwd_bwd:  du = g * s(z),  dz = g * u * beta * s(z) (1 - s(z)) */

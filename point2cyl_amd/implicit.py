@@ -156,7 +156,7 @@ class _SoftplusBwd(torch.autograd.Function):
 
 def softplus(z, beta=100.0, threshold=20.0):
     """F.softplus(z, beta, threshold) on the device kernels, twice differentiable (what a training step of the decoder needs)."""
-    return _Softplus.apply(_c(z), float(beta), float(threshold)) if z.numel() % 4 == 0 else F.softplus(z, beta=beta, threshold=threshold)
+    return _Softplus.apply(_c(z), float(beta), float(threshold))
 
 
 class _NNSig(torch.autograd.Function):

@@ -930,3 +930,22 @@ def test_sketch_branch_step_vs_oracle():
     for n, p in enc.named_parameters():
         ref = sd_e[n].grad.numpy()
         assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 5e-3 * np.linalg.norm(ref) + 1e-5 * gmax, n
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 4098, 300007])
+def test_softplus_kernels_match_torch_double_backward(n):
+    """softplus / its first and second derivative kernels (csrc/softplus.hip) against torch.nn.functional.softplus(beta=100) under
+    double backward, incl. sizes that are not multiples of 4 and values on both sides of the linear-region threshold."""
+    from point2cyl_amd.implicit import softplus
+    g = torch.Generator().manual_seed(n)
+    z0 = (torch.randn(n, generator=g) * 0.15).to(DEV)            # beta z in about +-45: both regions
+    w = torch.randn(n, generator=g).to(DEV)
+    outs = []
+    for fn in (lambda z: softplus(z, 100.0), lambda z: F.softplus(z, beta=100.0)):
+        z = z0.clone().requires_grad_(True)
+        h = fn(z)
+        (dz,) = torch.autograd.grad((h * w).sum(), z, create_graph=True)
+        (ddz,) = torch.autograd.grad((dz * dz).sum() + h.sum(), z)
+        outs.append((h.detach(), dz.detach(), ddz.detach()))
+    for a, b in zip(*outs):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-6 * max(1.0, float(b.abs().max())))

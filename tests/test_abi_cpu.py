@@ -41,6 +41,17 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_input_moments_f32(None, 4, 10, None, None) == -1
     assert L.p2c_linear_fwd_fold0_f32(None, 4, None, None, None, None, 64, None, 64, None, None, 64, 9000, 64, None, None) == -1
     assert L.p2c_fold0_bwd_finalize_f32(None, None, 10, None, None, None, None, 64, None, None, None, None) == -1
+    # sketch branch entries
+    assert L.p2c_sketch_projection_f32(None, None, None, None, None, None, None, 1, 16, 8, 4, 0, None, None, None, None, None, None) == -1
+    assert L.p2c_softplus_fwd_f32(None, None, 8, 100.0, 20.0, None) == -1
+    assert L.p2c_softplus_bwd_bwd_f32(None, None, None, None, None, 8, 100.0, 20.0, None) == -1
+    assert L.p2c_linear_bwd_data_sig_f32(None, 4, None, 4, None, 4, 100.0, 20.0, None, 4, 8, 4, 4, None) == -1
+    assert L.p2c_linear_sum_assignment_f64(None, 1, 8, 8, None, 1, None) == -1
+    one = ctypes.c_void_p(16)          # a non-null, 16-byte aligned dummy: shapes are validated before anything is dereferenced
+    assert L.p2c_linear_sum_assignment_f64(one, 1, 9, 8, one, 1, None) == -1      # more rows than columns
+    assert L.p2c_linear_sum_assignment_f64(one, 1, 8, 16, one, 1, None) == -1     # more than 15 columns
+    assert L.p2c_sketch_projection_f32(one, one, None, None, one, one, None, 1, 16, 8, 4, 1, one, one, one, one, one, None) == -1   # all_points needs S == N
+    assert L.p2c_linear_bwd_data_sig_f32(one, 4, one, 4, one, 4, 100.0, 20.0, one, 4, 8, 6, 4, None) == -2                          # N not a multiple of 4
 
 
 def test_shape_queries_describe_the_kernel_coverage():
@@ -64,3 +75,12 @@ def test_product_fails_loudly_on_cpu_tensors():
         ops.fps(torch.zeros(1, 16, 3), 4, torch.zeros(1, dtype=torch.long))
     with pytest.raises(RuntimeError, match="no CPU path"):
         backbone(output_sizes=[3, 16])(torch.zeros(1, 64, 3))
+    from point2cyl_amd import fitting
+    from point2cyl_amd.implicit import ImplicitNet
+    from point2cyl_amd.sketch import PointNetEncoder
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        PointNetEncoder(8, 2, with_normals=True)(torch.zeros(2, 16, 4))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ImplicitNet(d_in=6, dims=[8] * 8, skip_in=[4])(torch.zeros(4, 6))
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        fitting.sketch_implicit_projection3(torch.zeros(1, 8, 3), torch.zeros(1, 8, 3), None, None, torch.zeros(1, 2, 3), torch.zeros(1, 2, 3), 8)

@@ -256,6 +256,14 @@ int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int 
                               long long dw_slot_stride, float *dbias, int M, int N, int K, const int32_t *pool_arg, int pool_ns,
                               void *stream);
 
+/* Both of the above in ONE launch, for layers of a few thousand rows (SA3 / FP3 / FP2: pointnet_util.py:201-205, :317-319 under
+ * autograd) where neither GEMM fills the chip: the workgroups of the two run side by side.  grad_mode 1 or 2, in_mode 0 or 1, no
+ * dropout masks, N and K > 64; dW zeroed by the caller (atomic accumulation, one copy). */
+int p2c_linear_bwd_both_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
+                            const int32_t *pool_arg, int pool_ns, const float *X, int ldx, int in_mode, const float *in_scale,
+                            const float *in_shift, const float *W, int ldw, float *dX, int lddx, const float *Yprev, int ldyp,
+                            const float *prev_stat, double *bwd_partials, float *dW, int lddw, int M, int N, int K, void *stream);
+
 /* One-pass backward of a narrow layer (Co, Ci in {64,128}; in_mode 0/1): dX, dW, dbias and the fused reduction
  * for the layer below from a single stream over (dZ, Yfwd, X) -- see csrc/bwd_fused.hip.  Same argument meaning as
  * the two entry points above; dX may be NULL (then prev_stat/bwd_partials must be NULL too).

@@ -188,21 +188,32 @@ struct EpiAtomic {
     long long slot_stride;     // elements between the 8 copies of dW the split-k workgroups spread their atomics over (0: one copy)
 };
 
+// shared-memory floats one workgroup of the GEMM body needs
+template <int TM, int TN, bool AK, bool BK_>
+constexpr int gemm_smem_floats()
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int OPS = GK * Tile<BM, AK>::LD + GK * Tile<BN, BK_>::LD, OUT = BM * (BN + 4);
+    return (OPS > OUT ? OPS : OUT) + 2 * BN + BM;
+}
+
+// The GEMM of one workgroup (256 threads) for tile (bx, by) of the output and k-split bz; smem: gemm_smem_floats<...>() floats.
+// A __device__ body so that one launch can run the workgroups of two different GEMMs side by side (gemm_dual_kernel below).
 template <int TM, int TN, bool AK, bool BK_, class OpA, class OpB, class Epi>
-__global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, int I, int J, int K, int k_per_split)
+__device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB &opB, const Epi &epi, int I, int J, int K, int k_per_split,
+                                          int bx, int by, int bz)
 {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     using TA = Tile<BM, AK>;
     using TB = Tile<BN, BK_>;
     // operand tiles + [2][BN] stat scratch (+BM), or the BM x (BN+4) output tile the epilogue stages for full-row stores
     constexpr int SMEM_OPS = GK * TA::LD + GK * TB::LD, SMEM_OUT = BM * (BN + 4);
-    __shared__ __attribute__((aligned(16))) float smem[(SMEM_OPS > SMEM_OUT ? SMEM_OPS : SMEM_OUT) + 2 * BN + BM];
     float *As = smem, *Bs = smem + GK * TA::LD;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int i0 = blockIdx.x * BM, j0 = blockIdx.y * BN;
-    const int kbeg = blockIdx.z * k_per_split;
+    const int i0 = bx * BM, j0 = by * BN;
+    const int kbeg = bz * k_per_split;
     const int kend = min(K, kbeg + k_per_split);
 
     f32x16 acc[TM][TN];
@@ -227,7 +238,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
             TB::load(opB, j0, J, k0 + GK, kend, rb);
         }
         if constexpr (std::is_same<Epi, EpiAtomic>::value) {
-            if (epi.dbias && blockIdx.y == 0 && tid < BM) {
+            if (epi.dbias && by == 0 && tid < BM) {
                 float s = 0.f;
 #pragma unroll 8
                 for (int kk = 0; kk < GK; ++kk) s += As[kk * TA::LD + tid];
@@ -312,7 +323,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
         }
         if (epi.partials) {
             if (tid < BN && j0 + tid < J) {        // one fp64 atomic per column and workgroup into its slot
-                double *o = epi.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * J;
+                double *o = epi.partials + (size_t)(bx % P2C_STAT_SLOTS) * 2 * J;
                 atomicAdd(&o[j0 + tid], (double)sstat[tid]);
                 atomicAdd(&o[J + j0 + tid], (double)sstat[BN + tid]);
             }
@@ -384,7 +395,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
                 for (int c = 0; c < 4; ++c) { atomicAdd(&sstat[c4 + c], s1[c]); atomicAdd(&sstat[BN + c4 + c], s2[c]); }
                 __syncthreads();
                 if (tid < BN && j0 + tid < J) {        // one fp64 atomic per column and workgroup into its slot
-                    double *o = epi.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * J;
+                    double *o = epi.partials + (size_t)(bx % P2C_STAT_SLOTS) * 2 * J;
                     atomicAdd(&o[j0 + tid], (double)sstat[tid]);
                     atomicAdd(&o[J + j0 + tid], (double)sstat[BN + tid]);
                 }
@@ -450,7 +461,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
         if (epi.partials) {
             __syncthreads();
             if (tid < BN && j0 + tid < J) {        // one fp64 atomic per column and workgroup into its slot
-                double *o = epi.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * J;
+                double *o = epi.partials + (size_t)(bx % P2C_STAT_SLOTS) * 2 * J;
                 atomicAdd(&o[j0 + tid], (double)sstat[tid]);
                 atomicAdd(&o[J + j0 + tid], (double)sstat[BN + tid]);
             }
@@ -464,10 +475,36 @@ __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, in
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = i0 + wm * (TM * 32) + ta * 32 + (r & 3) + 8 * (r >> 2) + 4 * rquad;
-                    if (row < I && col < J) atomicAdd(&epi.dW[(size_t)(blockIdx.z & 7) * epi.slot_stride + (size_t)row * epi.lddw + col], acc[ta][tb][r]);
+                    if (row < I && col < J) atomicAdd(&epi.dW[(size_t)(bz & 7) * epi.slot_stride + (size_t)row * epi.lddw + col], acc[ta][tb][r]);
                 }
         }
-        if (epi.dbias && blockIdx.y == 0 && tid < BM && i0 + tid < I) atomicAdd(&epi.dbias[i0 + tid], dbias_acc);
+        if (epi.dbias && by == 0 && tid < BM && i0 + tid < I) atomicAdd(&epi.dbias[i0 + tid], dbias_acc);
+    }
+}
+
+template <int TM, int TN, bool AK, bool BK_, class OpA, class OpB, class Epi>
+__global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, int I, int J, int K, int k_per_split)
+{
+    __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<TM, TN, AK, BK_>()];
+    gemm_body<TM, TN, AK, BK_, OpA, OpB, Epi>(smem, opA, opB, epi, I, J, K, k_per_split, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Both backward GEMMs of one layer in ONE launch: workgroups [0, nA) run the data gradient (64 x 64*TNA tiles), the rest the weight
+// gradient (TMB x TNB tiles, split over the rows).  For the 4 k - 16 k-row layers neither GEMM alone has enough workgroups to fill
+// the chip and each is a chain of latency-bound steps; side by side they overlap (two streams would do the same at the price of
+// fork / join events in the graph; one launch has no price).
+template <int TNA, int TMB, int TNB, class OpG, class OpI>
+__global__ void __launch_bounds__(256) gemm_dual_kernel(OpG gA, OpPlain wA, EpiBwdData eA, int MA, int KA, int NA, int kpsA, int nAx, int nA,
+                                                        OpG gB, OpI xB, EpiAtomic eB, int NB, int KB, int MB, int kpsB, int nBx, int nBy)
+{
+    constexpr int FA = gemm_smem_floats<1, TNA, true, false>(), FB = gemm_smem_floats<TMB, TNB, false, false>();
+    __shared__ __attribute__((aligned(16))) float smem[FA > FB ? FA : FB];
+    const int b = blockIdx.x;
+    if (b < nA) {
+        gemm_body<1, TNA, true, false, OpG, OpPlain, EpiBwdData>(smem, gA, wA, eA, MA, KA, NA, kpsA, b % nAx, b / nAx, 0);
+    } else {
+        const int c = b - nA;
+        gemm_body<TMB, TNB, false, false, OpG, OpI, EpiAtomic>(smem, gB, xB, eB, NB, KB, MB, kpsB, c % nBx, (c / nBx) % nBy, c / (nBx * nBy));
     }
 }
 
@@ -748,4 +785,61 @@ extern "C" int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float 
     if (in_mode == 0) P2C_DISPATCH(2, 0);
     P2C_DISPATCH(2, 1);
 #undef P2C_DISPATCH
+}
+
+// ---- both backward GEMMs of a small layer in one launch ----------------------------------------------
+template <int GMODE, int IMODE>
+static int launch_bwd_both(const float *dZ, int lddz, const float *Yfwd, int ldy, const float *coef, const int32_t *pool_arg, int pool_ns,
+                           const float *X, int ldx, const float *in_scale, const float *in_shift, const float *W, int ldw, float *dX, int lddx,
+                           const float *Yprev, int ldyp, const float *prev_stat, double *bwd_partials, float *dW, int lddw, int M, int N, int K,
+                           hipStream_t s)
+{
+    // A: dX[M,K] = dY[M,N] . W[N,K]     (64 x 64 tiles)           B: dW[N,K] += dY[M,N]^T act_in(X)[M,K]   (128 x 128 tiles, split over M)
+    OpGrad<GMODE> g{dZ, lddz, Yfwd, ldy, coef, N, pool_arg, pool_ns};
+    OpPlain w{W, ldw};
+    EpiBwdData eA{dX, lddx, nullptr, 0, 1.f, 0u, Yprev, ldyp, prev_stat, bwd_partials, nullptr, 0, 0.f, 0.f};
+    OpActIn<IMODE> x{X, ldx, in_scale, in_shift, nullptr, 0, 1.f};
+    EpiAtomic eB{dW, lddw, nullptr, 0};
+    const int nAx = p2c_cdiv(M, 64), nAy = p2c_cdiv(K, 64), nA = nAx * nAy;
+    const int kpsA = (N + GK - 1) / GK * GK;
+    const int ti = p2c_cdiv(N, 128), tj = p2c_cdiv(K, 128);
+    const int ktiles = (M + GK - 1) / GK;
+    int splits = 512 / (ti * tj);
+    if (splits < 1) splits = 1;
+    if (splits > (ktiles + 3) / 4) splits = (ktiles + 3) / 4;
+    const int kpsB = (ktiles + splits - 1) / splits * GK;
+    splits = (M + kpsB - 1) / kpsB;
+    hipLaunchKernelGGL((gemm_dual_kernel<1, 2, 2, OpGrad<GMODE>, OpActIn<IMODE>>), dim3(nA + ti * tj * splits), dim3(256), 0, s, g, w, eA, M, K, N, kpsA,
+                       nAx, nA, g, x, eB, N, K, M, kpsB, ti, tj);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// dX and dW of one layer in ONE launch (see gemm_dual_kernel): for layers of a few thousand rows, where neither GEMM fills the chip.
+// Same operands as p2c_linear_bwd_data_f32 + p2c_linear_bwd_weight_f32 with grad_mode 1 or 2, in_mode 0 or 1, no dropout masks;
+// N, K > 64 and multiples of 4; dW (zeroed by the caller) is accumulated with atomics, one copy.
+extern "C" int p2c_linear_bwd_both_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,
+                                       const int32_t *pool_arg, int pool_ns, const float *X, int ldx, int in_mode, const float *in_scale,
+                                       const float *in_shift, const float *W, int ldw, float *dX, int lddx, const float *Yprev, int ldyp,
+                                       const float *prev_stat, double *bwd_partials, float *dW, int lddw, int M, int N, int K, void *stream)
+{
+    if (!dZ || !Yfwd || !coef || !X || !W || !dX || !dW || M <= 0 || N <= 64 || K <= 64 || grad_mode < 1 || grad_mode > 2 || in_mode < 0 || in_mode > 1)
+        return P2C_EINVAL;
+    if (grad_mode == 2 && (!pool_arg || pool_ns <= 0 || ((uintptr_t)pool_arg & 15))) return P2C_EINVAL;
+    if (in_mode == 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
+    if (bwd_partials && (!Yprev || !prev_stat)) return P2C_EINVAL;
+    if ((N & 3) || (K & 3)) return P2C_EALIGN;
+    P2C_REQ_ALIGNED(dZ, lddz);
+    P2C_REQ_ALIGNED(W, ldw);
+    P2C_REQ_ALIGNED(X, ldx);
+    P2C_REQ_ALIGNED(Yfwd, ldy);
+    P2C_REQ_ALIGNED(coef, 0);
+    hipStream_t s = (hipStream_t)stream;
+#define P2C_BB(G_, I_)                                                                                                                      \
+    return launch_bwd_both<G_, I_>(dZ, lddz, Yfwd, ldy, coef, pool_arg, pool_ns, X, ldx, in_scale, in_shift, W, ldw, dX, lddx, Yprev, ldyp, \
+                                   prev_stat, bwd_partials, dW, lddw, M, N, K, s)
+    if (grad_mode == 1) { if (in_mode == 0) P2C_BB(1, 0); P2C_BB(1, 1); }
+    if (in_mode == 0) P2C_BB(2, 0);
+    P2C_BB(2, 1);
+#undef P2C_BB
 }

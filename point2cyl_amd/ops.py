@@ -15,6 +15,7 @@ I32 = torch.int32
 PENDING_NBT = []      # num_batches_tracked counters to bump with ONE foreach add per forward (see backbone.forward)
 USE_FUSED_BWD = os.environ.get("P2C_FUSED_BWD", "1") != "0"
 USE_PRE_LINEAR = os.environ.get("P2C_PRE_LINEAR", "1") != "0"   # first conv of a gather-fed stack on the sparse rows (gather.hip)
+USE_DUAL_BWD = os.environ.get("P2C_DUAL_BWD", "1") != "0"   # dX and dW of the small layers in one launch (gemm_dual_kernel)
 USE_FOLD0 = os.environ.get("P2C_FOLD0", "1") != "0"         # first layer with <= 4 input channels never materialised (bn.hip)
 USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated backward of the gathers (no atomics)
 
@@ -614,6 +615,13 @@ class _MLPStack(torch.autograd.Function):
                      flops=(4.0 if need_dx else 2.0) * M * Co * Ci,
                      nbytes=4.0 * M * ((1 if grad_mode == 2 else 2) * Co + (2 if need_dx else 1) * Ci))   # dZ (unless pooled), Y, X read once; dX written once
                 dW_final = dW8.sum(0)
+            elif (USE_DUAL_BWD and need_dx and M <= 16384 and Co > 64 and Ci > 64 and grad_mode in (1, 2) and mode <= 1 and mptr is None):
+                # a few thousand rows: neither backward GEMM fills the chip -> both in one launch, side by side (csrc/gemm.hip)
+                dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
+                part = arena.f64(STAT_SLOTS, 2, Ci) if stats_below else None
+                call("p2c_linear_bwd_both_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(arg) if grad_mode == 2 else None,
+                     pool_ns, ptr(Xin), ldxin, mode, ptr(sc), ptr(sh), ptr(W2), Ci, ptr(dX), Ci, ptr(Ys[i - 1]) if stats_below else None, Ci,
+                     ptr(aff[i - 1]) if stats_below else None, ptr(part), ptr(dW), Ci, M, Co, Ci, stream(), flops=4.0 * M * Co * Ci)
             else:
                 use_slots = M >= 65536       # many split-k workgroups: spread the atomics over 8 copies of dW
                 dWs = arena.f32(8, Co, Ci) if use_slots else dW

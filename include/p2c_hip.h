@@ -256,7 +256,7 @@ int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float *Yfwd, int 
                               long long dw_slot_stride, float *dbias, int M, int N, int K, const int32_t *pool_arg, int pool_ns,
                               void *stream);
 
-/* Both of the above in ONE launch, for layers of a few thousand rows (SA3 / FP3 / FP2: pointnet_util.py:201-205, :317-319 under
+/* Both of the above in ONE launch, for layers of a few thousand rows (SA3 / FP3: pointnet_util.py:201-205, :317-319 under
  * autograd) where neither GEMM fills the chip: the workgroups of the two run side by side.  grad_mode 1 or 2, in_mode 0 or 1, no
  * dropout masks, N and K > 64; dW zeroed by the caller (atomic accumulation, one copy). */
 int p2c_linear_bwd_both_f32(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef,

@@ -615,7 +615,7 @@ class _MLPStack(torch.autograd.Function):
                      flops=(4.0 if need_dx else 2.0) * M * Co * Ci,
                      nbytes=4.0 * M * ((1 if grad_mode == 2 else 2) * Co + (2 if need_dx else 1) * Ci))   # dZ (unless pooled), Y, X read once; dX written once
                 dW_final = dW8.sum(0)
-            elif (USE_DUAL_BWD and need_dx and M <= 16384 and Co > 64 and Ci > 64 and grad_mode in (1, 2) and mode <= 1 and mptr is None):
+            elif (USE_DUAL_BWD and need_dx and M <= 8192 and Co > 64 and Ci > 64 and grad_mode in (1, 2) and mode <= 1 and mptr is None):
                 # a few thousand rows: neither backward GEMM fills the chip -> both in one launch, side by side (csrc/gemm.hip)
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
                 part = arena.f64(STAT_SLOTS, 2, Ci) if stats_below else None

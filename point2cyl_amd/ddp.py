@@ -17,6 +17,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("P2C_ONE_GPU_RANKS"):          # test hook: several ranks share GPU 0 (RCCL refuses that; use the gloo backend)
+        local, backend = 0, backend or "gloo"
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

@@ -949,3 +949,21 @@ def test_softplus_kernels_match_torch_double_backward(n):
         outs.append((h.detach(), dz.detach(), ddz.detach()))
     for a, b in zip(*outs):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-6 * max(1.0, float(b.abs().max())))
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The multi-process flow of bench.py (one HIP graph per rank, flat gradient exchange, fused Adam, max-over-ranks timing, one
+    JSON line from rank 0) with two ranks that SHARE this GPU (test hook P2C_ONE_GPU_RANKS: RCCL refuses two ranks per device, so the
+    exchange goes over gloo; the driver's 8-GPU run uses the same code with backend nccl)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, P2C_ONE_GPU_RANKS="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                          "--batch_size", "4", "--num_point", "2048", "--no_cpu_baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    assert np.isfinite(d["config"]["loss"]) and d["value"] > 0 and d["config"]["launch"].startswith("hip_graph")

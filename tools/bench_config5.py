@@ -7,6 +7,7 @@
   + backward of everything + Adam over backbone and encoder parameters.
 
     python tools/bench_config5.py [--steps 5] [--train_decoder]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_config5.py     # the 8-GPU form
 
 The implicit decoder is frozen by default like in the reference's optimiser (train_Point2Cyl.py:298-321: only `model` and `pn_encoder`
 parameters are optimised); --train_decoder also asks for its weight gradients.  One JSON line; the matrix products of the decoder
@@ -22,13 +23,16 @@ PEAK_MFMA = 157.3e12
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--train_decoder", action="store_true"); a = ap.parse_args()
-    from point2cyl_amd import fitting, ops, step, step_sketch, synth
+    from point2cyl_amd import ddp, fitting, ops, step, step_sketch, synth
+    import torch.distributed as dist
     from point2cyl_amd.backbone import backbone
     from point2cyl_amd.implicit import ImplicitNet, NormalPerPoint
     from point2cyl_amd.sketch import PointNetEncoder
-    dev = torch.device("cuda:0"); B, N, K, S = a.batch, 8192, 8, 2048
+    rank, world, local = ddp.init_from_env()         # one process per GPU, clouds sharded by rank, one flat gradient all-reduce per step
+    dev = torch.device("cuda", local); torch.cuda.set_device(dev)
+    B, N, K, S = a.batch, 8192, 8, 2048
     fl = step.StepFlags(K=K)
-    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=1234)
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=1234 + 1000 * rank)
     batch = tuple(x.to(dev) for x in (pcs.float(), nrm.float(), seg, bb, axes.float(), cen.float()))
     torch.manual_seed(0)
     model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
@@ -41,7 +45,10 @@ def main():
     torch.manual_seed(5)
     P0, X0, s0, _ = fitting.sketch_implicit_projection2(*batch[:1], batch[1], batch[2], batch[3], batch[4], batch[5], S)
     gt_sk = torch.cat([(P0 / s0.unsqueeze(-1).unsqueeze(-1)), F.normalize(X0 + 1e-6, dim=-1)], -1).permute(1, 0, 2, 3).contiguous()
+    for m_ in (model, enc, enc_gt, dec):
+        ddp.broadcast_module(m_)
     params = list(model.parameters()) + list(enc.parameters()) + (list(dec.parameters()) if a.train_decoder else [])
+    sync = ddp.FlatGradSync(params, world)
     opt = torch.optim.Adam(params, lr=1e-3, fused=True)
 
     def one_step():
@@ -55,22 +62,37 @@ def main():
             sk = step_sketch.sketch_branch_losses(batch[0], X, W, W2K, out["match"], out["mask"], batch[1], batch[2], batch[3], batch[4], batch[5], gt_sk,
                                                   enc, enc_gt, dec, sampler, K, S)
             total = out["total"] + sk["im_loss"]
-            opt.zero_grad(set_to_none=True)
+            sync.zero()
             total.backward()
+        sync.allreduce()
         opt.step()
         return total, sk
 
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     for _ in range(a.warmup): one_step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    fence(); t0 = time.perf_counter()
     for _ in range(a.steps): total, sk = one_step()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
-    ops.PROFILE.reset(enabled=True); one_step(); prof = ops.PROFILE.summary(); ops.PROFILE.enabled = False
+    fence(); dt = (time.perf_counter() - t0) / a.steps
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ops.PROFILE.reset(enabled=rank == 0); one_step(); prof = ops.PROFILE.summary(); ops.PROFILE.enabled = False      # every rank: the step has a collective
+    if world > 1:
+        fence()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     gemm = {k: v for k, v in prof.items() if v["flops"] > 0}
     fl_all, ms_all = sum(v["flops"] for v in gemm.values()), sum(v["ms"] for v in gemm.values())
     print(json.dumps(dict(
-        metric="with-sketch training-step points/sec (BxN) at N=8192", value=round(B * N / dt, 1), unit="points/s", n_gpus=1, steps=a.steps, warmup=a.warmup,
+        metric="with-sketch training-step points/sec (BxN) at N=8192", value=round(world * B * N / dt, 1), unit="points/s", n_gpus=world, scaling="weak", steps=a.steps, warmup=a.warmup,
         ms_per_step=round(dt * 1e3, 2), higher_is_better=True, dtype="f32", data="synthetic",
-        config=dict(workload="configs[4] on 1 GPU: B=%d clouds x N=%d, K=%d, %d points per sketch; backbone + seg/normal/bb losses + projection + sketch encoder "
+        config=dict(workload="configs[4]: B=%d clouds/GPU x N=%d, K=%d, %d points per sketch; backbone + seg/normal/bb losses + projection + sketch encoder "
                              "+ implicit decoder losses (decoder %s) + latent loss; fwd + bwd (double backward through the decoder) + Adam"
                              % (B, N, K, S, "trainable" if a.train_decoder else "frozen, as in the reference's optimiser"),
                     loss=round(float(total), 5), im_loss=round(float(sk["im_loss"]), 5)),

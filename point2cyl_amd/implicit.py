@@ -233,18 +233,17 @@ def linear(x, weight, bias):
 
 
 def gradient(inputs, outputs):
-    """IGR/network.py:8-17: d(outputs)/d(inputs) with the graph kept, last two columns (the sketch point)."""
-    d_points = torch.ones_like(outputs, requires_grad=False, device=outputs.device)
-    return torch.autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=d_points, create_graph=True, retain_graph=True,
-                               only_inputs=True)[0][:, -2:]
+    """IGR/network.py:8-17: d(sum of outputs)/d(inputs) with the graph kept (the result is differentiated again by the training step),
+    restricted to the last two input columns - the 2-D sketch point behind the latent code."""
+    (g,) = torch.autograd.grad(outputs, inputs, grad_outputs=torch.ones_like(outputs), create_graph=True, retain_graph=True)
+    return g[:, -2:]
 
 
 def add_latent(points, latent_codes):
-    """IGR/network.py:200-206: [latent code of the sketch | point] rows, (B'*S, L+dim)."""
-    batch_size, num_of_points, dim = points.shape
-    points = points.reshape(batch_size * num_of_points, dim)
-    latent_codes = latent_codes.unsqueeze(1).repeat(1, num_of_points, 1).reshape(batch_size * num_of_points, -1)
-    return torch.cat([latent_codes, points], 1)
+    """IGR/network.py:200-206: points (B', S, d), latent_codes (B', L) -> rows [code of the sketch | point], (B'*S, L + d)."""
+    nb, ns, d = points.shape
+    codes = latent_codes[:, None, :].expand(nb, ns, latent_codes.shape[-1])
+    return torch.cat([codes.reshape(nb * ns, -1), points.reshape(nb * ns, d)], dim=1)
 
 
 class ImplicitNet(nn.Module):
@@ -301,18 +300,17 @@ class ImplicitNet(nn.Module):
 
 
 class NormalPerPoint:
-    """IGR/sampler.py:18-40: off-surface samples = every sketch point + N(0, local_sigma) and S/8 uniform points in
-    [-global_sigma, global_sigma]^dim per sketch (drawn on the input's device, like the reference)."""
+    """IGR/sampler.py:18-40: off-surface samples of a batch of sketches (B', S, d): every sketch point jittered by N(0, local_sigma)
+    (a per-point sigma tensor may be passed instead), followed by S // 8 points drawn uniformly from [-global_sigma, global_sigma]^d;
+    drawn on the input's device with torch's generator, like the reference."""
 
     def __init__(self, global_sigma, local_sigma=0.01):
         self.global_sigma = global_sigma
         self.local_sigma = local_sigma
 
     def get_points(self, pc_input, local_sigma=None):
-        batch_size, sample_size, dim = pc_input.shape
-        if local_sigma is not None:
-            sample_local = pc_input + (torch.randn_like(pc_input) * local_sigma.unsqueeze(-1))
-        else:
-            sample_local = pc_input + (torch.randn_like(pc_input) * self.local_sigma)
-        sample_global = (torch.rand(batch_size, sample_size // 8, dim, device=pc_input.device) * (self.global_sigma * 2)) - self.global_sigma
-        return torch.cat([sample_local, sample_global], dim=1)
+        nb, ns, d = pc_input.shape
+        sigma = self.local_sigma if local_sigma is None else local_sigma.unsqueeze(-1)
+        near = pc_input + torch.randn_like(pc_input) * sigma
+        far = (torch.rand(nb, ns // 8, d, device=pc_input.device) * 2.0 - 1.0) * self.global_sigma
+        return torch.cat([near, far], dim=1)

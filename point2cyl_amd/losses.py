@@ -49,8 +49,11 @@ def reduce_mean_masked_instance(loss, mask_gt):
 
 
 def _reorder(W, matching_indices):
-    B, N, _ = W.shape
-    return torch.gather(W, 2, matching_indices.unsqueeze(1).expand(B, N, matching_indices.shape[1]))
+    """torch.gather(W, 2, matching_indices expanded over N) (losses.py:95; train...:479-521): the columns of every cloud permuted by its
+    matching.  Done as W @ P with P[b, j, k] = (matching_indices[b, k] == j): the same values bit for bit (each output is one input
+    times 1 plus zeros), and the backward is a batched 8 x 8 product instead of a scatter-add with atomics over B*N*K elements."""
+    P = torch.nn.functional.one_hot(matching_indices, W.shape[2]).to(W.dtype).transpose(1, 2)
+    return torch.bmm(W, P)
 
 
 def compute_miou_loss(W, I_gt, matching_indices, div_eps=1e-10):

@@ -261,6 +261,17 @@ class _ZeroArena:
         return out
 
 
+def _zero_padded(t, *shape):
+    """t copied into the top-left corner of a zero tensor of `shape`, the zeros coming out of the step arena (already cleared by the
+    step's one fill) - F.pad would launch a fill and a copy for each of the half-dozen odd-sized weights of a step."""
+    n = 1
+    for d in shape:
+        n *= d
+    buf = STEP_ARENA.take((n + 1) // 2, t.device).view(torch.float32)[:n].view(*shape)
+    buf[tuple(slice(0, d) for d in t.shape)].copy_(t)
+    return buf
+
+
 class _MLPStack(torch.autograd.Function):
     """A chain of 1x1-conv layers  Y_i = act_{i-1}(Y_{i-1}) W_i^T + b_i  with BatchNorm+ReLU folded into the
     NEXT layer's operand load.  tail: 'maxpool' (max over ns of relu(bn(Y_last))), 'bnrelu' (materialise
@@ -316,14 +327,15 @@ class _MLPStack(torch.autograd.Function):
                 W2 = W2[:, :K]
             if i == 0 and pre is not None and pre["kind"] == "group":
                 # reference column order [xyz(3) | features]: the coordinate part goes to the gather, the feature part to the GEMM
-                pre_wx = torch.nn.functional.pad(W2[:, :3], (0, 1, 0, _pad4(Co_true) - Co_true)).contiguous()
+                pre_wx = _zero_padded(W2[:, :3], _pad4(Co_true), 4)
                 W2 = W2[:, 3:]
             if i == 0 and cfg.get("xyz_last") and W2.shape[1] > 3:
                 W2 = torch.cat([W2[:, 3:], W2[:, :3]], 1)          # reference order [xyz(3) | feats] -> [feats | xyz(3)]
             Co = _pad4(Co_true)
             if W2.shape[1] != K or Co != Co_true:
-                W2 = torch.nn.functional.pad(W2, (0, K - W2.shape[1], 0, Co - Co_true))
-                b = torch.nn.functional.pad(b, (0, Co - Co_true))
+                W2 = _zero_padded(W2, Co, K)
+                if Co != Co_true:
+                    b = _zero_padded(b, Co)
             W2 = W2.contiguous()
             if fold0 and i == 0:
                 gamma, beta = params[pi], params[pi + 1]

@@ -326,6 +326,15 @@ int p2c_sketch_projection_f32(const float *P, const float *X, const int64_t *seg
                               const float *centers, const int64_t *rand_idx, int B, int N, int K, int S, int all_points,
                               float *P_proj, float *X_proj, float *scales_out, float *found_out, void *ws, void *stream);
 
+/* Head post-processing for the fitting losses (train_Point2Cyl_without_sketch.py:247-265, :319-325, :342-344): from heads [B*N, ld]
+ * (3 normal components at column xoff, 2K segmentation logits at woff) the unit normals X [B,N,3] (F.normalize, eps 1e-12) and the
+ * softmaxed barrel / base probabilities in matched order Wb, Wc [B,N,K] (= gather(W_2K[:, :, 0::2] / [1::2], 2, matching_indices)),
+ * and the backward of that map: dheads [B*N, ldd] (every column written, zero outside the two blocks) from dX, dWb, dWc (NULL = 0). */
+int p2c_head_post_f32(const float *heads, int ld, int xoff, int woff, const int64_t *match, int B, int N, int K, float *X, float *Wb,
+                      float *Wc, void *stream);
+int p2c_head_post_bwd_f32(const float *heads, int ld, int xoff, int woff, const int64_t *match, int B, int N, int K, const float *dX,
+                          const float *dWb, const float *dWc, float *dheads, int ldd, void *stream);
+
 /* scipy.optimize.linear_sum_assignment (minimising; the reference's call site is losses.py:43) for a batch of small dense problems:
  * cost [n_problems, nr, nc] fp64 (device), nr <= nc <= 15 -> col4row_out [n_problems, nr] int32.  solver 1: one wave per problem
  * (the solver inside the matching kernels); solver 0: the single-lane restatement of the same algorithm (cross-check). */

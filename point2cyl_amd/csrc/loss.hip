@@ -225,3 +225,105 @@ extern "C" int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Head post-processing for the fitting losses (train_Point2Cyl_without_sketch.py:247-265, :319-325, :342-344): from the raw head
+// output of a point - 3 normal components and 2K segmentation logits - the unit normal X = x / max(|x|, 1e-12) (F.normalize), the
+// softmax over the 2K logits, and the barrel / base probabilities of the segments in MATCHED order
+// (torch.gather(W_barrel, 2, matching_indices) etc.): what estimate_extrusion_axis / estimate_extrusion_centers consume.  One pass
+// forward, one pass backward (normalize and softmax Jacobians, the gather's scatter - matching_indices repeats column 0 for the
+// unmatched slots, so contributions are summed) instead of ~25 torch launches over [B*N, 2K] tensors.
+// ------------------------------------------------------------------------------------------------
+#define HP_MAXK 16
+__global__ void __launch_bounds__(256) head_post_kernel(const float *__restrict__ heads, int ld, int xoff, int woff, const int64_t *__restrict__ match,
+                                                        int B, int N, int K, float *__restrict__ X, float *__restrict__ Wb, float *__restrict__ Wc)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (size_t)B * N) return;
+    const int b = (int)(p / N);
+    const float *h = heads + p * ld;
+    const float x0 = h[xoff], x1 = h[xoff + 1], x2 = h[xoff + 2];
+    const float inv = 1.f / fmaxf(sqrtf(x0 * x0 + x1 * x1 + x2 * x2), 1e-12f);
+    X[p * 3 + 0] = x0 * inv; X[p * 3 + 1] = x1 * inv; X[p * 3 + 2] = x2 * inv;
+    float l[2 * HP_MAXK], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * HP_MAXK; ++j) if (j < 2 * K) { l[j] = h[woff + j]; mx = fmaxf(mx, l[j]); }
+#pragma unroll
+    for (int j = 0; j < 2 * HP_MAXK; ++j) if (j < 2 * K) { l[j] = expf(l[j] - mx); sum += l[j]; }
+    const float is = 1.f / sum;
+    const int64_t *m = match + (size_t)b * K;
+    for (int k = 0; k < K; ++k) {
+        const int c = (int)m[k];
+        float pb = 0.f, pc = 0.f;
+#pragma unroll
+        for (int j = 0; j < HP_MAXK; ++j) if (j == c) { pb = l[2 * j]; pc = l[2 * j + 1]; }
+        Wb[p * K + k] = pb * is;
+        Wc[p * K + k] = pc * is;
+    }
+}
+
+__global__ void __launch_bounds__(256) head_post_bwd_kernel(const float *__restrict__ heads, int ld, int xoff, int woff, const int64_t *__restrict__ match,
+                                                            int B, int N, int K, const float *__restrict__ dX, const float *__restrict__ dWb,
+                                                            const float *__restrict__ dWc, float *__restrict__ dheads, int ldd)
+{
+    const size_t p = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= (size_t)B * N) return;
+    const int b = (int)(p / N);
+    const float *h = heads + p * ld;
+    float *dh = dheads + p * ldd;
+    for (int j = 0; j < ldd; ++j) dh[j] = 0.f;
+    // normalize: X = x / n  ->  dx = (dX - X (X . dX)) / n   (n clamped at 1e-12: there the map is x / 1e-12, dx = dX / 1e-12)
+    const float x0 = h[xoff], x1 = h[xoff + 1], x2 = h[xoff + 2];
+    const float nrm = sqrtf(x0 * x0 + x1 * x1 + x2 * x2);
+    const float g0 = dX ? dX[p * 3 + 0] : 0.f, g1 = dX ? dX[p * 3 + 1] : 0.f, g2 = dX ? dX[p * 3 + 2] : 0.f;
+    if (nrm > 1e-12f) {
+        const float inv = 1.f / nrm, u0 = x0 * inv, u1 = x1 * inv, u2 = x2 * inv, dot = u0 * g0 + u1 * g1 + u2 * g2;
+        dh[xoff] = (g0 - u0 * dot) * inv; dh[xoff + 1] = (g1 - u1 * dot) * inv; dh[xoff + 2] = (g2 - u2 * dot) * inv;
+    } else {
+        dh[xoff] = g0 * 1e12f; dh[xoff + 1] = g1 * 1e12f; dh[xoff + 2] = g2 * 1e12f;
+    }
+    // softmax + matched gather
+    float l[2 * HP_MAXK], dp[2 * HP_MAXK], mx = -INFINITY, sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * HP_MAXK; ++j) { dp[j] = 0.f; if (j < 2 * K) { l[j] = h[woff + j]; mx = fmaxf(mx, l[j]); } }
+#pragma unroll
+    for (int j = 0; j < 2 * HP_MAXK; ++j) if (j < 2 * K) { l[j] = expf(l[j] - mx); sum += l[j]; }
+    const float is = 1.f / sum;
+    const int64_t *m = match + (size_t)b * K;
+    for (int k = 0; k < K; ++k) {
+        const int c = (int)m[k];
+        const float gb = dWb ? dWb[p * K + k] : 0.f, gc = dWc ? dWc[p * K + k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < HP_MAXK; ++j) if (j == c) { dp[2 * j] += gb; dp[2 * j + 1] += gc; }
+    }
+    float pd = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2 * HP_MAXK; ++j) if (j < 2 * K) { l[j] *= is; pd += l[j] * dp[j]; }
+#pragma unroll
+    for (int j = 0; j < 2 * HP_MAXK; ++j) if (j < 2 * K) dh[woff + j] = l[j] * (dp[j] - pd);
+}
+
+extern "C" int p2c_head_post_f32(const float *heads, int ld, int xoff, int woff, const int64_t *match, int B, int N, int K, float *X, float *Wb,
+                                 float *Wc, void *stream)
+{
+    if (!heads || !match || !X || !Wb || !Wc || B <= 0 || N <= 0 || K <= 0 || K > HP_MAXK || xoff < 0 || woff < 0 || ld < xoff + 3 || ld < woff + 2 * K)
+        return P2C_EINVAL;
+    const size_t n = (size_t)B * N;
+    hipLaunchKernelGGL(head_post_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, heads, ld, xoff, woff, match, B, N, K, X,
+                       Wb, Wc);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+extern "C" int p2c_head_post_bwd_f32(const float *heads, int ld, int xoff, int woff, const int64_t *match, int B, int N, int K, const float *dX,
+                                     const float *dWb, const float *dWc, float *dheads, int ldd, void *stream)
+{
+    if (!heads || !match || !dheads || B <= 0 || N <= 0 || K <= 0 || K > HP_MAXK || xoff < 0 || woff < 0 || ld < xoff + 3 || ld < woff + 2 * K ||
+        ldd < xoff + 3 || ldd < woff + 2 * K)
+        return P2C_EINVAL;
+    const size_t n = (size_t)B * N;
+    hipLaunchKernelGGL(head_post_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, heads, ld, xoff, woff, match, B, N, K,
+                       dX, dWb, dWc, dheads, ldd);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

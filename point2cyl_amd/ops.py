@@ -866,6 +866,41 @@ class _SegLosses(torch.autograd.Function):
         return (dheads * gout[0],) + (None,) * 11      # only d/d total is propagated (the other three scalars are logging values)
 
 
+class _HeadPost(torch.autograd.Function):
+    """heads (B*N, ld), matching_indices (B,K) -> unit normals X (B,N,3), matched barrel / base probabilities Wb, Wc (B,N,K)
+    (csrc/loss.hip: head_post_kernel and its backward)."""
+
+    @staticmethod
+    def forward(ctx, heads, match, B, N, K, xoff, woff):
+        _lib.require_device(heads, match)
+        heads = heads if heads.is_contiguous() else heads.contiguous()
+        match = match.to(torch.int64).contiguous()
+        ld = heads.stride(0)
+        X = torch.empty(B, N, 3, dtype=torch.float32, device=heads.device)
+        Wb = torch.empty(B, N, K, dtype=torch.float32, device=heads.device)
+        Wc = torch.empty(B, N, K, dtype=torch.float32, device=heads.device)
+        call("p2c_head_post_f32", ptr(heads), ld, xoff, woff, ptr(match), B, N, K, ptr(X), ptr(Wb), ptr(Wc), stream())
+        ctx.save_for_backward(heads, match)
+        ctx.cfg = (B, N, K, xoff, woff)
+        return X, Wb, Wc
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dX, dWb, dWc):
+        heads, match = ctx.saved_tensors
+        B, N, K, xoff, woff = ctx.cfg
+        c = lambda t: None if t is None else t.contiguous()
+        dX, dWb, dWc = c(dX), c(dWb), c(dWc)
+        dh = torch.empty_like(heads)
+        call("p2c_head_post_bwd_f32", ptr(heads), heads.stride(0), xoff, woff, ptr(match), B, N, K, ptr(dX), ptr(dWb), ptr(dWc), ptr(dh),
+             dh.stride(0), stream())
+        return dh, None, None, None, None, None, None
+
+
+def head_post(heads, match, B, N, K, xoff=0, woff=3):
+    return _HeadPost.apply(heads, match, B, N, K, xoff, woff)
+
+
 def seg_losses(heads, normals_gt, I_gt, bb_gt, B, N, K, xoff, woff, w_seg=1.0, w_normal=1.0, w_bb=1.0):
     """-> (out[4] = total, normal, miou, bb ; matching_indices (B,K) int64 ; mask (B,K) bool)."""
     out, match, mask = _SegLosses.apply(heads, normals_gt, I_gt, bb_gt, B, N, K, xoff, woff, w_seg, w_normal, w_bb)

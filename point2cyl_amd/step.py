@@ -69,18 +69,16 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
     ext_loss = center_loss = zero
     res = dict(normal=out4[1].detach(), miou=out4[2].detach(), bb=out4[3].detach(), match=match, mask=mask)
     if fl.pred_extrusion or fl.pred_center:
-        h = heads.view(B, N, -1)
-        X = F.normalize(h[:, :, 0:3], p=2, dim=2, eps=1e-12)
-        W_2K = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2)
-        W_barrel, W_base = W_2K[:, :, 0::2], W_2K[:, :, 1::2]
+        # normalised normals, softmax, barrel / base split and the reorder by the matching (train...:247-265, :319-325, :342-344) in
+        # one kernel forward and one backward (ops.head_post) instead of ~25 torch launches over (B,N,2K) tensors
+        X, Wb_re, Wc_re = ops.head_post(heads, match, B, N, K, 0, 3)
         mask_gt = losses.get_mask_gt(gt_inst, K)
         if fl.pred_extrusion:
-            E_AX = fitting.estimate_extrusion_axis(X, losses._reorder(W_barrel, match), losses._reorder(W_base, match), gt_bb, gt_inst,
-                                                   normalize=fl.norm_eig)
+            E_AX = fitting.estimate_extrusion_axis(X, Wb_re, Wc_re, gt_bb, gt_inst, normalize=fl.norm_eig)
             ext = losses.compute_normal_loss(E_AX, gt_axes, angle_diff=False, collapse=False)
             ext_loss = losses.reduce_mean_masked_instance(ext, mask_gt).mean() * fl.weight_extrusion
         if fl.pred_center:
-            cen = fitting.estimate_extrusion_centers(losses._reorder(W_barrel + W_base, match), pcs)
+            cen = fitting.estimate_extrusion_centers(Wb_re + Wc_re, pcs)
             diff = torch.square(cen - gt_centers).sum(dim=-1)
             center_loss = losses.reduce_mean_masked_instance(diff, mask_gt).mean() * fl.weight_center
         total = total + ext_loss + center_loss

@@ -967,3 +967,31 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
     assert np.isfinite(d["config"]["loss"]) and d["value"] > 0 and d["config"]["launch"].startswith("hip_graph")
+
+
+def test_head_post_matches_torch_expressions():
+    """ops.head_post (normalise + softmax + barrel/base split + reorder by the matching; csrc/loss.hip) against the torch expressions
+    of train_Point2Cyl_without_sketch.py:247-265, :319-325, forward and backward, with repeated matching columns (unmatched slots
+    point at column 0) and a near-zero normal."""
+    B, N, K = 3, 257, 8
+    g = torch.Generator().manual_seed(3)
+    heads0 = torch.randn(B * N, 20, generator=g)
+    heads0[5, 0:3] = 0.0
+    match = torch.stack([torch.randperm(K, generator=g) for _ in range(B)])
+    match[1, 5:] = 0
+    wX, wb, wc = torch.randn(B, N, 3, generator=g), torch.randn(B, N, K, generator=g), torch.randn(B, N, K, generator=g)
+    h = heads0.to(DEV).requires_grad_(True)
+    X, Wb, Wc = ops.head_post(h, match.to(DEV), B, N, K, 0, 3)
+    ((X * wX.to(DEV)).sum() + (Wb * wb.to(DEV)).sum() + (Wc * wc.to(DEV)).sum()).backward()
+    hr = heads0.clone().requires_grad_(True)
+    hv = hr.view(B, N, 20)
+    Xr = F.normalize(hv[:, :, 0:3], p=2, dim=2, eps=1e-12)
+    W2 = torch.softmax(hv[:, :, 3:19], dim=2)
+    idx = match.unsqueeze(1).expand(B, N, K)
+    Wbr, Wcr = torch.gather(W2[:, :, 0::2], 2, idx), torch.gather(W2[:, :, 1::2], 2, idx)
+    ((Xr * wX).sum() + (Wbr * wb).sum() + (Wcr * wc).sum()).backward()
+    np.testing.assert_allclose(X.detach().cpu().numpy(), Xr.detach().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(Wb.detach().cpu().numpy(), Wbr.detach().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(Wc.detach().cpu().numpy(), Wcr.detach().numpy(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(h.grad.cpu().numpy(), hr.grad.numpy(), rtol=1e-4, atol=1e-6)
+    assert float(h.grad[:, 19].abs().max()) == 0.0

@@ -537,7 +537,7 @@ class _MLPStack(torch.autograd.Function):
                 # dY0 -> sparse rows (CSR gather with the ReLU+BN backward rebuilt per element), then two small GEMMs
                 assert grad_mode == 1
                 offsets, rows_, ws_ = pre["csr"]
-                dG = (torch.empty if pre["kind"] == "interp" else torch.zeros)(Ms, Co, dtype=torch.float32, device=dev)
+                dG = torch.empty(Ms, Co, dtype=torch.float32, device=dev) if pre["kind"] == "interp" else STEP_ARENA.take((Ms * Co + 1) // 2, dev).view(torch.float32)[:Ms * Co].view(Ms, Co)   # zeroed: the grouped path accumulates with atomics
                 dwx = None
                 if pre["kind"] == "interp":
                     call("p2c_csr_gather_bn_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(coef), ptr(offsets), ptr(rows_), ptr(ws_), pre["B"],
@@ -853,7 +853,7 @@ class _SegLosses(torch.autograd.Function):
         call("p2c_hungarian_logits_f32", ptr(hd), ld, woff, ptr(I_gt), B, N, K, ptr(match), ptr(mask), ptr(_hungarian_ws(B, dev)), stream())
         out = torch.empty(4, dtype=torch.float32, device=dev)
         dheads = torch.empty(M, ld, dtype=torch.float32, device=dev)
-        ws = torch.zeros(_lib.lib().p2c_seg_losses_ws_bytes(B, K) // 8 + 8, dtype=torch.float64, device=dev)
+        ws = STEP_ARENA.take(_lib.lib().p2c_seg_losses_ws_bytes(B, K) // 8 + 8, dev)        # zeroed scratch: out of the step arena when one is active
         call("p2c_seg_losses_f32", ptr(hd), ld, xoff, woff, ptr(_f32c(normals_gt)), ptr(I_gt), ptr(bb_gt), ptr(match), ptr(mask), B, N, K,
              float(w_seg), float(w_normal), float(w_bb), ptr(out), ptr(dheads), ptr(ws), stream())
         ctx.save_for_backward(dheads)

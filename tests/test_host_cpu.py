@@ -139,3 +139,22 @@ def test_checkpoint_abi_matches_the_reference_module(tmp_path):
     step.update_momentum(m2, 0.25)
     hit = [n for n, mod in m2.named_modules() if "bn" in n]
     assert len(hit) == 23 and all(mod.momentum == 0.25 for n, mod in m2.named_modules() if "bn" in n)
+
+
+def test_reorder_by_matching_equals_gather():
+    """losses._reorder (a batched permutation product) == torch.gather(W, 2, matching_indices expanded) bit for bit, also when the
+    matching repeats a column (unmatched slots point at column 0), and its gradient equals the gather's scatter-add."""
+    from point2cyl_amd import losses
+    g = torch.Generator().manual_seed(0)
+    W = torch.rand(3, 40, 8, generator=g)
+    m = torch.stack([torch.randperm(8, generator=g) for _ in range(3)])
+    m[1, 4:] = 0
+    idx = m.unsqueeze(1).expand(3, 40, 8)
+    a = W.clone().requires_grad_(True)
+    b = W.clone().requires_grad_(True)
+    wa, wb = losses._reorder(a, m), torch.gather(b, 2, idx)
+    assert torch.equal(wa, wb)
+    w = torch.rand(3, 40, 8, generator=g)
+    (wa * w).sum().backward()
+    (wb * w).sum().backward()
+    assert torch.allclose(a.grad, b.grad, rtol=0, atol=1e-6)

@@ -46,6 +46,10 @@ struct BwdFusedArgs {
     int M;
     long long dw_slot_stride;        // elements between the 8 per-XCD copies of dW (0: a single copy)
     const float *w0, *b0;            // IMODE 2 (folded first layer below, bn.hip): x = its input [M,4], w0 [Ci,4], b0 [Ci] or NULL
+    // a layer wider than the kernel's Co (256 -> two launches over 128 output channels each): row strides of coef / arg in the FULL
+    // layer (0: Co), and dX accumulated with fire-and-forget atomics on top of what the first launch stored (the ReLU + BatchNorm
+    // backward sums are linear in dX, so each launch adds its part)
+    int coef_ld, arg_ld, dx_atomic;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -92,7 +96,7 @@ __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, 
         for (int sI = 0; sI < UDZ; ++sI) {
             const int grp = min(g0 + sI, glast);
             rdz[sI] = *reinterpret_cast<const float4 *>(a.dz + (size_t)grp * a.lddz + c4 * 4);
-            rarg[sI] = *reinterpret_cast<const int4 *>(a.arg + (size_t)grp * Co + c4 * 4);
+            rarg[sI] = *reinterpret_cast<const int4 *>(a.arg + (size_t)grp * (a.arg_ld ? a.arg_ld : Co) + c4 * 4);
         }
     }
 #pragma unroll
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     auto load_cf = [&]() {
 #pragma unroll
         for (int i = 0; i < 5; ++i)
-            cf[i] = GMODE >= 1 ? *reinterpret_cast<const float4 *>(a.coef + i * Co + c40 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            cf[i] = GMODE >= 1 ? *reinterpret_cast<const float4 *>(a.coef + i * (a.coef_ld ? a.coef_ld : Co) + c40 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     };
     load_cf();
     v4f w0r[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -422,14 +426,20 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                 // the layer below is folded: nobody reads dX; what its backward needs from it are the BatchNorm sums (below) and
                 // G[c, :] = sum_m g[m, c] x0[m, :], from which its weight gradient is assembled (p2c_fold0_bwd_finalize_f32)
             } else if (m0 + BM <= a.M) {
+                if (a.dx_atomic) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    a.dx[(size_t)(m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * a.lddx + xcol] = accX[r];
+                    for (int r = 0; r < 16; ++r)
+                        atomicAdd(&a.dx[(size_t)(m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * a.lddx + xcol], accX[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        a.dx[(size_t)(m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * a.lddx + xcol] = accX[r];
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < a.M) a.dx[(size_t)m * a.lddx + xcol] = accX[r];
+                    if (m < a.M) { if (a.dx_atomic) atomicAdd(&a.dx[(size_t)m * a.lddx + xcol], accX[r]); else a.dx[(size_t)m * a.lddx + xcol] = accX[r]; }
                 }
             }
             if (HAS_STATS) {
@@ -535,6 +545,7 @@ extern "C" int p2c_linear_bwd_fused_parts(int M, int Ci) { return fused_grid(M, 
 extern "C" int p2c_linear_bwd_fused_supported(int Co, int Ci, int in_mode)
 {
     if (Co == 128 && Ci == 132 && in_mode == 0) return 2;      // 128 feature columns + 4 trailing (xyz | pad) columns
+    if (Co == 256 && Ci == 128 && (in_mode == 0 || in_mode == 1)) return 3;      // two launches over 128 output channels each
     return (Co == 64 || Co == 128) && (Ci == 64 || Ci == 128) && (in_mode == 0 || in_mode == 1);
 }
 
@@ -598,8 +609,29 @@ extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *
     if ((lddz & 3) || (ldx & 3) || (ldw & 3) || (grad_mode >= 1 && (ldy & 3)) || ((uintptr_t)dZ & 15) || ((uintptr_t)X & 15) || ((uintptr_t)W & 15))
         return P2C_EALIGN;
     BwdFusedArgs a{dZ, lddz, Yfwd, ldy, coef, pool_arg, pool_ns, X, ldx, in_scale, in_shift, W, ldw, dX, lddx, dW, lddw, dbias, prev_stat,
-                   bwd_partials, M, dw_slot_stride, nullptr, nullptr};
+                   bwd_partials, M, dw_slot_stride, nullptr, nullptr, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
+    if (sup == 3) {
+        // Co = 256: W (133 KB) and the tiles do not fit in LDS together, so the layer runs as two passes over 128 output channels; the
+        // second adds its dX on top of the first's (atomics without return value: no register, no wait), each accumulates its own rows
+        // of dW and its share of the (linear) BatchNorm-backward sums
+        if (!dX || (grad_mode == 0 && dbias)) return P2C_EINVAL;
+        for (int h = 0; h < 2; ++h) {
+            BwdFusedArgs b = a;
+            const int c0 = 128 * h;
+            b.dz = dZ + c0; b.y = Yfwd ? Yfwd + c0 : nullptr; b.coef = coef ? coef + c0 : nullptr; b.arg = pool_arg ? pool_arg + c0 : nullptr;
+            b.w = W + (size_t)c0 * ldw; b.dw = dW + (size_t)c0 * lddw;
+            b.coef_ld = 256; b.arg_ld = 256; b.dx_atomic = h;
+            int rc;
+#define P2C_H(G_, I_) rc = launch_fused<2, 2, G_, I_>(b, 0, s)
+            if (grad_mode == 0) { if (in_mode == 0) P2C_H(0, 0); else P2C_H(0, 1); }
+            else if (grad_mode == 1) { if (in_mode == 0) P2C_H(1, 0); else P2C_H(1, 1); }
+            else { if (in_mode == 0) P2C_H(2, 0); else P2C_H(2, 1); }
+#undef P2C_H
+            if (rc != P2C_OK) return rc;
+        }
+        return P2C_OK;
+    }
 #define P2C_F(G_, I_) return dispatch_shape<G_, I_>(Co, Ci, extra, a, s)
     if (grad_mode == 0) { if (in_mode == 0) P2C_F(0, 0); P2C_F(0, 1); }
     if (grad_mode == 1) { if (in_mode == 0) P2C_F(1, 0); P2C_F(1, 1); }
@@ -621,7 +653,7 @@ extern "C" int p2c_linear_bwd_fused_fold0_f32(const float *dZ, int lddz, const f
     if ((lddz & 3) || (ldy & 3) || (ldw & 3) || ((uintptr_t)dZ & 15) || ((uintptr_t)X0 & 15) || ((uintptr_t)W & 15) || ((uintptr_t)W0 & 15))
         return P2C_EALIGN;
     BwdFusedArgs a{dZ, lddz, Yfwd, ldy, coef, nullptr, 0, X0, ldx0, stat0, stat0 + C0, W, ldw, nullptr, 0, dW, lddw, nullptr, stat0,
-                   partials5, M, dw_slot_stride, W0, b0};
+                   partials5, M, dw_slot_stride, W0, b0, 0, 0, 0};
     hipStream_t s = (hipStream_t)stream;
     constexpr int Ci = 64, BM = 64;
     const int grid = fused_grid(M, Ci);

@@ -15,6 +15,7 @@ I32 = torch.int32
 PENDING_NBT = []      # num_batches_tracked counters to bump with ONE foreach add per forward (see backbone.forward)
 USE_FUSED_BWD = os.environ.get("P2C_FUSED_BWD", "1") != "0"
 USE_PRE_LINEAR = os.environ.get("P2C_PRE_LINEAR", "1") != "0"   # first conv of a gather-fed stack on the sparse rows (gather.hip)
+USE_FUSED256 = os.environ.get("P2C_FUSED256", "1") != "0"   # 256-wide layers through the fused backward in two passes (A/B switch)
 USE_DUAL_BWD = os.environ.get("P2C_DUAL_BWD", "1") != "0"   # dX and dW of the small layers in one launch (gemm_dual_kernel)
 USE_FOLD0 = os.environ.get("P2C_FOLD0", "1") != "0"         # first layer with <= 4 input channels never materialised (bn.hip)
 USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated backward of the gathers (no atomics)
@@ -617,6 +618,8 @@ class _MLPStack(torch.autograd.Function):
                 fused_kind = 0           # the pooled variant wants a row tile to span at most two groups
             if fused_kind == 2 and not (i == 0 and cfg.get("xyz_last")):
                 fused_kind = 0           # kind 2 yields no dX for the 4 trailing input columns: fine for [feats | xyz | pad] only
+            if fused_kind == 3 and (not need_dx or M < 8192 or not USE_FUSED256):
+                fused_kind = 0           # the two-pass form of a 256-wide layer accumulates dX across its passes: long layers with a dX only
             if fused_kind:
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev) if need_dx else None
                 part = arena.f64(STAT_SLOTS, 2, Ci) if stats_below else None

@@ -64,7 +64,8 @@ def test_shape_queries_describe_the_kernel_coverage():
     # fused backward: Co, Ci in {64,128}; 2 = the grouped layer (no dX for the 4 trailing columns)
     assert L.p2c_linear_bwd_fused_supported(128, 128, 1) == 1
     assert L.p2c_linear_bwd_fused_supported(128, 132, 0) == 2
-    assert L.p2c_linear_bwd_fused_supported(256, 128, 1) == 0
+    assert L.p2c_linear_bwd_fused_supported(256, 128, 1) == 3        # two passes over 128 output channels each
+    assert L.p2c_linear_bwd_fused_supported(256, 256, 1) == 0
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -23,7 +23,7 @@ PEAK_HBM_GBS = 8000.0
 
 # HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE and
 # WRITE_SIZE need separate passes, so they cannot be read inside the timed run); launch-weighted over the family's kernels.
-_PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01j_pmc_hbm_traffic.json")
+_PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01k_pmc_hbm_traffic.json")
 _PMC_NAME = {"p2c_linear_bwd_fused_f32": "bwd_fused_pp_kernel", "p2c_linear_fwd_f32": "fwd_pp_kernel"}
 
 

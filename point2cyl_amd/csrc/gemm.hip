@@ -537,37 +537,39 @@ extern "C" int p2c_linear_stat_tiles(int M) { return (M + tile_m() - 1) / tile_m
 
 // ---- forward, very few rows ------------------------------------------------------------------------
 // Y[M,N] = X[M,K] . W[N,K]^T + bias for M <= 32 (FP3's global feature: one 1024-vector per cloud against 256 weight rows).  The tiled
-// kernel gives such a problem one row of tiles - N/64 workgroups walking K sequentially, 33 us for 17 MFLOP.  Here one WAVE owns one
-// output column: its lanes stride over K in 16-byte pieces (the weight row is read once, the <= 32 input rows come from L2), 32
-// accumulators per lane, one DPP reduction per row at the end.
+// kernel gives such a problem one row of tiles - N/64 workgroups walking K sequentially, 33 us for 17 MFLOP.  Here one WORKGROUP owns one
+// output column: its 256 lanes split K in 16-byte pieces (the weight row is read once, the <= 32 input rows come from L2), 32
+// accumulators per lane, a wave reduction per row and one LDS step across the four waves.
 #define SKINNY_MAXM 32
 __global__ void __launch_bounds__(256) skinny_fwd_kernel(const float *__restrict__ X, int ldx, const float *__restrict__ W, int ldw,
                                                          const float *__restrict__ bias, float *__restrict__ Y, int ldy, int M, int N, int K)
 {
-    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= N) return;
+    __shared__ float red[4][SKINNY_MAXM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = blockIdx.x;      // one WORKGROUP per output column: K split over 256 lanes
     float acc[SKINNY_MAXM];
 #pragma unroll
     for (int m = 0; m < SKINNY_MAXM; ++m) acc[m] = 0.f;
-    for (int k = lane * 4; k < K; k += 256) {
+    for (int k = tid * 4; k < K; k += 1024) {
         const float4 w = *reinterpret_cast<const float4 *>(W + (size_t)n * ldw + k);
+        // eight input rows in flight at a time (issued back to back, then consumed): one L2 round trip per batch instead of per row
 #pragma unroll
-        for (int m = 0; m < SKINNY_MAXM; ++m) {
-            if (m < M) {
-                const float4 x = *reinterpret_cast<const float4 *>(X + (size_t)m * ldx + k);
-                acc[m] += (x.x * w.x + x.y * w.y) + (x.z * w.z + x.w * w.w);
-            }
+        for (int m0 = 0; m0 < SKINNY_MAXM; m0 += 8) {
+            float4 x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = *reinterpret_cast<const float4 *>(X + (size_t)min(m0 + j, M - 1) * ldx + k);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[m0 + j] += (x[j].x * w.x + x[j].y * w.y) + (x[j].z * w.z + x[j].w * w.w);
         }
     }
-    const float b = bias ? bias[n] : 0.f;
 #pragma unroll
     for (int m = 0; m < SKINNY_MAXM; ++m) {
-        if (m < M) {
-            float v = acc[m];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            if (lane == 0) Y[(size_t)m * ldy + n] = v + b;
-        }
+        float v = acc[m];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) red[wave][m] = v;
     }
+    __syncthreads();
+    if (tid < M) Y[(size_t)tid * ldy + n] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]) + (bias ? bias[n] : 0.f);
 }
 
 // ---- forward --------------------------------------------------------------------------------------
@@ -604,7 +606,7 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     if (in_mode >= 1) { P2C_REQ_ALIGNED(in_scale, 0); P2C_REQ_ALIGNED(in_shift, 0); }
     hipStream_t s = (hipStream_t)stream;
     if (M <= SKINNY_MAXM && in_mode == 0 && !stat_partials && K >= 256) {
-        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(p2c_cdiv(N, 4)), dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, M, N, K);
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(N), dim3(256), 0, s, X, ldx, W, ldw, bias, Y, ldy, M, N, K);
         P2C_LAUNCH_CHECK();
         return P2C_OK;
     }

@@ -1033,3 +1033,51 @@ def test_fused_backward_256_wide_two_passes_equals_generic_kernels(grad_mode):
 
     for name, a, b in zip(("dX", "dW", "sums"), fused(), generic()):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-6, name
+
+
+def test_fitting_properties_at_config4_size():
+    """BASELINE configs[3] size (1250 clouds x 8192 points would take the CPU oracle minutes): size-independent properties of the
+    fitting kernels on 256 clouds x 8192 points instead.
+    (i) axis fit: rotating every normal by R rotates every fitted axis by R (up to the sign all consumers ignore);
+    (ii) hard centroids: translating the cloud translates them, and they are the label-wise means;
+    (iii) extents: translating points and centres together leaves them unchanged; flipping the axis swaps and negates (min, max)."""
+    from point2cyl_amd import synth
+    B, N, K, S = 256, 8192, 8, 512
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(64, N, K, seed=31)
+    rep = lambda t: t.repeat((B // 64,) + (1,) * (t.dim() - 1)).contiguous()
+    pcs, nrm, seg, bb, axes, cen = [rep(t) for t in (pcs.float(), nrm.float(), seg, bb, axes.float(), cen.float())]
+    g = torch.Generator().manual_seed(5)
+    nrm = F.normalize(nrm + 0.03 * torch.randn(nrm.shape, generator=g), dim=-1)
+    onehot = F.one_hot(seg, K).float()
+    Wb, Wc = onehot * (bb == 0).unsqueeze(-1), onehot * (bb == 1).unsqueeze(-1)
+    d = lambda t: t.to(DEV)
+    E = fitting.estimate_extrusion_axis(d(nrm), d(Wb), d(Wc), d(bb), d(seg), normalize=False)
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+    Rm = q * torch.sign(torch.det(q))
+    E2 = fitting.estimate_extrusion_axis(d(nrm @ Rm.T), d(Wb), d(Wc), d(bb), d(seg), normalize=False)
+    present = (onehot.sum(1) > 0)
+    barrel_cnt, base_cnt = Wb.sum(1), Wc.sum(1)
+    well = present & (barrel_cnt > 50) & (base_cnt > 50)                # both constraint sets populated: the smallest eigenvalue is isolated
+    dots = ((E.cpu() @ Rm.T) * E2.cpu()).sum(-1).abs()
+    assert float(dots[well].min()) > 1 - 1e-4, float(dots[well].min())
+    # (ii)
+    cen_k, found = ops.segment_centroids(d(pcs), d(seg), K)
+    sums = torch.einsum("bnk,bnc->bkc", onehot, pcs)
+    cnt = onehot.sum(1)
+    ref = sums / cnt.clamp(min=1).unsqueeze(-1)
+    ok = cnt > 1
+    assert torch.equal(found.cpu() > 0, ok)
+    np.testing.assert_allclose(cen_k.cpu()[ok].numpy(), ref[ok].numpy(), rtol=1e-4, atol=2e-6)
+    t3 = torch.tensor([0.3, -0.2, 0.1])
+    cen_t, _ = ops.segment_centroids(d(pcs + t3), d(seg), K)
+    np.testing.assert_allclose((cen_t.cpu() - cen_k.cpu())[ok].numpy(), np.broadcast_to(t3.numpy(), (int(ok.sum()), 3)), rtol=0, atol=3e-6)
+    # (iii)
+    ridx = torch.randint(0, 1 << 30, (B, K, S), generator=g) % barrel_cnt.long().clamp(min=1).unsqueeze(-1)
+    ext, f1 = fitting.get_extrusion_extents(d(pcs), d(seg), d(bb), E, cen_k, S, rand_idx=ridx)
+    ext_t, _ = fitting.get_extrusion_extents(d(pcs + t3), d(seg), d(bb), E, cen_k + d(t3), S, rand_idx=ridx)
+    fk = (f1.cpu() > 0).T                                   # (K,B): segments without barrel points keep zero samples, i.e. (0 - c).a - not invariant
+    np.testing.assert_allclose(ext_t.cpu().numpy()[fk.numpy()], ext.cpu().numpy()[fk.numpy()], rtol=0, atol=2e-5)      # (p + t) - (c + t) rounds at |p + t| ~ 1.5
+    ext_f, _ = fitting.get_extrusion_extents(d(pcs), d(seg), d(bb), -E, cen_k, S, rand_idx=ridx)
+    np.testing.assert_allclose(ext_f.cpu().numpy()[..., 0], -ext.cpu().numpy()[..., 1], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(ext_f.cpu().numpy()[..., 1], -ext.cpu().numpy()[..., 0], rtol=0, atol=1e-6)
+    assert float((ext[..., 1] - ext[..., 0]).min()) >= 0.0

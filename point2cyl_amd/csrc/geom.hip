@@ -186,21 +186,25 @@ __global__ void __launch_bounds__(256) ball_query_kernel(const float *__restrict
             sp[0][i] = x; sp[1][i] = y; sp[2][i] = z; sp[3][i] = p2c_norm2(x, y, z);
         }
         __syncthreads();
+        // points outer, the wave's queries inner: a point's four LDS words are read once for all of them (every query still sees the
+        // points in ascending index order, so the output is unchanged)
+        for (int off = 0; off < len; off += 64) {
+            bool all_done = true;
 #pragma unroll
-        for (int q = 0; q < BQ_QPW; ++q) {
-            if (cnt[q] >= nsample) continue;                 // wave-uniform
-            int32_t *o = idx_out + ((size_t)b * S + q0 + q) * nsample;
-            for (int off = 0; off < len && cnt[q] < nsample; off += 64) {
-                const int i = off + lane;
-                bool in = false;
-                if (i < len) {
-                    const float d = p2c_sqdist(cx[q], cy[q], cz[q], cn[q], sp[0][i], sp[1][i], sp[2][i], sp[3][i]);
-                    in = !(d > r2);                          // :102 excludes only d > r^2
-                }
+            for (int q = 0; q < BQ_QPW; ++q) all_done = all_done && (cnt[q] >= nsample);
+            if (all_done) break;                                 // wave-uniform
+            const int i = off + lane;
+            const bool ok = i < len;
+            const float px = ok ? sp[0][i] : 0.f, py = ok ? sp[1][i] : 0.f, pz = ok ? sp[2][i] : 0.f, pn = ok ? sp[3][i] : 0.f;
+#pragma unroll
+            for (int q = 0; q < BQ_QPW; ++q) {
+                if (cnt[q] >= nsample) continue;                 // wave-uniform
+                const float d = p2c_sqdist(cx[q], cy[q], cz[q], cn[q], px, py, pz, pn);
+                const bool in = ok && !(d > r2);                 // :102 excludes only d > r^2
                 const unsigned long long m = __ballot(in);
                 if (m) {
                     const int pos = cnt[q] + __popcll(m & ((1ull << lane) - 1ull));
-                    if (in && pos < nsample) o[pos] = base + i;
+                    if (in && pos < nsample) idx_out[((size_t)b * S + q0 + q) * nsample + pos] = base + i;
                     if (first[q] == N) first[q] = base + off + (__ffsll((long long)m) - 1);
                     cnt[q] += __popcll(m);
                 }

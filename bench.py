@@ -1,6 +1,10 @@
 """Point2Cyl hot-path bench: training-step points/sec at N=8192 (BASELINE.json configs[1]).
 
-    python bench.py [--gpus N --steps K --warmup W]       (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py [--gpus N --steps K --warmup W] [--full_losses]
+
+N > 1: either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU, the
+driver's form), or - when no WORLD_SIZE is in the environment - bench.py starts those N ranks ITSELF by re-executing under
+torch.distributed.run on 127.0.0.1.  Either way the run fails loudly unless exactly N ranks on N distinct GPUs take part.
 
 A step = backbone forward + (seg, normal, base/barrel) losses + backward + Adam on one synthetic batch of
 B=32 clouds x 8192 points per GPU, already resident in HBM.  Prints ONE JSON line on rank 0.
@@ -43,6 +47,25 @@ def _pmc_traffic(entry):
         return None, None
 
 
+def _self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) under torch.distributed.run on this node."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < n and not os.environ.get("P2C_ONE_GPU_RANKS"):
+        sys.stderr.write("bench: --gpus %d requested but this node exposes %d GPU(s); not reporting a %d-GPU number from fewer devices\n" % (n, have, n))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,13 +86,24 @@ def main():
     from point2cyl_amd.backbone import backbone
     import torch.distributed as dist
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
     rank, world, local = ddp.init_from_env()
     if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write("bench: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
+        raise SystemExit("bench: --gpus %d but %d rank(s) were launched (WORLD_SIZE); refusing to report a number for the wrong job size"
+                         % (args.gpus, world))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    backend = ddp.backend_name()
+    devices = [int(local)]
+    if world > 1:
+        assert dist.get_world_size() == world
+        got = [None] * world
+        dist.all_gather_object(got, (int(local), torch.cuda.get_device_properties(dev).name))
+        devices = [g[0] for g in got]
+        if len(set(devices)) != world and not os.environ.get("P2C_ONE_GPU_RANKS"):
+            raise SystemExit("bench: %d ranks share GPUs %s; one process per GPU is required" % (world, devices))
 
     B, N, K = args.batch_size, args.num_point, args.K
     fl = step.StepFlags(K=K, pred_extrusion=args.full_losses, pred_center=args.full_losses)
@@ -86,10 +120,12 @@ def main():
     loss_fn = step.compute_losses_fused if (step.fused_loss_applicable(fl) and not args.torch_losses) else step.compute_losses
 
     def fwd_bwd(geom=None):
+        ops.step_done()
         with ops.step_arena(dev):          # every zero-initialised accumulator of the step out of one buffer, one fill
             out = loss_fn(model, *batch, fl, geom=geom)
             sync.zero()
             out["total"].backward()
+            sync.pack()                    # N > 1: one multi-tensor copy into the exchange's flat buffer (a node of the captured graph)
         return {"total": out["total"].detach()}
 
     graphed = None
@@ -108,6 +144,7 @@ def main():
         out = graphed() if graphed is not None else fwd_bwd()
         sync.allreduce()
         opt.step()
+        ops.step_done()
         return out
 
     def fence():
@@ -133,7 +170,7 @@ def main():
         ops.PROFILE.reset(enabled=True)
         for _ in range(prof_steps):
             graphed.starts.cursor = 0
-            fwd_bwd()
+            fwd_bwd()                      # (step_done inside: these gradients are not used)
         torch.cuda.synchronize()
         ops.PROFILE.enabled = False
     if world > 1:
@@ -179,6 +216,7 @@ def main():
     line = dict(metric="training-step points/sec (BxN) at N=8192", value=round(value, 1), unit="points/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                 vs_baseline=None, dtype="f32", data="synthetic",
+                backend=backend, world_size=(dist.get_world_size() if world > 1 else 1), devices=devices,
                 config=dict(workload="configs[%d]: B=%d clouds/GPU x N=%d points, K=%d, %s, random-init backbone, synthetic "
                                      "extrusion-cylinder clouds; step = fwd + losses + bwd + Adam" %
                                      (2 if args.full_losses else 1, B, N, K,

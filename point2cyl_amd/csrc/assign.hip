@@ -155,22 +155,22 @@ __global__ void __launch_bounds__(HM_THREADS) hungarian_kernel(const float *__re
     int mx = -1;
     if (g < G) {
         for (int n = g; n < N; n += G) {
-            const int l = (int)lab[n];
-            mx = max(mx, l);
+            const int label = (int)lab[n];
+            mx = max(mx, label);
             float v;
             if (from_logits) {
-                const float *l = w + (size_t)n * ld + woff;
-                float mx = -INFINITY, sum = 0.f;
-                for (int j = 0; j < 2 * K; ++j) mx = fmaxf(mx, l[j]);
-                for (int j = 0; j < 2 * K; ++j) sum += expf(l[j] - mx);
-                v = (expf(l[2 * k] - mx) + expf(l[2 * k + 1] - mx)) / sum;
+                const float *logit = w + (size_t)n * ld + woff;
+                float top = -INFINITY, sum = 0.f;
+                for (int j = 0; j < 2 * K; ++j) top = fmaxf(top, logit[j]);
+                for (int j = 0; j < 2 * K; ++j) sum += expf(logit[j] - top);
+                v = (expf(logit[2 * k] - top) + expf(logit[2 * k + 1] - top)) / sum;
             } else {
                 v = w[(size_t)n * ld + k];
             }
             mine[K] += v;
-            if (l >= 0 && l < K) {
-                mine[l] += v;
-                if (k == 0) mine[K + 1 + l] += 1.f;
+            if (label >= 0 && label < K) {       // labels >= K are a contract violation the host wrappers reject (ops.hungarian, train.ResidentDataset)
+                mine[label] += v;
+                if (k == 0) mine[K + 1 + label] += 1.f;
             }
         }
     }

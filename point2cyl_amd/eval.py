@@ -1,0 +1,304 @@
+"""Evaluation counterpart of the reference's eval.py (fitting-accuracy path, eval.py:232-457 and the report :690-715), on the HIP kernels.
+
+Per batch: backbone forward (eval mode) -> unit normals, 2K-way softmax, barrel / base split (:268-305) -> hard one-hot
+segmentation with the null-column rule, Hungarian matching on the device, segmentation IoU (:314-320), reordered labels
+(:322-326), normal angle error (:331-333), base/barrel accuracy (:339-342), extrusion axis by the batched signed-smallest
+eigenvector fit with the four `--use_gt_*` operand choices (:347-397), axis angle error masked to the existing segments
+(:398-405), per-segment hard centroids (:409-445), extents along the fitted axis (:456).  Everything stays on the device; the
+per-cloud metric vectors come back in ONE transfer per batch (the reference syncs K*B times in its centroid loop alone).
+
+`eval_metrics` is the batch function on head outputs (what the parity test drives with a reference-generated fixture);
+`evaluate_batch` adds the model forward; `main` is the CLI (same flags as eval.py where they apply, plus --synthetic N because
+there is no dataset on the box).  The optional sketch-fitting losses (eval.py:459-590: projection -> PointNetEncoder ->
+ImplicitNet) run with --with_sketch_fit from randomly initialised / loaded sketch networks.
+
+    python -m point2cyl_amd.eval --synthetic 64 --batch_size 16 [--logdir DIR --ckpt model.pth] [--use_gt_normals ...]
+"""
+import argparse
+import os
+import sys
+import time
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import fitting, losses
+
+
+@dataclass
+class EvalFlags:
+    K: int = 8
+    pred_seg: bool = True
+    pred_normal: bool = True
+    pred_bb: bool = True
+    pred_extrusion: bool = True
+    norm_eig: bool = False
+    use_gt_normals: bool = False
+    use_gt_segmentation: bool = False
+    use_gt_bb: bool = False
+    num_sk_point: int = 2048
+
+    def pred_sizes(self):
+        """eval.py:167-179."""
+        return [3 if self.pred_normal else 1, 2 * self.K if (self.pred_seg and self.pred_bb) else (self.K if self.pred_seg else 1)]
+
+
+def _reorder_gather(W, matching_indices):
+    """torch.gather(W, 2, matching_indices expanded over N) (eval.py:322, :382, :393)."""
+    return losses._reorder(W, matching_indices)
+
+
+def eval_metrics(X_head, W_raw, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: EvalFlags, extent_rand_idx=None):
+    """eval.py:270-457 from the two head outputs.  gt_bb may be float (the reference casts it, :257) or integer.
+    Returns a dict: per-cloud `mIoU`, `normal_difference`, `pred_bb_acc`, `extrusion_difference`, `centroid_difference` (B,);
+    `extrusion_difference_uncollapsed`, `centroid_difference_uncollapsed` (B,K); `matching_indices`, `mask`, `label`,
+    `pred_bb_label`, `E_AX` (B,K,3), `predicted_centroids` (B,K,3), `found_centers_mask` (B,K), `extents` (B,K,2), `mask_gt`."""
+    B, N, _ = pcs.shape
+    K = fl.K
+    dev = pcs.device
+    out = {}
+    X = F.normalize(X_head, p=2, dim=2, eps=1e-12) if fl.pred_normal else torch.zeros(B, N, 3, device=dev)       # :270-274
+    W_barrel = W_base = BB = None
+    if fl.pred_seg and fl.pred_bb:
+        W_2K = torch.softmax(W_raw, dim=2)                                           # :278
+        W_barrel, W_base = W_2K[:, :, 0::2], W_2K[:, :, 1::2]                         # :282-286
+        W = W_barrel + W_base                                                         # :289
+        BB = torch.stack([W_barrel.sum(-1), W_base.sum(-1)], dim=-1)                  # :297-300
+    elif fl.pred_seg:
+        W = torch.softmax(W_raw, dim=2)
+    else:
+        W = torch.zeros(B, N, K, device=dev)
+    gt_bb_i = gt_bb.to(torch.long)
+    matching_indices = mask = W_reordered = W_ = None
+    if fl.pred_seg:
+        W_ = losses.hard_W_encoding(W, to_null_mask=True)                             # :316
+        matching_indices, mask = losses.hungarian_matching(W_, gt_inst, with_mask=True)   # :318
+        mask = mask.float()
+        out["mIoU"] = losses.compute_segmentation_iou(W_, gt_inst, matching_indices, mask)   # :320
+        W_re_un = _reorder_gather(W_, matching_indices)
+        W_reordered = torch.where(mask.unsqueeze(1) == 1, W_re_un, -torch.ones_like(W_re_un))     # :323-324
+        out["label"] = torch.argmax(W_reordered, dim=-1)                              # :326
+    else:
+        out["mIoU"] = torch.ones(B, device=dev)
+    out["normal_difference"] = (losses.compute_normal_difference(X, gt_normals, in_radians=False) if fl.pred_normal
+                                else torch.zeros(B, device=dev))                      # :331-336
+    if fl.pred_bb:
+        pred_bb_label = torch.argmax(BB, dim=-1)                                      # :340
+        out["pred_bb_label"] = pred_bb_label
+        out["pred_bb_acc"] = (pred_bb_label == gt_bb_i).sum(dim=-1) / float(N)        # :342
+    else:
+        out["pred_bb_acc"] = torch.zeros(B, device=dev)
+    mask_gt = losses.get_mask_gt(gt_inst, K)
+    out["mask_gt"] = mask_gt
+    if fl.pred_extrusion:
+        EA_X = gt_normals if fl.use_gt_normals else X                                 # :348-351
+        gt_onehot = F.one_hot(gt_inst.clamp(min=0), K).float() * (gt_inst >= 0).unsqueeze(-1)
+        if fl.use_gt_segmentation and fl.use_gt_bb:                                   # :353-360
+            EA_W, bbsel = gt_onehot, gt_bb_i
+        elif fl.use_gt_segmentation:                                                  # :363-372
+            EA_W, bbsel = gt_onehot, torch.argmax(BB, dim=-1)
+        elif fl.use_gt_bb:                                                            # :374-383
+            EA_W, bbsel = _reorder_gather(W_, matching_indices), gt_bb_i
+        else:                                                                         # :386-394
+            EA_W, bbsel = W_reordered, None
+        if bbsel is not None:
+            Wb_re = torch.where((bbsel == 0).unsqueeze(-1), EA_W, torch.zeros_like(EA_W))
+            Wc_re = torch.where((bbsel == 1).unsqueeze(-1), EA_W, torch.zeros_like(EA_W))
+        else:
+            Wb_re, Wc_re = _reorder_gather(W_barrel, matching_indices), _reorder_gather(W_base, matching_indices)
+        E_AX = fitting.estimate_extrusion_axis(EA_X, Wb_re, Wc_re, gt_bb_i, gt_inst, normalize=fl.norm_eig)        # :397
+        # :398, evaluated in float64 on the (B,K,3) axes: the angle of two nearly parallel unit vectors is an acos next to its clamp, where
+        # an fp32 dot product alone costs up to 1e-3 of the angle; the fp64 run of the reference is the yardstick
+        ext_diff = losses.compute_normal_difference(E_AX.double(), gt_axes.double(), in_radians=False, collapse=False).float()
+        out["extrusion_difference_uncollapsed"] = torch.where(mask_gt, ext_diff, torch.zeros_like(ext_diff))       # :403
+        out["extrusion_difference"] = losses.reduce_mean_masked_instance(ext_diff, mask_gt)                       # :405
+        cen, found = fitting.segment_centroids(EA_W, pcs)                                                          # :409-436
+        cdiff = torch.square(cen - gt_centers).sum(dim=-1)                                                         # :439
+        out["centroid_difference_uncollapsed"] = torch.where(mask_gt, cdiff, torch.zeros_like(cdiff))              # :445
+        out["centroid_difference"] = losses.reduce_mean_masked_instance(cdiff, mask_gt)                            # :446
+        out.update(E_AX=E_AX, predicted_centroids=cen, found_centers_mask=found)
+    else:
+        z = torch.zeros(B, device=dev)
+        out.update(extrusion_difference=z, centroid_difference=z, extrusion_difference_uncollapsed=torch.zeros(B, K, device=dev),
+                   centroid_difference_uncollapsed=torch.zeros(B, K, device=dev))
+    extents, _ = fitting.get_extrusion_extents(pcs, gt_inst, gt_bb_i, gt_axes, gt_centers, num_points_to_sample=fl.num_sk_point,
+                                               rand_idx=extent_rand_idx)                                           # :456
+    out["extents"] = extents.permute(1, 0, 2)                                                                      # :457
+    out.update(matching_indices=matching_indices, mask=mask, X=X, W=W)
+    return out
+
+
+@torch.no_grad()
+def evaluate_batch(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: EvalFlags, extent_rand_idx=None):
+    """eval.py:268 + eval_metrics."""
+    X_head, W_raw = model(pcs)
+    return eval_metrics(X_head, W_raw, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl, extent_rand_idx)
+
+
+@torch.no_grad()
+def sketch_fit_losses(m, pcs, gt_normals, gt_inst, gt_bb, implicit_net, pn_encoder, fl: EvalFlags):
+    """eval.py:459-590, default branch (no --use_gt_im / --use_whole_pc): project the predicted barrels (:492-501), encode them,
+    evaluate the implicit profile on the gt-label projection along the PREDICTED axis / centroid (:555-575, per-cylinder fitting
+    loss) and on all points (:577-590, global fitting loss).  `m` = the dict eval_metrics returned.  -> (pred_fit_cyl_loss (B,),
+    pred_fit_glob_loss (B,))."""
+    from .implicit import add_latent
+    B, N, _ = pcs.shape
+    K, S = fl.K, fl.num_sk_point
+    gt_bb_i = gt_bb.to(torch.long)
+    Wre = _reorder_gather(m["W"], m["matching_indices"]) * m["mask"].unsqueeze(1)                       # :465-466
+    label = torch.argmax(Wre, dim=-1)                                                                   # :489
+    E_AX, cen = m["E_AX"], m["predicted_centroids"]
+    ppc, pn, scales = fitting.sketch_implicit_projection(pcs, m["X"], label, m["pred_bb_label"], E_AX, cen, num_points_to_sample=S)     # :499
+    ppc = ppc / scales.unsqueeze(-1).unsqueeze(-1)
+    latent = pn_encoder(torch.cat([ppc.reshape(B * K, S, 2), pn.reshape(B * K, S, 2)], dim=-1))          # :502-506
+    ppc2, _, _, found2 = fitting.sketch_implicit_projection2(pcs, gt_normals, gt_inst, gt_bb_i, E_AX, cen, num_points_to_sample=S)     # :555
+    ppc2 = (ppc2 / scales.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2)
+    sk = implicit_net(add_latent(ppc2, latent)).reshape(K, B, S)                                         # :561-563
+    pmask = (m["mask"].T * found2.T).unsqueeze(-1)                                                       # :567-569
+    n_inst = (gt_inst.max(dim=1)[0] + 1).float()
+    cyl = (sk * pmask).abs().permute(1, 0, 2).mean(-1).reshape(B, -1).sum(1) / n_inst                    # :571-575
+    ppc3, _, _, found3 = fitting.sketch_implicit_projection3(pcs, gt_normals, gt_inst, gt_bb_i, E_AX, cen, num_points_to_sample=N)     # :577
+    ppc3 = (ppc3 / scales.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, N, 2)
+    sk3 = implicit_net(add_latent(ppc3, latent)).reshape(K, B, N)
+    pmask3 = (m["mask"].T * found3.T).unsqueeze(-1)
+    sk3 = torch.where(pmask3 == 1, sk3.abs().float(), torch.full_like(sk3, 10000.0))                     # :586
+    glob = sk3.min(dim=0)[0] * (1.0 - gt_bb.float())                                                     # :587-589
+    glob = glob.sum(1) / (float(N) - gt_bb.float().sum(1))                                               # :590
+    return cyl, glob
+
+
+REPORT = (("mIoU", "Mean mIOU= "), ("normal_difference", "Mean normal angle error (degrees) = "), ("pred_bb_acc", "Mean base/barrel accuracy= "),
+          ("extrusion_difference", "Mean extrusion angle error (degrees) = "), ("centroid_difference", "Mean centroid difference = "))
+
+
+class Accumulator:
+    """eval.py:638-676, :690-715: per-shape sums in float64 on the host, ONE device->host transfer per batch."""
+
+    def __init__(self, extra=()):
+        self.keys = [k for k, _ in REPORT] + list(extra)
+        self.n, self.tot = 0, np.zeros(len(self.keys), dtype=np.float64)
+
+    def add(self, m):
+        v = torch.stack([m[k].float() for k in self.keys], 0).double().cpu().numpy()          # (n_metrics, B)
+        self.tot += v.sum(1)
+        self.n += v.shape[1]
+
+    def means(self):
+        return dict(zip(self.keys, self.tot / max(1, self.n)))
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--model", type=str, default="pointnet_extrusion")
+    p.add_argument("--num_point", type=int, default=8192)
+    p.add_argument("--num_sk_point", type=int, default=2048)
+    p.add_argument("--K", type=int, default=8)
+    p.add_argument("--batch_size", type=int, default=4)
+    p.add_argument("--logdir", default="./results/", type=str)
+    p.add_argument("--ckpt", default="model.pth", type=str)
+    p.add_argument("--dump_dir", default="./results/", type=str)
+    p.add_argument("--data_dir", type=str, default="data/")
+    p.add_argument("--data_split", default="test", type=str)
+    for f in ("pred_seg", "pred_normal", "pred_bb", "pred_extrusion"):
+        p.add_argument("--" + f, action="store_false")          # eval.py:50-53: on by default, the flag switches the head OFF
+    for f in ("norm_eig", "add_noise", "use_gt_normals", "use_gt_segmentation", "use_gt_bb", "with_sketch_fit"):
+        p.add_argument("--" + f, action="store_true")
+    p.add_argument("--noise_sigma", type=float, default=0.01)
+    p.add_argument("--im_logdir", default="./results/IGR_dense/", type=str)
+    p.add_argument("--im_ckpt", default="latest.pth", type=str)
+    p.add_argument("--synthetic", type=int, default=0, help="evaluate N generated extrusion-cylinder clouds instead of <data_dir>/<split>.h5")
+    p.add_argument("--random_init", action="store_true", help="no checkpoint: evaluate a randomly initialised backbone (plumbing / timing runs)")
+    p.add_argument("--seed", type=int, default=0)
+    return p
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
+    if not torch.cuda.is_available():
+        raise SystemExit("point2cyl_amd.eval needs an MI355X (HIP) device; there is no CPU path")
+    from . import ddp, synth
+    from .backbone import backbone
+    rank, world, local = ddp.init_from_env()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    np.random.seed(0)                                                           # eval.py:128
+    torch.manual_seed(a.seed)
+    fl = EvalFlags(K=a.K, pred_seg=a.pred_seg, pred_normal=a.pred_normal, pred_bb=a.pred_bb, pred_extrusion=a.pred_extrusion,
+                   norm_eig=a.norm_eig, use_gt_normals=a.use_gt_normals, use_gt_segmentation=a.use_gt_segmentation, use_gt_bb=a.use_gt_bb,
+                   num_sk_point=a.num_sk_point)
+    if a.synthetic > 0:
+        ds = synth.SyntheticExtrusionDataset(a.synthetic, a.num_point, a.K, seed=99991)
+    else:
+        try:
+            import h5py  # noqa: F401
+        except Exception as e:
+            raise SystemExit("reading %s needs h5py (%s); use --synthetic N" % (os.path.join(a.data_dir, a.data_split + ".h5"), e))
+        from .h5data import AutodeskH5
+        ds = AutodeskH5(os.path.join(a.data_dir, a.data_split + ".h5"), a.num_point, a.K)
+    lo, hi = ddp.shard_range(len(ds), rank, world)                               # clouds are independent: shard, no data-path collective
+    loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=a.batch_size, num_workers=0, pin_memory=True,
+                                         shuffle=a.data_split != "test")
+    model = backbone(output_sizes=fl.pred_sizes())
+    if not a.random_init:
+        sd = torch.load(os.path.join(a.logdir, a.ckpt), map_location="cpu")["model"]            # eval.py:206-207
+        model.load_state_dict(sd)
+    model.to(dev).eval()
+    implicit_net = pn_encoder = None
+    if a.with_sketch_fit:
+        from .implicit import ImplicitNet
+        from .sketch import PointNetEncoder
+        implicit_net = ImplicitNet(d_in=2 + 256, dims=[512] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100)      # eval.py:190
+        pn_encoder = PointNetEncoder(256, 2, with_normals=True)                                                                 # eval.py:193
+        f = os.path.join(a.im_logdir, a.im_ckpt)
+        if os.path.exists(f):
+            ck = torch.load(f, map_location="cpu")
+            implicit_net.load_state_dict(ck["model_state_dict"])                                  # eval.py:209-210
+            pn_encoder.load_state_dict(ck["encoder_state_dict"])
+        implicit_net.to(dev).eval()
+        pn_encoder.to(dev).eval()
+    acc = Accumulator(("pred_fit_cyl_loss", "pred_fit_glob_loss") if a.with_sketch_fit else ())
+    os.makedirs(a.dump_dir, exist_ok=True)
+    log = open(os.path.join(a.dump_dir, "log_evaluate.txt" if world == 1 else "log_evaluate.%d.txt" % rank), "w")
+    log.write(str(a) + "\n")
+    t0 = time.time()
+    for i, b in enumerate(loader):
+        pcs, nrm, inst, bb, _, _, axes, _, cen = b[:9]
+        if a.add_noise:
+            pcs = fitting.add_noise(pcs, nrm, sigma=a.noise_sigma)                               # eval.py:241
+        pcs, nrm, axes, cen = [t.to(dev, torch.float) for t in (pcs, nrm, axes, cen)]
+        inst, bb = inst.to(dev, torch.long), bb.to(dev, torch.float)                             # eval.py:254-257
+        m = evaluate_batch(model, pcs, nrm, inst, bb, axes, cen, fl)
+        if a.with_sketch_fit:
+            m["pred_fit_cyl_loss"], m["pred_fit_glob_loss"] = sketch_fit_losses(m, pcs, nrm, inst, bb, implicit_net, pn_encoder, fl)
+        acc.add(m)
+        if i % 20 == 0 and rank == 0:
+            print("Time elapsed: %s sec for batch %d/%d." % (time.time() - t0, i, len(loader)))
+    tot, n = torch.tensor(acc.tot), torch.tensor([acc.n], dtype=torch.float64)
+    if world > 1:                                      # the only exchange of an evaluation run: the metric sums
+        import torch.distributed as dist
+        tot, n = tot.to(dev), n.to(dev)
+        dist.all_reduce(tot)
+        dist.all_reduce(n)
+        tot, n = tot.cpu(), n.cpu()
+    means = dict(zip(acc.keys, (tot / n.clamp(min=1)).tolist()))
+    if rank == 0:
+        lines = ["=" * 20, "", "Num evaluated= %d" % int(n.item()), ""]
+        for k, txt in REPORT:
+            lines += [txt + str(means[k]), ""]
+        if a.with_sketch_fit:
+            lines += ["Mean per-extrusion cylinder fitting loss= " + str(means["pred_fit_cyl_loss"]), "",
+                      "Mean global fitting loss= " + str(means["pred_fit_glob_loss"]), ""]
+        for ln in lines:
+            print(ln)
+            log.write(ln + "\n")
+    log.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return means
+
+
+if __name__ == "__main__":
+    main()
+    sys.exit(0)

@@ -1,42 +1,69 @@
 """HIP-graph capture of the forward+backward of one training step.
 
-A step launches ~400 kernels, many of them a few microseconds long; issued from Python they leave the GPU idle
-~20% of the time.  The shapes are static, so the whole forward + loss + backward is captured once into a HIP
+A step launches ~150 kernels, many of them a few microseconds long; issued from Python they leave the GPU idle
+a large part of the time.  The shapes are static, so the whole forward + loss + backward is captured once into a HIP
 graph (torch.cuda.CUDAGraph drives hipStreamBeginCapture on the stream our C-ABI launches use) and replayed.
 What is NOT static is handled explicitly:
-  * the FPS start indices are drawn on the CPU generator like the reference (pointnet_util.py:75); they go
-    through a pinned host buffer that is refreshed before every replay and copied to the device INSIDE the graph;
-  * dropout uses torch's graph-safe Philox offsets;
+  * the FPS start indices are drawn on the CPU generator like the reference (pointnet_util.py:75), in the reference's
+    order (SA1 then SA2, once per forward).  The graph reads them from STATIC DEVICE tensors; each replay is preceded by
+    an eager host->device copy out of a ring of pinned staging buffers.  A staging buffer is rewritten only after the
+    event recorded behind its last copy has completed, so a CPU running several replays ahead of the GPU can neither
+    tear nor overtake the draws an in-flight step is going to read (the copy is stream-ordered before the replay that
+    consumes it and after the previous replay that read the same device tensor);
+  * dropout uses a device-resident counter that the captured kernels advance themselves;
+  * BatchNorm momentum is a scalar kernel argument, i.e. baked into the graph: callers re-capture when the trainer's
+    staircase schedule changes it (every 200 k samples);
   * the gradient all-reduce and the optimizer step stay outside the graph (eager), so the multi-GPU path does
     not depend on capturing RCCL collectives.
+Capturing needs a few warm-up executions of the step; the BatchNorm running statistics / counters they touch and the
+dropout counter are restored afterwards, so building a graph does not change the model state.
 """
 import torch
 
 from . import backbone as _bb
+from . import ops as _ops
+
+_RING = 4
 
 
 class _PinnedStarts:
-    """FPS start indices: CPU draw -> pinned buffer -> device copy that is part of the captured graph."""
+    """FPS start indices: CPU draw -> pinned ring slot -> (eager, stream-ordered) copy into the static device tensor the graph reads."""
 
     def __init__(self, device):
         self.device = device
-        self.slots = []      # [(N, host_pinned, dev)]
+        self.slots = []      # [(N, [pinned host buffers], dev)]
+        self.events = [None] * _RING
+        self.ring = 0
         self.cursor = 0
 
     def __call__(self, N, B):
         if self.cursor == len(self.slots):
-            h = torch.empty(B, dtype=torch.long).pin_memory()
-            self.slots.append((N, h, torch.empty(B, dtype=torch.long, device=self.device)))
-            h.copy_(_bb.draw_fps_start(N, B))
-        N_, h, d = self.slots[self.cursor]
+            hs = [torch.empty(B, dtype=torch.long).pin_memory() for _ in range(_RING)]
+            d = torch.empty(B, dtype=torch.long, device=self.device)
+            hs[0].copy_(_bb.draw_fps_start(N, B))
+            d.copy_(hs[0])                               # synchronous: the first user (warm-up / capture) sees the draw
+            self.slots.append((N, hs, d))
+        d = self.slots[self.cursor][2]
         self.cursor += 1
-        d.copy_(h, non_blocking=True)
         return d
 
-    def refresh(self):
-        """Draw the next step's indices in the reference's order (SA1 then SA2)."""
-        for N, h, _ in self.slots:
-            h.copy_(_bb.draw_fps_start(N, h.shape[0]))
+    def stage(self):
+        """Draw the next step's indices in the reference's order (SA1 then SA2) and enqueue their copies on the current stream."""
+        r = self.ring = (self.ring + 1) % _RING
+        if self.events[r] is not None:
+            self.events[r].synchronize()                 # the copy that last read this staging slot has finished
+        for N, hs, d in self.slots:
+            hs[r].copy_(_bb.draw_fps_start(N, hs[r].shape[0]))
+            d.copy_(hs[r], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[r] = ev
+        self.cursor = 0
+
+    def set(self, values):
+        """Test / replay hook: put the given (B,) index tensors (one per level, SA1 first) into the static device tensors now."""
+        for (N, hs, d), v in zip(self.slots, values):
+            d.copy_(v.to(torch.long))
         self.cursor = 0
 
 
@@ -59,19 +86,30 @@ class GraphedForwardBackward:
     parameter-free geometry of that batch (FPS, ball query, 3-NN: backbone.compute_geometry) is computed on a forked
     stream INSIDE the same graph while the main stream trains on the current batch with the geometry produced by the
     previous replay; the results are copied into the static 'current' buffers after the join.  The 512-step FPS
-    loop keeps only B of the 256 CUs busy, so it disappears behind the GEMMs."""
+    loop keeps only B of the 256 CUs busy, so it disappears behind the GEMMs.
+    At construction prefetch_xyz must hold the clouds of the FIRST batch to be trained on (its geometry is computed here).
 
-    def __init__(self, model, fn, warmup=2, prefetch_xyz=None):
+    draw_starts=False leaves the FPS start tensors alone between replays (callers that set them through `starts.set`)."""
+
+    def __init__(self, model, fn, warmup=2, prefetch_xyz=None, draw_starts=True):
         dev = next(model.parameters()).device
         self.starts = _PinnedStarts(dev)
+        self.draw_starts = draw_starts
+        self._hooked = []
         for m in model.modules():
             if isinstance(m, _bb.PointNetSetAbstraction) and not m.group_all and m.fps_start is None:
                 m.fps_start = self.starts
+                self._hooked.append(m)
         self.fn = fn
         self.prefetch = prefetch_xyz is not None
         main = torch.cuda.current_stream()
+        # state the warm-up executions must not leave behind: BatchNorm running statistics / counters, the dropout counter
+        keep = [(b, b.detach().clone()) for b in model.buffers()]
+        seed = getattr(model, "_drop_seed", None)
+        keep_seed = None if seed is None else seed.detach().clone()
 
         def body():
+            _ops.step_done()                 # warm-up / capture passes: the previous pass's gradients are discarded
             if not self.prefetch:
                 return fn(None)
             cap = torch.cuda.current_stream()
@@ -106,15 +144,33 @@ class GraphedForwardBackward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = body()
-        self.starts.refresh()
-        # the gradient tensors the graph writes (static addresses).  A data-parallel exchange re-points .grad at views of its flat
-        # buffer after every step (ddp.FlatGradSync.allreduce); the next replay still writes HERE, so .grad is pointed back first
+        self.starts.cursor = 0
+        with torch.no_grad():
+            for b, v in keep:
+                b.copy_(v)
+            if keep_seed is not None and getattr(model, "_drop_seed", None) is not None:
+                model._drop_seed.copy_(keep_seed)
+        # the gradient tensors the graph leaves in .grad (static addresses): either the kernels' own output buffers, or - when fn packs
+        # them (ddp.FlatGradSync.pack, captured) - views of the exchange's flat buffer.  Code between replays that re-points .grad
+        # (an optimizer's zero_grad(set_to_none=True), a test) is undone before the next replay's results are consumed
         self._grads = [(p, p.grad) for p in model.parameters() if p.grad is not None]
+        self._first = True
+        _ops.step_done()
 
     def __call__(self):
+        if self.draw_starts and (self.prefetch or not self._first):
+            # with the prefetch the geometry of replay k+1's batch is computed DURING replay k, from the next pair of draws; without it
+            # the first replay consumes the pair drawn at construction
+            self.starts.stage()
+        self._first = False
         self.graph.replay()
         if self._grads and self._grads[0][0].grad is not self._grads[0][1]:
             for p, g in self._grads:
                 p.grad = g
-        self.starts.refresh()      # host work for the NEXT step overlaps this step's GPU time
         return self.out
+
+    def release(self):
+        """Detach the FPS-start hook from the model (before building a replacement graph)."""
+        for m in self._hooked:
+            if m.fps_start is self.starts:
+                m.fps_start = None

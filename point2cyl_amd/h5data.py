@@ -22,7 +22,10 @@ class AutodeskH5(torch.utils.data.Dataset):
         return self.pcs.shape[0]
 
     def __getitem__(self, i):
-        sel = torch.randperm(self.pcs.shape[1])[: self.num_point].numpy()      # dataloader.py:71-77
+        if self.num_point is None:             # whole item (the device-resident trainer draws the subsample on the GPU)
+            sel = np.arange(self.pcs.shape[1])
+        else:
+            sel = torch.randperm(self.pcs.shape[1])[: self.num_point].numpy()      # dataloader.py:71-77
         lab = self.labels[i][sel]
         K = self.K
         return (self.pcs[i][sel].astype(np.float32), self.normals[i][sel].astype(np.float32), lab.astype(np.int64),

@@ -204,6 +204,7 @@ class _StepArena:
 
     def __init__(self):
         self.buf, self.off, self.need, self.run, self.active = None, 0, 0, 0, False
+        self.pending = False      # gradients handed out by the last arena step have not been consumed yet (see step_done)
 
     def take(self, n_f64, dev):
         self.run += n_f64
@@ -217,12 +218,25 @@ class _StepArena:
 STEP_ARENA = _StepArena()
 
 
+def step_done():
+    """The gradients of the last `with step_arena(...)` step have been consumed (optimizer stepped, or copied away): the next
+    arena step may clear the buffer they alias."""
+    STEP_ARENA.pending = False
+
+
 class step_arena:
+    """`with ops.step_arena(dev): forward; backward` then consume the gradients and call ops.step_done().  Entering a second
+    arena step before that raises: parameter gradients of the first step are views of the buffer the second would clear
+    (gradient accumulation over several backward passes must run WITHOUT the arena, or copy .grad away first)."""
+
     def __init__(self, dev):
         self.dev = torch.device(dev)
 
     def __enter__(self):
         A = STEP_ARENA
+        if A.pending:
+            raise RuntimeError("point2cyl_amd.ops.step_arena: the previous arena step's gradients were not marked consumed (ops.step_done()); "
+                               "they alias the buffer this step is about to clear")
         if A.buf is None or A.buf.numel() < A.need or A.buf.device != self.dev:
             A.buf = torch.zeros(max(A.need, 1), dtype=torch.float64, device=self.dev)
         else:
@@ -233,6 +247,7 @@ class step_arena:
     def __exit__(self, *exc):
         A = STEP_ARENA
         A.need, A.active = max(A.need, A.run), False
+        A.pending = exc[0] is None
         return False
 
 
@@ -818,12 +833,22 @@ def linear_sum_assignment(cost, solver=1):
     return out
 
 
+def check_labels(I_gt, K):
+    """Instance labels must lie in [-1, K): losses.py:36-46 indexes eye(n_gt+1) and matching_indices[b, :n_gt] with them and raises
+    otherwise; the kernels would silently drop the offending points instead.  One device->host sync - the reference's matching pays B
+    of them per call; the graph-replayed training step validates its dataset once when it is loaded instead (train.ResidentDataset)."""
+    hi, lo = int(I_gt.max()), int(I_gt.min())
+    if hi >= K or lo < -1:
+        raise ValueError("instance labels must be in [-1, %d); got [%d, %d]" % (K, lo, hi))
+
+
 def hungarian(W, I_gt):
     """losses.py:22-52 on the device -> matching_indices (B,K) int64, mask (B,K) bool.  No gradient."""
     _lib.require_device(W, I_gt)
     W = _f32c(W.detach())
     B, N, K = W.shape
     I_gt = I_gt.to(torch.int64).contiguous()
+    check_labels(I_gt, K)
     match = torch.empty(B, K, dtype=torch.int64, device=W.device)
     mask = torch.empty(B, K, dtype=torch.uint8, device=W.device)
     call("p2c_hungarian_f32", ptr(W), ptr(I_gt), B, N, K, ptr(match), ptr(mask), stream())

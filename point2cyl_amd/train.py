@@ -1,17 +1,30 @@
 """Trainer counterpart of the reference's train_Point2Cyl_without_sketch.py: same flags, same step semantics
-(train…:28-62 flags, :143-164 schedules, :213-391 loop, :395-430 checkpoints), running on the HIP kernels.
+(train…:28-62 flags, :143-164 schedules, :213-391 loop, :395-430 checkpoints), running on the HIP kernels — and running the SAME
+launch path `bench.py` times: forward + losses + backward replayed as one HIP graph with the next batch's FPS / ball query /
+3-NN on a forked stream (point2cyl_amd/graph.py), one flat gradient exchange, fused Adam.
 
-Additions: --synthetic N (generate N extrusion-cylinder clouds instead of reading data/<split>.h5; there is no
-dataset on the box), and one-process-per-GPU data parallelism when launched with torch.distributed.run
-(batch sharded by cloud, one gradient all-reduce per step, per-replica BatchNorm statistics like N independent
-reference runs on the shards).
+Order of the per-step host actions follows the reference: forward (with the BatchNorm momentum set by the PREVIOUS step; the very
+first forward runs with the modules' constructor momentum 0.1, train…:207, :355-360), then the BatchNorm-momentum and
+learning-rate staircase updates, backward, optimizer step.  BatchNorm momentum is a scalar kernel argument, so the graph is
+captured at step 1 and re-captured when the staircase changes it (every --bn_decay_step samples); step 0 runs eagerly.
+
+Data: the whole dataset is RESIDENT IN HBM (a Fusion-Gallery-sized set of 8k clouds x 8192 points is 3.7 GB of 288 GB): an epoch's
+shuffled batches are index gathers on the device into the static tensors the graph reads; nothing crosses PCIe after start-up.
+With --synthetic N the N generated clouds are built once on the host; with data/<split>.h5 (needs h5py) the file is read once
+and each access draws its num_point-subsample on the device (dataloader.py:71-77 draws it on the host, per item).
+
+Additions over the reference: --synthetic N, --no_graph (launch every kernel from Python), --max_steps, and one-process-per-GPU
+data parallelism when launched with torch.distributed.run (batch sharded by cloud, one gradient all-reduce per step, per-replica
+BatchNorm statistics like N independent reference runs on the shards, averaged into the checkpoint; parameters initialised from
+the same seed and broadcast, data / noise / FPS-start / dropout generators seeded with seed + rank).
 
     python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 64 --batch_size 32 --num_epochs 1
 """
 import argparse
-import datetime
+import json
 import os
 import sys
+import time
 from collections import defaultdict
 
 import numpy as np
@@ -19,6 +32,8 @@ import torch
 
 from . import ops, ddp, step, synth
 from .backbone import backbone
+
+SCALARS = ("total", "normal", "miou", "bb", "ext", "center")
 
 
 def build_parser():
@@ -44,18 +59,108 @@ def build_parser():
     p.add_argument("--synthetic", type=int, default=0, help="number of generated shapes (0: read <data_dir>/<split>.h5)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--save_every", type=int, default=10)
+    p.add_argument("--no_graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
+    p.add_argument("--no_prefetch", action="store_true", help="compute FPS / ball query / 3-NN inline instead of one batch ahead on a forked stream")
+    p.add_argument("--max_steps", type=int, default=0, help="stop after this many optimizer steps (0: run all epochs)")
+    p.add_argument("--quiet", action="store_true", help="no per-batch log line (each costs a device synchronisation)")
+    p.add_argument("--report", type=str, default="", help="write a JSON throughput / loss report here at the end")
     return p
 
 
-def load_dataset(a):
+class ResidentDataset:
+    """All items of a map-style dataset stacked into device tensors once; batches are index gathers on the device."""
+
+    def __init__(self, ds, dev, num_point, subsample=False):
+        loader = torch.utils.data.DataLoader(ds, batch_size=64, num_workers=0, shuffle=False)
+        cols = None
+        for b in loader:
+            cols = [[] for _ in b] if cols is None else cols
+            for c, t in zip(cols, b):
+                c.append(t)
+        dt = (torch.float, torch.float, torch.long, torch.long, torch.float, torch.float, torch.float, torch.float, torch.float)
+        self.t = [torch.cat(c).to(dev, d) for c, d in zip(cols, dt)]
+        self.n, self.num_point, self.subsample = self.t[0].shape[0], num_point, subsample and self.t[0].shape[1] > num_point
+        self.dev = dev
+        ops.check_labels(self.t[2], self.t[6].shape[1])      # once per dataset: the replayed step itself never syncs to validate
+
+    def __len__(self):
+        return self.n
+
+    def gather(self, idx):
+        """idx: (B,) long on the device -> the reference's 9-tuple for those clouds."""
+        out = [t.index_select(0, idx) for t in self.t]
+        if self.subsample:                     # dataloader.py:71-77: a fresh random num_point-subset per access
+            B, Nfull = out[0].shape[0], out[0].shape[1]
+            sel = torch.rand(B, Nfull, device=self.dev).argsort(dim=1)[:, : self.num_point]
+            for j in (0, 1, 2, 3, 4, 5):       # the per-point tensors
+                t = out[j]
+                out[j] = torch.gather(t, 1, sel.unsqueeze(-1).expand(-1, -1, t.shape[2])) if t.dim() == 3 else torch.gather(t, 1, sel)
+        return out
+
+
+def load_dataset(a, rank=0):
     if a.synthetic > 0:
-        return synth.SyntheticExtrusionDataset(a.synthetic, a.num_point, a.K, seed=1234)
+        return synth.SyntheticExtrusionDataset(a.synthetic, a.num_point, a.K, seed=1234), False
     try:
         import h5py  # noqa: F401
     except Exception as e:
         raise SystemExit("reading %s needs h5py (%s); use --synthetic N" % (os.path.join(a.data_dir, a.data_split + ".h5"), e))
     from .h5data import AutodeskH5
-    return AutodeskH5(os.path.join(a.data_dir, a.data_split + ".h5"), a.num_point, a.K)
+    return AutodeskH5(os.path.join(a.data_dir, a.data_split + ".h5"), None, a.K), True
+
+
+class Runner:
+    """forward + losses + backward + exchange + Adam on static device tensors, eager or as a HIP-graph replay."""
+
+    def __init__(self, model, opt, sync, fl, dev, B, N, K, use_graph=True, prefetch=True):
+        self.model, self.opt, self.sync, self.fl, self.dev = model, opt, sync, fl, dev
+        f32, i64 = torch.float32, torch.int64
+        self.batch = (torch.zeros(B, N, 3, device=dev), torch.zeros(B, N, 3, device=dev), torch.zeros(B, N, dtype=i64, device=dev),
+                      torch.zeros(B, N, dtype=i64, device=dev), torch.zeros(B, K, 3, device=dev), torch.zeros(B, K, 3, device=dev))
+        self.next_xyz = torch.zeros(B, N, 3, dtype=f32, device=dev)
+        self.use_graph, self.prefetch = use_graph, prefetch and use_graph
+        self.graph, self.graph_momentum = None, None
+        self.loss_fn = step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses
+        self.captures = 0
+
+    def load(self, cur, nxt_xyz):
+        """cur = (pcs, normals, inst, bb, axes, centers) device tensors of the batch to train on; nxt_xyz = clouds of the batch after it."""
+        torch._foreach_copy_(list(self.batch), list(cur))
+        self.next_xyz.copy_(nxt_xyz if nxt_xyz is not None else cur[0])
+
+    def _fwd_bwd(self, geom=None):
+        ops.step_done()
+        with ops.step_arena(self.dev):
+            out = self.loss_fn(self.model, *self.batch, self.fl, geom=geom)
+            self.sync.zero()
+            out["total"].backward()
+            self.sync.pack()
+        return {"scalars": torch.stack([out[k].detach().float().reshape(()) for k in SCALARS])}
+
+    def step(self, momentum, eager=False):
+        """One optimizer step; `momentum` = the BatchNorm momentum this step's FORWARD uses.  eager=True launches this step from
+        Python even in graph mode (the trainer's first step: its momentum differs from every later one, not worth a capture)."""
+        step.update_momentum(self.model, momentum)
+        if eager or not self.use_graph:
+            out = self._fwd_bwd()
+        else:
+            if self.graph is None or self.graph_momentum != momentum:
+                from .graph import GraphedForwardBackward
+                if self.graph is not None:
+                    self.graph.release()
+                # the graph computes the geometry of `next_xyz` for the FOLLOWING replay; its first replay trains on the geometry of
+                # what next_xyz holds at construction, which must be the current batch
+                nxt = self.next_xyz.clone()
+                self.next_xyz.copy_(self.batch[0])
+                self.graph = GraphedForwardBackward(self.model, self._fwd_bwd, prefetch_xyz=self.next_xyz if self.prefetch else None)
+                self.next_xyz.copy_(nxt)
+                self.graph_momentum = momentum
+                self.captures += 1
+            out = self.graph()
+        self.sync.allreduce()
+        self.opt.step()
+        ops.step_done()
+        return out["scalars"]
 
 
 def main(argv=None):
@@ -65,67 +170,121 @@ def main(argv=None):
         raise SystemExit("point2cyl_amd.train needs an MI355X (HIP) device; there is no CPU path")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
-    np.random.seed(0)                                        # train…:135
-    torch.manual_seed(a.seed)
+    torch.manual_seed(a.seed)                                # identical parameter init on every rank (broadcast below as well)
     fl = step.StepFlags(K=a.K, pred_seg=a.pred_seg, pred_normal=a.pred_normal, pred_bb=a.pred_bb, pred_extrusion=a.pred_extrusion,
                         pred_center=a.pred_center, norm_eig=a.norm_eig, weight_seg=a.weight_seg, weight_normal=a.weight_normal,
                         weight_bb=a.weight_bb, weight_extrusion=a.weight_extrusion, weight_center=a.weight_center)
-    ds = load_dataset(a)
-    sampler = torch.utils.data.distributed.DistributedSampler(ds, world, rank, shuffle=True) if world > 1 else None
-    loader = torch.utils.data.DataLoader(ds, batch_size=a.batch_size, num_workers=0, pin_memory=True, shuffle=sampler is None, sampler=sampler)
     model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
     ddp.broadcast_module(model)
+    # everything random AFTER the parameters is per replica: data order / subsampling, noise, FPS starts, dropout
+    np.random.seed(0 + rank)                                 # train…:135 (rank 0 reproduces the reference's stream)
+    torch.manual_seed(a.seed + 7919 * rank)
+    ds, subsample = load_dataset(a, rank)
+    n_items = len(ds)
+    lo, hi = ddp.shard_range(n_items, rank, world)
+    if world > 1:
+        ds = torch.utils.data.Subset(ds, range(lo, hi))
+    data = ResidentDataset(ds, dev, a.num_point, subsample)
+    B = min(a.batch_size, len(data))
     opt = torch.optim.Adam(model.parameters(), lr=a.learning_rate, fused=True)    # train…:204, single multi-tensor kernel
     sync = ddp.FlatGradSync(model.parameters(), world)
+    run = Runner(model, opt, sync, fl, dev, B, a.num_point, a.K, use_graph=not a.no_graph, prefetch=not a.no_prefetch)
+    log = None
     if rank == 0:
         os.makedirs(a.logdir, exist_ok=True)
         log = open(os.path.join(a.logdir, "log.txt"), "w")
         log.write(str(a) + "\n")
-    gstep, old_lr, old_bn, best = 0, a.learning_rate, a.momentum, np.inf
-    for epoch in range(1, a.num_epochs + 1):
-        if sampler is not None:
-            sampler.set_epoch(epoch)
-        scal = defaultdict(list)
-        for i, b in enumerate(loader):
-            pcs, nrm, inst, bb, _, _, axes, _, cen = b
-            if a.add_noise:
-                from .fitting import add_noise
-                pcs = add_noise(pcs, nrm, sigma=a.noise_sigma)
-            batch = (pcs.to(dev, torch.float), nrm.to(dev, torch.float), inst.to(dev, torch.long), bb.to(dev, torch.long),
-                     axes.to(dev, torch.float), cen.to(dev, torch.float))
-            bn_m = step.get_batch_norm_decay(gstep, pcs.shape[0], a.bn_decay_step)
-            if old_bn != bn_m:
-                step.update_momentum(model, bn_m)
-                old_bn = bn_m
-            lr = step.get_learning_rate(a.learning_rate, gstep, pcs.shape[0], a.decay_step, a.decay_rate)
-            if old_lr != lr:
-                for g in opt.param_groups:
-                    g["lr"] = lr
-                old_lr = lr
-            with ops.step_arena(dev):
-                out = (step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses)(model, *batch, fl)
-                sync.zero()
-                out["total"].backward()
-            sync.allreduce()
-            opt.step()
-            gstep += 1
-            vals = torch.stack([out[k].detach() for k in ("total", "normal", "miou", "bb", "ext", "center")]).tolist()   # ONE sync
-            for k, v in zip(("total_loss", "normal_loss", "mIOU_loss", "bb_loss", "ext_loss", "center"), vals):
-                scal[k].append(v)
+    nb = len(data) // B                                      # static shapes: whole batches only (drop_last)
+    if world > 1:                                            # every rank must take the same number of steps
+        t = torch.tensor([nb], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        nb = int(t.item())
+    if nb == 0:
+        raise SystemExit("dataset shard (%d clouds) is smaller than one batch (%d)" % (len(data), B))
+
+    def batches():
+        """(epoch, i, (pcs, normals, inst, bb, axes, centers)) over all epochs, whole batches, shuffled per epoch."""
+        for epoch in range(1, a.num_epochs + 1):
+            perm = torch.randperm(len(data)).to(dev)
+            for i in range(nb):
+                it = data.gather(perm[i * B:(i + 1) * B])
+                pcs = it[0]
+                if a.add_noise:                               # data_utils.py:84-96 on the device: p + N(0, sigma) * normal
+                    pcs = pcs + torch.randn(pcs.shape[0], pcs.shape[1], 1, device=dev) * a.noise_sigma * it[1]
+                yield epoch, i, (pcs, it[1], it[2], it[3], it[6], it[8])
+
+    gstep, best = 0, np.inf
+    mom_fwd = 0.1                                            # the modules' constructor momentum: what the reference's first forward uses
+    old_lr = a.learning_rate
+    scal = defaultdict(list)
+    it = batches()
+    cur = next(it)
+    t_start = t_steady = None
+    steps_steady = 0
+    hist = []
+    while cur is not None:
+        nxt = next(it, None)
+        epoch, i, b = cur
+        run.load(b, None if nxt is None else nxt[2][0])
+        lr = step.get_learning_rate(a.learning_rate, gstep, B, a.decay_step, a.decay_rate)     # train…:361-365: before optimizer.step
+        if old_lr != lr:
+            for g in opt.param_groups:
+                g["lr"] = lr
+            old_lr = lr
+        sc = run.step(mom_fwd, eager=gstep == 0)
+        mom_fwd = step.get_batch_norm_decay(gstep, B, a.bn_decay_step)                         # train…:356-359: reaches the NEXT forward
+        gstep += 1
+        hist.append(sc)
+        if gstep == 3:                                       # steady state: graph captured (steps 0 and 1 build it)
+            torch.cuda.synchronize()
+            t_steady, steps_steady = time.perf_counter(), 0
+        elif gstep > 3:
+            steps_steady += 1
+        if not a.quiet:
+            vals = sc.tolist()                               # ONE sync per step
+            msg = ("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | normal loss: %.4f | mIOU loss: %.4f | bb loss: %.4f | "
+                   "ext loss: %.4f | center loss: %.4f" % ((epoch, a.num_epochs, i, nb) + tuple(vals)))
             if rank == 0:
-                msg = ("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | normal loss: %.4f | mIOU loss: %.4f | bb loss: %.4f | "
-                       "ext loss: %.4f | center loss: %.4f" % ((epoch, a.num_epochs, i, len(loader)) + tuple(vals)))
+                print(msg)
+                log.write(msg + "\n")
+        last_of_epoch = nxt is None or nxt[0] != epoch
+        if last_of_epoch:
+            ep = torch.stack(hist).mean(0).tolist()          # epoch means (one sync per epoch)
+            hist = []
+            for k, v in zip(SCALARS, ep):
+                scal[k].append(v)
+            if epoch % a.save_every == 0 or nxt is None:
+                ddp.average_buffers(model)                   # BatchNorm running statistics: mean over the replicas
+                if rank == 0:
+                    sd = {"model": model.state_dict()}       # same checkpoint layout as train…:408
+                    torch.save(sd, os.path.join(a.logdir, "checkpoint_%04d.pth" % epoch))
+                    torch.save(sd, os.path.join(a.logdir, "model.pth"))
+                    if epoch > 20 and ep[0] < best:
+                        best = ep[0]
+                        torch.save(sd, os.path.join(a.logdir, "best_model.pth"))
+            if rank == 0:
+                msg = "> Epoch [%04d/%04d] | " % (epoch, a.num_epochs) + " | ".join("%s: %.4f" % kv for kv in zip(SCALARS, ep))
                 print(msg)
                 log.write(msg + "\n")
                 log.flush()
-        if rank == 0 and epoch % a.save_every == 0:
-            sd = {"model": model.state_dict()}                                  # same checkpoint layout as train…:408
-            torch.save(sd, os.path.join(a.logdir, "checkpoint_%04d.pth" % epoch))
-            torch.save(sd, os.path.join(a.logdir, "model.pth"))
-            mean_total = float(np.mean(scal["total_loss"]))
-            if epoch > 20 and mean_total < best:
-                best = mean_total
-                torch.save(sd, os.path.join(a.logdir, "best_model.pth"))
+        if a.max_steps and gstep >= a.max_steps:
+            break
+        cur = nxt
+    torch.cuda.synchronize()
+    report = None
+    if t_steady is not None and steps_steady > 0:
+        dt = time.perf_counter() - t_steady
+        report = dict(steps=gstep, steady_steps=steps_steady, ms_per_step=dt / steps_steady * 1e3, points_per_s=world * B * a.num_point * steps_steady / dt,
+                      batch_per_gpu=B, num_point=a.num_point, world=world, graph=not a.no_graph, prefetch=run.prefetch, graph_captures=run.captures,
+                      per_step_log_sync=not a.quiet, epoch_means={k: v for k, v in scal.items()})
+        if rank == 0:
+            print("trainer throughput: %.3f ms/step, %.1f points/s over %d steady steps (%d graph captures)" %
+                  (report["ms_per_step"], report["points_per_s"], steps_steady, run.captures))
+            if a.report:
+                with open(a.report, "w") as f:
+                    json.dump(report, f)
+    if log is not None:
+        log.close()
     if world > 1:
         torch.distributed.destroy_process_group()
     return 0

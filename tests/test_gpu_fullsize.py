@@ -1,0 +1,408 @@
+"""GPU (MI355X): parity AT THE SHAPES THE BENCH RUNS (BASELINE configs[1]: B=32 clouds x 8192 points).
+
+The persistent kernels (csrc/fwd_pp.hip, csrc/bwd_fused.hip) launch <= 256 workgroups that each loop over `nk` row tiles with a
+two-deep register prefetch; their steady state (tile k+2 restaged, k+4 loading) only exists for nk >= 5.  The small-shape tests
+in test_gpu_parity.py reach nk <= 4, so everything here runs M = 131,072 ... 1,048,576 rows (nk = 8 ... 64 forward tiles of 64
+rows, 16 ... 128 backward tiles of 32 rows per workgroup) against the CPU fp32 torch restatement of the same layers (conv1x1 +
+train-mode BatchNorm + ReLU [+ max over neighbours], pointnet_util.py:201-205, :317-319) and against the oracle
+(oracle/ref_torch.py) for the module-level paths.  Forward values are compared element by element; data gradients per block
+of rows (a tile-local error cannot hide in a global norm); parameter gradients in relative norm (a million ReLU / max-pool
+decisions contain a few near-ties that resolve differently in any two fp32 implementations and move single rows).
+
+The measured error of every check is appended to gpurun_out/fullsize_metrics.json (scratch) so the bounds can be audited.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_torch as R
+from tests.test_gpu_parity import _ref_stack
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from point2cyl_amd import ops, step, synth
+    from point2cyl_amd.backbone import backbone, PointNetSetAbstraction
+
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_METRICS = []
+
+
+def _rec(name, value, bound):
+    _METRICS.append(dict(check=name, value=float(value), bound=float(bound), ok=bool(value <= bound)))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "fullsize_metrics.json"), "w") as f:
+            json.dump(_METRICS, f, indent=1)
+    except OSError:
+        pass
+    return value <= bound
+
+
+def _relnorm(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def _block_relnorm(a, b, rows=4096):
+    """max over blocks of `rows` rows of |a-b| / |b| (blocks whose reference is ~0 are measured against the mean block norm)."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    nb = a.shape[0] // rows
+    d = np.linalg.norm((a - b)[: nb * rows].reshape(nb, -1), axis=1)
+    r = np.linalg.norm(b[: nb * rows].reshape(nb, -1), axis=1)
+    return float((d / np.maximum(r, 0.05 * r.mean() + 1e-30)).max())
+
+
+# ------------------------------------------------------------------------------------------ MLP stacks at bench sizes
+@pytest.mark.parametrize("tail,M,K0,widths,G,ns,xgrad", [
+    # SA1 (3 -> 64 -> 64 -> 128, max over 64 neighbours; folded first layer since no gradient is wanted for the coordinates)
+    ("maxpool", 131072, 3, (64, 64, 128), 2048, 64, False),
+    ("maxpool", 1048576, 3, (64, 64, 128), 16384, 64, False),        # the bench's own SA1: 32 x 512 x 64 rows, nk = 64
+    # SA2 without the linear-before-gather route (131 -> 128 -> 128 -> 256: 132-wide grouped rows, two-pass 256-wide backward)
+    ("maxpool", 131072, 131, (128, 128, 256), 2048, 64, True),
+    ("maxpool", 262144, 131, (128, 128, 256), 4096, 64, True),       # the bench's own SA2: 32 x 128 x 64 rows
+    # FP1 + fc1 + heads (128 -> 128 -> 128 -> 128 -> 128 -> 19, last layer linear behind the dropout mask)
+    ("linear", 131072, 128, (128, 128, 128, 128, 19), None, None, True),
+    ("linear", 262144, 128, (128, 128, 128, 128, 19), None, None, False),   # the bench's own FP1/head: 32 x 8192 rows
+    # FP2-like dense stack with a 64-wide middle (Co,Ci in {64,128} instantiations of the fused backward)
+    ("bnrelu", 262144, 64, (128, 64, 128), None, None, True),
+])
+def test_mlp_stack_at_bench_shapes(tail, M, K0, widths, G, ns, xgrad):
+    g = torch.Generator().manual_seed(M % 1000 + K0)
+    ld = (K0 + 3) // 4 * 4
+    X0 = torch.zeros(M, ld)
+    X0[:, :K0] = torch.randn(M, K0, generator=g)
+    params, cin = [], K0
+    L = len(widths)
+    for i, co in enumerate(widths):
+        p = dict(W=torch.randn(co, cin, generator=g) / cin ** 0.5, b=torch.randn(co, generator=g) * 0.1)
+        if not (tail == "linear" and i == L - 1):
+            p.update(gamma=torch.rand(co, generator=g) + 0.5, beta=torch.randn(co, generator=g) * 0.2, rm=torch.zeros(co), rv=torch.ones(co))
+            if i == L - 1 or i == 0:
+                p["gamma"][1] = -0.6          # a negative BatchNorm scale: the max-pool must pick the MIN of the pre-activations there
+        params.append(p)
+        cin = co
+    mask = (torch.rand(M, widths[-2], generator=g) < 0.5).float() if tail == "linear" else None
+    ref_leaves = []
+    for p in params:
+        for k in ("W", "b", "gamma", "beta"):
+            if k in p:
+                p[k] = p[k].clone().requires_grad_(True)
+                ref_leaves.append((k, p[k]))
+    X0r = X0[:, :K0].clone().requires_grad_(xgrad)
+    yref, rstats = _ref_stack(X0r, params, tail, G, ns, True, mask)
+    go = torch.randn(yref.shape, generator=g)
+    yref.backward(go)
+    layers, dev_leaves = [], []
+    for p in params:
+        ly = {k: p[k].detach().to(DEV).requires_grad_(True) for k in ("W", "b", "gamma", "beta") if k in p}
+        dev_leaves += [ly[k] for k in ("W", "b", "gamma", "beta") if k in ly]
+        if "gamma" in ly:
+            co = ly["W"].shape[0]
+            ly["bn"] = ops.BNState(torch.zeros(co, device=DEV), torch.ones(co, device=DEV), torch.zeros((), dtype=torch.long, device=DEV), 0.1, 1e-5)
+        else:
+            ly.update(gamma=None, beta=None, bn=None)
+        layers.append(ly)
+    X0d = X0.to(DEV).requires_grad_(xgrad)
+    y = ops.mlp_stack(X0d, K0, layers, tail, True, G=G, ns=ns, drop_mask=None if mask is None else mask.to(DEV).to(torch.uint8), drop_scale=2.0)
+    tag = "%s/M=%d/%d->%s" % (tail, M, K0, "-".join(map(str, widths)))
+    ok = True
+    yr = yref.detach().numpy()
+    err = np.abs(y.detach().cpu().numpy() - yr)
+    scale = max(1.0, float(np.abs(yr).max()))
+    # forward: every element (all tiles of all persistent workgroups) within 1e-4 (relative to max(|y|, scale))
+    ok &= _rec(tag + " fwd max|err|/(1e-4*max(|y|,scale))", float((err / (1e-4 * np.maximum(np.abs(yr), scale))).max()), 1.0)
+    y.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    for i, (a, (kind, b)) in enumerate(zip(dev_leaves, ref_leaves)):
+        ref = b.grad.numpy()
+        assert a.grad is not None, "missing grad %d" % i
+        got = a.grad.cpu().numpy().reshape(ref.shape)
+        layer = i // 4
+        last_linear = tail == "linear" and layer == L - 1
+        if kind == "b" and not last_linear:
+            # conv bias in front of a train-mode BatchNorm: analytically zero (ours is exactly 0, the reference's is rounding noise)
+            assert np.abs(got).max() == 0.0
+            continue
+        ok &= _rec("%s grad[%d.%s] relnorm" % (tag, layer, kind), _relnorm(got, ref), 2e-3)
+    if xgrad:
+        gx, rx = X0d.grad[:, :K0].cpu().numpy(), X0r.grad.numpy()
+        ok &= _rec(tag + " dX relnorm", _relnorm(gx, rx), 2e-3)
+        ok &= _rec(tag + " dX worst 4096-row block relnorm", _block_relnorm(gx, rx), 1e-2)
+    else:
+        assert X0d.grad is None
+    for li, (ly, (rm, rv)) in enumerate(zip(layers, rstats)):
+        ok &= _rec("%s running_mean[%d]" % (tag, li), float(np.abs(ly["bn"].running_mean.cpu().numpy() - rm.numpy()).max()), 1e-5 + 1e-4 * float(rm.abs().max()))
+        ok &= _rec("%s running_var[%d]" % (tag, li), float(np.abs(ly["bn"].running_var.cpu().numpy() - rv.numpy()).max()), 1e-5 + 1e-4 * float(rv.abs().max()))
+    assert ok, [m for m in _METRICS if not m["ok"]]
+
+
+# ------------------------------------------------------------------------------------------ fused backward kernel at M = 262,144
+@pytest.mark.parametrize("Co,Ci", [(128, 128), (128, 64), (64, 128), (64, 64), (256, 128)])
+@pytest.mark.parametrize("grad_mode", [0, 1, 2])
+@pytest.mark.parametrize("in_mode", [0, 1])
+def test_fused_backward_equals_generic_kernels_at_262144_rows(Co, Ci, grad_mode, in_mode):
+    """p2c_linear_bwd_fused_f32 (persistent, 1024 32-row tiles per ... 32 tiles per workgroup) against p2c_linear_bwd_weight_f32 +
+    p2c_linear_bwd_data_f32 on the same operands: dX row-block by row-block, dW, and the ReLU + BatchNorm-backward sums of the layer
+    below.  grad_mode 0 = plain dZ, 1 = ReLU + BatchNorm backward rebuilt from (dZ, Y), 2 = pooled (winner index per group);
+    in_mode 0 = X as stored, 1 = relu(bn(X)) applied while staging."""
+    from point2cyl_amd import _lib
+    from point2cyl_amd._lib import call, ptr, stream
+    kind = _lib.lib().p2c_linear_bwd_fused_supported(Co, Ci, in_mode)
+    if not kind or kind == 2:
+        pytest.skip("no fused instantiation for Co=%d Ci=%d in_mode=%d (kind %d)" % (Co, Ci, in_mode, kind))
+    torch.manual_seed(Co + Ci + grad_mode)
+    ns, M = 64, 262144 + (0 if grad_mode == 2 else 40)        # + a ragged last tile
+    X = torch.randn(M, Ci, device=DEV)
+    W = torch.randn(Co, Ci, device=DEV) * 0.1
+    Y = torch.randn(M, Co, device=DEV)
+    sc, sh = torch.rand(Ci, device=DEV) + 0.5, torch.randn(Ci, device=DEV) * 0.1
+    coef = torch.randn(5, Co, device=DEV)
+    pstat = torch.rand(4, Ci, device=DEV)
+    G = M // ns
+    dZ = torch.randn(G if grad_mode == 2 else M, Co, device=DEV)
+    arg = torch.randint(0, ns, (G, Co), device=DEV, dtype=torch.int32) if grad_mode == 2 else None
+    pns = ns if grad_mode == 2 else 0
+    stats_below = in_mode == 1
+
+    def fused():
+        dX = torch.empty(M, Ci, device=DEV)
+        dW8 = torch.zeros(8, Co, Ci, device=DEV)
+        db = torch.zeros(Co, device=DEV)
+        parts = torch.zeros(64, 2, Ci, device=DEV, dtype=torch.float64)
+        call("p2c_linear_bwd_fused_f32", ptr(dZ), Co, ptr(Y), Co, grad_mode, ptr(coef), ptr(arg), pns, ptr(X), Ci, in_mode, ptr(sc), ptr(sh),
+             ptr(W), Ci, ptr(dX), Ci, ptr(dW8), Ci, Co * Ci, ptr(db) if grad_mode == 0 else None, ptr(pstat) if stats_below else None,
+             ptr(parts) if stats_below else None, M, Co, Ci, stream())
+        return dX, dW8.sum(0), parts.sum(0), db
+
+    def generic():
+        dX = torch.empty(M, Ci, device=DEV)
+        dW = torch.zeros(Co, Ci, device=DEV)
+        db = torch.zeros(Co, device=DEV)
+        parts = torch.zeros(64, 2, Ci, device=DEV, dtype=torch.float64)
+        call("p2c_linear_bwd_weight_f32", ptr(dZ), Co, ptr(Y), Co, grad_mode, ptr(coef), ptr(X), Ci, in_mode, ptr(sc), ptr(sh), None, 0, 1.0, ptr(dW), Ci, 0,
+             ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg), pns, stream())
+        call("p2c_linear_bwd_data_f32", ptr(dZ), Co, ptr(Y), Co, grad_mode, ptr(coef), ptr(W), Ci, ptr(dX), Ci, M, Co, Ci, None, 0, 1.0,
+             ptr(X) if stats_below else None, Ci, ptr(pstat) if stats_below else None, ptr(parts) if stats_below else None, ptr(arg), pns, stream())
+        return dX, dW, parts.sum(0), db
+
+    f, gnr = fused(), generic()
+    torch.cuda.synchronize()
+    tag = "fused-vs-generic Co=%d Ci=%d gm=%d im=%d" % (Co, Ci, grad_mode, in_mode)
+    ok = True
+    # dX: the same fp32 MFMA products in a different order -> rounding only, in every tile
+    dmax = float((f[0] - gnr[0]).abs().max())
+    ok &= _rec(tag + " dX max|diff|/max|dX|", dmax / float(gnr[0].abs().max()), 4e-6)
+    # dW: a reduction over 262,144 rows accumulated in fp32 in two different orders (per-XCD copies vs split-k atomics)
+    ok &= _rec(tag + " dW relnorm", _relnorm(f[1].cpu().numpy(), gnr[1].cpu().numpy()), 2e-5)
+    if stats_below:
+        ok &= _rec(tag + " BN-backward sums relnorm", _relnorm(f[2].cpu().numpy(), gnr[2].cpu().numpy()), 2e-6)
+    if grad_mode == 0:
+        ok &= _rec(tag + " dbias relnorm", _relnorm(f[3].cpu().numpy(), gnr[3].cpu().numpy()), 2e-5)
+    assert ok, [m for m in _METRICS if not m["ok"]]
+
+
+# ------------------------------------------------------------------------------------------ SA2 module (linear before the gather)
+@pytest.mark.parametrize("B", [16, 32])
+def test_sa2_module_linear_before_gather_vs_oracle(B):
+    """PointNetSetAbstraction(128, 0.4, 64, 131, [128,128,256]) on B clouds of 512 points with 128 features (what SA2 sees at
+    N=8192): the production route (first conv on the 512 source points, gather emits the dense pre-BN tensor with the coordinate
+    part and the BatchNorm sums, CSR-gather backward, fused two-pass 256-wide backward) against the oracle's literal
+    sample_and_group + conv/bn/relu + max (pointnet_util.py:110-143, :200-205).  B=16 -> 131,072 grouped rows, B=32 -> 262,144."""
+    g = torch.Generator().manual_seed(B)
+    N, D = 512, 128
+    xyz = torch.rand(B, N, 3, generator=g) * 1.6 - 0.8
+    feats = torch.randn(B, N, D, generator=g)
+    start = torch.randint(0, N, (B,), generator=g)
+    torch.manual_seed(11)
+    sa = PointNetSetAbstraction(npoint=128, radius=0.4, nsample=64, in_channel=D + 3, mlp=[128, 128, 256], group_all=False)
+    with torch.no_grad():
+        for bn in sa.mlp_bns:
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.2)
+        sa.mlp_bns[2].weight[3] = -0.8
+    sd = {"sa2." + k: v.detach().clone() for k, v in sa.state_dict().items()}
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+    fr = feats.clone().requires_grad_(True)
+    new_xyz_r, out_r, aux = R.set_abstraction(sd, R.SA_CFG[1], xyz, fr, start, True, 0.1, "c")
+    go = torch.randn(out_r.shape, generator=g)
+    out_r.backward(go)
+    sa = sa.to(DEV).train()
+    sa.fps_start = start
+    fd = feats.to(DEV).requires_grad_(True)
+    new_xyz, out = sa.forward_pm(xyz.to(DEV), fd)
+    out.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(sa.last_aux["fps_idx"].cpu().long(), aux["fps_idx"]) and torch.equal(sa.last_aux["group_idx"].cpu().long(), aux["group_idx"])
+    tag = "SA2 module B=%d" % B
+    ok = True
+    yr = out_r.detach().numpy()
+    scale = max(1.0, float(np.abs(yr).max()))
+    ok &= _rec(tag + " fwd max|err|/(1e-4*max(|y|,scale))", float((np.abs(out.detach().cpu().numpy() - yr) / (1e-4 * np.maximum(np.abs(yr), scale))).max()), 1.0)
+    ok &= _rec(tag + " dfeats relnorm", _relnorm(fd.grad.cpu().numpy(), fr.grad.numpy()), 2e-3)
+    ok &= _rec(tag + " dfeats worst cloud relnorm", _block_relnorm(fd.grad.cpu().numpy().reshape(B, -1), fr.grad.numpy().reshape(B, -1), rows=1), 1e-2)
+    for name, p in sa.named_parameters():
+        ref = leaves["sa2." + name].grad.numpy()
+        got = p.grad.cpu().numpy().reshape(ref.shape)
+        if name.endswith(".bias") and "convs" in name:
+            assert np.abs(got).max() == 0.0
+            continue
+        ok &= _rec("%s grad[%s] relnorm" % (tag, name), _relnorm(got, ref), 2e-3)
+    for i in range(3):
+        for s in ("running_mean", "running_var"):
+            a, b = getattr(sa.mlp_bns[i], s).cpu().numpy(), sd["sa2.mlp_bns.%d.%s" % (i, s)].numpy()
+            ok &= _rec("%s bn%d.%s" % (tag, i, s), float(np.abs(a - b).max()), 1e-5 + 1e-4 * float(np.abs(b).max()))
+    assert ok, [m for m in _METRICS if not m["ok"]]
+
+
+# ------------------------------------------------------------------------------------------ whole backbone, train mode, vs oracle fp32 AND fp64
+def test_backbone_train_b16_n8192_vs_oracle_fp32_and_fp64():
+    """Half a bench batch (16 clouds x 8192 points: SA1 524,288 grouped rows, FP1/head 131,072 rows -> every persistent kernel of
+    the step in its steady state) through forward + backward against the oracle's literal op sequence on the same weights, FPS
+    starts and dropout mask - once in fp32 and once in float64 (geometry pinned to the fp32 indices).  Bars: integer structure
+    bit-exact; head outputs within 1e-4 (abs, outputs are O(1)) of the float64 run or 3x the oracle's own fp32 error, whichever
+    is larger; every parameter gradient no further from float64 than 3x the oracle's fp32 run is (a chain of 17 train-mode
+    BatchNorms is ill-conditioned - DESIGN.md section 4 - so the fp32 oracle itself is the yardstick, measured here, live)."""
+    B, N, K = 16, 8192, 8
+    pcs = synth.make_batch(B, N, K, seed=4242)[0]
+    torch.manual_seed(21)
+    m = backbone(output_sizes=[3, 2 * K])
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    s1, s2 = torch.randint(0, N, (B,), generator=g), torch.randint(0, 512, (B,), generator=g)
+    mask = (torch.rand(B, N, 128, generator=g) < 0.5).float()
+    wX, wW = torch.randn(B, N, 3, generator=g), torch.randn(B, N, 2 * K, generator=g)
+
+    def oracle(dtype):
+        sd = {k: (v.clone().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in sd0.items()}
+        leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+        outs, aux = R.backbone_forward(sd, pcs.to(dtype), [s1, s2], mask.to(dtype), training=True, momentum=0.5, geom="c", return_aux=True)
+        loss = (outs[0] * wX.to(dtype)).mean() + (outs[1] * wW.to(dtype)).mean() + (outs[1] ** 2).mean() * 0.1
+        loss.backward()
+        return [o.detach() for o in outs], {k: v.grad for k, v in leaves.items()}, aux, sd
+
+    o32, g32, aux, sd32 = oracle(torch.float32)
+    o64, g64, _, _ = oracle(torch.float64)
+    m = m.to(DEV).train()
+    step.update_momentum(m, 0.5)
+    m.sa1.fps_start, m.sa2.fps_start = s1, s2
+    m.dropout_mask = mask
+    X, Wr = m(pcs.to(DEV))
+    loss = (X * wX.to(DEV)).mean() + (Wr * wW.to(DEV)).mean() + (Wr ** 2).mean() * 0.1
+    loss.backward()
+    torch.cuda.synchronize()
+    for lvl, key in (("sa1", "fps_idx"), ("sa1", "group_idx"), ("sa2", "fps_idx"), ("sa2", "group_idx")):
+        assert torch.equal(getattr(m, lvl).last_aux[key].cpu().long(), aux[lvl][key]), (lvl, key)
+    assert torch.equal(m.fp1.last_aux["nn_idx"].cpu().long(), aux["fp1"]["nn_idx"]) and torch.equal(m.fp2.last_aux["nn_idx"].cpu().long(), aux["fp2"]["nn_idx"])
+    ok = True
+    for name, mine, r32, r64 in (("X_head", X, o32[0], o64[0]), ("W_raw", Wr, o32[1], o64[1])):
+        ref_err = float((r32.double() - r64).abs().max())
+        my_err = float((mine.detach().cpu().double() - r64).abs().max())
+        ok &= _rec("backbone B=16 %s |ours-ref64|max (bound max(1e-4, 3*|ref32-ref64|=%.2e))" % (name, 3 * ref_err), my_err, max(1e-4, 3 * ref_err))
+    lab_diff = int((Wr.detach().cpu().view(B, N, K, 2).sum(-1).argmax(-1) != o32[1].view(B, N, K, 2).sum(-1).argmax(-1)).sum())
+    ok &= _rec("backbone B=16 raw-logit segment labels differing from the fp32 oracle (of %d; near-tie logits only)" % (B * N), lab_diff, 4)
+    for name, p in m.named_parameters():
+        r32, r64 = g32[name].double().numpy(), g64[name].numpy()
+        got = p.grad.cpu().double().numpy().reshape(r64.shape)
+        if name.endswith(".bias") and ("mlp_convs" in name or name == "fc1.bias"):
+            assert np.abs(got).max() == 0.0, name
+            continue
+        ref_err = np.abs(r32 - r64).max()
+        ok &= _rec("backbone B=16 grad[%s] |ours-ref64|max / (3*|ref32-ref64|max + 1e-6*|ref64|max)" % name,
+                   np.abs(got - r64).max() / (3 * ref_err + 1e-6 * np.abs(r64).max()), 1.0)
+    for k in ("sa1.mlp_bns.0.running_mean", "sa1.mlp_bns.2.running_var", "sa2.mlp_bns.2.running_var", "fp1.mlp_bns.0.running_mean", "bn1.running_var"):
+        a, b = m.state_dict()[k].cpu().numpy(), sd32[k].numpy()
+        ok &= _rec("backbone B=16 %s" % k, float(np.abs(a - b).max()), 1e-5 + 1e-4 * float(np.abs(b).max()))
+    assert ok, [mm for mm in _METRICS if not mm["ok"]]
+
+
+# ------------------------------------------------------------------------------------------ B=32: eval-BN forward vs oracle, graph vs eager gradients
+def test_b32_n8192_eval_forward_two_clouds_vs_oracle():
+    """BASELINE configs[1] batch (32 x 8192) in eval mode (running statistics: clouds are independent), dropout off: the head
+    outputs of clouds 5 and 29 must equal the oracle run on those two clouds alone (B=2) - values within 1e-4, segment labels
+    and all index structure bit-exact.  The running statistics are first moved off their 0/1 initial values by one train-mode pass."""
+    B, N, K = 32, 8192, 8
+    pcs = synth.make_batch(B, N, K, seed=777)[0]
+    torch.manual_seed(5)
+    m = backbone(output_sizes=[3, 2 * K]).to(DEV).train()
+    step.update_momentum(m, 0.5)
+    g = torch.Generator().manual_seed(9)
+    s1, s2 = torch.randint(0, N, (B,), generator=g), torch.randint(0, 512, (B,), generator=g)
+    m.sa1.fps_start, m.sa2.fps_start = s1, s2
+    m.dropout_mask = "off"
+    x = pcs.to(DEV)
+    with torch.no_grad():
+        m(x)                                     # one train-mode pass: running statistics away from (0, 1)
+        m.eval()
+        m.sa1.fps_start, m.sa2.fps_start = s1, s2
+        X, Wr = m(x)
+    torch.cuda.synchronize()
+    sel = [5, 29]
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    outs, aux = R.backbone_forward(sd, pcs[sel], [s1[sel], s2[sel]], None, training=False, momentum=0.5, geom="c", return_aux=True)
+    for lvl, key in (("sa1", "fps_idx"), ("sa1", "group_idx"), ("sa2", "fps_idx"), ("sa2", "group_idx")):
+        assert torch.equal(getattr(m, lvl).last_aux[key].cpu().long()[sel], aux[lvl][key]), (lvl, key)
+    ok = True
+    for name, mine, ref in (("X_head", X, outs[0]), ("W_raw", Wr, outs[1])):
+        ok &= _rec("B=32 eval %s max|err| vs oracle (clouds 5, 29)" % name, float((mine.cpu()[sel] - ref).abs().max()), 1e-4 * max(1.0, float(ref.abs().max())))
+    lab = Wr.cpu()[sel].view(2, N, K, 2).sum(-1).argmax(-1)
+    assert torch.equal(Wr.cpu()[sel].argmax(-1), outs[1].argmax(-1)), "2K-way labels must be bit-exact"
+    assert torch.equal(lab, outs[1].view(2, N, K, 2).sum(-1).argmax(-1))
+    assert ok, [mm for mm in _METRICS if not mm["ok"]]
+
+
+@pytest.mark.parametrize("prefetch", [False, True])
+def test_b32_n8192_graph_replay_gradients_equal_eager(prefetch):
+    """The path bench.py times (HIP-graph replay of forward + fused losses + backward at B=32, N=8192, optionally with the next
+    batch's geometry on the forked stream) must produce the gradients of the eager launch sequence on the same state: same FPS
+    starts, same dropout seed, parameters untouched in between.  Bound 1e-4 relative (fp32/fp64 atomics order is the only freedom)."""
+    from point2cyl_amd import backbone as bbmod
+    from point2cyl_amd.graph import GraphedForwardBackward
+    B, N, K = 32, 8192, 8
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=1234)
+    batch = tuple(v.to(DEV) for v in (pcs, nrm, seg, bb, axes, cen))
+    torch.manual_seed(0)
+    fl = step.StepFlags(K=K)
+    m = backbone(output_sizes=fl.pred_sizes()).to(DEV).train()
+    step.update_momentum(m, 0.5)
+    g = torch.Generator().manual_seed(2)
+    fixed = {N: torch.randint(0, N, (B,), generator=g), 512: torch.randint(0, 512, (B,), generator=g)}
+    orig_draw = bbmod.draw_fps_start
+    bbmod.draw_fps_start = lambda n, b: fixed[n].clone()
+    try:
+        def fwd_bwd(geom=None):
+            ops.step_done()
+            with ops.step_arena(DEV):
+                out = step.compute_losses_fused(m, *batch, fl, geom=geom)
+                for p in m.parameters():
+                    p.grad = None
+                out["total"].backward()
+            return {"total": out["total"].detach()}
+
+        SEED0 = 123456789
+        m._drop_seed = torch.tensor([SEED0], dtype=torch.int64, device=DEV)
+        out_e = fwd_bwd()
+        torch.cuda.synchronize()
+        loss_e = float(out_e["total"])
+        g_e = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+        gr = GraphedForwardBackward(m, fwd_bwd, prefetch_xyz=batch[0] if prefetch else None)
+        for rep in range(3):                     # several replays: every replay must reproduce the eager gradients
+            m._drop_seed.fill_(SEED0)
+            out_g = gr()
+            torch.cuda.synchronize()
+            ok = _rec("graph(prefetch=%s) replay %d |loss - eager|/loss" % (prefetch, rep), abs(float(out_g["total"]) - loss_e) / abs(loss_e), 1e-5)
+            gmax = max(float(v.norm()) for v in g_e.values())
+            worst, wname = 0.0, ""
+            for n, p in m.named_parameters():
+                r = float((p.grad - g_e[n]).norm()) / (float(g_e[n].norm()) + 1e-6 * gmax)
+                if r > worst:
+                    worst, wname = r, n
+            ok &= _rec("graph(prefetch=%s) replay %d worst parameter-gradient relnorm vs eager (%s)" % (prefetch, rep, wname), worst, 1e-4)
+            assert ok, [mm for mm in _METRICS if not mm["ok"]]
+    finally:
+        bbmod.draw_fps_start = orig_draw

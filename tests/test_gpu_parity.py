@@ -961,16 +961,31 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     exchange goes over gloo; the driver's 8-GPU run uses the same code with backend nccl)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, P2C_ONE_GPU_RANKS="1", MASTER_ADDR="127.0.0.1")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(P2C_ONE_GPU_RANKS="1", MASTER_ADDR="127.0.0.1")
+    # no launcher: `python bench.py --gpus 2` starts its two ranks itself (bench._self_launch)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                           "--batch_size", "4", "--num_point", "2048", "--no_cpu_baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    assert d["world_size"] == 2 and d["backend"] == "gloo" and d["devices"] == [0, 0]
     assert np.isfinite(d["config"]["loss"]) and d["value"] > 0 and d["config"]["launch"].startswith("hip_graph")
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` on a box with one GPU must fail loudly (no JSON line, non-zero exit), not report n_gpus 1."""
+    import os, subprocess, sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a single-GPU box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "P2C_ONE_GPU_RANKS")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no_cpu_baseline"],
+                         env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "GPU" in out.stderr
 
 
 def test_head_post_matches_torch_expressions():

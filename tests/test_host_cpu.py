@@ -99,6 +99,23 @@ gathered = [torch.zeros_like(local) for _ in range(world)]
 dist.all_gather(gathered, local)
 assert torch.allclose(avg, sum(gathered) / world, atol=1e-7)
 assert all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in m.parameters()), "grads must be views of the flat buffer"
+# second step: the SAME persistent buffer, packed by one multi-tensor copy right after backward
+flat_ptr = sync.flat.data_ptr()
+sync.zero()
+m(x * 2).square().mean().backward()
+local2 = torch.cat([p.grad.reshape(-1) for p in m.parameters()]).clone()
+sync.pack()
+assert sync.flat.data_ptr() == flat_ptr and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views))
+assert torch.equal(sync.flat, local2)
+sync.allreduce()
+g2 = [torch.zeros_like(local2) for _ in range(world)]
+dist.all_gather(g2, local2)
+assert torch.allclose(sync.flat, sum(g2) / world, atol=1e-7)
+# checkpoint policy: BatchNorm running statistics averaged over the replicas
+bn = m[1]
+bn.running_mean.fill_(float(rank)); bn.running_var.fill_(1.0 + rank)
+ddp.average_buffers(m)
+assert torch.allclose(bn.running_mean, torch.full((5,), (world - 1) / 2.0)) and torch.allclose(bn.running_var, torch.full((5,), 1.0 + (world - 1) / 2.0))
 lo, hi = ddp.shard_range(10, rank, world)
 print("rank", rank, "ok", lo, hi)
 dist.destroy_process_group()
@@ -158,3 +175,46 @@ def test_reorder_by_matching_equals_gather():
     (wa * w).sum().backward()
     (wb * w).sum().backward()
     assert torch.allclose(a.grad, b.grad, rtol=0, atol=1e-6)
+
+
+def test_bench_self_launch_refuses_without_gpus():
+    """bench.py --gpus 2 with no launcher and fewer than 2 GPUs: non-zero exit, no JSON line (never a silent 1-GPU number)."""
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "P2C_ONE_GPU_RANKS")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "GPU" in out.stderr
+
+
+def test_add_noise_golden():
+    """A19 add_noise (data_utils.py:84-96): same NumPy draws, same float64 result as the reference (fixture G14)."""
+    from tests.conftest import load_golden
+    from point2cyl_amd.fitting import add_noise
+    g = load_golden("g14_add_noise")
+    np.random.seed(int(g["np_seed"]))
+    out = add_noise(torch.from_numpy(g["pcs"]), torch.from_numpy(g["normals"]), sigma=float(g["sigma"]))
+    assert str(out.dtype) == str(g["out_dtype"]) == "torch.float64"
+    assert np.array_equal(out.numpy(), g["out"])
+
+
+def test_h5_reader_item_layout(tmp_path):
+    """dataloader.py:69-96 item logic on a tiny file written with the reference's schema (utils.py:1174-1188)."""
+    h5py = pytest.importorskip("h5py", reason="h5py is not installed in this image (no dataset on the box either)")
+    from point2cyl_amd.h5data import AutodeskH5
+    rng = np.random.default_rng(0)
+    n, P, K = 3, 40, 8
+    arrs = dict(point_cloud=rng.normal(size=(n, P, 3)), normals=rng.normal(size=(n, P, 3)), extrusion_labels=rng.integers(0, 3, (n, P)),
+                base_barrel_labels=rng.integers(0, 2, (n, P)), extrusion_axes=rng.normal(size=(n, K, 3)), extrusion_distances=rng.random((n, K)),
+                extrusion_centers=rng.normal(size=(n, K, 3)))
+    path = str(tmp_path / "t.h5")
+    with h5py.File(path, "w") as f:
+        for k, v in arrs.items():
+            f.create_dataset(k, data=v)
+    ds = AutodeskH5(path, 16, K)
+    it = ds[1]
+    assert len(ds) == 3 and len(it) == 9 and it[0].shape == (16, 3) and it[2].dtype == np.int64 and it[6].shape == (K, 3)
+    assert np.allclose(it[4], arrs["extrusion_axes"][1][it[2]])

@@ -238,3 +238,87 @@ def test_implicit_decoder_losses_and_double_backward():
     for n in sd:
         ref = g["grad:" + n]
         np.testing.assert_allclose(sd[n].grad.numpy(), ref, rtol=1e-3, atol=1e-5 * np.abs(ref).max() + 1e-9)
+
+
+# ------------------------------------------------------------------------------------------ round-2 fixtures (oracle/make_golden_r2.py)
+G12_STEP_RTOL = (1e-6, 1e-5, 2e-4, 1e-2, 5e-2)
+
+
+def test_oracle_five_adam_steps_match_the_reference():
+    """G12: the oracle's step (backbone restatement + losses + autograd + Adam) against the reference's loss trajectory over five
+    steps at B=8, N=1024 with the recorded FPS starts and dropout masks.  Bit-equal at step 0; after that the trajectory is chaotic
+    (Adam's sign-like first updates on ill-conditioned fp32 gradients): measured drift 2e-7, 4e-5, 2e-3, 1.4e-2 at steps 1..4 between
+    the reference and this restatement of its own torch ops - the per-step bounds below are 5x that."""
+    g = load_golden("g12_train_5steps")
+    B, N, K = 8, 1024, 8
+    sd = R.make_state_dict((3, 2 * K), seed=int(g["seed"]))
+    params = [v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    pcs, nrm, seg, bb = t(g["pcs"]), t(g["normals"]), t(g["seg"]), t(g["bb"])
+    gm = torch.Generator().manual_seed(int(g["mask_seed"]))
+    for s in range(int(g["steps"])):
+        dm = (torch.rand(B, 128, N, generator=gm) < 0.5).float()
+        ck = dm.double()
+        np.testing.assert_allclose([ck.sum().item(), ck.abs().sum().item(), (ck * ck).sum().item()], g["dropout_mask_ck"][s])
+        X, W_raw = R.backbone_forward(sd, pcs, [t(g["adam_start1"][s]), t(g["adam_start2"][s])], dm.permute(0, 2, 1), training=True, momentum=0.5,
+                                      geom="c")
+        X = F.normalize(X, p=2, dim=2, eps=1e-12)
+        W2 = torch.softmax(W_raw, 2)
+        W = W2[:, :, 0::2] + W2[:, :, 1::2]
+        total, nl, ml, match, msk = R.compute_all_losses(W, seg, X, nrm, 1.0, 1.0)
+        bbl = R.bb_loss(W, W_raw, match, msk, bb, K)
+        total = total + bbl
+        opt.zero_grad()
+        total.backward()
+        opt.step()
+        np.testing.assert_allclose([total.item(), nl.item(), ml.item(), bbl.item()], g["adam_losses"][s], rtol=G12_STEP_RTOL[s], err_msg="step %d" % s)
+        if s < 3:
+            assert np.array_equal(match.numpy(), g["adam_match_%d" % s])
+
+
+@pytest.mark.parametrize("tag,use_gt_seg,use_gt_bb", [("pred", False, False), ("gtseg_gtbb", True, True), ("gtbb", False, True)])
+def test_oracle_eval_flow_matches_the_reference(tag, use_gt_seg, use_gt_bb):
+    """G13: the oracle's pieces composed like eval.py:270-457 give the reference's metrics (the fixture executed those lines from the
+    reference file)."""
+    g = load_golden("g13_eval_flow")
+    K, S = 8, int(g["S"])
+    X = F.normalize(t(g["X_head"]), p=2, dim=2, eps=1e-12)
+    W2 = torch.softmax(t(g["W_raw"]), 2)
+    Wb, Wc = W2[:, :, 0::2], W2[:, :, 1::2]
+    W = Wb + Wc
+    seg, bb, pcs, nrm, axes, cen = t(g["seg"]), t(g["bb"]), t(g["pcs"]), t(g["normals"]), t(g["axes"]), t(g["centers"])
+    r = lambda k: g["%s:%s" % (tag, k)]
+    W_ = R.hard_W_encoding(W, to_null_mask=True)
+    match, mask = R.hungarian_matching(W_, seg)
+    assert np.array_equal(match.numpy(), r("matching_indices")) and np.array_equal(mask.numpy(), r("mask") > 0)
+    np.testing.assert_allclose(R.compute_segmentation_iou(W_, seg, match, mask.float()).numpy(), r("mIoU"), rtol=1e-5)
+    W_re_un = R.reorder(W_, match)
+    W_re = torch.where(mask.unsqueeze(1), W_re_un, -torch.ones_like(W_re_un))
+    assert np.array_equal(W_re.argmax(-1).numpy(), r("label"))
+    np.testing.assert_allclose(R.compute_normal_difference(X, nrm, in_radians=False).numpy(), r("normal_difference"), rtol=1e-5)
+    assert np.array_equal(torch.stack([Wb.sum(-1), Wc.sum(-1)], -1).argmax(-1).numpy(), r("pred_bb_label"))
+    onehot = F.one_hot(seg, K).float()
+    if use_gt_seg:
+        EA_W = onehot
+    elif use_gt_bb:
+        EA_W = W_re_un
+    else:
+        EA_W = W_re
+    if use_gt_bb:
+        Wbr, Wcr = EA_W * (bb == 0).unsqueeze(-1), EA_W * (bb == 1).unsqueeze(-1)
+    else:
+        Wbr, Wcr = R.reorder(Wb, match), R.reorder(Wc, match)
+    E = R.estimate_extrusion_axis(X, Wbr, Wcr, bb, seg, normalize=False, literal=True)
+    mg = R.get_mask_gt(seg, K)
+    dots = same_up_to_sign(E.numpy(), r("E_AX"))
+    assert (dots[mg.numpy()] > 1 - 1e-5).all()
+    ed = R.reduce_mean_masked_instance(R.compute_normal_difference(E, axes, in_radians=False, collapse=False), mg)
+    np.testing.assert_allclose(ed.numpy(), r("extrusion_difference"), rtol=2e-3, atol=2e-3)     # acos next to its clamp (fp32 both sides)
+    c, found = R.hard_centroids(EA_W, pcs)
+    assert np.array_equal(found.numpy(), r("found_centers_mask"))
+    np.testing.assert_allclose(c.numpy(), r("predicted_centroids"), rtol=1e-5, atol=1e-6)
+    cd = R.reduce_mean_masked_instance(torch.square(c - cen).sum(-1), mg)
+    np.testing.assert_allclose(cd.numpy(), r("centroid_difference"), rtol=1e-4, atol=1e-8)
+    ridx = {(int(k), int(b)): t(d) for (k, b), d in zip(g["rand_keys"], g["rand_idx"])}
+    ext, _ = R.get_extrusion_extents(pcs, seg, bb, axes, cen, ridx)
+    np.testing.assert_allclose(ext.permute(1, 0, 2).numpy(), g["pred:extents"], rtol=1e-5, atol=1e-6)

@@ -66,6 +66,7 @@ def main():
             total.backward()
         sync.allreduce()
         opt.step()
+        ops.step_done()
         return total, sk
 
     def fence():

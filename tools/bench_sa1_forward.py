@@ -35,6 +35,7 @@ def main():
         return g
 
     def mlp(g):
+        ops.step_done()
         with torch.no_grad(), ops.step_arena(dev):
             return sa1.forward_pm(xyz, None, g)
 

@@ -30,6 +30,7 @@ def main():
         return fitting.sketch_implicit_projection2(*d, S, rand_idx=ridx_d)
 
     def encode(Pp, Xp, sc):
+        ops.step_done()
         with ops.step_arena(dev):
             q = (Pp / sc.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2)                # train_Point2Cyl.py:592-596
             x = torch.cat((q, Xp.reshape(B * K, S, 2)), -1)

@@ -13,6 +13,7 @@ batch = tuple(x.to(dev) for x in [synth.make_batch(B, N, K, seed=1234)[i] for i 
 torch.manual_seed(0)
 model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
 def fwd_bwd():
+    ops.step_done()          # the previous step's gradients are discarded here
     with ops.step_arena(dev):
         out = step.compute_losses_fused(model, *batch, fl)
         for p in model.parameters(): p.grad = None

@@ -75,6 +75,58 @@ def g12(ref):
                      "dropout_mask_ck": np.stack(masks), tag + "_param_ck": np.stack([cksum(p) for _, p in model.named_parameters()])})
         arrs.update({"%s_after:%s" % (tag, n): sd[n] for n in ("sa1.mlp_bns.0.running_mean", "bn1.running_var", "fp1.mlp_bns.2.running_mean")})
     arrs["param_names"] = np.array([n for n, _ in model.named_parameters()])
+    # the same five steps with the reference module in float64 (geometry pinned to the fp32 indices, same starts / masks): the
+    # yardstick that tells how far the reference's own fp32 trajectory is from the exact one at every step
+    pu = ref["pointnet_util"]
+    torch.manual_seed(2468)
+    m64 = pe.backbone(output_sizes=[3, 2 * K]).double().train()
+    for name, m in m64.named_modules():
+        if "bn" in name:
+            m.momentum = 0.5
+    opt = torch.optim.Adam(m64.parameters(), lr=1e-3)
+    gm = torch.Generator().manual_seed(12)
+    o_fps, o_ball, o_sq, o_randint = pu.farthest_point_sample, pu.query_ball_point, pu.square_distance, torch.randint
+    def in_f32(fn):                 # the geometry stays the fp32 one (indices / distances pinned), whatever the default dtype is
+        def w(*a):
+            torch.set_default_dtype(torch.float32)
+            try:
+                return fn(*a)
+            finally:
+                torch.set_default_dtype(torch.float64)
+        return w
+
+    pu.farthest_point_sample = in_f32(lambda xyz, n: o_fps(xyz.float(), n))
+    pu.query_ball_point = in_f32(lambda r, ns_, xyz, nx: o_ball(r, ns_, xyz.float(), nx.float()))
+    pu.square_distance = in_f32(lambda a, b: o_sq(a.float(), b.float()).to(a.dtype))
+    scal64 = []
+    torch.set_default_dtype(torch.float64)          # the reference's torch.eye / torch.zeros constants follow the run's dtype
+    try:
+        for s in range(STEPS):
+            dmask = (torch.rand(B, 128, N, generator=gm) < 0.5).double()
+            forced = iter([arrs["adam_start1"][s], arrs["adam_start2"][s]])
+            torch.randint = lambda *a, **k: next(forced).clone()
+            with DropoutOff(dmask):
+                Xo, W_raw = m64(pcs.double())
+            torch.randint = o_randint
+            Xo = F.normalize(Xo, p=2, dim=2, eps=1e-12)
+            W_2K = torch.softmax(W_raw, dim=2)
+            W = W_2K[:, :, ::2] + W_2K[:, :, 1::2]
+            total, nl, ml, match, mask = ls.compute_all_losses(pcs.double(), W, seg, Xo, normals.double(), 1.0, 1.0, return_match_indices=True)
+            ns = dict(torch=torch, F=F, W=W, matching_indices=match, mask=mask, sampled_pcs=pcs, NUM_POINT=N, K=K,
+                      W_barrel_bb=W_raw[:, :, ::2], W_base_bb=W_raw[:, :, 1::2], gt_bb_labels=bb, batch_size=B)
+            exec_reference_lines(os.path.join(_refload.REF_ROOT, "train_Point2Cyl_without_sketch.py"), 286, 307, ns)
+            bbl = ns["total_bb_loss"]
+            total = total + 1.0 * bbl
+            opt.zero_grad()
+            total.backward()
+            opt.step()
+            scal64.append([total.item(), nl.item(), ml.item(), bbl.item()])
+    finally:
+        pu.farthest_point_sample, pu.query_ball_point, pu.square_distance, torch.randint = o_fps, o_ball, o_sq, o_randint
+        torch.set_default_dtype(torch.float32)
+    arrs["adam_losses64"] = np.array(scal64)
+    print("fp32 reference vs its float64 run, max relative loss difference per step:",
+          np.abs(arrs["adam_losses"] / arrs["adam_losses64"] - 1).max(1))
     save("g12_train_5steps", **arrs)
 
 

@@ -126,7 +126,11 @@ class PointNetFeaturePropagation(nn.Module):
             interp = ops.three_interpolate(feats2, idx, w, csr)
             self.last_aux = dict(nn_idx=idx, nn_w=w)
         if feats1 is not None:
-            return torch.cat([feats1.reshape(B * N, -1), interp], 1)              # [skip | interpolated] :312
+            cols = [feats1.reshape(B * N, -1), interp]                            # [skip | interpolated] :312
+            pad = (-(cols[0].shape[1] + cols[1].shape[1])) % 4                    # the kernels take 16-byte aligned rows (3 + 128 -> 132)
+            if pad:
+                cols.append(torch.zeros(B * N, pad, device=interp.device, dtype=interp.dtype))
+            return torch.cat(cols, 1)
         return interp
 
     def forward_pm(self, xyz1, xyz2, feats1, feats2, tail="bnrelu", extra_layers=(), drop_mask=None, drop_scale=1.0, drop_seed=None,
@@ -158,7 +162,7 @@ class PointNetFeaturePropagation(nn.Module):
                                 keep_padding=keep_padding, pre=pre)
             return out.view(B, N, -1)
         X0 = self._input_pm(xyz1, xyz2, feats1, feats2, nn_)
-        out = ops.mlp_stack(X0, X0.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
+        out = ops.mlp_stack(X0, self.mlp_convs[0].weight.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
                             keep_padding=keep_padding)
         return out.view(B, N, -1)
 

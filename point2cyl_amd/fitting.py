@@ -31,11 +31,16 @@ def estimate_extrusion_centers(W, pcs):
 
 
 def segment_centroids(EA_W, pcs):
-    """eval.py:409-436: per-segment mean of the points with EA_W == 1 -> (centroids (B,K,3), found (B,K))."""
-    K = EA_W.shape[2]
-    is_one = EA_W == 1
-    label = torch.where(is_one.any(dim=2), is_one.float().argmax(dim=2), torch.full_like(is_one[:, :, 0], -1, dtype=torch.long))
-    return ops.segment_centroids(pcs, label, K)
+    """eval.py:409-436: per-segment mean of the points with EA_W == 1 -> (centroids (B,K,3), found (B,K)); a segment with <= 1 such point
+    is "not found" (zeros).  EA_W may be multi-hot: eval.py's --use_gt_bb branch gathers the hard encoding by matching_indices, whose
+    unmatched slots all point at column 0 (:382), so a point can carry a 1 in several columns.  The per-segment coordinate sums are the
+    weighted-centre kernel on the 0/1 indicator (fit.hip: (1/N) sum_n w p), rescaled by N / count."""
+    N = EA_W.shape[1]
+    ind = (EA_W == 1).to(torch.float32)
+    cnt = ind.sum(dim=1)                                            # (B,K)
+    cen = ops.extrusion_centers(ind, pcs) * (float(N) / cnt.clamp(min=1.0)).unsqueeze(-1)
+    found = (cnt > 1).to(torch.float32)
+    return cen * found.unsqueeze(-1), found
 
 
 def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample=1024, rand_idx=None):

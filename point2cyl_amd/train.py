@@ -71,14 +71,9 @@ class ResidentDataset:
     """All items of a map-style dataset stacked into device tensors once; batches are index gathers on the device."""
 
     def __init__(self, ds, dev, num_point, subsample=False):
-        loader = torch.utils.data.DataLoader(ds, batch_size=64, num_workers=0, shuffle=False)
-        cols = None
-        for b in loader:
-            cols = [[] for _ in b] if cols is None else cols
-            for c, t in zip(cols, b):
-                c.append(t)
+        items = [ds[i] for i in range(len(ds))]                  # (no DataLoader: its iterator would draw a seed from torch's generator)
         dt = (torch.float, torch.float, torch.long, torch.long, torch.float, torch.float, torch.float, torch.float, torch.float)
-        self.t = [torch.cat(c).to(dev, d) for c, d in zip(cols, dt)]
+        self.t = [torch.from_numpy(np.stack([np.asarray(it[j]) for it in items])).to(dev, d) for j, d in enumerate(dt)]
         self.n, self.num_point, self.subsample = self.t[0].shape[0], num_point, subsample and self.t[0].shape[1] > num_point
         self.dev = dev
         ops.check_labels(self.t[2], self.t[6].shape[1])      # once per dataset: the replayed step itself never syncs to validate

@@ -95,6 +95,16 @@ def main():
                          % (args.gpus, world))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # everything - warm-up, capture, replays, exchange, Adam, the event-timed eager leg - on ONE non-default stream (a HIP graph cannot be
+    # captured on the default stream; autograd binds its accumulator nodes to the stream they first ran on)
+    with torch.cuda.stream(torch.cuda.Stream(dev)):
+        _bench(args, rank, world, local, dev)
+
+
+def _bench(args, rank, world, local, dev):
+    from point2cyl_amd import ddp, ops, step, synth
+    from point2cyl_amd.backbone import backbone
+    import torch.distributed as dist
     backend = ddp.backend_name()
     devices = [int(local)]
     if world > 1:
@@ -132,7 +142,7 @@ def main():
     if not args.no_graph:
         from point2cyl_amd.graph import GraphedForwardBackward
         try:
-            graphed = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=None if args.no_prefetch else batch[0])
+            graphed = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=None if args.no_prefetch else batch[0], stream=torch.cuda.current_stream())
         except Exception as e:      # keep the bench alive: fall back to eager launches
             sys.stderr.write("bench: HIP graph capture failed (%s: %s); running eager\n" % (type(e).__name__, e))
             for m in model.modules():

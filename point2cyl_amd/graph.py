@@ -91,7 +91,11 @@ class GraphedForwardBackward:
 
     draw_starts=False leaves the FPS start tensors alone between replays (callers that set them through `starts.set`)."""
 
-    def __init__(self, model, fn, warmup=2, prefetch_xyz=None, draw_starts=True):
+    def __init__(self, model, fn, warmup=2, prefetch_xyz=None, draw_starts=True, stream=None):
+        import gc
+        gc.collect()       # autograd graphs of earlier eager steps that only reference cycles keep alive: their AccumulateGrad nodes are
+        # bound to the stream they were created on, and autograd would order the capture stream against that stream (work the capture
+        # never joins -> hipErrorStreamCaptureUnjoined)
         dev = next(model.parameters()).device
         self.starts = _PinnedStarts(dev)
         self.draw_starts = draw_starts
@@ -132,17 +136,19 @@ class GraphedForwardBackward:
             with torch.no_grad():
                 self.cur = model.compute_geometry(prefetch_xyz)     # geometry for the first replay
             self.starts.cursor = 0
-        warm = torch.cuda.Stream()
-        warm.wait_stream(main)
-        with torch.cuda.stream(warm):
+        # warm-up passes and the capture run on ONE stream (`stream`, e.g. the stream the caller's whole loop lives on, or a private one):
+        # the autograd accumulator nodes created by the warm-up are then bound to the stream that is captured
+        cap = stream if stream is not None else torch.cuda.Stream()
+        cap.wait_stream(main)
+        with torch.cuda.stream(cap):
             for _ in range(warmup):
                 self.starts.cursor = 0
                 body()
-        main.wait_stream(warm)
+        main.wait_stream(cap)
         torch.cuda.synchronize()
         self.starts.cursor = 0
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=cap):
             self.out = body()
         self.starts.cursor = 0
         with torch.no_grad():

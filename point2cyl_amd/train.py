@@ -107,8 +107,9 @@ def load_dataset(a, rank=0):
 class Runner:
     """forward + losses + backward + exchange + Adam on static device tensors, eager or as a HIP-graph replay."""
 
-    def __init__(self, model, opt, sync, fl, dev, B, N, K, use_graph=True, prefetch=True):
+    def __init__(self, model, opt, sync, fl, dev, B, N, K, use_graph=True, prefetch=True, stream=None):
         self.model, self.opt, self.sync, self.fl, self.dev = model, opt, sync, fl, dev
+        self.stream = stream          # the stream the caller's loop runs on (graph warm-up and capture use it too); None: a private one
         f32, i64 = torch.float32, torch.int64
         self.batch = (torch.zeros(B, N, 3, device=dev), torch.zeros(B, N, 3, device=dev), torch.zeros(B, N, dtype=i64, device=dev),
                       torch.zeros(B, N, dtype=i64, device=dev), torch.zeros(B, K, 3, device=dev), torch.zeros(B, K, 3, device=dev))
@@ -130,7 +131,9 @@ class Runner:
             self.sync.zero()
             out["total"].backward()
             self.sync.pack()
-        return {"scalars": torch.stack([out[k].detach().float().reshape(()) for k in SCALARS])}
+        res = {"scalars": torch.stack([out[k].detach().float().reshape(()) for k in SCALARS])}
+        del out
+        return res
 
     def step(self, momentum, eager=False):
         """One optimizer step; `momentum` = the BatchNorm momentum this step's FORWARD uses.  eager=True launches this step from
@@ -147,7 +150,8 @@ class Runner:
                 # what next_xyz holds at construction, which must be the current batch
                 nxt = self.next_xyz.clone()
                 self.next_xyz.copy_(self.batch[0])
-                self.graph = GraphedForwardBackward(self.model, self._fwd_bwd, prefetch_xyz=self.next_xyz if self.prefetch else None)
+                self.graph = GraphedForwardBackward(self.model, self._fwd_bwd, prefetch_xyz=self.next_xyz if self.prefetch else None,
+                                                    stream=self.stream)
                 self.next_xyz.copy_(nxt)
                 self.graph_momentum = momentum
                 self.captures += 1
@@ -165,6 +169,14 @@ def main(argv=None):
         raise SystemExit("point2cyl_amd.train needs an MI355X (HIP) device; there is no CPU path")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    # the whole loop - data gathers, the eager first step, graph warm-up, capture, replays, Adam - lives on ONE non-default stream:
+    # a HIP graph cannot be captured on the default stream, and autograd binds its accumulator nodes to the stream they first ran on
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        return _main(a, rank, world, local, dev, stream)
+
+
+def _main(a, rank, world, local, dev, stream):
     torch.manual_seed(a.seed)                                # identical parameter init on every rank (broadcast below as well)
     fl = step.StepFlags(K=a.K, pred_seg=a.pred_seg, pred_normal=a.pred_normal, pred_bb=a.pred_bb, pred_extrusion=a.pred_extrusion,
                         pred_center=a.pred_center, norm_eig=a.norm_eig, weight_seg=a.weight_seg, weight_normal=a.weight_normal,
@@ -183,7 +195,7 @@ def main(argv=None):
     B = min(a.batch_size, len(data))
     opt = torch.optim.Adam(model.parameters(), lr=a.learning_rate, fused=True)    # train…:204, single multi-tensor kernel
     sync = ddp.FlatGradSync(model.parameters(), world)
-    run = Runner(model, opt, sync, fl, dev, B, a.num_point, a.K, use_graph=not a.no_graph, prefetch=not a.no_prefetch)
+    run = Runner(model, opt, sync, fl, dev, B, a.num_point, a.K, use_graph=not a.no_graph, prefetch=not a.no_prefetch, stream=stream)
     log = None
     if rank == 0:
         os.makedirs(a.logdir, exist_ok=True)
@@ -216,7 +228,19 @@ def main(argv=None):
     cur = next(it)
     t_start = t_steady = None
     steps_steady = 0
-    hist = []
+    hist, pending = [], []
+    host_ring = [torch.empty(len(SCALARS), dtype=torch.float32).pin_memory() for _ in range(2)]
+    lagged = None
+
+    def emit(item):
+        ep_, i_, hb_, ev_ = item
+        ev_.synchronize()
+        msg = ("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | normal loss: %.4f | mIOU loss: %.4f | bb loss: %.4f | "
+               "ext loss: %.4f | center loss: %.4f" % ((ep_, a.num_epochs, i_, nb) + tuple(hb_.tolist())))
+        if rank == 0:
+            print(msg)
+            log.write(msg + "\n")
+
     while cur is not None:
         nxt = next(it, None)
         epoch, i, b = cur
@@ -236,32 +260,45 @@ def main(argv=None):
         elif gstep > 3:
             steps_steady += 1
         if not a.quiet:
-            vals = sc.tolist()                               # ONE sync per step
-            msg = ("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | normal loss: %.4f | mIOU loss: %.4f | bb loss: %.4f | "
-                   "ext loss: %.4f | center loss: %.4f" % ((epoch, a.num_epochs, i, nb) + tuple(vals)))
-            if rank == 0:
-                print(msg)
-                log.write(msg + "\n")
+            # the reference prints every step from .item() syncs (train...:372-376).  Here step k's six scalars go to a pinned host buffer
+            # asynchronously and the line is printed after step k+1 has been ENQUEUED: the host waits for an event that precedes step k+1's
+            # work, so the per-step log never drains the GPU queue
+            if lagged is not None:
+                emit(lagged)
+            hb = host_ring[gstep % 2]
+            hb.copy_(sc, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            lagged = (epoch, i, hb, ev)
         last_of_epoch = nxt is None or nxt[0] != epoch
+        if last_of_epoch and lagged is not None and (not a.quiet):
+            emit(lagged)                                         # keep the per-batch lines in front of their epoch's summary
+            lagged = None
         if last_of_epoch:
-            ep = torch.stack(hist).mean(0).tolist()          # epoch means (one sync per epoch)
+            pending.append((epoch, torch.stack(hist).mean(0)))       # epoch means stay on the device ...
             hist = []
-            for k, v in zip(SCALARS, ep):
-                scal[k].append(v)
-            if epoch % a.save_every == 0 or nxt is None:
-                ddp.average_buffers(model)                   # BatchNorm running statistics: mean over the replicas
+            saving = epoch % a.save_every == 0 or nxt is None
+            if saving or not a.quiet:                            # ... until something needs them on the host (one sync for all pending epochs)
+                for ep_no, ep_t in pending:
+                    ep = ep_t.tolist()
+                    for k, v in zip(SCALARS, ep):
+                        scal[k].append(v)
+                    if rank == 0:
+                        msg = "> Epoch [%04d/%04d] | " % (ep_no, a.num_epochs) + " | ".join("%s: %.4f" % kv for kv in zip(SCALARS, ep))
+                        print(msg)
+                        log.write(msg + "\n")
+                pending = []
                 if rank == 0:
-                    sd = {"model": model.state_dict()}       # same checkpoint layout as train…:408
+                    log.flush()
+            if saving:
+                ddp.average_buffers(model)                       # BatchNorm running statistics: mean over the replicas
+                if rank == 0:
+                    sd = {"model": model.state_dict()}           # same checkpoint layout as train…:408
                     torch.save(sd, os.path.join(a.logdir, "checkpoint_%04d.pth" % epoch))
                     torch.save(sd, os.path.join(a.logdir, "model.pth"))
                     if epoch > 20 and ep[0] < best:
                         best = ep[0]
                         torch.save(sd, os.path.join(a.logdir, "best_model.pth"))
-            if rank == 0:
-                msg = "> Epoch [%04d/%04d] | " % (epoch, a.num_epochs) + " | ".join("%s: %.4f" % kv for kv in zip(SCALARS, ep))
-                print(msg)
-                log.write(msg + "\n")
-                log.flush()
         if a.max_steps and gstep >= a.max_steps:
             break
         cur = nxt

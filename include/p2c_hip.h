@@ -209,6 +209,21 @@ int p2c_bn_relu_apply_f32(const float *Y, int ldy, const float *scale, const flo
  * arg [G,C] (row offset j of the winner, first on ties), ywin [G,C] (optional: Y at the winner, for backward). */
 int p2c_maxpool_bnrelu_f32(const float *Y, int ldy, const float *scale, const float *shift, int G, int ns, int C, float *out,
                            int ldo, int32_t *arg, float *ywin, void *stream);
+/* The last layer of a set-abstraction stack with the pooling folded into the GEMM epilogue (replaces the
+ * p2c_linear_fwd_f32 + p2c_maxpool_bnrelu_f32 pair, i.e. the pass that re-reads the 268-537 MB pre-BN tensor to pool it):
+ *   p2c_linear_fwd_pool_f32: Y and stat slots exactly as p2c_linear_fwd_f32 with in_mode 1, plus - per 32-row half of every
+ *     64-row neighbourhood and column - the largest / smallest pre-BN value and their rows: pool_max, pool_min [2*M/64, N] fp32,
+ *     pool_idx [2*M/64, N] int32 (row_of_max | row_of_min << 16).  Requires p2c_linear_fwd_pool_supported(M, N, K, 1, 64)
+ *     (groups of exactly 64 rows, K in {64,128}, N in {128,256}, M >= 8192, M % 64 == 0);
+ *   p2c_pool_select_f32: once the layer's BatchNorm affine exists, out [G,C] = max over the group of relu(scale*y + shift)
+ *     (the largest pre-BN value for scale >= 0, the smallest for scale < 0), arg / ywin as p2c_maxpool_bnrelu_f32.
+ *     Ties: lowest row among equal PRE-BN values (models/pointnet_util.py:205 leaves ties to torch.max). */
+int p2c_linear_fwd_pool_supported(int M, int N, int K, int in_mode, int ns);
+int p2c_linear_fwd_pool_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
+                            int K, const float *in_scale, const float *in_shift, double *stat_slots, float *pool_max,
+                            float *pool_min, int32_t *pool_idx, void *stream);
+int p2c_pool_select_f32(const float *pool_max, const float *pool_min, const int32_t *pool_idx, const float *scale,
+                        const float *shift, int G, int C, float *out, int ldo, int32_t *arg, float *ywin, void *stream);
 /* dZ [G*ns, C] (dense, zero except the winners) from dOut [G,C] */
 int p2c_maxpool_bwd_f32(const float *dout, int ldo, const int32_t *arg, int G, int ns, int C, float *dZ, int ldz, void *stream);
 

@@ -142,6 +142,50 @@ extern "C" int p2c_maxpool_bnrelu_f32(const float *Y, int ldy, const float *scal
     return P2C_OK;
 }
 
+// The same result from the per-half-group extremes the pooled forward emitted (fwd_pp.hip, POOL): relu(scale*y + shift) is monotone
+// in y, increasing for scale >= 0 and decreasing for scale < 0, so the group's maximum is taken by its largest (smallest) pre-BN
+// value.  First row wins among equal pre-BN values, like the scan above (which breaks ties on the POST-activation value: two
+// different pre-BN values that round to the same activation - or are both clamped to 0 - may resolve to another row here; the
+// pooled value is the same, and for a clamped winner the gradient is zero either way).
+__global__ void __launch_bounds__(256) pool_select_kernel(const float *__restrict__ pmax, const float *__restrict__ pmin,
+                                                          const int32_t *__restrict__ pidx, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int G, int C, float *__restrict__ out, int ldo,
+                                                          int32_t *__restrict__ arg, float *__restrict__ ywin)
+{
+    const int c = blockIdx.y * blockDim.x + threadIdx.x;
+    const int g = blockIdx.x;
+    if (c >= C) return;
+    const float sc = scale[c], sh = shift[c];
+    const size_t o0 = ((size_t)2 * g) * C + c, o1 = o0 + C;
+    float yb;
+    int bj;
+    if (sc >= 0.f) {
+        const float v0 = pmax[o0], v1 = pmax[o1];
+        const bool second = v1 > v0;
+        yb = second ? v1 : v0;
+        bj = (second ? pidx[o1] : pidx[o0]) & 0xffff;
+    } else {
+        const float v0 = pmin[o0], v1 = pmin[o1];
+        const bool second = v1 < v0;
+        yb = second ? v1 : v0;
+        bj = ((second ? pidx[o1] : pidx[o0]) >> 16) & 0xffff;
+    }
+    out[(size_t)g * ldo + c] = fmaxf(sc * yb + sh, 0.f);
+    arg[(size_t)g * C + c] = bj;
+    if (ywin) ywin[(size_t)g * C + c] = yb;
+}
+
+extern "C" int p2c_pool_select_f32(const float *pool_max, const float *pool_min, const int32_t *pool_idx, const float *scale,
+                                   const float *shift, int G, int C, float *out, int ldo, int32_t *arg, float *ywin, void *stream)
+{
+    if (!pool_max || !pool_min || !pool_idx || !scale || !shift || !out || !arg || G <= 0 || C <= 0) return P2C_EINVAL;
+    const int bx = C >= 256 ? 256 : ((C + 63) & ~63);
+    hipLaunchKernelGGL(pool_select_kernel, dim3(G, p2c_cdiv(C, bx)), dim3(bx), 0, (hipStream_t)stream, pool_max, pool_min, pool_idx, scale,
+                       shift, G, C, out, ldo, arg, ywin);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
 __global__ void __launch_bounds__(256) maxpool_bwd_kernel(const float *__restrict__ dout, int ldo, const int32_t *__restrict__ arg, int G,
                                                           int ns, int C, float *__restrict__ dZ, int ldz)
 {

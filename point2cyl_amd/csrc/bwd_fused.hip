@@ -68,12 +68,15 @@ struct BwdFusedArgs {
 template <int C4>
 __device__ __forceinline__ void fused_unit(int u, int &m, int &c4)
 {
+    // lanes 0..31 of a wave (the LDS serves a 4-byte store 32 lanes at a time): 8 float4-columns x 4 rows -> with the rotation of
+    // fused_pos the 32 stores of each half-wave land on 32 different banks (measured before this map: SQ_LDS_BANK_CONFLICT = 0.42 of
+    // SQ_LDS_IDX_ACTIVE in the 128-wide kernels: 16 columns x 2 rows per half-wave hit 16 banks twice); lanes 32..63 take the next 8 columns
     if (C4 == 32) {
-        c4 = (u & 15) | (((u >> 6) & 1) << 4);
-        m = ((u >> 4) & 3) | ((u >> 7) << 2);
+        c4 = (u & 7) | (((u >> 5) & 3) << 3);
+        m = ((u >> 3) & 3) | ((u >> 7) << 2);
     } else {
-        c4 = u & 15;
-        m = u >> 4;
+        c4 = (u & 7) | (((u >> 5) & 1) << 3);
+        m = ((u >> 3) & 3) | ((u >> 6) << 2);
     }
 }
 template <int BM>

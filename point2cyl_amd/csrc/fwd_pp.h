@@ -14,8 +14,13 @@ struct FwdPPArgs {
     int Kfull;                            // width used in the dropout element index (row * Kfull + col)
     double *partials;                     // [P2C_STAT_SLOTS][2][N] or NULL
     const float *w0, *b0;                 // MODE == 4: x is the folded first layer's INPUT [M,4]; w0 [K,4], b0 [K]; in_scale/in_shift = its BN
+    // POOL: per 32-row half of every 64-row tile (= one neighbourhood of 64) and column, the largest and the smallest pre-BN value
+    // and their rows: pool_max / pool_min [2*M/64][N] fp32, pool_idx [2*M/64][N] int32 = row_of_max | row_of_min << 16 (rows 0..63)
+    float *pool_max, *pool_min;
+    int32_t *pool_idx;
 };
 
 
 extern "C" int p2c_linear_fwd_pp_supported(int M, int N, int K, int in_mode);
 int p2c_fwd_pp_launch(const FwdPPArgs &a, int in_mode, hipStream_t s);
+extern "C" int p2c_linear_fwd_pool_supported(int M, int N, int K, int in_mode, int ns);

@@ -27,7 +27,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 
-template <int KP, int NT, int MODE, int EX>
+// Register budget: at most 160 VGPRs.  Two waves per SIMD of this kernel then leave room for the four 48-register waves per SIMD of the
+// farthest-point sampling kernel that the forked geometry stream runs on 32 of the CUs at the same time (2 x 160 + 4 x 48 = 512); a
+// workgroup that cannot share its CU waits for another to finish and the whole launch takes twice as long (measured: +85 us per launch
+// with a 196-register variant).  Check with -Rpass-analysis=kernel-resource-usage after touching the epilogue.
+template <int KP, int NT, int MODE, int EX, bool POOL = false>
 __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
 {
     constexpr int LD = KP + 4, BM = 64, BN = 64 * NT;
@@ -269,6 +273,30 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
                         if (m0 + wm * 32 + rf0 + i * (64 / V) < a.M) *reinterpret_cast<v4f *>(yp + (size_t)(i * (64 / V)) * a.ldy) = o[i];
                 }
             }
+            if (POOL) {
+                // max over the 64 neighbours of relu(bn(y)) (pointnet_util.py:205) needs, per column, only the largest pre-BN value
+                // (BatchNorm scale > 0) or the smallest (scale < 0) of the group and its row - but the scale is known only after the whole
+                // layer's statistics.  So each wave emits both extremes of its 32 rows x 64 columns, read back from the fragment it has
+                // just parked (one column per lane, rows in ascending order, strict compares keep the first; the accumulators are dead
+                // here, so the kernel's register count - it must share CUs with the sampling kernel of the forked stream - does not
+                // grow); p2c_pool_select_f32 picks when the affine exists.  The 268-537 MB pass that re-read Y for the pooling is gone.
+                static_assert(!POOL || NT == 2, "one column per lane");
+                float vmax = -INFINITY, vmin = INFINITY;
+                int imax = 0, imin = 0;
+#pragma unroll 8
+                for (int r = 0; r < 32; ++r) {              // (a full unroll costs 6 more registers: 165 > the 160 budget above)
+                    const float v = out[r * (32 * NT) + lane];
+                    if (v > vmax) { vmax = v; imax = r; }
+                    if (v < vmin) { vmin = v; imin = r; }
+                }
+                const int pcol = j0 + wn * (NT * 32) + lane;
+                if (pcol < a.N) {
+                    const size_t po = ((size_t)2 * tile_of(k) + wm) * a.N + pcol;
+                    a.pool_max[po] = vmax;
+                    a.pool_min[po] = vmin;
+                    a.pool_idx[po] = (wm * 32 + imax) | ((wm * 32 + imin) << 16);
+                }
+            }
             __builtin_amdgcn_wave_barrier();
         }
         P2C_TR(5);
@@ -308,7 +336,7 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
     }
 }
 
-template <int KP, int NT, int MODE, int EX>
+template <int KP, int NT, int MODE, int EX, bool POOL = false>
 static int launch_pp(const FwdPPArgs &a, hipStream_t s)
 {
     constexpr int LD = KP + 4, BN = 64 * NT, FR = 32 * 32 * NT, R = 16 * LD > FR ? 16 * LD : FR;
@@ -317,8 +345,8 @@ static int launch_pp(const FwdPPArgs &a, hipStream_t s)
     const int ntiles = (a.M + 63) / 64;
     int gx = 256 / gy;
     if (gx > ntiles) gx = ntiles;
-    (void)hipFuncSetAttribute((const void *)fwd_pp_kernel<KP, NT, MODE, EX>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((fwd_pp_kernel<KP, NT, MODE, EX>), dim3(gx, gy), dim3(512), lds, s, a);
+    (void)hipFuncSetAttribute((const void *)fwd_pp_kernel<KP, NT, MODE, EX, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((fwd_pp_kernel<KP, NT, MODE, EX, POOL>), dim3(gx, gy), dim3(512), lds, s, a);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -333,9 +361,21 @@ extern "C" int p2c_linear_fwd_pp_supported(int M, int N, int K, int in_mode)
     return 1;
 }
 
+// The pooled forward: BatchNorm'ed input (in_mode 1), 64 or 128 input channels, a multiple of 128 output channels, whole groups of
+// exactly 64 rows (a row tile IS a neighbourhood).
+extern "C" int p2c_linear_fwd_pool_supported(int M, int N, int K, int in_mode, int ns)
+{
+    return in_mode == 1 && ns == 64 && M >= 8192 && (M % 64) == 0 && (K == 64 || K == 128) && (N % 128) == 0 && N <= 256;
+}
+
 int p2c_fwd_pp_launch(const FwdPPArgs &a, int in_mode, hipStream_t s)
 {
     const int K = a.K;          // EX columns already split off by the caller
+    if (a.pool_max) {
+        if (!a.pool_min || !a.pool_idx || !p2c_linear_fwd_pool_supported(a.M, a.N, K, in_mode, 64)) return P2C_EINVAL;
+        if (K == 64) return launch_pp<64, 2, 1, 0, true>(a, s);
+        return launch_pp<128, 2, 1, 0, true>(a, s);
+    }
     const bool ex = a.Kfull == 132 && in_mode != 3;
     const int nt = a.N <= 64 ? 1 : 2;
 #define P2C_PP(KP_, NT_, MODE_, EX_) return launch_pp<KP_, NT_, MODE_, EX_>(a, s)

@@ -613,7 +613,7 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     static const bool use_pp = !(getenv("P2C_FWD_PP") && atoi(getenv("P2C_FWD_PP")) == 0);      // A/B switch for profiling
     if (use_pp && p2c_linear_fwd_pp_supported(M, N, K, in_mode)) {
         FwdPPArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K == 132 ? 128 : K, in_scale, in_shift, (const uint32_t *)drop_mask,
-                    (uint32_t)ldmask, drop_scale, K, stat_partials, nullptr, nullptr};
+                    (uint32_t)ldmask, drop_scale, K, stat_partials, nullptr, nullptr, nullptr, nullptr, nullptr};
         return p2c_fwd_pp_launch(a, in_mode, s);
     }
     switch (in_mode) {
@@ -622,6 +622,23 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     case 2: return launch_fwd<2>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
     default: return launch_fwd<3>(X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, drop_mask, ldmask, drop_scale, stat_partials, s);
     }
+}
+
+// ---- forward of the LAST layer of a set-abstraction stack (BatchNorm'ed input, neighbourhoods of 64 rows): Y as p2c_linear_fwd_f32
+// writes it, plus the per-half-neighbourhood extremes the max-pool needs (fwd_pp.hip, POOL) - see p2c_pool_select_f32 in bn.hip.
+extern "C" int p2c_linear_fwd_pool_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N,
+                                       int K, const float *in_scale, const float *in_shift, double *stat_partials, float *pool_max,
+                                       float *pool_min, int32_t *pool_idx, void *stream)
+{
+    if (!X || !W || !Y || !in_scale || !in_shift || !pool_max || !pool_min || !pool_idx || M <= 0) return P2C_EINVAL;
+    if (!p2c_linear_fwd_pool_supported(M, N, K, 1, 64)) return P2C_EINVAL;
+    P2C_REQ_ALIGNED(X, ldx);
+    P2C_REQ_ALIGNED(W, ldw);
+    P2C_REQ_ALIGNED(in_scale, 0);
+    P2C_REQ_ALIGNED(in_shift, 0);
+    FwdPPArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K, in_scale, in_shift, nullptr, 0u, 1.0f, K, stat_partials, nullptr, nullptr,
+                pool_max, pool_min, pool_idx};
+    return p2c_fwd_pp_launch(a, 1, (hipStream_t)stream);
 }
 
 // ---- forward with a per-row-group additive term: Y[m,:] = act_in(X)[m,:] . W^T + gbias[m / rows_per_group, :] + bias.

@@ -19,6 +19,7 @@ USE_FUSED256 = os.environ.get("P2C_FUSED256", "1") != "0"   # 256-wide layers th
 USE_DUAL_BWD = os.environ.get("P2C_DUAL_BWD", "1") != "0"   # dX and dW of the small layers in one launch (gemm_dual_kernel)
 USE_FOLD0 = os.environ.get("P2C_FOLD0", "1") != "0"         # first layer with <= 4 input channels never materialised (bn.hip)
 USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated backward of the gathers (no atomics)
+USE_POOL_EPI = os.environ.get("P2C_POOL_EPI", "1") != "0"    # max over 64 neighbours from extremes emitted by the last layer's GEMM epilogue
 
 
 def _f32c(t):
@@ -317,6 +318,7 @@ class _MLPStack(torch.autograd.Function):
         seed = cfg.get("drop_seed")       # device int64 scalar: counter-hash dropout (no mask tensor)
         dscale = cfg.get("drop_scale", 1.0)
         Ys, aff, Ws = [], [], []
+        pool = None
         fold_b0 = pre_wx = pre_wb = None
         X, ldx, in_mode, sc, sh = X0, ldx0, 0, None, None
         pi = 0
@@ -417,6 +419,13 @@ class _MLPStack(torch.autograd.Function):
                 else:
                     call("p2c_group_linear_bias_stats_f32", ptr(Gs), Co, ptr(pre["xyz"]), ptr(pre["new_xyz"]), ptr(pre["idx"]), ptr(pre_wx),
                          ptr(b), pre["B"], pre["N"], pre["S"], pre["ns"], Co, ptr(Y), Co, ptr(partials), stream())
+            elif (USE_POOL_EPI and tail == "maxpool" and i == L - 1 and mode == 1 and mptr is None and training and ldx == K
+                  and _lib.lib().p2c_linear_fwd_pool_supported(M, Co, K, 1, cfg["ns"])):
+                # last layer of a set-abstraction stack: the GEMM epilogue also emits the extremes the max over the 64 neighbours needs
+                pool = (torch.empty(2 * cfg["G"], Co, dtype=torch.float32, device=dev), torch.empty(2 * cfg["G"], Co, dtype=torch.float32, device=dev),
+                        torch.empty(2 * cfg["G"], Co, dtype=I32, device=dev))
+                call("p2c_linear_fwd_pool_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, ptr(sc), ptr(sh), ptr(partials),
+                     ptr(pool[0]), ptr(pool[1]), ptr(pool[2]), stream(), flops=2.0 * M * Co * K)
             else:
                 call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
                      mptr, mld, float(dscale), ptr(partials), stream(), flops=2.0 * M * Co * K)
@@ -444,7 +453,10 @@ class _MLPStack(torch.autograd.Function):
             out = torch.empty(G, K, dtype=torch.float32, device=dev)
             arg = torch.empty(G, K, dtype=I32, device=dev)
             ywin = torch.empty(G, K, dtype=torch.float32, device=dev)
-            call("p2c_maxpool_bnrelu_f32", ptr(Ys[-1]), K, ptr(sc), ptr(sh), G, ns, K, ptr(out), K, ptr(arg), ptr(ywin), stream())
+            if pool is not None:
+                call("p2c_pool_select_f32", ptr(pool[0]), ptr(pool[1]), ptr(pool[2]), ptr(sc), ptr(sh), G, K, ptr(out), K, ptr(arg), ptr(ywin), stream())
+            else:
+                call("p2c_maxpool_bnrelu_f32", ptr(Ys[-1]), K, ptr(sc), ptr(sh), G, ns, K, ptr(out), K, ptr(arg), ptr(ywin), stream())
             arg = (arg, ywin)
         elif tail == "bnrelu":
             out = torch.empty(M, K, dtype=torch.float32, device=dev)

@@ -29,6 +29,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));   // native vector: stays in registers (HIP's float4 struct copy can pin an array in scratch)
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct BwdFusedArgs {
     const float *dz; int lddz;            // upstream gradient (or pooled gradient [G,Co] when gmode == 2)
@@ -65,35 +66,54 @@ struct BwdFusedArgs {
 // positions (mod BM, so groups of 4 rows stay aligned for the 16-byte reads) spreads them over 8, and mapping a wave's
 // 64 lanes to 16 float4-columns x 4 rows covers the other 4: conflict-free.
 // ------------------------------------------------------------------------------------------------
-template <int C4>
-__device__ __forceinline__ void fused_unit(int u, int &m, int &c4)
-{
-    // lanes 0..31 of a wave (the LDS serves a 4-byte store 32 lanes at a time): 8 float4-columns x 4 rows -> with the rotation of
-    // fused_pos the 32 stores of each half-wave land on 32 different banks (measured before this map: SQ_LDS_BANK_CONFLICT = 0.42 of
-    // SQ_LDS_IDX_ACTIVE in the 128-wide kernels: 16 columns x 2 rows per half-wave hit 16 banks twice); lanes 32..63 take the next 8 columns
-    if (C4 == 32) {
-        c4 = (u & 7) | (((u >> 5) & 3) << 3);
-        m = ((u >> 3) & 3) | ((u >> 7) << 2);
-    } else {
-        c4 = (u & 7) | (((u >> 5) & 1) << 3);
-        m = ((u >> 3) & 3) | ((u >> 6) << 2);
+// Thread -> tile elements.  A thread owns, per unit u, R CONSECUTIVE rows of one float4 column c4 (4 channels): p = tid + 256 u,
+// c4 = p % (C/4), row group g = p / (C/4), rows R g .. R g + R - 1, with R = 4 (R = 2 only for the 64-channel x 32-row tile, which has
+// half a 4-row block per thread).  Global loads: the lanes of a wave walk c4 first, so load j of a unit covers whole 256/512-byte rows.
+// LDS: the thread transposes its R x 4 block in registers and writes ONE 16-byte (8-byte) piece per channel - R consecutive m of
+// channel row c - instead of R x 4 scalar stores (ds_write_b128: 8 lanes per cycle = c4 0..7 at one g; with the rotation of fused_pos
+// those start at banks 0,16,4,20,8,24,12,28: conflict-free).
+template <int C, int BM>
+struct TileMap {
+    static constexpr int C4 = C / 4;
+    static constexpr int R = (BM * C4 / 256) >= 4 ? 4 : 2;            // rows per unit
+    static constexpr int NU = BM * C4 / (256 * R);                    // units per thread
+    static constexpr int NV = NU * R;                                 // float4 registers per thread (= BM * C / 4 / 256)
+    static __device__ __forceinline__ void unit(int tid, int u, int &row0, int &c4)
+    {
+        const int p = tid + 256 * u;
+        c4 = p % C4;
+        row0 = (p / C4) * R;
     }
-}
+};
 template <int BM>
 __device__ __forceinline__ int fused_pos(int c, int m) { return c * (BM + 4) + ((m + 4 * ((c >> 3) & 7)) & (BM - 1)); }
+
+template <int R>
+__device__ __forceinline__ void lds_store_rows(float *d, const float (&v)[4])
+{
+    if (R == 4) *reinterpret_cast<v4f *>(d) = v4f{v[0], v[1], v[2], v[3]};
+    else *reinterpret_cast<v2f *>(d) = v2f{v[0], v[1]};
+}
 
 // Raw tile fetch (no arithmetic: the values stay in flight during the MFMAs of the previous tile).
 // GMODE 2 (the layer feeds the max-pool): the gradient and the winner index are per GROUP of ns rows, and a tile spans at
 // most two groups (host-checked: ns % 16 == 0, 2 ns >= BM), so a thread fetches its float4 column of those two group rows
-// once instead of once per row unit: UDZ = 2 register sets instead of UDY.
-template <int GMODE, int IMODE, int Co, int Ci, int BM, int UDY, int UDZ, int UX>
+// once instead of once per row: UDZ = 2 register sets instead of UDY.
+// LDZ / LDY / LDX > 0: the row strides are compile-time constants (dense tensors: stride = channel count), so the R rows of a unit are
+// ONE 64-bit address plus immediate offsets; 0: the stride comes from the argument block (a 64-bit multiply-add per row).
+template <int GMODE, int IMODE, int Co, int Ci, int BM, int UDY, int UDZ, int UX, int LDZ, int LDY, int LDX>
 __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, int t, float4 (&rdz)[UDZ], float4 (&ry)[UDY],
                                                 int4 (&rarg)[UDZ], v4f (&rx)[UX])
 {
+    using MY = TileMap<Co, BM>;
+    using MX = TileMap<Ci, BM>;
+    static_assert(MY::NV == UDY && MX::NV == UX, "");
     const int m0 = t * BM;
+    const bool full = m0 + BM <= a.M;                 // uniform: only the last tile can be ragged
+    const int lddz = LDZ ? LDZ : a.lddz, ldy = LDY ? LDY : a.ldy, ldx = LDX ? LDX : a.ldx;
     if (GMODE == 2) {
         int row, c4;
-        fused_unit<Co / 4>(tid, row, c4);
+        MY::unit(tid, 0, row, c4);                    // c4 is the same for every unit of the thread (256 % C4 == 0)
         const int g0 = m0 / a.ns, glast = (a.M - 1) / a.ns;
 #pragma unroll
         for (int sI = 0; sI < UDZ; ++sI) {
@@ -103,18 +123,40 @@ __device__ __forceinline__ void fused_load_tile(const BwdFusedArgs &a, int tid, 
         }
     }
 #pragma unroll
-    for (int i = 0; i < UDY; ++i) {
-        int row, c4;
-        fused_unit<Co / 4>(tid + 256 * i, row, c4);
-        const int r = min(m0 + row, a.M - 1);
-        if (GMODE != 2) rdz[i] = *reinterpret_cast<const float4 *>(a.dz + (size_t)r * a.lddz + c4 * 4);
-        if (GMODE >= 1) ry[i] = *reinterpret_cast<const float4 *>(a.y + (size_t)r * a.ldy + c4 * 4);
+    for (int u = 0; u < MY::NU; ++u) {
+        int row0, c4;
+        MY::unit(tid, u, row0, c4);
+        if (full) {
+            const float *pz = a.dz + (size_t)(m0 + row0) * lddz + c4 * 4, *py = a.y + (size_t)(m0 + row0) * ldy + c4 * 4;
+#pragma unroll
+            for (int j = 0; j < MY::R; ++j) {
+                if (GMODE != 2) rdz[u * MY::R + j] = *reinterpret_cast<const float4 *>(pz + j * lddz);
+                if (GMODE >= 1) ry[u * MY::R + j] = *reinterpret_cast<const float4 *>(py + j * ldy);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < MY::R; ++j) {
+                const int r = min(m0 + row0 + j, a.M - 1);
+                if (GMODE != 2) rdz[u * MY::R + j] = *reinterpret_cast<const float4 *>(a.dz + (size_t)r * lddz + c4 * 4);
+                if (GMODE >= 1) ry[u * MY::R + j] = *reinterpret_cast<const float4 *>(a.y + (size_t)r * ldy + c4 * 4);
+            }
+        }
     }
 #pragma unroll
-    for (int i = 0; i < UX; ++i) {
-        int row, c4;
-        fused_unit<Ci / 4>(tid + 256 * i, row, c4);
-        rx[i] = *reinterpret_cast<const v4f *>(a.x + (size_t)min(m0 + row, a.M - 1) * a.ldx + (IMODE == 2 ? 0 : c4 * 4));
+    for (int u = 0; u < MX::NU; ++u) {
+        int row0, c4;
+        MX::unit(tid, u, row0, c4);
+        if (full) {
+            const float *px = a.x + (size_t)(m0 + row0) * ldx + (IMODE == 2 ? 0 : c4 * 4);
+#pragma unroll
+            for (int j = 0; j < MX::R; ++j) rx[u * MX::R + j] = *reinterpret_cast<const v4f *>(px + j * ldx);
+        } else {
+#pragma unroll
+            for (int j = 0; j < MX::R; ++j) {
+                const int r = min(m0 + row0 + j, a.M - 1);
+                rx[u * MX::R + j] = *reinterpret_cast<const v4f *>(a.x + (size_t)r * ldx + (IMODE == 2 ? 0 : c4 * 4));
+            }
+        }
     }
 }
 
@@ -128,58 +170,73 @@ __device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid,
                                                  const float4 (&ry)[UDY], const int4 (&rarg)[UDZ], const v4f (&rx)[UX],
                                                  const float4 (&cf)[5], const v4f (&w0r)[4], const v4f &b0r, float *x0s)
 {
+    using MY = TileMap<Co, BM>;
+    using MX = TileMap<Ci, BM>;
     const int m0 = t * BM;
-    constexpr int RS = 1024 / Co;                  // rows a unit index spans: unit i holds rows [RS*i, RS*i + RS) of the tile
+    const bool full = m0 + BM <= a.M;                 // uniform
 #pragma unroll
-    for (int i = 0; i < UDY; ++i) {
-        int row, c4;
-        fused_unit<Co / 4>(tid + 256 * i, row, c4);
-        const int m = m0 + row;
-        float4 g;
-        if (GMODE == 2) {
-            const int gi = (m0 + RS * i) / a.ns;   // uniform: the group of every row of this unit
-            const int j = m - gi * a.ns;           // the row's index inside its group
-            const bool second = gi != m0 / a.ns;
-            const float4 d = second ? rdz[UDZ - 1] : rdz[0];
-            const int4 w = second ? rarg[UDZ - 1] : rarg[0];
-            g = make_float4(w.x == j ? d.x : 0.f, w.y == j ? d.y : 0.f, w.z == j ? d.z : 0.f, w.w == j ? d.w : 0.f);
-        } else {
-            g = rdz[i];
+    for (int u = 0; u < MY::NU; ++u) {
+        int row0, c4;
+        MY::unit(tid, u, row0, c4);
+        float ox[4], oy[4], oz[4], ow[4];             // [row j] of channels 4c4 .. 4c4+3
+#pragma unroll
+        for (int j = 0; j < MY::R; ++j) {
+            const int m = m0 + row0 + j;
+            float4 g;
+            if (GMODE == 2) {
+                const int gi = m / a.ns;              // rows R g .. R g + R - 1 lie in one group (ns % 16 == 0)
+                const int jj = m - gi * a.ns;         // the row's index inside its group
+                const bool second = gi != m0 / a.ns;
+                const float4 d = second ? rdz[UDZ - 1] : rdz[0];
+                const int4 w = second ? rarg[UDZ - 1] : rarg[0];
+                g = make_float4(w.x == jj ? d.x : 0.f, w.y == jj ? d.y : 0.f, w.z == jj ? d.z : 0.f, w.w == jj ? d.w : 0.f);
+            } else {
+                g = rdz[u * MY::R + j];
+            }
+            float4 o = g;
+            if (GMODE >= 1) {
+                const float4 yy = ry[u * MY::R + j];
+                // the ReLU mask with the forward's own two roundings (mul, add); the affine rest as fmas
+                o.x = __builtin_fmaf(cf[2].x, (cf[0].x * yy.x + cf[1].x > 0.f) ? g.x : 0.f, __builtin_fmaf(cf[3].x, yy.x, cf[4].x));
+                o.y = __builtin_fmaf(cf[2].y, (cf[0].y * yy.y + cf[1].y > 0.f) ? g.y : 0.f, __builtin_fmaf(cf[3].y, yy.y, cf[4].y));
+                o.z = __builtin_fmaf(cf[2].z, (cf[0].z * yy.z + cf[1].z > 0.f) ? g.z : 0.f, __builtin_fmaf(cf[3].z, yy.z, cf[4].z));
+                o.w = __builtin_fmaf(cf[2].w, (cf[0].w * yy.w + cf[1].w > 0.f) ? g.w : 0.f, __builtin_fmaf(cf[3].w, yy.w, cf[4].w));
+            }
+            if (!full) {                              // rows past M contribute nothing to dW / dbias
+                const float ok = m < a.M ? 1.f : 0.f;
+                o.x *= ok; o.y *= ok; o.z *= ok; o.w *= ok;
+            }
+            ox[j] = o.x; oy[j] = o.y; oz[j] = o.z; ow[j] = o.w;
         }
-        float4 o = g;
-        if (GMODE >= 1) {
-            const float4 yy = ry[i];
-            // the ReLU mask with the forward's own two roundings (mul, add); the affine rest as fmas
-            o.x = __builtin_fmaf(cf[2].x, (cf[0].x * yy.x + cf[1].x > 0.f) ? g.x : 0.f, __builtin_fmaf(cf[3].x, yy.x, cf[4].x));
-            o.y = __builtin_fmaf(cf[2].y, (cf[0].y * yy.y + cf[1].y > 0.f) ? g.y : 0.f, __builtin_fmaf(cf[3].y, yy.y, cf[4].y));
-            o.z = __builtin_fmaf(cf[2].z, (cf[0].z * yy.z + cf[1].z > 0.f) ? g.z : 0.f, __builtin_fmaf(cf[3].z, yy.z, cf[4].z));
-            o.w = __builtin_fmaf(cf[2].w, (cf[0].w * yy.w + cf[1].w > 0.f) ? g.w : 0.f, __builtin_fmaf(cf[3].w, yy.w, cf[4].w));
-        }
-        const float ok = m < a.M ? 1.f : 0.f;                       // rows past M contribute nothing to dW / dbias
-        float *d = dy + fused_pos<BM>(c4 * 4, row);                 // channels 4c4 .. 4c4+3 share (c >> 3): same rotation
-        d[0] = o.x * ok;
-        d[BM + 4] = o.y * ok;
-        d[2 * (BM + 4)] = o.z * ok;
-        d[3 * (BM + 4)] = o.w * ok;
+        float *d = dy + fused_pos<BM>(c4 * 4, row0);  // channels 4c4 .. 4c4+3 share (c >> 3): same rotation; row0 % R == 0
+        lds_store_rows<MY::R>(d, ox);
+        lds_store_rows<MY::R>(d + (BM + 4), oy);
+        lds_store_rows<MY::R>(d + 2 * (BM + 4), oz);
+        lds_store_rows<MY::R>(d + 3 * (BM + 4), ow);
     }
 #pragma unroll
-    for (int i = 0; i < UX; ++i) {
-        int row, c4;
-        fused_unit<Ci / 4>(tid + 256 * i, row, c4);
-        float *d = xt + fused_pos<BM>(c4 * 4, row);
-        v4f v = rx[i];
-        if (IMODE == 2) {
-            const v4f x = rx[i];
-            v.x = p2c_l0_preact(w0r[0].x, w0r[0].y, w0r[0].z, b0r.x, x.x, x.y, x.z);
-            v.y = p2c_l0_preact(w0r[1].x, w0r[1].y, w0r[1].z, b0r.y, x.x, x.y, x.z);
-            v.z = p2c_l0_preact(w0r[2].x, w0r[2].y, w0r[2].z, b0r.z, x.x, x.y, x.z);
-            v.w = p2c_l0_preact(w0r[3].x, w0r[3].y, w0r[3].z, b0r.w, x.x, x.y, x.z);
-            if (c4 == 0) *reinterpret_cast<v4f *>(&x0s[row * 4]) = (m0 + row < a.M) ? x : v4f{0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < MX::NU; ++u) {
+        int row0, c4;
+        MX::unit(tid, u, row0, c4);
+        float vx[4], vy[4], vz[4], vw[4];
+#pragma unroll
+        for (int j = 0; j < MX::R; ++j) {
+            v4f v = rx[u * MX::R + j];
+            if (IMODE == 2) {
+                const v4f x = v;
+                v.x = p2c_l0_preact(w0r[0].x, w0r[0].y, w0r[0].z, b0r.x, x.x, x.y, x.z);
+                v.y = p2c_l0_preact(w0r[1].x, w0r[1].y, w0r[1].z, b0r.y, x.x, x.y, x.z);
+                v.z = p2c_l0_preact(w0r[2].x, w0r[2].y, w0r[2].z, b0r.z, x.x, x.y, x.z);
+                v.w = p2c_l0_preact(w0r[3].x, w0r[3].y, w0r[3].z, b0r.w, x.x, x.y, x.z);
+                if (c4 == 0) *reinterpret_cast<v4f *>(&x0s[(row0 + j) * 4]) = (m0 + row0 + j < a.M) ? x : v4f{0.f, 0.f, 0.f, 0.f};
+            }
+            vx[j] = v.x; vy[j] = v.y; vz[j] = v.z; vw[j] = v.w;
         }
-        d[0] = v.x;
-        d[BM + 4] = v.y;
-        d[2 * (BM + 4)] = v.z;
-        d[3 * (BM + 4)] = v.w;
+        float *d = xt + fused_pos<BM>(c4 * 4, row0);
+        lds_store_rows<MX::R>(d, vx);
+        lds_store_rows<MX::R>(d + (BM + 4), vy);
+        lds_store_rows<MX::R>(d + 2 * (BM + 4), vz);
+        lds_store_rows<MX::R>(d + 3 * (BM + 4), vw);
     }
 }
 
@@ -195,10 +252,13 @@ __device__ __forceinline__ void fused_store_tile(const BwdFusedArgs &a, int tid,
 // ------------------------------------------------------------------------------------------------
 // EX: extra input columns [Ci, Ci+EX) of X (the 3 relative coordinates + pad of a grouped layer, laid out AFTER the
 // feature block): they only contribute EX more columns of dW (no dX, no act_in), accumulated on the VALU.
-template <int COT, int CIT, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS, int EX>
+// DENSE (compile-time row strides for dense tensors: immediates instead of 64-bit address arithmetic) is kept as a switch but not
+// instantiated: measured on the 128x128 layer it changes nothing (232-247 us either way) and costs two spilled registers.
+template <int COT, int CIT, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS, int EX, bool DENSE = false>
 __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 {
     constexpr int Co = 64 * COT, Ci = 64 * CIT;
+    constexpr int LDZ = (DENSE && GMODE != 2) ? Co : 0, LDY = DENSE ? Co : 0, LDX = DENSE ? (IMODE == 2 ? 4 : Ci + EX) : 0;
     constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
     constexpr int LDT = Co + 4, LDM = BM + 4, NG = BM / 8, NQ = Co / 8;
     constexpr int UDY = BM * Co / 4 / 256, UX = BM * Ci / 4 / 256;
@@ -250,7 +310,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     // coef of the thread's float4 column (it does not depend on the unit index i)
     float4 cf[5];
     int row0_, c40;
-    fused_unit<Co / 4>(tid, row0_, c40);
+    TileMap<Co, BM>::unit(tid, 0, row0_, c40);
     auto load_cf = [&]() {
 #pragma unroll
         for (int i = 0; i < 5; ++i)
@@ -262,7 +322,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     float g0 = 0.f, g1 = 0.f, g2 = 0.f;            // IMODE 2: sum_m g[m, xcol] * x0[m, 0..2] (weight gradient of the folded layer)
     if (IMODE == 2) {
         int rowx_, c4x;
-        fused_unit<Ci / 4>(tid, rowx_, c4x);
+        TileMap<Ci, BM>::unit(tid, 0, rowx_, c4x);
 #pragma unroll
         for (int e = 0; e < 4; ++e) w0r[e] = *reinterpret_cast<const v4f *>(a.w0 + (size_t)(4 * c4x + e) * 4);
         if (a.b0) b0r = *reinterpret_cast<const v4f *>(a.b0 + 4 * c4x);
@@ -306,13 +366,13 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     // prologue: this half's first tile -> its LDS buffer; its second tile -> registers (in flight)
     {
         const int k0 = half, k1 = half + 2;
-        fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
+        fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX, LDZ, LDY, LDX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
         fused_store_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xt, rdz, ry, rarg, rx, cf, w0r, b0r, x0h);
         if (EX > 0 && tid < BM) {
             const int m = min(tile_of(k0 < nk ? k0 : 0) * BM + tid, a.M - 1);
             *reinterpret_cast<v4f *>(&xe[tid * 4]) = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
         }
-        fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k1 < nk ? k1 : 0), rdz, ry, rarg, rx);
+        fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX, LDZ, LDY, LDX>(a, tid, tile_of(k1 < nk ? k1 : 0), rdz, ry, rarg, rx);
         if (EX > 0 && tid < BM) {
             const int m = min(tile_of(k1 < nk ? k1 : 0) * BM + tid, a.M - 1);
             rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
@@ -424,55 +484,74 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         // ================= non-MFMA phase (the other half is in its MFMA phase) =================
         __builtin_amdgcn_s_setprio(1);
 #ifndef P2C_TRACE_NODATA
-        if (valid && NEED_DX) {
-            if (IMODE == 2) {
-                // the layer below is folded: nobody reads dX; what its backward needs from it are the BatchNorm sums (below) and
-                // G[c, :] = sum_m g[m, c] x0[m, :], from which its weight gradient is assembled (p2c_fold0_bwd_finalize_f32)
-            } else if (m0 + BM <= a.M) {
-                if (a.dx_atomic) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        atomicAdd(&a.dx[(size_t)(m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * a.lddx + xcol], accX[r]);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        a.dx[(size_t)(m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * a.lddx + xcol] = accX[r];
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < a.M) { if (a.dx_atomic) atomicAdd(&a.dx[(size_t)m * a.lddx + xcol], accX[r]); else a.dx[(size_t)m * a.lddx + xcol] = accX[r]; }
+        // Order matters for the memory counters: the next tile is staged FIRST (its operands were fetched a whole phase ago), the
+        // prefetch of the tile after it is issued SECOND, and the dX stores of the finished tile go out LAST.  vmcnt retires in issue
+        // order and the compiler cannot count the stores across this block's branches, so a wait for the prefetched registers placed
+        // after freshly issued stores drains those stores too (a full write round trip per tile in the previous order: staging
+        // started with s_waitcnt vmcnt(8..0) right behind 16 global stores).
+        auto stage_next = [&]() {
+        if (IMODE != 2) asm volatile("" ::"v"(rx[UX - 1]));        // the newest prefetch register: wait here, while nothing younger is outstanding
+            if (EX > 0) asm volatile("" ::"v"(rxe));
+            {
+                const int k2 = k + 2, k4 = k + 4;
+                if (k2 < nk) fused_store_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k2), dy, xt, rdz, ry, rarg, rx, cf, w0r, b0r, x0h + ((it + 1) & 1) * BM * 4);
+                P2C_TR(4);
+                if (EX > 0 && tid < BM) *reinterpret_cast<v4f *>(&xe[tid * 4]) = rxe;
+                fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX, LDZ, LDY, LDX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
+                if (EX > 0 && tid < BM) {
+                    const int m = min(tile_of(k4 < nk ? k4 : 0) * BM + tid, a.M - 1);
+                    rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
                 }
             }
-            if (HAS_STATS) {
-                const float *x0t = x0h + (it & 1) * BM * 4;
+        };
+        auto epilogue = [&]() {
+        if (valid && NEED_DX) {
+                if (IMODE == 2) {
+                    // the layer below is folded: nobody reads dX; what its backward needs from it are the BatchNorm sums (below) and
+                    // G[c, :] = sum_m g[m, c] x0[m, :], from which its weight gradient is assembled (p2c_fold0_bwd_finalize_f32)
+                } else if (m0 + BM <= a.M) {
+                    const int lddx = DENSE ? Ci : a.lddx;
+                    float *dxp = a.dx + (size_t)(m0 + wr * 32 + 4 * lh) * lddx + xcol;      // one 64-bit address; the 16 rows are offsets of it
+                    if (a.dx_atomic) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = accX[r];
-                    const float g = (psc * yp[r] + psh > 0.f) ? v : 0.f;          // mask: the forward's two roundings
-                    s1 += g;
-                    s2 = __builtin_fmaf(g, __builtin_fmaf(yp[r], pis, npm), s2);    // g * (y - mean) * invstd
-                    if (IMODE == 2) {
-                        const v4f x = *reinterpret_cast<const v4f *>(&x0t[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4]);   // zero past M
-                        g0 = __builtin_fmaf(g, x.x, g0);
-                        g1 = __builtin_fmaf(g, x.y, g1);
-                        g2 = __builtin_fmaf(g, x.z, g2);
+                        for (int r = 0; r < 16; ++r) atomicAdd(dxp + ((r & 3) + 8 * (r >> 2)) * lddx, accX[r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) dxp[((r & 3) + 8 * (r >> 2)) * lddx] = accX[r];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (m < a.M) { if (a.dx_atomic) atomicAdd(&a.dx[(size_t)m * a.lddx + xcol], accX[r]); else a.dx[(size_t)m * a.lddx + xcol] = accX[r]; }
+                    }
+                }
+                if (HAS_STATS) {
+                    const float *x0t = x0h + (it & 1) * BM * 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = accX[r];
+                        const float g = (psc * yp[r] + psh > 0.f) ? v : 0.f;          // mask: the forward's two roundings
+                        s1 += g;
+                        s2 = __builtin_fmaf(g, __builtin_fmaf(yp[r], pis, npm), s2);    // g * (y - mean) * invstd
+                        if (IMODE == 2) {
+                            const v4f x = *reinterpret_cast<const v4f *>(&x0t[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4]);   // zero past M
+                            g0 = __builtin_fmaf(g, x.x, g0);
+                            g1 = __builtin_fmaf(g, x.y, g1);
+                            g2 = __builtin_fmaf(g, x.z, g2);
+                        }
                     }
                 }
             }
-        }
-        P2C_TR(4);
-        {
-            const int k2 = k + 2, k4 = k + 4;
-            if (k2 < nk) fused_store_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k2), dy, xt, rdz, ry, rarg, rx, cf, w0r, b0r, x0h + ((it + 1) & 1) * BM * 4);
+        };
+        if (IMODE == 2) {          // folded layer below: no dX stores at all - statistics first (its registers die before the staging)
+            epilogue();
             P2C_TR(5);
-            if (EX > 0 && tid < BM) *reinterpret_cast<v4f *>(&xe[tid * 4]) = rxe;
-            fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k4 < nk ? k4 : 0), rdz, ry, rarg, rx);   // unconditional: stays in registers
-            if (EX > 0 && tid < BM) {
-                const int m = min(tile_of(k4 < nk ? k4 : 0) * BM + tid, a.M - 1);
-                rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
-            }
+            stage_next();
+        } else {
+            stage_next();
+            P2C_TR(5);
+            epilogue();
         }
 #endif
         __builtin_amdgcn_s_setprio(0);

@@ -225,6 +225,11 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
         P2C_TR(2);
         // ================= wave-local phase (the other half is in its MFMA phase) =================
         __builtin_amdgcn_s_setprio(1);
+        // vmcnt retires in issue order and the compiler cannot count stores across this phase's branches: its wait for the prefetched
+        // rows (consumed by stage() below) would land BEHIND the freshly issued global stores and drain them too - a write round trip
+        // per tile.  Touching the last prefetched register here makes it wait while only loads are outstanding.
+        asm volatile("" ::"v"(rx[UPW - 1]));
+        if (EX) asm volatile("" ::"v"(rxe));
         if (valid) {
             // fragment (+ the EX trailing input columns, + bias) -> this wave's region; BatchNorm sums on the bias-free value.
             // Register pairs along r are adjacent, so the sums run as packed-fp32 ops on (r, r+1) pairs.
@@ -246,10 +251,10 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
                     const v2f v = {acc[y][r], acc[y][r + 1]};
                     s1v[y] += v;
                     s2v[y] += v * v;
-                    const v2f o = v + v2f{bias[y], bias[y]};
+                    const v2f ov = v + v2f{bias[y], bias[y]};
                     const int rf = (r & 3) + 8 * (r >> 2) + 4 * lh;        // r even: rows rf and rf+1
-                    out[rf * (32 * NT) + y * 32 + l31] = o.x;
-                    out[(rf + 1) * (32 * NT) + y * 32 + l31] = o.y;
+                    out[rf * (32 * NT) + y * 32 + l31] = ov.x;
+                    out[(rf + 1) * (32 * NT) + y * 32 + l31] = ov.y;
                 }
             }
             P2C_TR(3);

@@ -1,8 +1,8 @@
 """Phase timeline of the ping-pong fused backward kernel (csrc/bwd_fused.hip built with -DP2C_TRACE into a throw-away
 library).  Build here:  python tools/fused_trace.py --build      Run on the GPU box:  python tools/fused_trace.py [M Co Ci]
 Stamps (shader clock) of workgroup 0, thread 0 of each half:
-  0 MFMA phase start | 1 end of dW MFMAs | 2 end of MFMA phase (before barrier) | 3 after barrier | 4 dX stored + sums
-  5 next tile transformed into LDS (waits for its global loads) | 6 prefetch issued | 7 after 2nd barrier"""
+  0 MFMA phase start | 1 end of dW MFMAs | 2 end of MFMA phase (before barrier) | 3 after barrier
+  4 next tile transformed into LDS (waits for its global loads) | 5 prefetch issued | 6 dX stored + sums | 7 after 2nd barrier"""
 import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -71,7 +71,7 @@ print("kernel %.1f us (mean of 20)" % (e0.elapsed_time(e1) * 1e3 / 20))
 buf = np.zeros((2, 12, 8), dtype=np.uint64)
 assert L.p2c_trace_read(buf.ctypes.data_as(vp)) == 0
 t0 = buf[0, 2, 0]
-names = ["mfma0", "dW_end", "mfma_end", "bar1", "dx+sums", "stage", "prefetch", "bar2"]
+names = ["mfma0", "dW_end", "mfma_end", "bar1", "stage", "prefetch", "dx+sums", "bar2"]
 for it in range(2, 10):
     for h in range(2):
         row = buf[h, it].astype(np.int64) - int(t0)

@@ -1,0 +1,286 @@
+"""Trainer counterpart of the reference's train_Point2Cyl.py (the with-sketch trainer: flags :33-90, networks and optimiser
+:256-321, checkpoint loading :327-350, loop :369-700, checkpoints :746-775) on the HIP kernels.
+
+Per step (default path: predicted labels, not --use_gt_im / --use_whole_pc, which are not built - DESIGN.md section 7):
+backbone forward + segmentation / normal / base-barrel (+ axis, + centre) losses exactly as the without-sketch step
+(point2cyl_amd/step.py), then the sketch branch (point2cyl_amd/step_sketch.py, train_Point2Cyl.py:519-672): projection of the
+predicted and the ground-truth barrels, trainable sketch encoder vs the frozen pre-trained one (latent loss, angle or --is_L2),
+and with --with_im_loss the implicit decoder's manifold / eikonal / SALD-normal losses (double backward through the decoder).
+`total = (point-cloud losses if --is_pc_train) + im_loss`; Adam over the parameter groups the reference builds
+({backbone at --learning_rate} and/or {encoder at StepLearningRateSchedule(0.001, 1000, 0.5)(0)}, the decoder and the loaded
+encoder frozen, :298-321, :364-365); BatchNorm-momentum and learning-rate staircases applied after the forward like the reference.
+
+Checkpoints are the reference's triple {"model", "implicit_net", "pn_encoder"} (:348, :760); --is_pc_init loads
+<pc_logdir>/<pc_ckpt>["model"] (this package's without-sketch trainer writes that file), --is_im_init / the frozen networks load
+<im_logdir>/<im_ckpt>["model_state_dict" | "encoder_state_dict"] when the file exists (there is no pre-trained IGR checkpoint on
+the box: without it the frozen networks keep their seeded initialisation and a warning is logged).
+
+Data: --synthetic N generates N clouds plus their ground-truth sketches (dataloader.py's `sampled_sketch`, (K, S, 4) = [2-D point |
+2-D normal]: here the ground-truth barrels projected along the ground-truth axes, scaled to unit radius); resident in HBM like the
+without-sketch trainer's data.  One process per GPU under torch.distributed.run (clouds sharded, one flat gradient exchange).
+
+    python -m point2cyl_amd.train_sketch --pred_seg --pred_normal --pred_bb --is_pc_train --is_im_train --with_im_loss \
+        --synthetic 32 --batch_size 8 --num_epochs 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from collections import defaultdict
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ddp, fitting, ops, step, step_sketch, synth
+from .backbone import backbone
+from .implicit import ImplicitNet, NormalPerPoint
+from .sketch import PointNetEncoder
+from .train import ResidentDataset
+
+PC_SCALARS = ("normal", "miou", "ext", "bb", "center")
+IM_SCALARS = ("im_loss", "latent_loss", "mnfld_loss", "grad_loss", "normals_loss")
+
+
+def step_lr(initial, interval, factor, epoch):
+    """IGR/general.py:70-77 StepLearningRateSchedule."""
+    return float(np.maximum(initial * (factor ** (epoch // interval)), 5.0e-6))
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--model", type=str, default="pointnet_extrusion")
+    p.add_argument("--num_point", type=int, default=8192)
+    p.add_argument("--num_sk_point", type=int, default=2048)
+    p.add_argument("--K", type=int, default=8)
+    p.add_argument("--batch_size", type=int, default=4)
+    p.add_argument("--logdir", default="Point2Cyl", type=str)
+    p.add_argument("--data_dir", type=str, default="data/")
+    p.add_argument("--data_split", default="train", type=str)
+    p.add_argument("--num_epochs", type=int, default=300)
+    p.add_argument("--decay_step", type=int, default=200000)
+    p.add_argument("--bn_decay_step", type=int, default=200000)
+    p.add_argument("--decay_rate", type=float, default=0.7)
+    p.add_argument("--learning_rate", type=float, default=0.001)
+    p.add_argument("--momentum", type=float, default=0.9)
+    for f in ("pred_seg", "pred_normal", "pred_bb", "pred_extrusion", "pred_center", "norm_eig", "add_noise", "sald", "is_pc_init", "is_im_init",
+              "is_pc_train", "is_im_train", "is_implicitnet_train", "is_L2", "with_im_loss", "use_whole_pc", "use_gt_im", "use_extrusion_axis_feat"):
+        p.add_argument("--" + f, action="store_true")
+    for f in ("seg", "normal", "bb", "extrusion", "center"):
+        p.add_argument("--weight_" + f, type=float, default=1.0)
+    p.add_argument("--noise_sigma", type=float, default=0.01)
+    p.add_argument("--pc_logdir", default="Point2Cyl_without_sketch", type=str)
+    p.add_argument("--pc_ckpt", default="model.pth", type=str)
+    p.add_argument("--im_logdir", default="./results/IGR_dense/", type=str)
+    p.add_argument("--im_ckpt", default="latest.pth", type=str)
+    p.add_argument("--synthetic", type=int, default=0, help="number of generated shapes with ground-truth sketches (0: read <data_dir>/<split>.h5)")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--save_every", type=int, default=10)
+    p.add_argument("--max_steps", type=int, default=0)
+    p.add_argument("--report", type=str, default="")
+    return p
+
+
+def synthetic_sketches(data, K, S, dev, chunk=16):
+    """Ground-truth sketches of the resident clouds: the ground-truth barrels projected along the ground-truth axes about the
+    ground-truth centres, divided by their scale (what utils.py stores per extrusion as `sketch` after normalisation), with the
+    projected normals; (n, K, S, 4).  Absent segments keep zeros."""
+    out = []
+    for i in range(0, len(data), chunk):
+        idx = torch.arange(i, min(i + chunk, len(data)), device=dev)
+        pcs, nrm, inst, bb, _, _, axes, _, cen = data.gather(idx)
+        P0, X0, s0, found = fitting.sketch_implicit_projection2(pcs, nrm, inst, bb, axes, cen, S)
+        sk = torch.cat([P0 / s0.clamp(min=1e-12).unsqueeze(-1).unsqueeze(-1), F.normalize(X0 + 1e-6, dim=-1)], -1).permute(1, 0, 2, 3)
+        out.append(sk * found.unsqueeze(-1).unsqueeze(-1))
+    return torch.cat(out).contiguous()
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
+    if a.use_whole_pc or a.use_gt_im or a.use_extrusion_axis_feat or a.is_implicitnet_train:
+        raise SystemExit("--use_whole_pc / --use_gt_im / --use_extrusion_axis_feat / --is_implicitnet_train are variants of the reference "
+                         "trainer that this package does not build (DESIGN.md section 7)")
+    if not (a.is_pc_train or a.is_im_train):
+        raise SystemExit("nothing to train: pass --is_pc_train and/or --is_im_train (train_Point2Cyl.py:298-321)")
+    rank, world, local = ddp.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("point2cyl_amd.train_sketch needs an MI355X (HIP) device; there is no CPU path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    with torch.cuda.stream(torch.cuda.Stream(dev)):
+        return _main(a, rank, world, dev)
+
+
+def _main(a, rank, world, dev):
+    K, S, N = a.K, a.num_sk_point, a.num_point
+    torch.manual_seed(a.seed)
+    fl = step.StepFlags(K=K, pred_seg=a.pred_seg, pred_normal=a.pred_normal, pred_bb=a.pred_bb, pred_extrusion=a.pred_extrusion,
+                        pred_center=a.pred_center, norm_eig=a.norm_eig, weight_seg=a.weight_seg, weight_normal=a.weight_normal,
+                        weight_bb=a.weight_bb, weight_extrusion=a.weight_extrusion, weight_center=a.weight_center)
+    if not (fl.pred_seg and fl.pred_bb and fl.pred_normal):
+        raise SystemExit("the sketch branch needs --pred_seg --pred_normal --pred_bb (labels, base/barrel split and normals feed the projection)")
+    model = backbone(output_sizes=fl.pred_sizes()).to(dev)                                                   # train_Point2Cyl.py:256
+    implicit_net = ImplicitNet(d_in=2 + 256, dims=[512] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100).to(dev)   # :268
+    pn_encoder = PointNetEncoder(256, 2, with_normals=True).to(dev)                                          # :270
+    loaded_pn_encoder = PointNetEncoder(256, 2, with_normals=True).to(dev)                                   # :280
+    for m_ in (model, implicit_net, pn_encoder, loaded_pn_encoder):
+        ddp.broadcast_module(m_)
+    groups = []
+    if a.is_pc_train:
+        groups.append({"params": list(model.parameters()), "lr": a.learning_rate})                           # :298-311
+    if a.is_im_train:
+        groups.append({"params": list(pn_encoder.parameters()), "lr": step_lr(0.001, 1000, 0.5, 0)})
+    opt = torch.optim.Adam(groups, fused=True)
+    log = None
+    if rank == 0:
+        os.makedirs(a.logdir, exist_ok=True)
+        log = open(os.path.join(a.logdir, "log.txt"), "w")
+        log.write(str(a) + "\n")
+
+    def say(msg):
+        if rank == 0:
+            print(msg)
+            log.write(msg + "\n")
+
+    if a.is_pc_init:                                                                                         # :327-330
+        model.load_state_dict(torch.load(os.path.join(a.pc_logdir, a.pc_ckpt), map_location="cpu")["model"])
+        say("3D model loaded.")
+    im_file = os.path.join(a.im_logdir, a.im_ckpt)
+    if os.path.exists(im_file):                                                                              # :332-342
+        ck = torch.load(im_file, map_location="cpu")
+        if a.is_im_init:
+            pn_encoder.load_state_dict(ck["encoder_state_dict"])
+            say("Implicit model loaded.")
+        implicit_net.load_state_dict(ck["model_state_dict"])
+        loaded_pn_encoder.load_state_dict(ck["encoder_state_dict"])
+        say("Pre-trained fixed implicit model loaded.")
+    else:
+        say("WARNING: %s not found - the frozen decoder / ground-truth encoder keep their seeded initialisation" % im_file)
+    for p in list(implicit_net.parameters()) + list(loaded_pn_encoder.parameters()):
+        p.requires_grad_(False)
+    if not a.is_pc_train:
+        for p in model.parameters():
+            p.requires_grad_(False)
+    if not a.is_im_train:
+        for p in pn_encoder.parameters():
+            p.requires_grad_(False)
+
+    def save(name):
+        ddp.average_buffers(model)
+        ddp.average_buffers(pn_encoder)
+        if rank == 0:
+            torch.save({"model": model.state_dict(), "implicit_net": implicit_net.state_dict(), "pn_encoder": pn_encoder.state_dict()},
+                       os.path.join(a.logdir, name))                                                         # :348, :760
+    save("model.pth")                                                                                        # :345-349: the initial combined model
+    model.train() if a.is_pc_train else model.eval()                                                         # :352-365
+    pn_encoder.train() if a.is_im_train else pn_encoder.eval()
+    implicit_net.eval()
+    loaded_pn_encoder.eval()
+    np.random.seed(0 + rank)
+    torch.manual_seed(a.seed + 7919 * rank)
+    if a.synthetic <= 0:
+        raise SystemExit("reading %s needs h5py and the dataset; use --synthetic N" % os.path.join(a.data_dir, a.data_split + ".h5"))
+    ds = synth.SyntheticExtrusionDataset(a.synthetic, N, K, seed=1234)
+    lo, hi = ddp.shard_range(len(ds), rank, world)
+    data = ResidentDataset(torch.utils.data.Subset(ds, range(lo, hi)) if world > 1 else ds, dev, N)
+    sketches = synthetic_sketches(data, K, S, dev)
+    B = min(a.batch_size, len(data))
+    nb = len(data) // B
+    if world > 1:
+        t = torch.tensor([nb], device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        nb = int(t.item())
+    if nb == 0:
+        raise SystemExit("dataset shard (%d clouds) is smaller than one batch (%d)" % (len(data), B))
+    trainable = [p for g in groups for p in g["params"]]
+    sync = ddp.FlatGradSync(trainable, world)
+    sampler = NormalPerPoint(1.8, 0.01)                                                                       # :262-266
+    gstep, best, old_lr = 0, np.inf, a.learning_rate
+    mom_fwd = 0.1
+    scal = defaultdict(list)
+    t0, steps_timed = None, 0
+    for epoch in range(1, a.num_epochs + 1):
+        perm = torch.randperm(len(data)).to(dev)
+        hist = []
+        for i in range(nb):
+            idx = perm[i * B:(i + 1) * B]
+            it = data.gather(idx)
+            pcs, nrm, inst, bb, axes, cen = it[0], it[1], it[2], it[3], it[6], it[8]
+            gt_sk = sketches.index_select(0, idx)
+            if a.add_noise:
+                pcs = pcs + torch.randn(B, N, 1, device=dev) * a.noise_sigma * nrm
+            step.update_momentum(model, mom_fwd)
+            ops.step_done()
+            with ops.step_arena(dev):
+                out = (step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses)(model, pcs, nrm, inst, bb, axes, cen, fl)
+                h = out["heads"].view(B, N, -1) if "heads" in out else None
+                with torch.no_grad():
+                    if h is not None:
+                        X = F.normalize(h[:, :, 0:3], p=2, dim=2, eps=1e-12)
+                        W2K = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2)
+                    else:
+                        X, W2K = out["X"].detach(), torch.softmax(out["W_raw"].detach(), dim=2)
+                    W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
+                sk = step_sketch.sketch_branch_losses(pcs, X, W, W2K, out["match"], out["mask"], nrm, inst, bb, axes, cen, gt_sk, pn_encoder,
+                                                      loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2)
+                total = (out["total"] + sk["im_loss"]) if a.is_pc_train else sk["im_loss"]                    # :690-693
+                sync.zero()
+                mom_fwd = step.get_batch_norm_decay(gstep, B, a.bn_decay_step)                                # :698-701 (reaches the next forward)
+                lr = step.get_learning_rate(a.learning_rate, gstep, B, a.decay_step, a.decay_rate)             # :703-706: group 0 only
+                if old_lr != lr:
+                    opt.param_groups[0]["lr"] = lr
+                    old_lr = lr
+                total.backward()
+                sync.pack()
+            sync.allreduce()
+            opt.step()
+            ops.step_done()
+            gstep += 1
+            row = torch.stack([total.detach()] + [sk[k].detach().float().reshape(()) for k in IM_SCALARS] +
+                              [out[k].detach().float().reshape(()) for k in PC_SCALARS])
+            hist.append(row)
+            v = row.tolist()                                                                                   # one sync per step (the reference: ~12)
+            say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | latent loss: %.4f | manifold loss: %.4f | eikonal loss: %.4f | normal loss: %.4f"
+                % (epoch, a.num_epochs, i, nb, v[1], v[2], v[3], v[4], v[5]))
+            if a.is_pc_train:
+                say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | normal loss: %.4f | mIOU loss: %.4f | ext loss: %.4f | bb loss: %.4f | center loss: %.4f"
+                    % (epoch, a.num_epochs, i, nb, v[0], v[6], v[7], v[8], v[9], v[10]))
+            if gstep == 2:
+                torch.cuda.synchronize()
+                t0, steps_timed = time.perf_counter(), 0
+            elif gstep > 2:
+                steps_timed += 1
+            if a.max_steps and gstep >= a.max_steps:
+                break
+        ep = torch.stack(hist).mean(0).tolist()
+        for k, val in zip(("total_loss",) + tuple("IM_" + s for s in IM_SCALARS) + PC_SCALARS, ep):
+            scal[k].append(val)
+        last = epoch == a.num_epochs or (a.max_steps and gstep >= a.max_steps)
+        if epoch % a.save_every == 0 or last:
+            save("checkpoint_%04d.pth" % epoch)
+            save("model.pth")
+            if epoch > 20 and ep[0] < best:
+                best = ep[0]
+                save("best_model.pth")
+            say("> Epoch [%04d/%04d] | total_loss: %.4f | IM_total_loss: %.4f | IM_latent_loss: %.4f" % (epoch, a.num_epochs, ep[0], ep[1], ep[2]))
+        if last:
+            break
+    torch.cuda.synchronize()
+    if t0 is not None and steps_timed > 0 and rank == 0:
+        dt = (time.perf_counter() - t0) / steps_timed
+        rep = dict(steps=gstep, ms_per_step=dt * 1e3, points_per_s=world * B * N / dt, batch_per_gpu=B, num_point=N, num_sk_point=S, world=world,
+                   epoch_means={k: v for k, v in scal.items()})
+        print("with-sketch trainer throughput: %.2f ms/step, %.1f points/s" % (rep["ms_per_step"], rep["points_per_s"]))
+        if a.report:
+            with open(a.report, "w") as f:
+                json.dump(rep, f)
+    if log is not None:
+        log.close()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -258,3 +258,99 @@ def test_hungarian_rejects_out_of_range_labels():
     with pytest.raises((RuntimeError, ValueError)):
         losses.hungarian_matching(W, I)
         torch.cuda.synchronize()
+
+
+def test_eval_sketch_fit_losses_vs_oracle():
+    """eval.py:459-590 (default branch): projection of the predicted barrels -> PointNetEncoder -> ImplicitNet on the gt-label
+    projection along the predicted axes (per-cylinder fitting loss) and on all points (global fitting loss), against the same
+    composition of the oracle's pieces (projection with the recorded sampling draws, encoder and decoder restatements).  The rotation
+    matrix inside the projection is the one part of this chain whose oracle is not pinned by the reference (torchgeometry absent)."""
+    from point2cyl_amd import fitting
+    from point2cyl_amd.implicit import ImplicitNet
+    from point2cyl_amd.sketch import PointNetEncoder
+    g = load_golden("g13_eval_flow")
+    B, N, K, S = 3, 1024, 8, 128
+    pcs, nrm, seg, bb, axes, cen = (t(g[k]) for k in ("pcs", "normals", "seg", "bb", "axes", "centers"))
+    fl = p2c_eval.EvalFlags(K=K, num_sk_point=S)
+    m = p2c_eval.eval_metrics(cu(g["X_head"]), cu(g["W_raw"]), cu(pcs), cu(nrm), cu(seg), cu(bb).float(), cu(axes), cu(cen), fl)
+    torch.manual_seed(12)
+    dec = ImplicitNet(d_in=2 + 64, dims=[128] * 4, skip_in=[2], geometric_init=True, radius_init=1, beta=100).to(DEV).eval()
+    enc = PointNetEncoder(64, 2, with_normals=True).to(DEV).eval()
+    with torch.no_grad():                        # running statistics away from (0, 1) so that eval-mode BatchNorm is not the identity
+        for mod in enc.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.running_mean.normal_(0, 0.1)
+                mod.running_var.uniform_(0.5, 1.5)
+    # the sampling draws of the three projections, made here and handed to both sides
+    gen = torch.Generator().manual_seed(4)
+    W = m["W"].cpu()
+    Wre = torch.gather(W, 2, m["matching_indices"].cpu().unsqueeze(1).expand(B, N, K)) * m["mask"].cpu().unsqueeze(1)
+    label = Wre.argmax(-1)
+    pbb = m["pred_bb_label"].cpu()
+
+    def draws(seg_, bb_):
+        barrel = F.one_hot(seg_, K).bool() & (bb_ == 0).unsqueeze(-1)
+        cnt = barrel.sum(1)
+        r = torch.zeros(B, K, S, dtype=torch.int64)
+        d = {}
+        for k in range(K):
+            for b in range(B):
+                if int(cnt[b, k]) > 1:
+                    r[b, k] = torch.randint(0, int(cnt[b, k]), (S,), generator=gen)
+                    d[(k, b)] = r[b, k]
+        return r, d
+    r1, d1 = draws(label, pbb)
+    r2, d2 = draws(seg, bb)
+    E, C = m["E_AX"], m["predicted_centroids"]
+    # device side (the three projections of sketch_fit_losses with the draws injected)
+    with torch.no_grad():
+        ppc, pn, sc, _ = fitting.sketch_implicit_projection2(cu(pcs), m["X"], cu(label), cu(pbb), E, C, S, rand_idx=r1)
+        lat = enc(torch.cat([(ppc / sc.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2), pn.reshape(B * K, S, 2)], -1))
+        p2, _, _, f2 = fitting.sketch_implicit_projection2(cu(pcs), cu(nrm), cu(seg), cu(bb), E, C, S, rand_idx=r2)
+        from point2cyl_amd.implicit import add_latent
+        sk = dec(add_latent((p2 / sc.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2), lat)).reshape(K, B, S)
+        pm = (m["mask"].T * f2.T).unsqueeze(-1)
+        cyl = (sk * pm).abs().permute(1, 0, 2).mean(-1).reshape(B, -1).sum(1) / (cu(seg).max(1)[0] + 1).float()
+    # oracle side
+    Ec, Cc, Xc = E.cpu(), C.cpu(), m["X"].cpu()
+    Pp, Xp, scl, _ = R.sketch_implicit_projection(pcs, Xc, label, pbb, Ec, Cc, d1, S)
+    sd_e = {k: v.detach().cpu().clone() for k, v in enc.state_dict().items()}
+    lat_r = R.pointnet_encoder_forward(sd_e, torch.cat([(Pp / scl.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2), Xp.reshape(B * K, S, 2)], -1),
+                                       training=False)
+    P2, _, _, F2 = R.sketch_implicit_projection(pcs, nrm, seg, bb, Ec, Cc, d2, S)
+    sd_d = {k: v.detach().cpu() for k, v in dec.state_dict().items()}
+    q = (P2 / scl.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2)
+    inp = torch.cat([lat_r.unsqueeze(1).repeat(1, S, 1).reshape(B * K * S, -1), q.reshape(B * K * S, 2)], 1)
+    sk_r = R.implicit_net_forward(sd_d, inp, skip_in=(2,)).reshape(K, B, S)
+    pm_r = (m["mask"].cpu().T * F2.T).unsqueeze(-1)
+    cyl_r = (sk_r * pm_r).abs().permute(1, 0, 2).mean(-1).reshape(B, -1).sum(1) / (seg.max(1)[0] + 1).float()
+    np.testing.assert_allclose(lat.cpu().numpy(), lat_r.numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(cyl.cpu().numpy(), cyl_r.numpy(), rtol=2e-4, atol=1e-6)
+    # and the packaged function runs end to end (its own random draws): finite, non-negative
+    c2, g2 = p2c_eval.sketch_fit_losses(m, cu(pcs), cu(nrm), cu(seg), cu(bb).float(), dec, enc, fl)
+    assert c2.shape == (B,) and g2.shape == (B,) and bool(torch.isfinite(c2).all()) and bool(torch.isfinite(g2).all())
+    assert float(c2.min()) >= 0 and float(g2.min()) >= 0
+
+
+def test_with_sketch_trainer_cli(tmp_path):
+    """train_Point2Cyl.py counterpart: two steps at a small size with every loss switched on; the log lines, the checkpoint triple
+    {"model", "implicit_net", "pn_encoder"} with the reference's key sets, and --is_pc_init from a without-sketch checkpoint."""
+    pc = str(tmp_path / "pc")
+    out = _run(["-m", "point2cyl_amd.train", "--pred_seg", "--pred_normal", "--pred_bb", "--synthetic", "4", "--batch_size", "2", "--num_point", "1024",
+                "--num_epochs", "1", "--save_every", "1", "--logdir", pc, "--quiet"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    logdir = str(tmp_path / "sk")
+    out = _run(["-m", "point2cyl_amd.train_sketch", "--pred_seg", "--pred_normal", "--pred_bb", "--pred_extrusion", "--pred_center", "--is_pc_train",
+                "--is_im_train", "--with_im_loss", "--is_pc_init", "--pc_logdir", pc, "--synthetic", "4", "--batch_size", "2", "--num_point", "1024",
+                "--num_sk_point", "256", "--num_epochs", "1", "--save_every", "1", "--logdir", logdir, "--im_logdir", str(tmp_path / "none")])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "3D model loaded." in out.stdout and "WARNING" in out.stdout
+    im = [l for l in out.stdout.splitlines() if "latent loss" in l]
+    pcl = [l for l in out.stdout.splitlines() if "mIOU loss" in l]
+    assert len(im) == 2 and len(pcl) == 2
+    vals = np.array([float(x.split(":")[1]) for l in im + pcl for x in l.split("|")[2:]])
+    assert vals.size == 2 * 5 + 2 * 6 and np.isfinite(vals).all()
+    ck = torch.load(os.path.join(logdir, "model.pth"), map_location="cpu")
+    assert set(ck.keys()) == {"model", "implicit_net", "pn_encoder"} and len(ck["model"]) == 123
+    assert "lin0.weight" in ck["implicit_net"] and "mlp1.0.weight" in ck["pn_encoder"] and "fc.weight" in ck["pn_encoder"]
+    assert os.path.exists(os.path.join(logdir, "checkpoint_0001.pth"))

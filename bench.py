@@ -102,7 +102,7 @@ def main():
 
 
 def _bench(args, rank, world, local, dev):
-    from point2cyl_amd import ddp, ops, step, synth
+    from point2cyl_amd import ddp, ops, optim, step, synth
     from point2cyl_amd.backbone import backbone
     import torch.distributed as dist
     backend = ddp.backend_name()
@@ -125,7 +125,7 @@ def _bench(args, rank, world, local, dev):
     ddp.broadcast_module(model)
     step.update_momentum(model, step.get_batch_norm_decay(0, B, 200000))
     sync = ddp.FlatGradSync(model.parameters(), world)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)     # same update rule as the reference's Adam, one kernel
+    opt = optim.Adam(model.parameters(), lr=1e-3)     # the reference's torch.optim.Adam update rule as ONE launch (point2cyl_amd/optim.py)
 
     loss_fn = step.compute_losses_fused if (step.fused_loss_applicable(fl) and not args.torch_losses) else step.compute_losses
 

@@ -224,6 +224,12 @@ int p2c_linear_fwd_pool_f32(const float *X, int ldx, const float *W, int ldw, co
                             float *pool_min, int32_t *pool_idx, void *stream);
 int p2c_pool_select_f32(const float *pool_max, const float *pool_min, const int32_t *pool_idx, const float *scale,
                         const float *shift, int G, int C, float *out, int ldo, int32_t *arg, float *ywin, void *stream);
+/* Adam (torch.optim.Adam defaults: no weight decay, no amsgrad; the optimiser of train_Point2Cyl_without_sketch.py:204) over a list
+ * of fp32 tensors in ONE launch with 1024-element work items.  table [n][4] int64 = (param, grad, exp_avg, exp_avg_sq) device
+ * pointers, numel [n] int64, chunks [n_chunks][2] int32 = (tensor, first element / 1024), all in device memory; `step` = the
+ * 1-based step count (bias corrections are formed on the host in double). */
+int p2c_adam_multi_f32(const long long *table, const long long *numel, const int32_t *chunks, int n_chunks, float lr, float beta1,
+                       float beta2, float eps, long long step, void *stream);
 /* dZ [G*ns, C] (dense, zero except the winners) from dOut [G,C] */
 int p2c_maxpool_bwd_f32(const float *dout, int ldo, const int32_t *arg, int G, int ns, int C, float *dZ, int ldz, void *stream);
 

@@ -48,6 +48,7 @@ _SIGS = {
     "p2c_bn_relu_apply_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p],
     "p2c_maxpool_bnrelu_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p],
     "p2c_maxpool_bwd_f32": [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p],
+    "p2c_adam_multi_f32": [c_p, c_p, c_p, c_i, c_f, c_f, c_f, c_f, c_ll, c_p],
     "p2c_linear_fwd_pool_supported": [c_i, c_i, c_i, c_i, c_i],
     "p2c_linear_fwd_pool_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_pool_select_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p],

@@ -512,3 +512,48 @@ extern "C" int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float 
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Adam over a LIST of tensors in one launch (train_Point2Cyl_without_sketch.py:204, :369 torch.optim.Adam with default
+// betas / eps, no weight decay, no amsgrad).  torch's multi-tensor path gives every 65536-element chunk to ONE block
+// (1.4 M parameters in 123 tensors -> ~140 blocks, 2 launches, ~88 us per step); here a block takes 1024 elements.
+//   tab  [n_tensors][4] int64: param, grad, exp_avg, exp_avg_sq pointers;  numel [n_tensors] int64
+//   chunks [n_chunks][2] int32: (tensor, first element / 1024)
+// Update rule, in torch's order of operations:
+//   m = m + (g - m)*(1-b1);  v = v*b2 + g*g*(1-b2);  p = p - (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) adam_multi_kernel(const long long *__restrict__ tab, const long long *__restrict__ numel,
+                                                         const int32_t *__restrict__ chunks, float step_size, float b1, float b2,
+                                                         float eps, float inv_sqrt_bc2)
+{
+    const int t = chunks[2 * blockIdx.x], c = chunks[2 * blockIdx.x + 1];
+    float *p = reinterpret_cast<float *>(tab[4 * t + 0]);
+    const float *g = reinterpret_cast<const float *>(tab[4 * t + 1]);
+    float *m = reinterpret_cast<float *>(tab[4 * t + 2]);
+    float *v = reinterpret_cast<float *>(tab[4 * t + 3]);
+    const long long n = numel[t];
+    const long long i0 = (long long)c * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = i0 + 256 * k;
+        if (i < n) {
+            const float gi = g[i];
+            const float mi = m[i] + (gi - m[i]) * (1.0f - b1);
+            const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+            m[i] = mi;
+            v[i] = vi;
+            p[i] = p[i] - step_size * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+        }
+    }
+}
+
+extern "C" int p2c_adam_multi_f32(const long long *table, const long long *numel, const int32_t *chunks, int n_chunks, float lr, float beta1,
+                                  float beta2, float eps, long long step, void *stream)
+{
+    if (!table || !numel || !chunks || n_chunks <= 0 || step <= 0) return P2C_EINVAL;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, table, numel, chunks, (float)((double)lr / bc1), beta1,
+                       beta2, eps, (float)(1.0 / sqrt(bc2)));
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

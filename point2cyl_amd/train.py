@@ -30,7 +30,7 @@ from collections import defaultdict
 import numpy as np
 import torch
 
-from . import ops, ddp, step, synth
+from . import ops, ddp, optim, step, synth
 from .backbone import backbone
 
 SCALARS = ("total", "normal", "miou", "bb", "ext", "center")
@@ -193,7 +193,7 @@ def _main(a, rank, world, local, dev, stream):
         ds = torch.utils.data.Subset(ds, range(lo, hi))
     data = ResidentDataset(ds, dev, a.num_point, subsample)
     B = min(a.batch_size, len(data))
-    opt = torch.optim.Adam(model.parameters(), lr=a.learning_rate, fused=True)    # train…:204, single multi-tensor kernel
+    opt = optim.Adam(model.parameters(), lr=a.learning_rate)    # train…:204; one launch for all 123 tensors (point2cyl_amd/optim.py)
     sync = ddp.FlatGradSync(model.parameters(), world)
     run = Runner(model, opt, sync, fl, dev, B, a.num_point, a.K, use_graph=not a.no_graph, prefetch=not a.no_prefetch, stream=stream)
     log = None

@@ -33,7 +33,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import ddp, fitting, ops, step, step_sketch, synth
+from . import ddp, fitting, ops, optim, step, step_sketch, synth
 from .backbone import backbone
 from .implicit import ImplicitNet, NormalPerPoint
 from .sketch import PointNetEncoder
@@ -131,7 +131,7 @@ def _main(a, rank, world, dev):
         groups.append({"params": list(model.parameters()), "lr": a.learning_rate})                           # :298-311
     if a.is_im_train:
         groups.append({"params": list(pn_encoder.parameters()), "lr": step_lr(0.001, 1000, 0.5, 0)})
-    opt = torch.optim.Adam(groups, fused=True)
+    opt = optim.Adam(groups)
     log = None
     if rank == 0:
         os.makedirs(a.logdir, exist_ok=True)

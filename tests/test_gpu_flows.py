@@ -354,3 +354,29 @@ def test_with_sketch_trainer_cli(tmp_path):
     assert set(ck.keys()) == {"model", "implicit_net", "pn_encoder"} and len(ck["model"]) == 123
     assert "lin0.weight" in ck["implicit_net"] and "mlp1.0.weight" in ck["pn_encoder"] and "fc.weight" in ck["pn_encoder"]
     assert os.path.exists(os.path.join(logdir, "checkpoint_0001.pth"))
+
+
+def test_multi_tensor_adam_matches_torch():
+    """point2cyl_amd.optim.Adam (one launch over all tensors) against torch.optim.Adam, five steps, odd sizes, two parameter groups
+    with their own learning rates, a parameter without gradient."""
+    from point2cyl_amd import optim
+    g = torch.Generator().manual_seed(0)
+    shapes = [(1,), (7, 3), (1023,), (1025,), (70000,), (128, 128, 1), (19, 128)]
+    base = [torch.randn(s, generator=g) for s in shapes]
+    mine = [b.clone().to(DEV).requires_grad_(True) for b in base]
+    ref = [b.clone().to(DEV).requires_grad_(True) for b in base]
+    idle_m, idle_r = torch.zeros(5, device=DEV, requires_grad=True), torch.zeros(5, device=DEV, requires_grad=True)
+    o1 = optim.Adam([{"params": mine[:4] + [idle_m], "lr": 1e-3}, {"params": mine[4:], "lr": 3e-4}])
+    o2 = torch.optim.Adam([{"params": ref[:4] + [idle_r], "lr": 1e-3}, {"params": ref[4:], "lr": 3e-4}])
+    for s in range(5):
+        grads = [torch.randn(b.shape, generator=g).to(DEV) * (10.0 ** (s - 2)) for b in base]
+        for p, q, gr in zip(mine, ref, grads):
+            p.grad = gr.clone()
+            q.grad = gr.clone()
+        if s == 3:
+            o1.param_groups[0]["lr"] = o2.param_groups[0]["lr"] = 5e-4
+        o1.step()
+        o2.step()
+    for p, q in zip(mine, ref):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=2e-6, atol=1e-7)
+    assert float(idle_m.abs().max()) == 0.0

@@ -27,7 +27,8 @@ PEAK_HBM_GBS = 8000.0
 
 # HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE and
 # WRITE_SIZE need separate passes, so they cannot be read inside the timed run); launch-weighted over the family's kernels.
-_PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01k_pmc_hbm_traffic.json")
+_PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+_PMC_FILE = os.path.join(_PROFILES, "r02_pmc_step.json")        # written by tools/collect_pmc.py (every kernel of the step, all counters)
 _PMC_NAME = {"p2c_linear_bwd_fused_f32": "bwd_fused_pp_kernel", "p2c_linear_fwd_f32": "fwd_pp_kernel"}
 
 
@@ -45,6 +46,16 @@ def _pmc_traffic(entry):
         return round(tot / n), "profiles/" + os.path.basename(_PMC_FILE)
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def _self_launch(n):
@@ -219,10 +230,14 @@ def _bench(args, rank, world, local, dev):
         from oracle import ref_step
         cb = args.cpu_batch
         sample = tuple(x[:cb].contiguous() for x in (pcs, normals, seg, bb))
-        pps, sec, thr, nst = ref_step.time_cpu_baseline(sample, threads=min(32, os.cpu_count() or 1), budget_s=12.0)
-        cpu = dict(value=round(pps, 1), unit="points/s", cores=thr, kind="port",
+        pps, sec, thr, nst = ref_step.time_cpu_baseline(sample, threads=min(32, os.cpu_count() or 1), budget_s=10.0)
+        one = tuple(x[:1].contiguous() for x in (pcs, normals, seg, bb))
+        pps1, sec1, _, nst1 = ref_step.time_cpu_baseline(one, threads=1, budget_s=8.0)
+        cpu = dict(value=round(pps, 1), unit="points/s", cores=thr, kind="port", cpu_model=_cpu_model(), host_cores=os.cpu_count(),
+                   single_thread_value=round(pps1, 1),
                    sample="%d full training steps (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
-                          "points (same generator as the GPU batch), %.1f s of CPU work" % (nst, cb, N, sec * nst))
+                          "points (same generator as the GPU batch) on %d threads, %.1f s of CPU work; single_thread_value: %d step(s) of the "
+                          "same on B=1 cloud with 1 thread, %.1f s" % (nst, cb, N, thr, sec * nst, nst1, sec1 * nst1))
     line = dict(metric="training-step points/sec (BxN) at N=8192", value=round(value, 1), unit="points/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                 vs_baseline=None, dtype="f32", data="synthetic",

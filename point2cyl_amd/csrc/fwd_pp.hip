@@ -250,7 +250,8 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
                 for (int r = 0; r < 16; r += 2) {
                     const v2f v = {acc[y][r], acc[y][r + 1]};
                     s1v[y] += v;
-                    s2v[y] += v * v;
+                    s2v[y] = __builtin_elementwise_fma(v, v, s2v[y]);      // one packed fma instead of packed mul + add (every instruction of
+                                                                          // this phase costs an issue slot of the other half's MFMA stream)
                     const v2f ov = v + v2f{bias[y], bias[y]};
                     const int rf = (r & 3) + 8 * (r >> 2) + 4 * lh;        // r even: rows rf and rf+1
                     out[rf * (32 * NT) + y * 32 + l31] = ov.x;

@@ -323,3 +323,35 @@ def test_oracle_eval_flow_matches_the_reference(tag, use_gt_seg, use_gt_bb):
     ridx = {(int(k), int(b)): t(d) for (k, b), d in zip(g["rand_keys"], g["rand_idx"])}
     ext, _ = R.get_extrusion_extents(pcs, seg, bb, axes, cen, ridx)
     np.testing.assert_allclose(ext.permute(1, 0, 2).numpy(), g["pred:extents"], rtol=1e-5, atol=1e-6)
+
+
+def test_rotation_restatement_against_independent_rodrigues():
+    """torchgeometry 0.1.2 is neither installed nor vendored, so `angle_axis_to_rotation_matrix` (call site data_utils.py:1101) cannot be
+    pinned by a reference-made vector.  What CAN be pinned is its published contract: the rotation by |aa| about aa.  Two independent
+    implementations of that contract in float64 - scipy's Rotation.from_rotvec and the matrix exponential of [aa]x - against the
+    restatement; the `theta + eps` normalisation of the library bounds the difference by eps/theta on the axis."""
+    from scipy.linalg import expm
+    from scipy.spatial.transform import Rotation
+    g = np.random.default_rng(5)
+    aa = g.standard_normal((256, 3)) * g.uniform(0.05, 3.0, (256, 1))
+    got = R.angle_axis_to_rotation_matrix(torch.from_numpy(aa)).numpy()
+    want = Rotation.from_rotvec(aa).as_matrix()
+    th = np.linalg.norm(aa, axis=1)
+    assert np.all(np.abs(got - want).reshape(256, -1).max(1) <= 4e-6 / th + 1e-12)
+    for i in range(8):
+        K = np.array([[0, -aa[i, 2], aa[i, 1]], [aa[i, 2], 0, -aa[i, 0]], [-aa[i, 1], aa[i, 0], 0]])
+        assert np.abs(expm(K) - want[i]).max() < 1e-12
+    # orthogonal, proper, axis fixed
+    assert np.abs(got @ got.transpose(0, 2, 1) - np.eye(3)).max() < 1e-4
+    assert np.abs(np.linalg.det(got) - 1).max() < 1e-4
+    # the first-order branch below theta^2 <= eps: I + [aa]x
+    tiny = g.standard_normal((16, 3)) * 1e-4
+    gt = R.angle_axis_to_rotation_matrix(torch.from_numpy(tiny)).numpy()
+    assert np.abs(gt - Rotation.from_rotvec(tiny).as_matrix()).max() < 1e-7
+    # the call site: the un-normalised cross product keeps the AXIS, so ax is turned towards z (exactly onto it only for small angles
+    # or right angles; data_utils.py:1095-1101 multiplies the unnormalised cross product by the angle) - the axis of rotation is
+    # perpendicular to both ax and z, for every input
+    ax = F.normalize(torch.from_numpy(g.standard_normal((32, 3))), dim=-1).float()
+    Rz = R.axis_to_z_rotation(ax).double().numpy()
+    n = np.cross(ax.numpy(), [0, 0, 1.0])
+    assert np.abs(np.einsum("bij,bj->bi", Rz, n) - n).max() < 1e-5

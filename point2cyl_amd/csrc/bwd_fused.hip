@@ -271,6 +271,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     static_assert(!(EX > 0 && IMODE == 2), "");
 
     const int half = threadIdx.x >> 8, tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+    P2C_TR_WG(0);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;       // dW wave grid (within the half)
     const int wr = wave / WC, wc = wave % WC;      // dX wave grid
@@ -379,7 +380,9 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         }
     }
     __syncthreads();
+#ifndef P2C_LOCKSTEP                               // (tools/fused_trace.py --lockstep: both halves in the same phase - measured slower)
     if (half == 1) P2C_LDS_BARRIER();             // run one phase behind half 0
+#endif
     for (int it = 0; it < niter; ++it) {
         const int k = 2 * it + half;
         const bool valid = k < nk;                 // uniform within the half
@@ -469,11 +472,32 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #undef P2C_DXLOAD
-                if (HAS_STATS) {                    // the epilogue runs after the barrier, when Xt may already be restaged
+                // ReLU + BatchNorm-backward sums of the layer below, at the tail of the MFMA phase (before the barrier) rather than in the phase
+                // after it: there they ran in the shadow of the other half's MFMA stream, where a wave gets about one issue slot per MFMA
+                // (tools/ubench/coissue.hip, interleave.hip); here they compete with the other half's memory phase only, and accX / yp
+                // are dead before the next tile is staged (236 instead of 256 registers; the folded-input variant no longer spills).
+                // Measured in the step: 4.91 -> 4.87 ms.  Going further - the dY transform of the next tile in front of the dX MFMAs, the
+                // sums under the next tile's dW MFMAs, coef in LDS - shortens the period of a workgroup from 13.4 k to 11.4 k cycles and
+                // makes the step SLOWER (4.93 ms): the kernel runs at the socket power limit, the shader clock gives way.
+                if (HAS_STATS) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const v4f v = *reinterpret_cast<const v4f *>(xt + ayp[g]);
                         yp[4 * g] = v.x; yp[4 * g + 1] = v.y; yp[4 * g + 2] = v.z; yp[4 * g + 3] = v.w;
+                    }
+                    const float *x0t = x0h + (it & 1) * BM * 4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = accX[r];
+                        const float g = (psc * yp[r] + psh > 0.f) ? v : 0.f;          // mask: the forward's two roundings
+                        s1 += g;
+                        s2 = __builtin_fmaf(g, __builtin_fmaf(yp[r], pis, npm), s2);    // g * (y - mean) * invstd
+                        if (IMODE == 2) {
+                            const v4f x = *reinterpret_cast<const v4f *>(&x0t[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4]);   // zero past M
+                            g0 = __builtin_fmaf(g, x.x, g0);
+                            g1 = __builtin_fmaf(g, x.y, g1);
+                            g2 = __builtin_fmaf(g, x.z, g2);
+                        }
                     }
                 }
             }
@@ -526,22 +550,6 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
                         if (m < a.M) { if (a.dx_atomic) atomicAdd(&a.dx[(size_t)m * a.lddx + xcol], accX[r]); else a.dx[(size_t)m * a.lddx + xcol] = accX[r]; }
                     }
                 }
-                if (HAS_STATS) {
-                    const float *x0t = x0h + (it & 1) * BM * 4;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = accX[r];
-                        const float g = (psc * yp[r] + psh > 0.f) ? v : 0.f;          // mask: the forward's two roundings
-                        s1 += g;
-                        s2 = __builtin_fmaf(g, __builtin_fmaf(yp[r], pis, npm), s2);    // g * (y - mean) * invstd
-                        if (IMODE == 2) {
-                            const v4f x = *reinterpret_cast<const v4f *>(&x0t[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * 4]);   // zero past M
-                            g0 = __builtin_fmaf(g, x.x, g0);
-                            g1 = __builtin_fmaf(g, x.y, g1);
-                            g2 = __builtin_fmaf(g, x.z, g2);
-                        }
-                    }
-                }
             }
         };
         if (IMODE == 2) {          // folded layer below: no dX stores at all - statistics first (its registers die before the staging)
@@ -559,7 +567,9 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
         P2C_LDS_BARRIER();                         // the prefetch above stays in flight across this barrier
         P2C_TR(7);
     }
+#ifndef P2C_LOCKSTEP
     if (half == 0) P2C_LDS_BARRIER();
+#endif
     // ---------------- flush: half 1 hands its dW accumulators to half 0 through LDS (the tile buffers and W are dead
     // now), half 0 adds them and issues ONE set of atomics per workgroup into the slot of its XCD (blockIdx % 8 is the
     // XCD the dispatcher places the workgroup on, so the read-modify-writes stay inside one L2; the host sums the 8
@@ -614,6 +624,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
             atomicAdd(&o[u], (double)red[u]);
         }
     }
+    P2C_TR_WG(1);
 }
 
 static int fused_grid(int M, int Ci)

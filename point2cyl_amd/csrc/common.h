@@ -93,10 +93,25 @@ __device__ unsigned long long p2c_trace_buf[2][P2C_TR_IT][P2C_TR_PT];
     do {                                                                                             \
         if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && it < P2C_TR_IT) p2c_trace_buf[half][it][pt] = __builtin_readcyclecounter(); \
     } while (0)
+// every workgroup: shader clock (s_memtime) and the constant 100 MHz counter (s_memrealtime) at its start (e = 0) and end (e = 1):
+// per-workgroup durations (is there a tail?) and the clock the kernel actually ran at
+__device__ unsigned long long p2c_trace_wg[1024][4];
+#define P2C_TR_WG(e)                                                                                 \
+    do {                                                                                             \
+        if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                 \
+            p2c_trace_wg[blockIdx.x][2 * (e)] = __builtin_readcyclecounter();                        \
+            p2c_trace_wg[blockIdx.x][2 * (e) + 1] = __builtin_amdgcn_s_memrealtime();                \
+        }                                                                                            \
+    } while (0)
 extern "C" int p2c_trace_read(void *host_out)
 {
     return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(p2c_trace_buf), sizeof(unsigned long long) * 2 * P2C_TR_IT * P2C_TR_PT);
 }
+extern "C" int p2c_trace_read_wg(void *host_out)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(p2c_trace_wg), sizeof(unsigned long long) * 1024 * 4);
+}
 #else
 #define P2C_TR(pt) do { } while (0)
+#define P2C_TR_WG(e) do { } while (0)
 #endif

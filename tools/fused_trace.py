@@ -8,9 +8,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 FWD = "--fwd" in sys.argv             # trace fwd_pp.hip instead of bwd_fused.hip
 NODATA = "--nodata" in sys.argv       # MFMA phases only: no global traffic, no LDS staging (isolates the MFMA loops)
-LIB = os.path.join(HERE, "libp2c_trace_fwd.so" if FWD else "libp2c_trace_nodata.so" if NODATA else "libp2c_trace.so")
+LOCK = "--lockstep" in sys.argv       # both halves in the same phase (no one-phase offset)
+OLD = "--old" in sys.argv             # a library built by hand from an earlier revision of bwd_fused.hip (A/B runs)
+LIB = os.path.join(HERE, "libp2c_trace_fwd.so" if FWD else "libp2c_trace_nodata.so" if NODATA else "libp2c_trace_lock.so" if LOCK else "libp2c_trace_old.so" if OLD else "libp2c_trace.so")
 if "--build" in sys.argv:
-    for lib, extra in ((os.path.join(HERE, "libp2c_trace.so"), []), (os.path.join(HERE, "libp2c_trace_nodata.so"), ["-DP2C_TRACE_NODATA"])):
+    for lib, extra in ((os.path.join(HERE, "libp2c_trace.so"), []), (os.path.join(HERE, "libp2c_trace_nodata.so"), ["-DP2C_TRACE_NODATA"]),
+                       (os.path.join(HERE, "libp2c_trace_lock.so"), ["-DP2C_LOCKSTEP"])):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_TRACE"] + extra +
                               ["-shared", "-o", lib, os.path.join(ROOT, "point2cyl_amd", "csrc", "bwd_fused.hip")])
         print(lib)
@@ -67,7 +70,32 @@ e0.record()
 for _ in range(20):
     run()
 e1.record(); torch.cuda.synchronize()
-print("kernel %.1f us (mean of 20)" % (e0.elapsed_time(e1) * 1e3 / 20))
+print("kernel %.1f us (mean of 20 back-to-back launches: sustained, at the socket power cap)" % (e0.elapsed_time(e1) * 1e3 / 20))
+# single launches with idle gaps: what the kernel takes when the moving-average power is below the cap, as inside a training step
+import time
+ts = []
+for _ in range(12):
+    time.sleep(0.03)
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) * 1e3)
+ts.sort()
+print("kernel %.1f us median, %.1f us min (single launches, 30 ms apart)" % (ts[len(ts) // 2], ts[0]))
+if not OLD:
+    wg = np.zeros((1024, 4), dtype=np.uint64)
+    assert L.p2c_trace_read_wg(wg.ctypes.data_as(vp)) == 0
+    wg = wg[:min(256, (M + 31) // 32)].astype(np.float64)
+    cyc = wg[:, 2] - wg[:, 0]; us = (wg[:, 3] - wg[:, 1]) / 100.0
+    span = (wg[:, 3].max() - wg[:, 1].min()) / 100.0
+    print("workgroups: %d | duration us min %.1f median %.1f max %.1f | first start -> last end %.1f us | start skew %.1f us | shader clock %.2f GHz (median)"
+          % (len(us), us.min(), np.median(us), us.max(), span, (wg[:, 1].max() - wg[:, 1].min()) / 100.0, np.median(cyc / us) / 1e3))
+if not OLD:
+    wg = np.zeros((1024, 4), dtype=np.uint64)
+    assert L.p2c_trace_read_wg(wg.ctypes.data_as(vp)) == 0
+    wg = wg[:min(256, (M + 31) // 32)].astype(np.float64)
+    cyc = wg[:, 2] - wg[:, 0]; us = (wg[:, 3] - wg[:, 1]) / 100.0
+    span = (wg[:, 3].max() - wg[:, 1].min()) / 100.0
+    print("workgroups: %d | duration us min %.1f median %.1f max %.1f | first start -> last end %.1f us | start skew %.1f us | shader clock %.2f GHz (median)"
+          % (len(us), us.min(), np.median(us), us.max(), span, (wg[:, 1].max() - wg[:, 1].min()) / 100.0, np.median(cyc / us) / 1e3))
 buf = np.zeros((2, 12, 8), dtype=np.uint64)
 assert L.p2c_trace_read(buf.ctypes.data_as(vp)) == 0
 t0 = buf[0, 2, 0]

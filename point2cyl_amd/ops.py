@@ -898,11 +898,14 @@ class _SegLosses(torch.autograd.Function):
              float(w_seg), float(w_normal), float(w_bb), ptr(out), ptr(dheads), ptr(ws), stream())
         ctx.save_for_backward(dheads)
         ctx.mark_non_differentiable(match, mask)
+        ctx.set_materialize_grads(False)       # no zero tensors (a fill launch each, ~5 us of the stream) for the outputs nobody differentiates
         return out, match, mask
 
     @staticmethod
     def backward(ctx, gout, gmatch, gmask):
         (dheads,) = ctx.saved_tensors
+        if gout is None:
+            return (None,) * 12
         return (dheads * gout[0],) + (None,) * 11      # only d/d total is propagated (the other three scalars are logging values)
 
 

@@ -24,7 +24,9 @@ def main():
     for r in csv.DictReader(open(sys.argv[1])):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), r.get("Stream_Id") or r.get("Queue_Id") or "?"))
     rows.sort()
-    back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    everything = "--all" in sys.argv          # every launch (also the < 8 us ones) with the idle time in front of it
+    argv = [a for a in sys.argv if a != "--all"]
+    back = int(argv[2]) if len(argv) > 2 else 2
     marks = [i for i, r in enumerate(rows) if r[2].startswith("fps_kernel<8, false>")]
     if len(marks) < back + 2:
         raise SystemExit("trace holds %d steps only" % len(marks))
@@ -53,7 +55,7 @@ def main():
         d = r[1] - r[0]
         if under and d > 20000:
             infl += d - mn
-        if d >= 8000:
+        if d >= 8000 or everything:
             print("| %.1f | %.1f | %.1f | %.2f | %s | %s | `%s` |" % ((r[0] - t0) / 1e3, d / 1e3, mn / 1e3, d / mn, "yes" if under else "", r[3], r[2]))
     print("\nsum over the launches under FPS of (duration - shortest duration of the same launch in the trace): %.1f us" % (infl / 1e3))
 

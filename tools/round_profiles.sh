@@ -43,7 +43,7 @@ python tools/bench_config4.py > "$OUT/${TAG}_config4_fitting.json.log" 2> "$OUT/
 python tools/bench_sa1_forward.py > "$OUT/${TAG}_sa1_forward_stage.json.log" 2> "$OUT/sa1.err"
 python tools/bench_config5.py --steps 3 > "$OUT/${TAG}_config5_with_sketch_step.json.log" 2> "$OUT/config5.err"
 # 5. the trainers and the evaluation script (throughput through the CLI, convergence log)
-python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 1024 --batch_size 32 --num_epochs 6 --quiet --logdir /tmp/${TAG}_tr \
+python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 1024 --batch_size 32 --num_epochs 60 --quiet --logdir /tmp/${TAG}_tr \
     --report "$OUT/${TAG}_trainer_report.json" > "$OUT/${TAG}_train_convergence_synthetic.log" 2> "$OUT/train.err"
 python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 256 --batch_size 32 --num_epochs 2 --logdir /tmp/${TAG}_tr2 \
     --report "$OUT/${TAG}_trainer_report_per_step_log.json" > /dev/null 2>> "$OUT/train.err"

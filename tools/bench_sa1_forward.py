@@ -59,6 +59,52 @@ def main():
         main_s.wait_stream(side)
         state["g"] = nxt
     t_pipe = timed(piped, a.steps)
+
+    # The same two schedules as HIP-graph replays - how the training step runs the stage.  Launched from Python the ~12 launches of the
+    # MLP cost more host time than the GPU needs for them, so the eager figures above are launch-bound (mlp_only in particular).
+    def capture(fn):
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cap):
+            for _ in range(2): fn()
+            cap.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=cap):
+                out = fn()
+        torch.cuda.current_stream().wait_stream(cap)
+        return gr, out
+
+    gr_serial, _ = capture(lambda: mlp(geometry()))
+    gr_mlp, _ = capture(lambda: mlp(g0))
+    # pipelined: graph A reads geometry set gA and computes set gB next to it on a forked stream; graph B reads gB and refills gA
+    side2 = torch.cuda.Stream()
+    gA = geometry()
+    keys = [k for k, v in gA.items() if torch.is_tensor(v)]
+
+    def stage_with_next(cur, dst=None):
+        capst = torch.cuda.current_stream()
+        side2.wait_stream(capst)
+        with torch.cuda.stream(side2):
+            nxt = geometry()
+            if dst is not None:
+                for k in keys: dst[k].copy_(nxt[k])
+        mlp(cur)
+        capst.wait_stream(side2)
+        return nxt
+
+    gr_a, gB = capture(lambda: stage_with_next(gA))
+    gr_b, _ = capture(lambda: stage_with_next(gB, gA))
+
+    def replay_timed(graphs, steps):
+        for _ in range(3):
+            for g in graphs: g.replay()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps): graphs[i % len(graphs)].replay()
+        torch.cuda.synchronize(); return (time.perf_counter() - t0) / steps
+
+    t_gserial = replay_timed([gr_serial], a.steps)
+    t_gmlp = replay_timed([gr_mlp], a.steps)
+    t_gpipe = replay_timed([gr_a, gr_b], a.steps)
     ops.PROFILE.reset(enabled=True)
     for _ in range(3): mlp(geometry())
     prof = ops.PROFILE.summary(); ops.PROFILE.enabled = False
@@ -70,7 +116,10 @@ def main():
                           dtype="f32", data="synthetic", n_gpus=1, steps=a.steps,
                           stage=dict(gflop=round(fl / 1e9, 2), module_boundary_mb=round(by / 1e6, 2), mfma_floor_us=round(fl / PEAK_MFMA * 1e6, 1),
                                      hbm_floor_us=round(by / PEAK_HBM * 1e6, 2), bound="mfma"),
+                          graph_serial=mk(t_gserial), graph_pipelined=mk(t_gpipe), graph_mlp_only=mk(t_gmlp),
                           serial=mk(t_serial), pipelined=mk(t_pipe), geometry_only=dict(ms=round(t_geom * 1e3, 3)), mlp_only=mk(t_mlp),
+                          note="graph_*: HIP-graph replays (GPU-bound, as in the training step); the other figures are launched from Python and are "
+                               "host-bound wherever the kernels are short",
                           kernels={k: dict(us_per_pass=round(v["ms"] / 3 * 1e3, 1), launches=v["launches"] // 3) for k, v in
                                    sorted(prof.items(), key=lambda kv: -kv[1]["ms"])})))
 

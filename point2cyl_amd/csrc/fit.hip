@@ -58,14 +58,16 @@ __device__ void p2c_eigh3(const double a_in[6], double lam[3], double v[3][3])
     }
 }
 
-__global__ void __launch_bounds__(FIT_THREADS) axis_kernel(const float *__restrict__ X, const float *__restrict__ Wb,
+template <int THREADS>      // 1024: one workgroup per CU (few clouds: each gets a whole CU); 512: two per CU, one streams while the other is in its
+                            // serial tail (LDS reduction, fp64 eigen-solve on K threads) - the fitting-only path runs 1250 clouds
+__global__ void __launch_bounds__(THREADS) axis_kernel(const float *__restrict__ X, const float *__restrict__ Wb,
                                                            const float *__restrict__ Wc, const int64_t *__restrict__ bb_gt,
                                                            const int64_t *__restrict__ inst_gt, int normalize, int N, int K,
                                                            float *__restrict__ axis_out, float *__restrict__ eig_out)
 {
-    __shared__ float red[14][FIT_THREADS];
+    __shared__ float red[14][THREADS];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int G = FIT_THREADS / K;            // point slices
+    const int G = THREADS / K;                // point slices
     const int g = tid / K, k = tid - g * K;
     float acc[14];
 #pragma unroll
@@ -73,7 +75,8 @@ __global__ void __launch_bounds__(FIT_THREADS) axis_kernel(const float *__restri
     if (g < G) {
         const float *x = X + (size_t)b * N * 3;
         const float *wb = Wb + (size_t)b * N * K, *wc = Wc + (size_t)b * N * K;
-        for (int n = g; n < N; n += G) {
+#pragma unroll 8
+        for (int n = g; n < N; n += G) {          // 8 iterations' loads in flight: the kernel streams 76 B per point and nothing else
             const float x0 = x[n * 3 + 0], x1 = x[n * 3 + 1], x2 = x[n * 3 + 2];
             const float b_ = wb[(size_t)n * K + k], c_ = wc[(size_t)n * K + k];
             const float b2 = b_ * b_, c2 = c_ * c_;
@@ -134,8 +137,13 @@ extern "C" int p2c_extrusion_axis_f32(const float *X, const float *Wb, const flo
 {
     if (!X || !Wb || !Wc || !axis_out || B <= 0 || N <= 0 || K <= 0 || K > FIT_MAXK) return P2C_EINVAL;
     if (normalize && (!bb_gt || !inst_gt)) return P2C_EINVAL;
-    hipLaunchKernelGGL(axis_kernel, dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K, axis_out,
-                       eig_out);
+    if (B >= 1024)
+        hipLaunchKernelGGL(axis_kernel<256>, dim3(B), dim3(256), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K, axis_out, eig_out);
+    else if (B >= 512)
+        hipLaunchKernelGGL(axis_kernel<512>, dim3(B), dim3(512), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K, axis_out, eig_out);
+    else
+        hipLaunchKernelGGL(axis_kernel<FIT_THREADS>, dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K,
+                           axis_out, eig_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -211,14 +219,14 @@ extern "C" int p2c_extrusion_axis_bwd_f32(const float *daxis, const float *axis,
 //                   found = count > 1 (a single point counts as "not found", zeros).
 // Same (slice, k) thread mapping as the axis kernel; one workgroup per cloud.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ void __launch_bounds__(FIT_THREADS) centers_kernel(const float *__restrict__ W, const int64_t *__restrict__ label,
-                                                              const float *__restrict__ P, int N, int K, float *__restrict__ out,
-                                                              float *__restrict__ found)
+template <int MODE, int THREADS>      // THREADS as in axis_kernel: 1024 for a few clouds, 256 when there are enough to keep four per CU busy
+__global__ void __launch_bounds__(THREADS) centers_kernel(const float *__restrict__ W, const int64_t *__restrict__ label,
+                                                          const float *__restrict__ P, int N, int K, float *__restrict__ out,
+                                                          float *__restrict__ found)
 {
-    __shared__ float red[4][FIT_THREADS];
+    __shared__ float red[4][THREADS];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int G = FIT_THREADS / K;
+    const int G = THREADS / K;
     const int g = tid / K, k = tid - g * K;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, cnt = 0.f;
     if (g < G) {
@@ -255,11 +263,68 @@ __global__ void __launch_bounds__(FIT_THREADS) centers_kernel(const float *__res
     }
 }
 
+// Hard centroids, one thread per POINT (K compile-time): label and coordinates are read once (20 B per point) instead of once per
+// segment by the (slice, k) mapping above; per-thread bins over k, LDS tree over the threads.  Same result (sums of the same fp32
+// values in a different order; fp64 across threads).
+template <int KK, int THREADS>
+__global__ void __launch_bounds__(THREADS) centroids_by_point_kernel(const int64_t *__restrict__ label, const float *__restrict__ P, int N,
+                                                                    float *__restrict__ out, float *__restrict__ found)
+{
+    __shared__ float red[4 * KK][THREADS];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float acc[KK][4];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.f;
+    const float *p = P + (size_t)b * N * 3;
+    const int64_t *lab = label + (size_t)b * N;
+#pragma unroll 4
+    for (int n = tid; n < N; n += THREADS) {
+        const int l = (int)lab[n];
+        const float x = p[n * 3 + 0], y = p[n * 3 + 1], z = p[n * 3 + 2];
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+            const float w = l == k ? 1.f : 0.f;
+            acc[k][0] += w * x; acc[k][1] += w * y; acc[k][2] += w * z; acc[k][3] += w;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < KK; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) red[k * 4 + e][tid] = acc[k][e];
+    __syncthreads();
+    // 4*KK rows of THREADS values: 8 threads per row (fp64), then lane 0 of each group finishes
+    __shared__ double part[4 * KK][8];
+    const int row = tid / 8, sub = tid % 8;
+    if (row < 4 * KK) {
+        double rs = 0.0;
+        for (int t = sub; t < THREADS; t += 8) rs += (double)red[row][t];
+        part[row][sub] = rs;
+    }
+    __syncthreads();
+    if (tid < KK) {
+        double v[4];
+        for (int e = 0; e < 4; ++e) {
+            double rs = 0.0;
+            for (int q = 0; q < 8; ++q) rs += part[tid * 4 + e][q];
+            v[e] = rs;
+        }
+        const float c = (float)v[3];
+        const bool ok = c > 1.f;
+        float *o = out + ((size_t)b * KK + tid) * 3;
+        o[0] = ok ? (float)v[0] / c : 0.f; o[1] = ok ? (float)v[1] / c : 0.f; o[2] = ok ? (float)v[2] / c : 0.f;
+        found[(size_t)b * KK + tid] = ok ? 1.f : 0.f;
+    }
+}
+
 extern "C" int p2c_extrusion_centers_f32(const float *W, const float *P, int B, int N, int K, float *centers_out, void *stream)
 {
     if (!W || !P || !centers_out || K <= 0 || K > FIT_MAXK) return P2C_EINVAL;
-    hipLaunchKernelGGL(centers_kernel<0>, dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, W, (const int64_t *)nullptr, P, N, K,
-                       centers_out, (float *)nullptr);
+    if (B >= 1024)
+        hipLaunchKernelGGL((centers_kernel<0, 256>), dim3(B), dim3(256), 0, (hipStream_t)stream, W, (const int64_t *)nullptr, P, N, K, centers_out,
+                           (float *)nullptr);
+    else
+        hipLaunchKernelGGL((centers_kernel<0, FIT_THREADS>), dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, W, (const int64_t *)nullptr, P, N, K,
+                           centers_out, (float *)nullptr);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -268,8 +333,14 @@ extern "C" int p2c_segment_centroids_f32(const float *P, const int64_t *label, i
                                          float *found_out, void *stream)
 {
     if (!P || !label || !centroids_out || !found_out || K <= 0 || K > FIT_MAXK) return P2C_EINVAL;
-    hipLaunchKernelGGL(centers_kernel<1>, dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, (const float *)nullptr, label, P, N, K,
-                       centroids_out, found_out);
+    if (K == 8 && B >= 256)
+        hipLaunchKernelGGL((centroids_by_point_kernel<8, 256>), dim3(B), dim3(256), 0, (hipStream_t)stream, label, P, N, centroids_out, found_out);
+    else if (B >= 1024)
+        hipLaunchKernelGGL((centers_kernel<1, 256>), dim3(B), dim3(256), 0, (hipStream_t)stream, (const float *)nullptr, label, P, N, K,
+                           centroids_out, found_out);
+    else
+        hipLaunchKernelGGL((centers_kernel<1, FIT_THREADS>), dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, (const float *)nullptr, label, P, N, K,
+                           centroids_out, found_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

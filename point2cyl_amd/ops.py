@@ -260,22 +260,24 @@ class _ZeroArena:
         self.buf = STEP_ARENA.take(n_f64, dev)
         self.off = 0
 
+    def _take(self, n64):
+        if self.off + n64 > self.buf.numel():          # reservation too small (it is an estimate): a zero tensor of its own
+            return STEP_ARENA.take(n64, self.buf.device)
+        out = self.buf[self.off:self.off + n64]
+        self.off += n64
+        return out
+
     def f64(self, *shape):
         n = 1
         for d in shape:
             n *= d
-        out = self.buf[self.off:self.off + n].view(*shape)
-        self.off += n
-        return out
+        return self._take(n).view(*shape)
 
     def f32(self, *shape):
         n = 1
         for d in shape:
             n *= d
-        n64 = (n + 1) // 2
-        out = self.buf[self.off:self.off + n64].view(torch.float32)[:n].view(*shape)
-        self.off += n64
-        return out
+        return self._take((n + 1) // 2).view(torch.float32)[:n].view(*shape)
 
 
 def _zero_padded(t, *shape):
@@ -488,8 +490,11 @@ class _MLPStack(torch.autograd.Function):
         Cl = Ys[-1].shape[1]
         grads = [None] * len(params)
         n64 = 0
-        for W2 in Ws:       # per layer: 8 dW copies + dW + dbias (fp32) and two sets of fp64 stat slots (own top-of-stack + layer below)
-            n64 += (9 * W2.shape[0] * W2.shape[1] + W2.shape[0]) // 2 + 8 + STAT_SLOTS * 5 * (W2.shape[0] + W2.shape[1])
+        for W2 in Ws:       # per layer: dW + dbias (fp32), 8 per-XCD dW copies where the long narrow layers use them (the fused backward, or the
+            # split-k weight kernel from 65536 rows on), two sets of fp64 stat slots (own top-of-stack + layer below).  The step's one fill
+            # clears all of it: 8 copies of the 512 x 1024 matrices of the 4096-row levels alone were 40 of its 72 MB
+            copies = 9 if (M >= 65536 or (M >= 4096 and W2.shape[0] <= 256 and W2.shape[1] <= 132)) else 1
+            n64 += (copies * W2.shape[0] * W2.shape[1] + W2.shape[0]) // 2 + 8 + STAT_SLOTS * 5 * (W2.shape[0] + W2.shape[1])
         arena = _ZeroArena(n64, dev)
         slots, pi = [], 0
         for i in range(L):

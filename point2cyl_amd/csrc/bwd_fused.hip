@@ -383,6 +383,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 #ifndef P2C_LOCKSTEP                               // (tools/fused_trace.py --lockstep: both halves in the same phase - measured slower)
     if (half == 1) P2C_LDS_BARRIER();             // run one phase behind half 0
 #endif
+    P2C_TR_WG_MID(0);
     for (int it = 0; it < niter; ++it) {
         const int k = 2 * it + half;
         const bool valid = k < nk;                 // uniform within the half
@@ -570,6 +571,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 #ifndef P2C_LOCKSTEP
     if (half == 0) P2C_LDS_BARRIER();
 #endif
+    P2C_TR_WG_MID(1);
     // ---------------- flush: half 1 hands its dW accumulators to half 0 through LDS (the tile buffers and W are dead
     // now), half 0 adds them and issues ONE set of atomics per workgroup into the slot of its XCD (blockIdx % 8 is the
     // XCD the dispatcher places the workgroup on, so the read-modify-writes stay inside one L2; the host sums the 8

@@ -287,6 +287,14 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     for (int i = 0; i < EPT; ++i) acce[i] = 0.f;
     v4f rxe = {0.f, 0.f, 0.f, 0.f};
 
+    constexpr int UDZ = GMODE == 2 ? 2 : UDY;
+    float4 rdz[UDZ], ry[UDY];
+    v4f rx[UX];
+    int4 rarg[UDZ];
+    auto tile_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
+    // the first tile's rows are requested BEFORE W is staged: their HBM round trip then runs under the weight copy and the constant set-up
+    // below instead of after them (the prologue was 13-29 k cycles of a workgroup's 110-750 k)
+    fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX, LDZ, LDY, LDX>(a, tid, tile_of(half < nk ? half : 0), rdz, ry, rarg, rx);
     if (NEED_DX) {                                 // W [Co,Ci] -> Wt[ci][co]
         for (int u = threadIdx.x; u < Co * Ci / 4; u += 512) {
             const int r = u / (Ci / 4), c4 = u % (Ci / 4);
@@ -359,15 +367,9 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accX[r] = 0.f; yp[r] = 0.f; }
 
-    constexpr int UDZ = GMODE == 2 ? 2 : UDY;
-    float4 rdz[UDZ], ry[UDY];
-    v4f rx[UX];
-    int4 rarg[UDZ];
-    auto tile_of = [&](int k) { return (int)blockIdx.x + k * (int)gridDim.x; };
-    // prologue: this half's first tile -> its LDS buffer; its second tile -> registers (in flight)
+    // prologue: this half's first tile -> its LDS buffer (its rows were requested at the top of the kernel); its second tile -> registers (in flight)
     {
         const int k0 = half, k1 = half + 2;
-        fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX, LDZ, LDY, LDX>(a, tid, tile_of(k0 < nk ? k0 : 0), rdz, ry, rarg, rx);
         fused_store_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX>(a, tid, tile_of(k0 < nk ? k0 : 0), dy, xt, rdz, ry, rarg, rx, cf, w0r, b0r, x0h);
         if (EX > 0 && tid < BM) {
             const int m = min(tile_of(k0 < nk ? k0 : 0) * BM + tid, a.M - 1);

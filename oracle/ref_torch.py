@@ -16,7 +16,6 @@ Two geometry back-ends:
 """
 import math
 
-import numpy as np
 import torch
 import torch.nn.functional as F
 

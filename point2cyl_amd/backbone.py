@@ -9,7 +9,6 @@ layout (rows = points, channels contiguous) so the reference's permutes disappea
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 

@@ -282,14 +282,17 @@ def test_sa2_module_linear_before_gather_vs_oracle(B):
 
 
 # ------------------------------------------------------------------------------------------ whole backbone, train mode, vs oracle fp32 AND fp64
-def test_backbone_train_b16_n8192_vs_oracle_fp32_and_fp64():
-    """Half a bench batch (16 clouds x 8192 points: SA1 524,288 grouped rows, FP1/head 131,072 rows -> every persistent kernel of
+@pytest.mark.parametrize("B,N", [(16, 8192), (3, 3000), (5, 2500)])
+def test_backbone_train_b16_n8192_vs_oracle_fp32_and_fp64(B, N):
+    """(3, 3000) and (5, 2500): cloud sizes that are multiples of nothing - 9,000 / 12,500 dense rows put a ragged last tile (8 and 20 of
+    32 rows) into the persistent forward and the fused backward of FP1 and the heads, the samplers and the 3-NN see N % 64 != 0.
+    (16, 8192): half a bench batch (16 clouds x 8192 points: SA1 524,288 grouped rows, FP1/head 131,072 rows -> every persistent kernel of
     the step in its steady state) through forward + backward against the oracle's literal op sequence on the same weights, FPS
     starts and dropout mask - once in fp32 and once in float64 (geometry pinned to the fp32 indices).  Bars: integer structure
     bit-exact; head outputs within 1e-4 (abs, outputs are O(1)) of the float64 run or 3x the oracle's own fp32 error, whichever
     is larger; every parameter gradient no further from float64 than 3x the oracle's fp32 run is (a chain of 17 train-mode
     BatchNorms is ill-conditioned - DESIGN.md section 4 - so the fp32 oracle itself is the yardstick, measured here, live)."""
-    B, N, K = 16, 8192, 8
+    K = 8
     pcs = synth.make_batch(B, N, K, seed=4242)[0]
     torch.manual_seed(21)
     m = backbone(output_sizes=[3, 2 * K])
@@ -324,13 +327,13 @@ def test_backbone_train_b16_n8192_vs_oracle_fp32_and_fp64():
     for name, mine, r32, r64 in (("X_head", X, o32[0], o64[0]), ("W_raw", Wr, o32[1], o64[1])):
         ref_err = float((r32.double() - r64).abs().max())
         my_err = float((mine.detach().cpu().double() - r64).abs().max())
-        ok &= _rec("backbone B=16 %s |ours-ref64|max (bound max(1e-4, 3*|ref32-ref64|=%.2e))" % (name, 3 * ref_err), my_err, max(1e-4, 3 * ref_err))
+        ok &= _rec("backbone B=%d N=%d %s |ours-ref64|max (bound max(1e-4, 3*|ref32-ref64|=%.2e))" % (B, N, name, 3 * ref_err), my_err, max(1e-4, 3 * ref_err))
     # 2K-way labels: identical to the fp32 oracle except where the float64 run's two largest logits are within 2e-4 of each other
     mine_lab, o32_lab = Wr.detach().cpu().argmax(-1), o32[1].argmax(-1)
     top2 = o64[1].topk(2, dim=-1)[0]
     near_tie = (top2[..., 0] - top2[..., 1]) < 2e-4
-    ok &= _rec("backbone B=16 labels differing from the fp32 oracle where the float64 logits are NOT within 2e-4 of a tie (of %d; %d differ in all)"
-               % (B * N, int((mine_lab != o32_lab).sum())), int(((mine_lab != o32_lab) & ~near_tie).sum()), 0)
+    ok &= _rec("backbone B=%d N=%d labels differing from the fp32 oracle where the float64 logits are NOT within 2e-4 of a tie (of %d; %d differ in all)"
+               % (B, N, B * N, int((mine_lab != o32_lab).sum())), int(((mine_lab != o32_lab) & ~near_tie).sum()), 0)
     for name, p in m.named_parameters():
         r32, r64 = g32[name].double().numpy(), g64[name].numpy()
         got = p.grad.cpu().double().numpy().reshape(r64.shape)
@@ -342,11 +345,11 @@ def test_backbone_train_b16_n8192_vs_oracle_fp32_and_fp64():
         b = _relnorm(got, r64) / (3 * _relnorm(r32, r64) + 1e-6)
         # max-abs OR norm criterion: one max-pool winner that resolves differently moves a whole row of a weight gradient (max-abs
         # jumps, the norm barely moves); a systematic error would fail both
-        ok &= _rec("backbone B=16 grad[%s] min(max-abs ratio %.2f, relnorm ratio %.2f) vs 3x the fp32 oracle's distance from float64" % (name, a, b),
+        ok &= _rec("backbone B=%d N=%d grad[%s] min(max-abs ratio %.2f, relnorm ratio %.2f) vs 3x the fp32 oracle's distance from float64" % (B, N, name, a, b),
                    min(a, b), 1.0)
     for k in ("sa1.mlp_bns.0.running_mean", "sa1.mlp_bns.2.running_var", "sa2.mlp_bns.2.running_var", "fp1.mlp_bns.0.running_mean", "bn1.running_var"):
         a, b = m.state_dict()[k].cpu().numpy(), sd32[k].numpy()
-        ok &= _rec("backbone B=16 %s" % k, float(np.abs(a - b).max()), 1e-5 + 1e-4 * float(np.abs(b).max()))
+        ok &= _rec("backbone B=%d N=%d %s" % (B, N, k), float(np.abs(a - b).max()), 1e-5 + 1e-4 * float(np.abs(b).max()))
     assert ok, [mm for mm in _METRICS if not mm["ok"]]
 
 

@@ -156,6 +156,7 @@ def _bench(args, rank, world, local, dev):
             graphed = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=None if args.no_prefetch else batch[0], stream=torch.cuda.current_stream())
         except Exception as e:      # keep the bench alive: fall back to eager launches
             sys.stderr.write("bench: HIP graph capture failed (%s: %s); running eager\n" % (type(e).__name__, e))
+            torch.cuda.set_stream(torch.cuda.Stream(dev))      # a failed capture can leave its stream in capture mode: continue on a fresh one
             for m in model.modules():
                 if hasattr(m, "fps_start"):
                     m.fps_start = None

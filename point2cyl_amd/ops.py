@@ -854,6 +854,8 @@ def check_labels(I_gt, K):
     """Instance labels must lie in [-1, K): losses.py:36-46 indexes eye(n_gt+1) and matching_indices[b, :n_gt] with them and raises
     otherwise; the kernels would silently drop the offending points instead.  One device->host sync - the reference's matching pays B
     of them per call; the graph-replayed training step validates its dataset once when it is loaded instead (train.ResidentDataset)."""
+    if I_gt.is_cuda and torch.cuda.is_current_stream_capturing():
+        return        # a device->host read cannot be captured; the eager warm-up passes in front of every capture have checked these labels
     hi, lo = int(I_gt.max()), int(I_gt.min())
     if hi >= K or lo < -1:
         raise ValueError("instance labels must be in [-1, %d); got [%d, %d]" % (K, lo, hi))

@@ -150,8 +150,19 @@ class Runner:
                 # what next_xyz holds at construction, which must be the current batch
                 nxt = self.next_xyz.clone()
                 self.next_xyz.copy_(self.batch[0])
-                self.graph = GraphedForwardBackward(self.model, self._fwd_bwd, prefetch_xyz=self.next_xyz if self.prefetch else None,
-                                                    stream=self.stream)
+                try:
+                    self.graph = GraphedForwardBackward(self.model, self._fwd_bwd, prefetch_xyz=self.next_xyz if self.prefetch else None,
+                                                        stream=self.stream)
+                except Exception as e:      # something in this configuration cannot be captured: train on, launched from Python
+                    import sys
+                    sys.stderr.write("point2cyl_amd.train: HIP graph capture failed (%s: %s); continuing without the graph\n" % (type(e).__name__, e))
+                    torch.cuda.set_stream(torch.cuda.Stream(self.dev))      # the capture stream may be left in capture mode
+                    for m in self.model.modules():
+                        if hasattr(m, "fps_start"):
+                            m.fps_start = None
+                    self.use_graph, self.graph = False, None
+                    self.next_xyz.copy_(nxt)
+                    return self.step(momentum, eager=True)
                 self.next_xyz.copy_(nxt)
                 self.graph_momentum = momentum
                 self.captures += 1

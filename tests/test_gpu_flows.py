@@ -169,6 +169,20 @@ def test_trainer_cli_config0_then_eval_cli(tmp_path):
     assert len(nums) == 5 and np.isfinite(nums).all()
 
 
+def test_trainer_cli_other_k_runs_the_torch_loss_path_through_the_graph(tmp_path):
+    """--K 4: the fused loss kernels are written for K = 8, so the step composes the losses from torch ops (step.compute_losses) - which
+    must still go through the HIP-graph path (the label check's device->host read is skipped while capturing) and train."""
+    rep = str(tmp_path / "rep.json")
+    out = _run(["-m", "point2cyl_amd.train", "--pred_seg", "--pred_normal", "--pred_bb", "--K", "4", "--synthetic", "8", "--batch_size", "4",
+                "--num_point", "2048", "--num_epochs", "3", "--logdir", str(tmp_path / "run"), "--report", rep])
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "capture failed" not in out.stderr, out.stderr[-2000:]
+    r = json.load(open(rep))
+    assert r["graph"] and r["graph_captures"] == 1 and r["steps"] == 6
+    tot = r["epoch_means"]["total"]
+    assert np.isfinite(tot).all() and tot[-1] < tot[0] + 0.05, tot
+
+
 def test_trainer_graph_and_eager_paths_agree():
     """The trainer's Runner: after an identical first (eager) step, the second step through the HIP-graph path (capture at this step,
     geometry of the current batch computed at capture, next batch's on the forked stream) and launched from Python give the same six

@@ -148,7 +148,9 @@ class GraphedForwardBackward:
         torch.cuda.synchronize()
         self.starts.cursor = 0
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=cap):
+        # thread_local: only THIS thread's calls are policed while capturing.  With the default ("global") a HIP call from any other thread -
+        # RCCL's watchdog polling its events in a multi-GPU job - invalidates the capture
+        with torch.cuda.graph(self.graph, stream=cap, capture_error_mode="thread_local"):
             self.out = body()
         self.starts.cursor = 0
         with torch.no_grad():

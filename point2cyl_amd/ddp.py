@@ -53,6 +53,7 @@ class FlatGradSync:
         self.flat = None
         self.views = None
         self._src = None          # keeps the packed-from tensors of a captured step alive
+        self._avg_ok = True
 
     def zero(self):
         for p in self.params:
@@ -93,11 +94,14 @@ class FlatGradSync:
         if self.flat is None or any(p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(self.params, self.views)):
             self.pack()           # eager callers that did not pack after backward
         with torch.no_grad():
-            if dist.get_backend() == "nccl":
-                dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
-            else:
-                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-                self.flat.div_(self.world)
+            if dist.get_backend() == "nccl" and self._avg_ok:
+                try:
+                    dist.all_reduce(self.flat, op=dist.ReduceOp.AVG)
+                    return
+                except (RuntimeError, ValueError):      # a collective library without ncclAvg: sum and scale from here on
+                    self._avg_ok = False
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.div_(self.world)
 
 
 def broadcast_module(module, src=0):

@@ -295,16 +295,33 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
     // the first tile's rows are requested BEFORE W is staged: their HBM round trip then runs under the weight copy and the constant set-up
     // below instead of after them (the prologue was 13-29 k cycles of a workgroup's 110-750 k)
     fused_load_tile<GMODE, IMODE, Co, Ci, BM, UDY, UDZ, UX, LDZ, LDY, LDX>(a, tid, tile_of(half < nk ? half : 0), rdz, ry, rarg, rx);
-    if (NEED_DX) {                                 // W [Co,Ci] -> Wt[ci][co]
-        for (int u = threadIdx.x; u < Co * Ci / 4; u += 512) {
-            const int r = u / (Ci / 4), c4 = u % (Ci / 4);
-            const float4 v = *reinterpret_cast<const float4 *>(a.w + (size_t)r * a.ldw + c4 * 4);
-            Wt[(c4 * 4 + 0) * LDT + r] = v.x;
-            Wt[(c4 * 4 + 1) * LDT + r] = v.y;
-            Wt[(c4 * 4 + 2) * LDT + r] = v.z;
-            Wt[(c4 * 4 + 3) * LDT + r] = v.w;
+    P2C_TR_WG_MID(2);
+    if (NEED_DX) {
+        // W [Co,Ci] -> Wt[ci][co]: 4 x 4 blocks transposed in registers, 16-byte LDS stores.  Lanes 0-7 of each group of 8 take 8
+        // consecutive co-quads (one contiguous 128-byte piece of a Wt row: conflict-free), the 8 groups of a wave 8 consecutive ci-quads
+        // (so the four row loads of a lane group read whole 128-byte pieces of 8 rows of W).  The scalar transposing stores this replaces
+        // put a wave's 64 writes on two banks and made the copy 11 k of the kernel's 21 k prologue cycles.
+        constexpr int RH = Co / 32, NBLK = (Co / 4) * (Ci / 4), NWU = (NBLK + 511) / 512;      // 4 x 4 blocks: 256 .. 1024, per thread 1 or 2
+        v4f v[NWU][4];
+#pragma unroll
+        for (int u = 0; u < NWU; ++u) {                // every row load of the thread in flight before the first store
+            const int p = min((int)threadIdx.x + 512 * u, NBLK - 1), rest = p >> 6;
+            const int r4 = (rest % RH) * 8 + (p & 7), c4 = (rest / RH) * 8 + ((p >> 3) & 7);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[u][j] = *reinterpret_cast<const v4f *>(a.w + (size_t)(4 * r4 + j) * a.ldw + 4 * c4);
+        }
+#pragma unroll
+        for (int u = 0; u < NWU; ++u) {
+            const int p = threadIdx.x + 512 * u, rest = p >> 6;
+            const int r4 = (rest % RH) * 8 + (p & 7), c4 = (rest / RH) * 8 + ((p >> 3) & 7);
+            if (p < NBLK) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<v4f *>(&Wt[(4 * c4 + i) * LDT + 4 * r4]) = v4f{v[u][0][i], v[u][1][i], v[u][2][i], v[u][3][i]};
+            }
         }
     }
+    P2C_TR_WG_MID(3);
     float isc[CIT], ish[CIT];
 #pragma unroll
     for (int t = 0; t < CIT; ++t) {
@@ -367,6 +384,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { accX[r] = 0.f; yp[r] = 0.f; }
 
+    P2C_TR_WG_MID(4);
     // prologue: this half's first tile -> its LDS buffer (its rows were requested at the top of the kernel); its second tile -> registers (in flight)
     {
         const int k0 = half, k1 = half + 2;
@@ -381,6 +399,7 @@ __global__ void __launch_bounds__(512, 2) bwd_fused_pp_kernel(BwdFusedArgs a)
             rxe = *reinterpret_cast<const v4f *>(a.x + (size_t)m * a.ldx + Ci);
         }
     }
+    P2C_TR_WG_MID(5);
     __syncthreads();
 #ifndef P2C_LOCKSTEP                               // (tools/fused_trace.py --lockstep: both halves in the same phase - measured slower)
     if (half == 1) P2C_LDS_BARRIER();             // run one phase behind half 0

@@ -96,7 +96,7 @@ __device__ unsigned long long p2c_trace_buf[2][P2C_TR_IT][P2C_TR_PT];
 // every workgroup: shader clock (s_memtime) and the constant 100 MHz counter (s_memrealtime) at its start (e = 0) and end (e = 1):
 // per-workgroup durations (is there a tail?) and the clock the kernel actually ran at
 __device__ unsigned long long p2c_trace_wg[1024][4];
-__device__ unsigned long long p2c_trace_wg_mid[1024][2];      // shader clock when the main loop starts / ends (prologue and flush lengths)
+__device__ unsigned long long p2c_trace_wg_mid[1024][8];      // shader clock when the main loop starts / ends (prologue and flush lengths), [2..7]: prologue stages
 #define P2C_TR_WG_MID(e) do { if (threadIdx.x == 0 && blockIdx.x < 1024) p2c_trace_wg_mid[blockIdx.x][e] = __builtin_readcyclecounter(); } while (0)
 #define P2C_TR_WG(e)                                                                                 \
     do {                                                                                             \
@@ -115,7 +115,7 @@ extern "C" int p2c_trace_read_wg(void *host_out)
 }
 extern "C" int p2c_trace_read_wg_mid(void *host_out)
 {
-    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(p2c_trace_wg_mid), sizeof(unsigned long long) * 1024 * 2);
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(p2c_trace_wg_mid), sizeof(unsigned long long) * 1024 * 8);
 }
 #else
 #define P2C_TR(pt) do { } while (0)

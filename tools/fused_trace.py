@@ -86,11 +86,14 @@ if not OLD:
     wg = wg[:min(256, (M + 31) // 32)].astype(np.float64)
     cyc = wg[:, 2] - wg[:, 0]; us = (wg[:, 3] - wg[:, 1]) / 100.0
     span = (wg[:, 3].max() - wg[:, 1].min()) / 100.0
-    mid = np.zeros((1024, 2), dtype=np.uint64)
+    mid = np.zeros((1024, 8), dtype=np.uint64)
     assert L.p2c_trace_read_wg_mid(mid.ctypes.data_as(vp)) == 0
     mid = mid[:len(wg)].astype(np.float64)
     print("cycles (median over workgroups): prologue %.0f | main loop %.0f | flush %.0f" % (np.median(mid[:, 0] - wg[:, 0]), np.median(mid[:, 1] - mid[:, 0]),
                                                                                           np.median(wg[:, 2] - mid[:, 1])))
+    print("prologue stages (median cycles): first loads issued %.0f | W staged %.0f | constants %.0f | first tile transformed + stored, second requested %.0f | barrier %.0f"
+          % (np.median(mid[:, 2] - wg[:, 0]), np.median(mid[:, 3] - mid[:, 2]), np.median(mid[:, 4] - mid[:, 3]), np.median(mid[:, 5] - mid[:, 4]),
+             np.median(mid[:, 0] - mid[:, 5])))
     print("workgroups: %d | duration us min %.1f median %.1f max %.1f | first start -> last end %.1f us | start skew %.1f us | shader clock %.2f GHz (median)"
           % (len(us), us.min(), np.median(us), us.max(), span, (wg[:, 1].max() - wg[:, 1].min()) / 100.0, np.median(cyc / us) / 1e3))
 if not OLD:

@@ -2,6 +2,7 @@
 //   mode 0: fp32 MFMA stream (v_mfma_f32_32x32x2_f32), 1 wave per SIMD      mode 1: the same, 2 waves per SIMD
 //   mode 2: bf16 MFMA stream (v_mfma_f32_32x32x16_bf16), 1 wave per SIMD     mode 3: HBM copy (read 512 MB + write 512 MB per pass)
 //   mode 4: VALU fma stream, 2 waves per SIMD                                  mode 5: HBM read only (512 MB per pass)
+//   mode 6: every CU occupied by 8 waves that only sleep (s_sleep): the clocked-but-idle power      mode 7: LDS read stream (ds_read_b128)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -35,6 +36,18 @@ __global__ void __launch_bounds__(512) k(float *buf, int iters, size_t n4)
         float s = 0.f;
         for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
         if (s == 12345.f) buf[tid] = s;
+    } else if (MODE == 6) {
+        for (int it = 0; it < iters * 4; ++it) __builtin_amdgcn_s_sleep(127);
+    } else if (MODE == 7) {
+        __shared__ f32x4 lds[4096];
+        lds[tid] = f32x4{1.f, 2.f, 3.f, 4.f}; lds[tid + 512] = lds[tid];
+        __syncthreads();
+        f32x4 acc = {0, 0, 0, 0};
+        for (int it = 0; it < iters * 4; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += lds[(tid + 64 * j + it) & 1023];
+        }
+        if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.f) buf[tid] = acc[0];
     } else if (MODE == 4) {
         float v[8];
         for (int j = 0; j < 8; ++j) v[j] = tid + j;
@@ -71,6 +84,8 @@ int main(int argc, char **argv)
         case 2: hipLaunchKernelGGL(k<2>, dim3(256), dim3(256), 0, 0, buf, iters, n4); break;
         case 3: hipLaunchKernelGGL(k<3>, dim3(2048), dim3(512), 0, 0, buf, iters, n4); break;
         case 4: hipLaunchKernelGGL(k<4>, dim3(256), dim3(512), 0, 0, buf, iters * 8, n4); break;
+        case 6: hipLaunchKernelGGL(k<6>, dim3(256), dim3(512), 0, 0, buf, iters, n4); break;
+        case 7: hipLaunchKernelGGL(k<7>, dim3(256), dim3(512), 0, 0, buf, iters, n4); break;
         default: hipLaunchKernelGGL(k<5>, dim3(2048), dim3(512), 0, 0, buf, iters, n4); break;
         }
     };
@@ -86,6 +101,10 @@ int main(int argc, char **argv)
     if (mode <= 2) {
         const double waves = 256.0 * (mode == 1 ? 8 : 4), flops = waves * iters * 4.0 * (mode == 2 ? 32768.0 : 4096.0);
         printf("mode %d: %.3f ms per launch, %.1f TFLOP/s\n", mode, per * 1e3, flops / per / 1e12);
+    } else if (mode == 6) {
+        printf("mode 6: %.3f ms per launch (sleeping waves on every CU)\n", per * 1e3);
+    } else if (mode == 7) {
+        printf("mode 7: %.3f ms per launch, %.1f TB/s of LDS reads\n", per * 1e3, 256.0 * 512 * 16.0 * 8 * iters * 4 / per / 1e12);
     } else if (mode == 4) {
         printf("mode 4: %.3f ms per launch, %.2f T VALU lane-fma/s\n", per * 1e3, 256.0 * 512 * 8.0 * iters * 8 / per / 1e12);
     } else {

@@ -3,6 +3,7 @@
 //   mode 2: bf16 MFMA stream (v_mfma_f32_32x32x16_bf16), 1 wave per SIMD     mode 3: HBM copy (read 512 MB + write 512 MB per pass)
 //   mode 4: VALU fma stream, 2 waves per SIMD                                  mode 5: HBM read only (512 MB per pass)
 //   mode 6: every CU occupied by 8 waves that only sleep (s_sleep): the clocked-but-idle power      mode 7: LDS read stream (ds_read_b128)
+//   mode 8: fp32 MFMA stream whose operands change every instruction (one VALU op per MFMA keeps them moving): data-dependent switching
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -32,6 +33,18 @@ __global__ void __launch_bounds__(512) k(float *buf, int iters, size_t n4)
                 a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
                 a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
             }
+        }
+        float s = 0.f;
+        for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+        if (s == 12345.f) buf[tid] = s;
+    } else if (MODE == 8) {
+        f32x16 a0 = {0}, a1 = {0}, a2 = {0}, a3 = {0};
+        float x = tid * 1.37e-3f + 0.5f, y = 1.f - tid * 0.77e-3f;
+        for (int it = 0; it < iters; ++it) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0); x = x * 1.000173f + 0.3711f;
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a1, 0, 0, 0); y = y * 0.999871f - 0.2913f;
+            a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0); x = x * 0.999613f + 0.1177f;
+            a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(y, x, a3, 0, 0, 0); y = y * 1.000291f - 0.4421f;
         }
         float s = 0.f;
         for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
@@ -85,6 +98,7 @@ int main(int argc, char **argv)
         case 3: hipLaunchKernelGGL(k<3>, dim3(2048), dim3(512), 0, 0, buf, iters, n4); break;
         case 4: hipLaunchKernelGGL(k<4>, dim3(256), dim3(512), 0, 0, buf, iters * 8, n4); break;
         case 6: hipLaunchKernelGGL(k<6>, dim3(256), dim3(512), 0, 0, buf, iters, n4); break;
+        case 8: hipLaunchKernelGGL(k<8>, dim3(256), dim3(256), 0, 0, buf, iters, n4); break;
         case 7: hipLaunchKernelGGL(k<7>, dim3(256), dim3(512), 0, 0, buf, iters, n4); break;
         default: hipLaunchKernelGGL(k<5>, dim3(2048), dim3(512), 0, 0, buf, iters, n4); break;
         }
@@ -98,7 +112,9 @@ int main(int argc, char **argv)
         el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
     const double per = el / n;
-    if (mode <= 2) {
+    if (mode == 8) {
+        printf("mode 8: %.3f ms per launch, %.1f TFLOP/s (operands change every MFMA)\n", per * 1e3, 256.0 * 4 * iters * 4.0 * 4096.0 / per / 1e12);
+    } else if (mode <= 2) {
         const double waves = 256.0 * (mode == 1 ? 8 : 4), flops = waves * iters * 4.0 * (mode == 2 ? 32768.0 : 4096.0);
         printf("mode %d: %.3f ms per launch, %.1f TFLOP/s\n", mode, per * 1e3, flops / per / 1e12);
     } else if (mode == 6) {

@@ -66,7 +66,40 @@ __device__ void p2c_lsa_min(const double *cost, int nr, int nc, int *col4row)
 // in fp64.  Twice as fast as the single-lane version (whose every step is a dependent LDS round trip); a variant that publishes
 // the columns in LDS and lets every lane rescan them was slower than both.
 // Called by all 64 lanes of one wave (converged), nr <= nc <= HM_MAXK (<= 15: one DPP row).  cost, col4row: LDS.
-__device__ __forceinline__ double p2c_shfl_xor_f64(double v, int m) { return __shfl_xor(v, m, 16); }
+// Cross-lane traffic of the solver: DPP inside the row of 16 lanes and v_readlane for the wave-uniform picks.  __shfl / __shfl_xor go
+// through ds_bpermute (an LDS crossbar round trip, ~100 cycles each, a dozen dependent ones per step of the search): the 8 x 8 problems
+// of a training step took 26 us that way.
+template <int CTRL>
+__device__ __forceinline__ double p2c_dpp_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = p2c_dpp<CTRL>((int)(b & 0xffffffffll)), hi = p2c_dpp<CTRL>((int)(b >> 32));
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double p2c_row16_min_f64(double v)     // every lane of the row ends with the row's minimum
+{
+    v = fmin(v, p2c_dpp_f64<0xB1>(v));    // quad_perm [1,0,3,2]
+    v = fmin(v, p2c_dpp_f64<0x4E>(v));    // quad_perm [2,3,0,1]
+    v = fmin(v, p2c_dpp_f64<0x141>(v));   // row_half_mirror
+    v = fmin(v, p2c_dpp_f64<0x140>(v));   // row_mirror
+    return v;
+}
+__device__ __forceinline__ int p2c_row16_min_i32(int v)
+{
+    v = min(v, p2c_dpp<0xB1>(v));
+    v = min(v, p2c_dpp<0x4E>(v));
+    v = min(v, p2c_dpp<0x141>(v));
+    v = min(v, p2c_dpp<0x140>(v));
+    return v;
+}
+__device__ __forceinline__ int p2c_readlane_i32(int v, int lane_uniform) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane_uniform)); }
+__device__ __forceinline__ double p2c_readlane_f64(double v, int lane_uniform)
+{
+    const int l = __builtin_amdgcn_readfirstlane(lane_uniform);
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), l), hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 __device__ void p2c_lsa_min_wave(const double *cost, int nr, int nc, int *col4row)
 {
     const int lane = threadIdx.x & 63;
@@ -81,27 +114,23 @@ __device__ void p2c_lsa_min_wave(const double *cost, int nr, int nc, int *col4ro
         int sink = -1, i = cur;
         while (sink == -1) {
             if (lane == i) SR = true;
-            const double ui = __shfl(u, i, 64);
+            const double ui = p2c_readlane_f64(u, i);
             const bool active = pos >= 0;
             if (active) {
                 const double r = minVal + cost[i * nc + lane] - ui - v;
                 if (r < spc) { path = i; spc = r; }
             }
-            double m = active ? spc : INFINITY;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) m = fmin(m, p2c_shfl_xor_f64(m, o));
-            m = __shfl(m, 0, 64);
+            double m = p2c_readlane_f64(p2c_row16_min_f64(active ? spc : INFINITY), 0);
             if (!(m < INFINITY)) return;                     // infeasible (cannot happen for finite costs)
             const bool eq = active && spc == m;
             int ku = (eq && row4col == -1) ? pos : -1;       // last unassigned among the cheapest ...
             int ka = eq ? pos : 0x7fffffff;                  // ... else the first of them
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { ku = max(ku, __shfl_xor(ku, o, 16)); ka = min(ka, __shfl_xor(ka, o, 16)); }
-            ku = __shfl(ku, 0, 64); ka = __shfl(ka, 0, 64);
+            ku = __builtin_amdgcn_readlane(p2c_row16_max_i32(ku), 0);
+            ka = __builtin_amdgcn_readlane(p2c_row16_min_i32(ka), 0);
             const int psel = ku >= 0 ? ku : ka;
             const int jsel = __ffsll((long long)(__ballot(active && pos == psel) & 0xFFFFull)) - 1;
             minVal = m;
-            const int rc = __shfl(row4col, jsel, 64);
+            const int rc = p2c_readlane_i32(row4col, jsel);
             if (rc == -1) sink = jsel; else i = rc;
             if (lane == jsel) SC = true;
             // remaining[index] = remaining[--num_remaining]
@@ -110,16 +139,16 @@ __device__ void p2c_lsa_min_wave(const double *cost, int nr, int nc, int *col4ro
             if (lane == jsel) pos = -1;
         }
         // dual updates (rows of the tree other than cur read the path cost of their assigned column)
-        const double spc_c = __shfl(spc, c4r >= 0 ? c4r : 0, 64);
+        const double spc_c = __shfl(spc, c4r >= 0 ? c4r : 0, 64);        // per-lane index: a real permute
         if (lane == cur) u += minVal;
         else if (SR && lane < nr) u += minVal - spc_c;
         if (SC) v -= minVal - spc;
         // augment along the predecessors
         int j = sink;
         for (;;) {
-            const int r = __shfl(path, j, 64);
+            const int r = p2c_readlane_i32(path, j);
             if (lane == j) row4col = r;
-            const int t = __shfl(c4r, r, 64);
+            const int t = p2c_readlane_i32(c4r, r);
             if (lane == r) c4r = j;
             j = t;
             if (r == cur) break;

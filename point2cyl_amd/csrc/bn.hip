@@ -416,7 +416,9 @@ __global__ void fold0_bwd_finalize_kernel(const double *__restrict__ part, const
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double sv[5] = {0, 0, 0, 0, 0};
-    for (int t = 0; t < P2C_STAT_SLOTS; ++t)
+#pragma unroll 16
+    for (int t = 0; t < P2C_STAT_SLOTS; ++t)       // 80 independent loads in flight per round: one wave does all of this, latency is all it costs
+#pragma unroll
         for (int q = 0; q < 5; ++q) sv[q] += part[((size_t)t * 5 + q) * C + c];
     const double s1 = sv[0], s2 = sv[1];
     dgamma[c] = (float)s2;

@@ -28,24 +28,50 @@ PEAK_HBM_GBS = 8000.0
 # HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE and
 # WRITE_SIZE need separate passes, so they cannot be read inside the timed run); launch-weighted over the family's kernels.
 _PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-_PMC_FILE = os.path.join(_PROFILES, "r02_pmc_step.json")        # written by tools/collect_pmc.py (every kernel of the step, all counters)
+
+
+def _newest_pmc():
+    """profiles/r<NN>*_pmc_step.json of the highest round (then newest file), written by tools/collect_pmc.py (every kernel of the step)."""
+    best = None
+    try:
+        for f in os.listdir(_PROFILES):
+            m = re.match(r"r(\d+)([a-z]*)_pmc_step\.json$", f)
+            if m:
+                key = (int(m.group(1)), m.group(2), os.path.getmtime(os.path.join(_PROFILES, f)))
+                if best is None or key > best[0]:
+                    best = (key, os.path.join(_PROFILES, f))
+    except OSError:
+        pass
+    return best[1] if best else None
+
+
 _PMC_NAME = {"p2c_linear_bwd_fused_f32": "bwd_fused_pp_kernel", "p2c_linear_fwd_f32": "fwd_pp_kernel"}
 
 
 def _pmc_traffic(entry):
+    """-> (bytes per launch, source file, source_hash of the tree the counters were collected on, stale?).  The counters need their own
+    rocprofv3 passes, so `traffic` cannot be measured by the run that prints it: the line names the file it was read from and says
+    whether the kernels have changed since (stale = the sources hash differently now)."""
+    pmc = _newest_pmc()
+    if pmc is None:
+        return None, None, None, None
     try:
-        with open(_PMC_FILE) as f:
-            ks = json.load(f)["kernels"]
+        with open(pmc) as f:
+            doc = json.load(f)
+        ks = doc["kernels"]
+        from point2cyl_amd.build import source_hash
+        shash = doc.get("source_hash")
+        stale = (shash != source_hash()) if shash else None
         sub = _PMC_NAME.get(entry)
         # (the IMODE-2 instantiation "<.., .., .., 2, ...>" belongs to p2c_linear_bwd_fused_fold0_f32, a different entry point)
         sel = [v for k, v in ks.items() if sub and sub in k and not re.search(r"bwd_fused_pp_kernel<\d+, \d+, \d+, 2,", k)]
         n = sum(v["launches"] for v in sel)
         if not n:
-            return None, None
+            return None, None, None, None
         tot = sum(v["launches"] * (v.get("fetch_bytes_per_launch", 0.0) + v.get("write_bytes_per_launch", 0.0)) for v in sel)
-        return round(tot / n), "profiles/" + os.path.basename(_PMC_FILE)
+        return round(tot / n), "profiles/" + os.path.basename(pmc), shash, stale
     except (OSError, KeyError, ValueError):
-        return None, None
+        return None, None, None, None
 
 
 def _cpu_model():
@@ -162,9 +188,18 @@ def _bench(args, rank, world, local, dev):
                     m.fps_start = None
             graphed = None
 
-    def one_step():
+    ar_events = []          # N > 1: HIP events around the gradient exchange of every timed step (on the step's stream)
+
+    def one_step(timed=False):
         out = graphed() if graphed is not None else fwd_bwd()
-        sync.allreduce()
+        if world > 1 and timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            sync.allreduce()
+            e1.record()
+            ar_events.append((e0, e1))
+        else:
+            sync.allreduce()
         opt.step()
         ops.step_done()
         return out
@@ -180,7 +215,7 @@ def _bench(args, rank, world, local, dev):
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = one_step()
+        out = one_step(timed=True)
     fence()
     dt = time.perf_counter() - t0
     ops.PROFILE.enabled = False
@@ -195,7 +230,21 @@ def _bench(args, rank, world, local, dev):
             fwd_bwd()                      # (step_done inside: these gradients are not used)
         torch.cuda.synchronize()
         ops.PROFILE.enabled = False
+    multi = None
     if world > 1:
+        # what a scaling line needs to be diagnosable: every rank's own time, the event-timed exchange, and proof that the replicas
+        # hold the same parameters after the timed steps (sum of squares in float64, gathered)
+        ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
+        with torch.no_grad():
+            ck = sum(float((p.detach().double() ** 2).sum()) for p in model.parameters())
+        mine = torch.tensor([dt / args.steps * 1e3, ar_ms, ck], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        multi = dict(rank_ms_per_step=[round(float(v), 4) for v in allr[:, 0]], allreduce_ms=[round(float(v), 4) for v in allr[:, 1]],
+                     allreduce_bytes=int(sync.flat.numel() * 4) if sync.flat is not None else 0,
+                     param_checksum=[float(v) for v in allr[:, 2]], params_identical=bool((allr[:, 2] == allr[0, 2]).all()),
+                     recapture_count=1 if graphed is not None else 0)
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -214,10 +263,10 @@ def _bench(args, rank, world, local, dev):
         d = dom[1]
         if d["flops"] > 0:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic, tsrc = _pmc_traffic(dom[0])
+            traffic, tsrc, thash, tstale = _pmc_traffic(dom[0])
             roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
                             frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (HBM read+write, PMC)",
-                            traffic_source=tsrc, algorithmic_bytes_per_launch=round(d["bytes"] / max(1, d["launches"])),
+                            traffic_source=tsrc, traffic_source_hash=thash, traffic_stale=tstale, algorithmic_bytes_per_launch=round(d["bytes"] / max(1, d["launches"])),
                             launches_per_step=d["launches"] / prof_steps, avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
                             share_of_step=round(d["ms"] / prof_steps / ms, 3))
         else:
@@ -249,7 +298,7 @@ def _bench(args, rank, world, local, dev):
                                       "full loss set" if args.full_losses else "pred_seg+pred_normal+pred_bb"),
                             batch_per_gpu=B, global_batch=B * world, num_point=N, parallelism="dp%d" % world, loss=round(loss, 5),
                             launch=("hip_graph(fwd+bwd%s)+eager(allreduce,adam)" % ("" if args.no_prefetch else ", next batch's FPS/ball-query/3-NN on a forked stream")) if graphed is not None else "eager"),
-                roofline=roofline, cpu_baseline=cpu,
+                roofline=roofline, cpu_baseline=cpu, multi_gpu=multi,
                 kernels={k: dict(ms_per_step=round(v["ms"] / prof_steps, 3), launches_per_step=v["launches"] / prof_steps)
                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])})
     print(json.dumps(line))

@@ -18,6 +18,19 @@ SOURCES = ["geom.hip", "gather.hip", "gemm.hip", "fwd_pp.hip", "bwd_fused.hip", 
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
 
 
+def source_hash():
+    """sha1 over the kernel sources (csrc/*.hip, csrc/*.h, include/p2c_hip.h): stamps profiles so that a number measured on other
+    kernels than the ones in the tree is recognisable (bench.py: roofline.traffic_stale)."""
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) 
+    for f in files:
+        h.update(f.encode())
+        h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(os.path.join(HERE, "..", "include", "p2c_hip.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

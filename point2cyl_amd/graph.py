@@ -132,32 +132,47 @@ class GraphedForwardBackward:
             return out
 
         self._side = torch.cuda.Stream() if self.prefetch else None
-        if self.prefetch:
+
+        def restore():          # BatchNorm running statistics / counters and the dropout counter as they were before warm-up and capture
             with torch.no_grad():
-                self.cur = model.compute_geometry(prefetch_xyz)     # geometry for the first replay
-            self.starts.cursor = 0
-        # warm-up passes and the capture run on ONE stream (`stream`, e.g. the stream the caller's whole loop lives on, or a private one):
-        # the autograd accumulator nodes created by the warm-up are then bound to the stream that is captured
-        cap = stream if stream is not None else torch.cuda.Stream()
-        cap.wait_stream(main)
-        with torch.cuda.stream(cap):
-            for _ in range(warmup):
+                for b, v in keep:
+                    b.copy_(v)
+                if keep_seed is not None and getattr(model, "_drop_seed", None) is not None:
+                    model._drop_seed.copy_(keep_seed)
+
+        try:
+            if self.prefetch:
+                with torch.no_grad():
+                    self.cur = model.compute_geometry(prefetch_xyz)     # geometry for the first replay
                 self.starts.cursor = 0
-                body()
-        main.wait_stream(cap)
-        torch.cuda.synchronize()
+            # warm-up passes and the capture run on ONE stream (`stream`, e.g. the stream the caller's whole loop lives on, or a private one):
+            # the autograd accumulator nodes created by the warm-up are then bound to the stream that is captured
+            cap = stream if stream is not None else torch.cuda.Stream()
+            cap.wait_stream(main)
+            with torch.cuda.stream(cap):
+                for _ in range(warmup):
+                    self.starts.cursor = 0
+                    body()
+            main.wait_stream(cap)
+            torch.cuda.synchronize()
+            self.starts.cursor = 0
+            self.graph = torch.cuda.CUDAGraph()
+            # thread_local: only THIS thread's calls are policed while capturing.  With the default ("global") a HIP call from any other thread -
+            # RCCL's watchdog polling its events in a multi-GPU job - invalidates the capture
+            with torch.cuda.graph(self.graph, stream=cap, capture_error_mode="thread_local"):
+                self.out = body()
+        except BaseException:
+            # a failed warm-up / capture must not leave 1-2 extra BatchNorm updates and an advanced dropout counter behind: the caller
+            # falls back to eager launches of the SAME batch
+            try:
+                torch.cuda.synchronize()
+                restore()
+            except Exception:
+                pass
+            self.release()
+            raise
         self.starts.cursor = 0
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: only THIS thread's calls are policed while capturing.  With the default ("global") a HIP call from any other thread -
-        # RCCL's watchdog polling its events in a multi-GPU job - invalidates the capture
-        with torch.cuda.graph(self.graph, stream=cap, capture_error_mode="thread_local"):
-            self.out = body()
-        self.starts.cursor = 0
-        with torch.no_grad():
-            for b, v in keep:
-                b.copy_(v)
-            if keep_seed is not None and getattr(model, "_drop_seed", None) is not None:
-                model._drop_seed.copy_(keep_seed)
+        restore()
         # the gradient tensors the graph leaves in .grad (static addresses): either the kernels' own output buffers, or - when fn packs
         # them (ddp.FlatGradSync.pack, captured) - views of the exchange's flat buffer.  Code between replays that re-points .grad
         # (an optimizer's zero_grad(set_to_none=True), a test) is undone before the next replay's results are consumed

@@ -21,7 +21,10 @@ class Adam(torch.optim.Optimizer):
 
     def _table(self, gi, group):
         ps = [p for p in group["params"] if p.grad is not None]
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in ps)
+        # the key covers every pointer the table holds: after load_state_dict (or anything else that replaces exp_avg / exp_avg_sq) the
+        # cached table would otherwise keep pointing at the old, freed moment tensors
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), *((st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()) if (st := self.state.get(p)) else (0, 0)))
+                    for p in ps)
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == key:
             return cached
@@ -42,9 +45,18 @@ class Adam(torch.optim.Optimizer):
         tab = torch.tensor(rows, dtype=torch.int64).to(dev, non_blocking=True)
         nel = torch.tensor(numel, dtype=torch.int64).to(dev, non_blocking=True)
         chk = torch.tensor(chunks, dtype=torch.int32).to(dev, non_blocking=True)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in ps)
         cached = (key, tab, nel, chk, len(chunks), ps)
         self._tables[gi] = cached
         return cached
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables = {}
+
+    def add_param_group(self, param_group):
+        super().add_param_group(param_group)
+        self._tables = {}
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -58,6 +70,10 @@ class Adam(torch.optim.Optimizer):
             _, tab, nel, chk, n_chunks, ps = self._table(gi, group)
             for p in ps:
                 self.state[p]["step"] += 1
+            steps = {int(self.state[p]["step"]) for p in ps}
+            if len(steps) != 1:     # one bias correction per launch: every tensor of the group must have taken the same number of updates
+                raise RuntimeError("point2cyl_amd.optim.Adam: parameters of one group have different step counts %s (a parameter that first "
+                                   "received a gradient later than the others); put it in its own param group" % sorted(steps))
             b1, b2 = group["betas"]
             call("p2c_adam_multi_f32", ptr(tab), ptr(nel), ptr(chk), n_chunks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                  int(self.state[ps[0]]["step"]), stream())

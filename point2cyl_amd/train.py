@@ -156,7 +156,9 @@ class Runner:
                 except Exception as e:      # something in this configuration cannot be captured: train on, launched from Python
                     import sys
                     sys.stderr.write("point2cyl_amd.train: HIP graph capture failed (%s: %s); continuing without the graph\n" % (type(e).__name__, e))
-                    torch.cuda.set_stream(torch.cuda.Stream(self.dev))      # the capture stream may be left in capture mode
+                    self.stream = torch.cuda.Stream(self.dev)                # the capture stream may be left in capture mode: everything
+                    self.stream.wait_stream(torch.cuda.current_stream())    # from here on (autograd included) lives on a fresh one
+                    torch.cuda.set_stream(self.stream)
                     for m in self.model.modules():
                         if hasattr(m, "fps_start"):
                             m.fps_start = None
@@ -239,7 +241,9 @@ def _main(a, rank, world, local, dev, stream):
     cur = next(it)
     t_start = t_steady = None
     steps_steady = 0
-    hist, pending = [], []
+    # epoch means: a running device sum.  (Keeping the per-step tensors in a list does not work in graph mode: every replay returns the SAME
+    # static output tensor, so the list would hold N aliases of the last step's scalars.)
+    ep_sum, ep_n, pending = torch.zeros(len(SCALARS), dtype=torch.float32, device=dev), 0, []
     host_ring = [torch.empty(len(SCALARS), dtype=torch.float32).pin_memory() for _ in range(2)]
     lagged = None
 
@@ -256,15 +260,18 @@ def _main(a, rank, world, local, dev, stream):
         nxt = next(it, None)
         epoch, i, b = cur
         run.load(b, None if nxt is None else nxt[2][0])
-        lr = step.get_learning_rate(a.learning_rate, gstep, B, a.decay_step, a.decay_rate)     # train…:361-365: before optimizer.step
+        # the staircases count SAMPLES (train…:143-164: global_step * batch_size); under data parallelism a step consumes world * B of them,
+        # so an N-GPU run follows the schedule of the single-GPU run with the same global batch
+        lr = step.get_learning_rate(a.learning_rate, gstep, B * world, a.decay_step, a.decay_rate)     # train…:361-365: before optimizer.step
         if old_lr != lr:
             for g in opt.param_groups:
                 g["lr"] = lr
             old_lr = lr
         sc = run.step(mom_fwd, eager=gstep == 0)
-        mom_fwd = step.get_batch_norm_decay(gstep, B, a.bn_decay_step)                         # train…:356-359: reaches the NEXT forward
+        mom_fwd = step.get_batch_norm_decay(gstep, B * world, a.bn_decay_step)                 # train…:356-359: reaches the NEXT forward
         gstep += 1
-        hist.append(sc)
+        ep_sum += sc                                         # stream-ordered behind the step that wrote `sc`, before the next replay overwrites it
+        ep_n += 1
         if gstep == 3:                                       # steady state: graph captured (steps 0 and 1 build it)
             torch.cuda.synchronize()
             t_steady, steps_steady = time.perf_counter(), 0
@@ -281,14 +288,15 @@ def _main(a, rank, world, local, dev, stream):
             ev = torch.cuda.Event()
             ev.record()
             lagged = (epoch, i, hb, ev)
-        last_of_epoch = nxt is None or nxt[0] != epoch
+        stopping = bool(a.max_steps) and gstep >= a.max_steps    # --max_steps ends the run like the end of the data: summary + checkpoint
+        last_of_epoch = nxt is None or nxt[0] != epoch or stopping
         if last_of_epoch and lagged is not None and (not a.quiet):
             emit(lagged)                                         # keep the per-batch lines in front of their epoch's summary
             lagged = None
         if last_of_epoch:
-            pending.append((epoch, torch.stack(hist).mean(0)))       # epoch means stay on the device ...
-            hist = []
-            saving = epoch % a.save_every == 0 or nxt is None
+            pending.append((epoch, ep_sum / ep_n))                   # epoch means stay on the device ...
+            ep_sum, ep_n = torch.zeros_like(ep_sum), 0
+            saving = epoch % a.save_every == 0 or nxt is None or stopping
             if saving or not a.quiet:                            # ... until something needs them on the host (one sync for all pending epochs)
                 for ep_no, ep_t in pending:
                     ep = ep_t.tolist()
@@ -310,7 +318,7 @@ def _main(a, rank, world, local, dev, stream):
                     if epoch > 20 and ep[0] < best:
                         best = ep[0]
                         torch.save(sd, os.path.join(a.logdir, "best_model.pth"))
-        if a.max_steps and gstep >= a.max_steps:
+        if stopping:
             break
         cur = nxt
     torch.cuda.synchronize()

@@ -1,0 +1,277 @@
+"""GPU (MI355X): BASELINE.json configs[2] and configs[4] AT THEIR OWN PER-GPU SIZE against the oracle.
+
+configs[2] per rank = ONE full training step at B=32 clouds x 8192 points in train mode with the full loss set (--pred_seg --pred_normal
+--pred_bb --pred_extrusion --pred_center; train_Point2Cyl_without_sketch.py:244-369) through the launch path bench.py times - HIP-graph
+replay with the next batch's geometry on the forked stream, the counter-hash dropout inside the head kernels, the flat gradient buffer,
+the one-launch Adam - against oracle/ref_step.full_loss_step on the same weights, FPS starts and dropout mask in fp32 AND float64 on all
+32 clouds (train-mode BatchNorm couples them).  The dropout mask the oracle gets is the one the kernels' hash implies: it is recomputed
+here on the host from (seed, element index) with the arithmetic of csrc/common.h p2c_hash32.
+
+configs[4] per rank = the implicit-sketch branch of one with-sketch step (train_Point2Cyl.py:519-672) at B=16 clouds x 8192 points,
+128 sketches x 2048 points, 256-wide latent, 8 x 512 decoder: projections, trainable + frozen encoder, decoder losses with their double
+backward, latent loss - against the oracle's composition of its restatements on all 128 sketches in fp32; the float64 yardstick runs
+on a 2-cloud (16-sketch) job of the same shapes (the encoder's train-mode BatchNorm makes a subset of a batch a different problem,
+so the subset is its own job on both sides).
+
+Bars: matching, labels and all index structure bit-exact (labels: except where the float64 run's two largest logits are within 2e-4
+of a tie); loss scalars 1e-4 relative; head outputs max(1e-4, 3 x the fp32 oracle's own distance from float64); parameter gradients and
+the Adam'd parameters no further from float64 than 3 x the fp32 oracle is (max-abs or norm - DESIGN.md section 4).
+Every measured value lands in gpurun_out/configs_metrics.json."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import ref_step, ref_torch as R
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from point2cyl_amd import ddp, fitting, ops, optim, step, step_sketch, synth
+    from point2cyl_amd.backbone import backbone
+
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_METRICS = []
+
+
+def _rec(name, value, bound):
+    _METRICS.append(dict(check=name, value=float(value), bound=float(bound), ok=bool(value <= bound)))
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "configs_metrics.json"), "w") as f:
+            json.dump(_METRICS, f, indent=1)
+    except OSError:
+        pass
+    return value <= bound
+
+
+def _relnorm(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+def hashed_keep_mask(seed_i64, rows, cols=128, thr=1 << 31):
+    """Host restatement of the kernels' dropout bits (csrc/common.h p2c_hash32; fwd_pp.hip MODE 3): keep(row, col) = hash(seed, row*cols+col) >= thr."""
+    lo, hi = np.uint32(seed_i64 & 0xFFFFFFFF), np.uint32((seed_i64 >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        x = np.arange(rows * cols, dtype=np.uint32) * np.uint32(0x9E3779B1) ^ lo
+        x ^= x >> np.uint32(16); x *= np.uint32(0x85EBCA6B)
+        x ^= x >> np.uint32(13); x *= np.uint32(0xC2B2AE35)
+        x ^= x >> np.uint32(16); x += hi * np.uint32(0x27D4EB2F)
+        x ^= x >> np.uint32(15); x *= np.uint32(0x2C1B3C6D)
+        x ^= x >> np.uint32(12)
+    return (x >= np.uint32(thr)).reshape(rows, cols)
+
+
+# ------------------------------------------------------------------------------------------ configs[2], one rank's step
+@pytest.mark.parametrize("B,N", [(32, 8192)])
+def test_config2_full_loss_step_graph_path_vs_oracle_fp32_and_fp64(B, N):
+    from point2cyl_amd import backbone as bbmod
+    from point2cyl_amd.graph import GraphedForwardBackward
+    K = 8
+    fl = step.StepFlags(K=K, pred_extrusion=True, pred_center=True)
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=20262)
+    cpu_batch = (pcs.float(), nrm.float(), seg, bb, axes.float(), cen.float())
+    batch = tuple(v.to(DEV) for v in cpu_batch)
+    torch.manual_seed(17)
+    m = backbone(output_sizes=fl.pred_sizes())
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    m = m.to(DEV).train()
+    mom = step.get_batch_norm_decay(0, B, 200000)
+    step.update_momentum(m, mom)
+    g = torch.Generator().manual_seed(4)
+    fixed = {N: torch.randint(0, N, (B,), generator=g), 512: torch.randint(0, 512, (B,), generator=g)}
+    orig_draw = bbmod.draw_fps_start
+    bbmod.draw_fps_start = lambda n, b: fixed[n].clone()
+    stream = torch.cuda.Stream()
+    try:
+        with torch.cuda.stream(stream):
+            sync = ddp.FlatGradSync(m.parameters(), 1)
+            opt = optim.Adam(m.parameters(), lr=1e-3)
+
+            def fwd_bwd(geom=None):                      # bench.py's fwd_bwd, returning everything the comparison needs
+                ops.step_done()
+                with ops.step_arena(DEV):
+                    out = step.compute_losses_fused(m, *batch, fl, geom=geom)
+                    sync.zero()
+                    out["total"].backward()
+                    sync.pack()
+                keep = {k: out[k].detach() for k in ("total", "normal", "miou", "bb", "ext", "center", "match", "mask")}
+                keep["heads"] = out["heads"].detach()
+                return keep
+
+            SEED0 = 0x1234567890ABCDE
+            m._drop_seed = torch.tensor([SEED0], dtype=torch.int64, device=DEV)
+            gr = GraphedForwardBackward(m, fwd_bwd, prefetch_xyz=batch[0], stream=stream)
+            m._drop_seed.fill_(SEED0)
+            out = gr()
+            sync.allreduce()
+            torch.cuda.synchronize()
+            used_seed = int(m._drop_seed.item())
+            res = {k: v.clone() for k, v in out.items()}
+            grads = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+            before = {n: p.detach().clone() for n, p in m.named_parameters()}
+            opt.step()
+            torch.cuda.synchronize()
+            after = {n: p.detach().clone() for n, p in m.named_parameters()}
+    finally:
+        bbmod.draw_fps_start = orig_draw
+    assert used_seed != SEED0, "the replay must have advanced the dropout counter"
+    mask = torch.from_numpy(hashed_keep_mask(used_seed, B * N).astype(np.float32)).view(B, N, 128)
+    starts = [fixed[N], fixed[512]]
+    r32 = ref_step.full_loss_step(sd0, cpu_batch, starts, mask, K=K, momentum=mom, dtype=torch.float32)
+    r64 = ref_step.full_loss_step(sd0, cpu_batch, starts, mask, K=K, momentum=mom, dtype=torch.float64, forced_match=(r32["match"], r32["mask"]))
+    tag = "config2 B=%d N=%d " % (B, N)
+    # ---- integer structure
+    assert torch.equal(res["match"].cpu(), r32["match"]), "Hungarian matching must be bit-exact"
+    assert torch.equal(res["mask"].cpu().bool(), r32["mask"].bool())
+    for lvl, key in (("sa1", "fps_idx"), ("sa1", "group_idx"), ("sa2", "fps_idx"), ("sa2", "group_idx")):
+        assert torch.equal(getattr(m, lvl).last_aux[key].cpu().long(), r32["aux"][lvl][key]), (lvl, key)
+    heads = res["heads"].view(B, N, -1).cpu()
+    Xh, Wr = heads[:, :, 0:3], heads[:, :, 3:3 + 2 * K]
+    ok = True
+    for name, mine, a32, a64 in (("X_head", Xh, r32["heads"][0], r64["heads"][0]), ("W_raw", Wr, r32["heads"][1], r64["heads"][1])):
+        ref_err = float((a32.double() - a64).abs().max())
+        ok &= _rec(tag + "%s |ours-ref64|max (bound max(1e-4, 3*|ref32-ref64| = %.2e))" % (name, 3 * ref_err),
+                   float((mine.double() - a64).abs().max()), max(1e-4, 3 * ref_err))
+    for kway, f in (("2K-way", lambda w: w), ("K-way", lambda w: torch.softmax(w, -1).view(B, N, K, 2).sum(-1))):
+        mine_lab, lab32 = f(Wr).argmax(-1), f(r32["heads"][1]).argmax(-1)
+        top2 = f(r64["heads"][1]).topk(2, dim=-1)[0]
+        near = (top2[..., 0] - top2[..., 1]) < 2e-4
+        ok &= _rec(tag + "%s labels differing from the fp32 oracle away from float64 near-ties (of %d points; %d differ in all)"
+                   % (kway, B * N, int((mine_lab != lab32).sum())), int(((mine_lab != lab32) & ~near).sum()), 0)
+    # ---- the five loss terms and their sum
+    for k in ("total", "normal", "miou", "bb", "ext", "center"):
+        v = float(res[k])
+        ok &= _rec(tag + "loss[%s] rel. diff vs fp32 oracle (ours %.7f, ref32 %.7f, ref64 %.7f)" % (k, v, r32[k], r64[k]), abs(v - r32[k]) / abs(r32[k]), 1e-4)
+        ok &= _rec(tag + "loss[%s] rel. diff vs float64 oracle" % k, abs(v - r64[k]) / abs(r64[k]), 1e-4)
+    # ---- parameter gradients and the Adam'd parameters: float64 yardstick
+    for name in grads:
+        a32, a64 = r32["grads"][name].double().numpy(), r64["grads"][name].numpy()
+        got = grads[name].cpu().double().numpy().reshape(a64.shape)
+        if name.endswith(".bias") and ("mlp_convs" in name or name == "fc1.bias"):
+            assert np.abs(got).max() == 0.0, name         # analytically zero (a bias in front of a train-mode BatchNorm)
+            continue
+        ref_err = np.abs(a32 - a64).max()
+        a = np.abs(got - a64).max() / (3 * ref_err + 1e-6 * np.abs(a64).max())
+        b = _relnorm(got, a64) / (3 * _relnorm(a32, a64) + 1e-6)
+        ok &= _rec(tag + "grad[%s] min(max-abs ratio %.2f, relnorm ratio %.2f) vs 3x the fp32 oracle's distance from float64" % (name, a, b), min(a, b), 1.0)
+        d_me = (after[name] - before[name]).cpu().double().numpy().reshape(a64.shape)
+        d32 = (r32["params_after"][name].double() - sd0[name].double()).numpy()
+        d64 = (r64["params_after"][name] - sd0[name].double()).numpy()
+        # Adam's first update is -lr * g / (|g| + eps): where |g| is not >> eps it amplifies any gradient difference, for the fp32 oracle alike
+        ok &= _rec(tag + "Adam delta[%s] relnorm vs float64 (bound 3x the fp32 oracle's %.2e + 1e-4)" % (name, _relnorm(d32, d64)),
+                   _relnorm(d_me, d64), 3 * _relnorm(d32, d64) + 1e-4)
+    for k in ("sa1.mlp_bns.0.running_mean", "sa1.mlp_bns.2.running_var", "sa2.mlp_bns.2.running_var", "sa3.mlp_bns.1.running_var",
+              "fp3.mlp_bns.0.running_mean", "fp1.mlp_bns.0.running_mean", "bn1.running_var"):
+        a, b = m.state_dict()[k].cpu().numpy(), r32["buffers"][k].numpy()
+        ok &= _rec(tag + k, float(np.abs(a - b).max()), 1e-5 + 1e-4 * float(np.abs(b).max()))
+    assert int(m.state_dict()["bn1.num_batches_tracked"]) == 1, "graph construction must leave no trace; one replay = one forward"
+    assert ok, [mm for mm in _METRICS if not mm["ok"]]
+
+
+# ------------------------------------------------------------------------------------------ configs[4], one rank's sketch branch
+@pytest.mark.parametrize("B,with_f64", [(16, False), (2, True)])
+def test_config4_sketch_branch_full_size_vs_oracle(B, with_f64):
+    from point2cyl_amd.sketch import PointNetEncoder
+    from point2cyl_amd.implicit import ImplicitNet
+    N, K, S, E = 8192, 8, 2048, 256
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=404)
+    pcs, nrm, axes, cen = pcs.float(), nrm.float(), axes.float(), cen.float()
+    gen = torch.Generator().manual_seed(8)
+    X = F.normalize(nrm + 0.1 * torch.randn(B, N, 3, generator=gen), dim=-1)
+    W2K = torch.softmax(torch.randn(B, N, 2 * K, generator=gen) + 5 * F.one_hot(seg * 2 + bb, 2 * K), -1)
+    W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
+    match, mask = R.hungarian_matching(W, seg)
+    torch.manual_seed(13)
+    enc, enc_gt = PointNetEncoder(E, 2, with_normals=True), PointNetEncoder(E, 2, with_normals=True).eval()
+    dec = ImplicitNet(d_in=2 + E, dims=[512] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100)
+    sd_e = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    sd_g = {k: v.detach().clone() for k, v in enc_gt.state_dict().items()}
+    sd_d = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    gt_sk = torch.cat([torch.randn(B, K, S, 2, generator=gen) * 0.4, F.normalize(torch.randn(B, K, S, 2, generator=gen), dim=-1)], -1)
+    non = torch.cat([gt_sk[..., :2].reshape(B * K, S, 2) + 0.02 * torch.randn(B * K, S, 2, generator=gen), torch.rand(B * K, S // 8, 2, generator=gen) * 2 - 1], 1)
+    Wre = torch.gather(W, 2, match.unsqueeze(1).expand(B, N, K))
+    Wre = torch.where(mask.unsqueeze(1).expand(B, N, K), Wre, torch.zeros_like(Wre))
+    label, pbb = Wre.argmax(-1), torch.stack([W2K[:, :, 0::2].sum(-1), W2K[:, :, 1::2].sum(-1)], -1).argmax(-1)
+    torch.manual_seed(1); r_pred = fitting._barrel_draws(label, pbb, K, S)
+    torch.manual_seed(2); r_gt = fitting._barrel_draws(seg, bb, K, S)
+    d = lambda x: x.to(DEV)
+    enc, enc_gt, dec = enc.to(DEV).train(), enc_gt.to(DEV), dec.to(DEV)
+    for p in enc_gt.parameters():
+        p.requires_grad_(False)
+    out = step_sketch.sketch_branch_losses(d(pcs), d(X), d(W), d(W2K), d(match), d(mask), d(nrm), d(seg), d(bb), d(axes), d(cen), d(gt_sk), enc, enc_gt, dec,
+                                           None, K, S, rand_idx_pred=r_pred, rand_idx_gt=r_gt, nonmnfld_pnts=d(non))
+    out["im_loss"].backward()
+    torch.cuda.synchronize()
+    got = {k: out[k].item() for k in ("im_loss", "latent_loss", "mnfld_loss", "grad_loss", "normals_loss")}
+    g_enc = {n: p.grad.detach().cpu() for n, p in enc.named_parameters()}
+    g_dec = {n: p.grad.detach().cpu() for n, p in dec.named_parameters() if p.grad is not None}
+    lat_mine = out["latent_codes"].detach().cpu()
+
+    def oracle(dtype):
+        old = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            c = lambda v: v.to(dtype) if v.dtype.is_floating_point else v
+            dk = lambda r: {(k, b): r[b, k] for k in range(K) for b in range(B)}
+            # the projections are integer sampling + one rotation per segment: always evaluated in fp32 (they feed both sides the same way)
+            pP, pX, _, _ = R.sketch_implicit_projection(pcs, X, label, pbb, axes, cen, dk(r_pred), S)
+            _, _, gsc, _ = R.sketch_implicit_projection(pcs, nrm, seg, bb, axes, cen, dk(r_gt), S)
+            gpc = torch.cat(((pP / gsc.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2), pX.reshape(B * K, S, 2)), -1)
+            e = {k: c(v.clone()) for k, v in sd_e.items()}
+            gg = {k: c(v.clone()) for k, v in sd_g.items()}
+            dd = {k: c(v.clone()) for k, v in sd_d.items()}
+            for sdx in (e, dd):
+                for k in sdx:
+                    if sdx[k].dtype.is_floating_point and "running" not in k:
+                        sdx[k].requires_grad_(True)
+            lat = R.pointnet_encoder_forward(e, c(gpc), training=True)
+            skp, skn = c(gt_sk[..., :2].reshape(B * K, S, 2)), c(gt_sk[..., -2:].reshape(B * K, S, 2))
+            lat_gt = R.pointnet_encoder_forward(gg, torch.cat((skp, skn), -1), training=False)
+            mask_gt = R.get_mask_gt(seg, K)
+            im, mn, ek, nl = R.implicit_losses(dd, skp, skn, c(non), lat, mask_gt, B, K)
+            ll = R.reduce_mean_masked_instance(1.0 - (lat.reshape(B, K, -1) * lat_gt.reshape(B, K, -1)).sum(-1), mask_gt).mean()
+            (im + ll).backward()
+            return (dict(im_loss=(im + ll).item(), latent_loss=ll.item(), mnfld_loss=mn.item(), grad_loss=ek.item(), normals_loss=nl.item()),
+                    {k: v.grad.detach() for k, v in e.items() if v.requires_grad}, {k: v.grad.detach() for k, v in dd.items() if v.requires_grad and v.grad is not None},
+                    lat.detach(), gpc)
+        finally:
+            torch.set_default_dtype(old)
+
+    l32, ge32, gd32, lat32, gpc = oracle(torch.float32)
+    tag = "config4 sketch branch B=%d (%d sketches x %d) " % (B, B * K, S)
+    ok = True
+    if with_f64:
+        l64, ge64, gd64, lat64, _ = oracle(torch.float64)
+    for k in got:
+        ok &= _rec(tag + "loss[%s] rel. diff vs fp32 oracle (ours %.7f, ref32 %.7f)" % (k, got[k], l32[k]), abs(got[k] - l32[k]) / abs(l32[k]), 2e-4)
+        if with_f64:
+            ok &= _rec(tag + "loss[%s] rel. diff vs float64 oracle (ref64 %.7f; the fp32 oracle: %.2e)" % (k, l64[k], abs(l32[k] - l64[k]) / abs(l64[k])),
+                       abs(got[k] - l64[k]) / abs(l64[k]), 2e-4)
+    ok &= _rec(tag + "latent codes max|ours - ref32| (unit vectors)", float((lat_mine - lat32).abs().max()), 1e-4)
+    gmax = max(float(v.norm()) for v in ge32.values())
+    for n, gmine in g_enc.items():
+        r = ge32[n].double().numpy()
+        if with_f64:
+            r64 = ge64[n].numpy()
+            ok &= _rec(tag + "encoder grad[%s] relnorm vs float64 (bound 3x the fp32 oracle's %.2e + 1e-4)" % (n, _relnorm(r, r64)),
+                       _relnorm(gmine.double().numpy().reshape(r64.shape), r64), 3 * _relnorm(r, r64) + 1e-4)
+        else:
+            ok &= _rec(tag + "encoder grad[%s] |ours-ref32| / (|ref32| + 2e-3 gmax)" % n,
+                       float(np.linalg.norm(gmine.double().numpy().reshape(r.shape) - r) / (np.linalg.norm(r) + 2e-3 * gmax)), 5e-3)
+    gdmax = max(float(v.norm()) for v in gd32.values())
+    for n, gmine in g_dec.items():
+        r = gd32[n].double().numpy()
+        if with_f64:
+            r64 = gd64[n].numpy()
+            ok &= _rec(tag + "decoder grad[%s] relnorm vs float64 (bound 3x the fp32 oracle's %.2e + 1e-4)" % (n, _relnorm(r, r64)),
+                       _relnorm(gmine.double().numpy().reshape(r64.shape), r64), 3 * _relnorm(r, r64) + 1e-4)
+        else:
+            ok &= _rec(tag + "decoder grad[%s] |ours-ref32| / (|ref32| + 2e-3 gmax)" % n,
+                       float(np.linalg.norm(gmine.double().numpy().reshape(r.shape) - r) / (np.linalg.norm(r) + 2e-3 * gdmax)), 5e-3)
+    assert ok, [mm for mm in _METRICS if not mm["ok"]]

@@ -141,6 +141,14 @@ def test_trainer_cli_config0_then_eval_cli(tmp_path):
     assert vals[-2:, 0].mean() < vals[:2, 0].mean() + 0.05, vals[:, 0]                 # six Adam steps do not diverge
     r = json.load(open(rep))
     assert r["graph"] and r["graph_captures"] == 1 and r["steps"] == 6
+    # the '> Epoch' summaries are the MEANS of their epoch's per-step lines - also in graph mode, where every replay returns the same
+    # static scalars tensor (epochs 2 and 3 are graph replays; ADVICE r2: a list of those aliases averaged to the last step's values)
+    summ = [l for l in out.stdout.splitlines() if l.startswith("> Epoch")]
+    assert len(summ) == 3, out.stdout[-2000:]
+    ep_tot = np.array([float(l.split("total:")[1].split("|")[0]) for l in summ])
+    np.testing.assert_allclose(ep_tot, vals[:, 0].reshape(3, 2).mean(1), atol=2e-4)
+    np.testing.assert_allclose(r["epoch_means"]["total"], vals[:, 0].reshape(3, 2).mean(1), atol=1e-4)
+    assert abs(vals[4, 0] - vals[5, 0]) > 1e-5, "the two steps of the last epoch must differ for this check to mean anything"
     ck = torch.load(os.path.join(logdir, "model.pth"), map_location="cpu")
     assert set(ck.keys()) == {"model"} and len(ck["model"]) == 123
     assert os.path.exists(os.path.join(logdir, "checkpoint_0001.pth"))
@@ -167,6 +175,22 @@ def test_trainer_cli_config0_then_eval_cli(tmp_path):
         assert key in ev.stdout, ev.stdout[-1500:]
     nums = [float(l.split("=")[-1]) for l in ev.stdout.splitlines() if l.startswith("Mean ")]
     assert len(nums) == 5 and np.isfinite(nums).all()
+
+
+def test_trainer_cli_max_steps_ends_like_the_end_of_the_data(tmp_path):
+    """--max_steps in the middle of an epoch: the last step's log line, the epoch summary (mean over the steps taken) and model.pth are
+    written, as train_sketch.py does."""
+    logdir = str(tmp_path / "run")
+    out = _run(["-m", "point2cyl_amd.train", "--pred_seg", "--pred_normal", "--pred_bb", "--synthetic", "8", "--batch_size", "2",
+                "--num_point", "1024", "--num_epochs", "2", "--max_steps", "3", "--logdir", logdir])
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("Epoch:")]
+    assert len(lines) == 3, out.stdout[-2000:]
+    vals = np.array([float(l.split("total loss:")[1].split("|")[0]) for l in lines])
+    summ = [l for l in out.stdout.splitlines() if l.startswith("> Epoch")]
+    assert len(summ) == 1
+    np.testing.assert_allclose(float(summ[0].split("total:")[1].split("|")[0]), vals.mean(), atol=2e-4)
+    assert os.path.exists(os.path.join(logdir, "model.pth"))
 
 
 def test_trainer_cli_other_k_runs_the_torch_loss_path_through_the_graph(tmp_path):

@@ -71,7 +71,9 @@ def main():
             "FETCH_SIZE x 1024 x 2 (MI355X_MICROARCH.md gfx950 correction), write bytes uncorrected")
     steps = 3
     P = os.path.join(ROOT, "profiles")
-    json.dump({"note": note, "steps_in_trace": steps, "kernels": res}, open(os.path.join(P, tag + "_pmc_step.json"), "w"), indent=1)
+    sys.path.insert(0, ROOT)
+    from point2cyl_amd.build import source_hash
+    json.dump({"note": note, "steps_in_trace": steps, "source_hash": source_hash(), "kernels": res}, open(os.path.join(P, tag + "_pmc_step.json"), "w"), indent=1)
     tot_f = sum(e.get("fetch_bytes_per_launch", 0) * e["launches"] for e in res.values()) / steps
     tot_w = sum(e.get("write_bytes_per_launch", 0) * e["launches"] for e in res.values()) / steps
     with open(os.path.join(P, tag + "_pmc_step.md"), "w") as f:

@@ -134,11 +134,81 @@ def g9b(ref):
     save("g9b_step_grads", **arrs)
 
 
+def g15(ref):
+    """G15 g15_dataloader: items of the reference's AutodeskDataset_h5 / AutodeskDataset_h5_sketches (dataloader.py:15-296) on a small
+    in-memory file of the schema utils.py:1174-1188 / :1251-1268 writes (its load_h5 / load_h5_sk are pointed at the arrays: h5py is not
+    installed here), for the flag combinations the scripts use and the full ones, under fixed torch seeds."""
+    import importlib
+    saved = list(sys.path)
+    sys.path[:0] = [_refload.REF_ROOT, os.path.join(_refload.REF_ROOT, "models")]
+    try:
+        dl = importlib.import_module("dataloader")
+    finally:
+        sys.path[:] = saved
+        for name in ("dataloader", "utils", "data_utils", "global_variables", "losses", "pointnet_util", "models", "models.pointnet_util"):
+            sys.modules.pop(name, None)
+    rng = np.random.default_rng(15)
+    n, P, K, S = 3, 96, 8, 40
+    f = dict(point_cloud=rng.normal(size=(n, P, 3)).astype(np.float32), normals=rng.normal(size=(n, P, 3)).astype(np.float32),
+             extrusion_labels=rng.integers(0, 5, (n, P)).astype(np.int64), base_barrel_labels=rng.integers(0, 2, (n, P)).astype(np.int64),
+             n_instances=np.array([5, 8, 3], dtype=np.int64), extrusion_axes=rng.normal(size=(n, K, 3)).astype(np.float32),
+             extrusion_distances=rng.random((n, K)).astype(np.float32), extrusion_operation=rng.integers(0, 3, (n, P)).astype(np.int64),
+             extrusion_centers=rng.normal(size=(n, K, 3)).astype(np.float32), extrusion_extents=rng.random((n, K, 2)).astype(np.float32),
+             sketches=rng.normal(size=(n, K, S, 4)).astype(np.float32), sketches_norms=rng.random((n, K)).astype(np.float32))
+
+    def load_h5(fn, op=False, center=False, extent=False):
+        out = [f[k] for k in ("point_cloud", "normals", "extrusion_labels", "base_barrel_labels", "n_instances", "extrusion_axes", "extrusion_distances")]
+        if op:
+            out.append(f["extrusion_operation"])
+        if center:
+            out.append(f["extrusion_centers"])
+        if extent:
+            out.append(f["extrusion_extents"])
+        return tuple(out)
+
+    def load_h5_sk(fn, op=False, center=False, extent=False):
+        out = [f[k] for k in ("point_cloud", "normals", "extrusion_labels", "base_barrel_labels", "n_instances", "extrusion_axes", "extrusion_distances")]
+        if op:
+            out.append(f["extrusion_operation"])
+        if center:
+            out.append(f["extrusion_centers"])
+        out += [f["sketches"], f["sketches_norms"]]
+        if extent:
+            out.append(f["extrusion_extents"])
+        return tuple(out)
+
+    dl.load_h5, dl.load_h5_sk = load_h5, load_h5_sk
+    arrs = {"file:" + k: v for k, v in f.items()}
+    cases = []
+    for ci, (op, center, extent) in enumerate([(False, True, False), (False, False, False), (True, True, True), (True, False, False)]):
+        ds = dl.AutodeskDataset_h5("mem", 32, K, op=op, center=center, extent=extent)
+        torch.manual_seed(150 + ci)
+        item = ds[ci % n]
+        cases.append(("h5", op, center, False, extent, 150 + ci, ci % n, len(item)))
+        for j, v in enumerate(item):
+            arrs["h5_%d:%d" % (ci, j)] = np.asarray(v)
+    for ci, (op, center, scale, extent) in enumerate([(False, True, False, False), (False, False, False, False), (True, True, True, True),
+                                                      (False, True, True, False), (True, False, False, True)]):
+        ds = dl.AutodeskDataset_h5_sketches("mem", 32, 16, K, op=op, center=center, with_scale=scale, extent=extent)
+        torch.manual_seed(250 + ci)
+        item = ds[(ci + 1) % n]
+        cases.append(("sk", op, center, scale, extent, 250 + ci, (ci + 1) % n, len(item)))
+        for j, v in enumerate(item):
+            arrs["sk_%d:%d" % (ci, j)] = np.asarray(v)
+    arrs["cases"] = np.array([[c[0]] + [str(int(x)) for x in c[1:]] for c in cases])
+    save("g15_dataloader", **arrs)
+
+
 def main():
     ref = _refload.load()
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:
+        for name in sys.argv[1:]:
+            globals()[name](ref)
+        return
     g7b(ref)
     g9b(ref)
+    g15(ref)
 
 
 if __name__ == "__main__":

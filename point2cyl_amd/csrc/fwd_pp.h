@@ -24,3 +24,9 @@ struct FwdPPArgs {
 extern "C" int p2c_linear_fwd_pp_supported(int M, int N, int K, int in_mode);
 int p2c_fwd_pp_launch(const FwdPPArgs &a, int in_mode, hipStream_t s);
 extern "C" int p2c_linear_fwd_pool_supported(int M, int N, int K, int in_mode, int ns);
+
+// bf16x3-split twin of the persistent forward (fwd_pp3.hip): same arguments, same results at fp32 accuracy, 2.7x fewer matrix-pipe cycles.
+int p2c_fwd_pp3_launch(const FwdPPArgs &a, int in_mode, hipStream_t s);
+// 1 (default): the persistent kernels run on the bf16 matrix pipe with three-way split operands; 0: v_mfma_f32_32x32x2_f32.
+// Initialised from the environment (P2C_MFMA=f32 selects 0), changed by p2c_set_mfma_mode (A/B runs, tests).
+int p2c_mfma_split();

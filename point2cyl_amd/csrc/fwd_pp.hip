@@ -20,6 +20,7 @@
 //  * BatchNorm sums stay in registers for the whole kernel: one set of fp64 atomics per workgroup.
 #include "common.h"
 #include "fwd_pp.h"
+#include <stdlib.h>
 
 #define P2C_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -374,8 +375,26 @@ extern "C" int p2c_linear_fwd_pool_supported(int M, int N, int K, int in_mode, i
     return in_mode == 1 && ns == 64 && M >= 8192 && (M % 64) == 0 && (K == 64 || K == 128) && (N % 128) == 0 && N <= 256;
 }
 
+static int g_mfma_split = -1;
+int p2c_mfma_split()
+{
+    if (g_mfma_split < 0) {
+        const char *e = getenv("P2C_MFMA");
+        g_mfma_split = (e && (e[0] == 'f' || e[0] == 'F' || e[0] == '0')) ? 0 : 1;      // "f32" / "0": the fp32-MFMA kernels
+    }
+    return g_mfma_split;
+}
+extern "C" int p2c_set_mfma_mode(int split)
+{
+    const int old = p2c_mfma_split();
+    g_mfma_split = split ? 1 : 0;
+    return old;
+}
+extern "C" int p2c_get_mfma_mode(void) { return p2c_mfma_split(); }
+
 int p2c_fwd_pp_launch(const FwdPPArgs &a, int in_mode, hipStream_t s)
 {
+    if (p2c_mfma_split()) return p2c_fwd_pp3_launch(a, in_mode, s);
     const int K = a.K;          // EX columns already split off by the caller
     if (a.pool_max) {
         if (!a.pool_min || !a.pool_idx || !p2c_linear_fwd_pool_supported(a.M, a.N, K, in_mode, 64)) return P2C_EINVAL;

@@ -234,12 +234,8 @@ def main(argv=None):
     if a.synthetic > 0:
         ds = synth.SyntheticExtrusionDataset(a.synthetic, a.num_point, a.K, seed=99991)
     else:
-        try:
-            import h5py  # noqa: F401
-        except Exception as e:
-            raise SystemExit("reading %s needs h5py (%s); use --synthetic N" % (os.path.join(a.data_dir, a.data_split + ".h5"), e))
-        from .h5data import AutodeskH5
-        ds = AutodeskH5(os.path.join(a.data_dir, a.data_split + ".h5"), a.num_point, a.K)
+        from .h5data import AutodeskH5, dataset_path
+        ds = AutodeskH5(dataset_path(a.data_dir, a.data_split), a.num_point, a.K)
     lo, hi = ddp.shard_range(len(ds), rank, world)                               # clouds are independent: shard, no data-path collective
     loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=a.batch_size, num_workers=0, pin_memory=True,
                                          shuffle=a.data_split != "test")

@@ -1,5 +1,6 @@
-"""The implicit-sketch part of one step of the with-sketch trainer (train_Point2Cyl.py:519-672), default path: predicted labels
-(not --use_gt_im, not --use_whole_pc), angle or L2 latent loss, --with_im_loss.  Composition only - every piece is a kernel path of
+"""The implicit-sketch part of one step of the with-sketch trainer (train_Point2Cyl.py:519-672): predicted labels (not --use_gt_im),
+projected sketches or - --use_whole_pc - the whole cloud with the soft segment membership as a fourth channel (:522-536; the membership
+keeps its gradient, so the latent and decoder losses reach the backbone through the encoder's input), angle or L2 latent loss, --with_im_loss.  Composition only - every piece is a kernel path of
 this package: fitting.sketch_implicit_projection (csrc/fit.hip), sketch.PointNetEncoder (MLP-stack kernels), implicit.ImplicitNet and
 its double backward (csrc/gemm.hip)."""
 import torch
@@ -25,29 +26,39 @@ def implicit_losses(implicit_net, sk_pnts, sk_normals, nonmnfld_pnts, latent_cod
 
 def sketch_branch_losses(pcs, X, W, W_2K, matching_indices, mask, gt_normals, gt_extrusion_instances, gt_bb_labels, gt_extrusion_axes,
                          gt_extrusion_centers, gt_sketches, pn_encoder, loaded_pn_encoder, implicit_net, sampler, K, num_sk_point,
-                         with_im_loss=True, is_l2=False, rand_idx_pred=None, rand_idx_gt=None, nonmnfld_pnts=None):
+                         with_im_loss=True, is_l2=False, rand_idx_pred=None, rand_idx_gt=None, nonmnfld_pnts=None, use_whole_pc=False,
+                         W_encoder=None):
     """train_Point2Cyl.py:519-672.  pcs (B,N,3); X (B,N,3) predicted normals; W (B,N,K) and W_2K (B,N,2K) the softmaxed segmentation;
     matching_indices / mask from hungarian_matching; gt_sketches (B,K,S,4) = [point | normal] of the ground-truth profiles.
+    use_whole_pc: the encoder (4 input channels) sees [xyz | W_reordered[:, :, k]] of all N points per segment instead of the projected
+    sketch; W_encoder = the (B,N,K) segmentation WITH its autograd history (default: W as given).
     -> dict(im_loss, latent_loss, mnfld_loss, grad_loss, normals_loss, latent_codes)."""
     B, N, _ = pcs.shape
     S = num_sk_point
     mask_gt = losses.get_mask_gt(gt_extrusion_instances, K)
-    with torch.no_grad():                                                              # labels: no gradient through the arg-max / sampling
-        W_reordered = torch.gather(W, 2, matching_indices.unsqueeze(1).expand(B, N, K))                                   # :521
-        W_reordered = torch.where(mask.unsqueeze(1).expand(B, N, K) == 1, W_reordered, torch.zeros_like(W_reordered))   # :522
-        label = torch.argmax(W_reordered, dim=-1)                                                                        # :541
-        BB = torch.stack([W_2K[:, :, 0::2].sum(-1), W_2K[:, :, 1::2].sum(-1)], -1)                                       # :544-547
-        pred_bb_label = torch.argmax(BB, dim=-1)
-        pred_pc, pred_nrm, _ = fitting.sketch_implicit_projection(pcs, X, label, pred_bb_label, gt_extrusion_axes, gt_extrusion_centers, S,
-                                                                  rand_idx=rand_idx_pred)                                # :549
-        _, _, gt_scales = fitting.sketch_implicit_projection(pcs, gt_normals, gt_extrusion_instances, gt_bb_labels, gt_extrusion_axes,
-                                                             gt_extrusion_centers, S, rand_idx=rand_idx_gt)             # :550
-        pred_pc = pred_pc / gt_scales.unsqueeze(-1).unsqueeze(-1)                                                        # :552-553
-        global_pc = torch.cat((pred_pc.reshape(B * K, S, 2), pred_nrm.reshape(B * K, S, 2)), dim=-1)                     # :555-558 (the reference's own
-        #                                                                                   (K,B,..) -> (B*K,..) reshape, kept as it is)
+    with torch.no_grad():
         sk_pnts = gt_sketches[:, :, :, :2].reshape(B * K, S, 2)                                                          # :602-604
         sk_normals = gt_sketches[:, :, :, -2:].reshape(B * K, S, 2)
         latent_codes_gt = loaded_pn_encoder(torch.cat((sk_pnts, sk_normals), dim=-1))                                    # :605 (its parameters are frozen)
+    if use_whole_pc:                                                                                                     # :522-536
+        Wg = W if W_encoder is None else W_encoder
+        W_reordered = torch.gather(Wg, 2, matching_indices.unsqueeze(1).expand(B, N, K))                                 # :519
+        W_reordered = torch.where(mask.unsqueeze(1).expand(B, N, K) == 1, W_reordered, torch.zeros_like(W_reordered))   # :520
+        global_pc = torch.cat((pcs.unsqueeze(1).expand(B, K, N, 3), W_reordered.permute(0, 2, 1).unsqueeze(-1)), dim=-1).reshape(B * K, N, 4)
+    else:
+        with torch.no_grad():                                                          # labels: no gradient through the arg-max / sampling
+            W_reordered = torch.gather(W, 2, matching_indices.unsqueeze(1).expand(B, N, K))                               # :519
+            W_reordered = torch.where(mask.unsqueeze(1).expand(B, N, K) == 1, W_reordered, torch.zeros_like(W_reordered))
+            label = torch.argmax(W_reordered, dim=-1)                                                                    # :539
+            BB = torch.stack([W_2K[:, :, 0::2].sum(-1), W_2K[:, :, 1::2].sum(-1)], -1)                                   # :542-546
+            pred_bb_label = torch.argmax(BB, dim=-1)
+            pred_pc, pred_nrm, _ = fitting.sketch_implicit_projection(pcs, X, label, pred_bb_label, gt_extrusion_axes, gt_extrusion_centers, S,
+                                                                      rand_idx=rand_idx_pred)                            # :548
+            _, _, gt_scales = fitting.sketch_implicit_projection(pcs, gt_normals, gt_extrusion_instances, gt_bb_labels, gt_extrusion_axes,
+                                                                 gt_extrusion_centers, S, rand_idx=rand_idx_gt)         # :549
+            pred_pc = pred_pc / gt_scales.unsqueeze(-1).unsqueeze(-1)                                                    # :551-552
+            global_pc = torch.cat((pred_pc.reshape(B * K, S, 2), pred_nrm.reshape(B * K, S, 2)), dim=-1)                 # :554-557 (the reference's own
+            #                                                                               (K,B,..) -> (B*K,..) reshape, kept as it is)
     latent_codes = pn_encoder(global_pc)                                                                                 # :559
     zero = torch.zeros((), device=pcs.device)
     if with_im_loss:

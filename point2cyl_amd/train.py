@@ -96,12 +96,8 @@ class ResidentDataset:
 def load_dataset(a, rank=0):
     if a.synthetic > 0:
         return synth.SyntheticExtrusionDataset(a.synthetic, a.num_point, a.K, seed=1234), False
-    try:
-        import h5py  # noqa: F401
-    except Exception as e:
-        raise SystemExit("reading %s needs h5py (%s); use --synthetic N" % (os.path.join(a.data_dir, a.data_split + ".h5"), e))
-    from .h5data import AutodeskH5
-    return AutodeskH5(os.path.join(a.data_dir, a.data_split + ".h5"), None, a.K), True
+    from .h5data import AutodeskH5, dataset_path
+    return AutodeskH5(dataset_path(a.data_dir, a.data_split), None, a.K), True
 
 
 class Runner:

@@ -98,8 +98,8 @@ def synthetic_sketches(data, K, S, dev, chunk=16):
 
 def main(argv=None):
     a = build_parser().parse_args(argv)
-    if a.use_whole_pc or a.use_gt_im or a.use_extrusion_axis_feat or a.is_implicitnet_train:
-        raise SystemExit("--use_whole_pc / --use_gt_im / --use_extrusion_axis_feat / --is_implicitnet_train are variants of the reference "
+    if a.use_gt_im or a.use_extrusion_axis_feat or a.is_implicitnet_train:
+        raise SystemExit("--use_gt_im / --use_extrusion_axis_feat / --is_implicitnet_train are variants of the reference "
                          "trainer that this package does not build (DESIGN.md section 7)")
     if not (a.is_pc_train or a.is_im_train):
         raise SystemExit("nothing to train: pass --is_pc_train and/or --is_im_train (train_Point2Cyl.py:298-321)")
@@ -122,7 +122,10 @@ def _main(a, rank, world, dev):
         raise SystemExit("the sketch branch needs --pred_seg --pred_normal --pred_bb (labels, base/barrel split and normals feed the projection)")
     model = backbone(output_sizes=fl.pred_sizes()).to(dev)                                                   # train_Point2Cyl.py:256
     implicit_net = ImplicitNet(d_in=2 + 256, dims=[512] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100).to(dev)   # :268
-    pn_encoder = PointNetEncoder(256, 2, with_normals=True).to(dev)                                          # :270
+    if a.use_whole_pc:                                                                                       # :268-276: [xyz | membership] of the whole cloud
+        pn_encoder = PointNetEncoder(256, 4, with_normals=False).to(dev)
+    else:
+        pn_encoder = PointNetEncoder(256, 2, with_normals=True).to(dev)                                      # :270
     loaded_pn_encoder = PointNetEncoder(256, 2, with_normals=True).to(dev)                                   # :280
     for m_ in (model, implicit_net, pn_encoder, loaded_pn_encoder):
         ddp.broadcast_module(m_)
@@ -179,12 +182,31 @@ def _main(a, rank, world, dev):
     loaded_pn_encoder.eval()
     np.random.seed(0 + rank)
     torch.manual_seed(a.seed + 7919 * rank)
-    if a.synthetic <= 0:
-        raise SystemExit("reading %s needs h5py and the dataset; use --synthetic N" % os.path.join(a.data_dir, a.data_split + ".h5"))
-    ds = synth.SyntheticExtrusionDataset(a.synthetic, N, K, seed=1234)
+    file_sketches = None
+    if a.synthetic > 0:
+        ds = synth.SyntheticExtrusionDataset(a.synthetic, N, K, seed=1234)
+    else:
+        # train_Point2Cyl.py:215: AutodeskDataset_h5_sketches(H5_FILENAME, NUM_POINT, NUM_SK_POINT, K, op=False, center=True, extent=False).
+        # The resident loader keeps every cloud whole (the per-step subsample is drawn on the device); the sketches come with it
+        from .h5data import AutodeskH5Sketches, dataset_path
+        ds = AutodeskH5Sketches(dataset_path(a.data_dir, a.data_split), None, S, K, op=False, center=True, extent=False)
+        file_sketches = True
     lo, hi = ddp.shard_range(len(ds), rank, world)
-    data = ResidentDataset(torch.utils.data.Subset(ds, range(lo, hi)) if world > 1 else ds, dev, N)
-    sketches = synthetic_sketches(data, K, S, dev)
+    if file_sketches:
+        items = [ds[i] for i in range(lo, hi)]
+        file_sketches = torch.from_numpy(np.stack([np.asarray(it[9]) for it in items])).to(dev, torch.float)        # (n, K, S, 4)
+
+        class _Nine(torch.utils.data.Dataset):          # the 9 fields of the sketch-free item (the sketch is item 9)
+            def __len__(self):
+                return len(items)
+
+            def __getitem__(self, i):
+                return items[i][:9]
+        data = ResidentDataset(_Nine(), dev, N, subsample=True)
+        sketches = file_sketches
+    else:
+        data = ResidentDataset(torch.utils.data.Subset(ds, range(lo, hi)) if world > 1 else ds, dev, N)
+        sketches = synthetic_sketches(data, K, S, dev)
     B = min(a.batch_size, len(data))
     nb = len(data) // B
     if world > 1:
@@ -222,8 +244,13 @@ def _main(a, rank, world, dev):
                     else:
                         X, W2K = out["X"].detach(), torch.softmax(out["W_raw"].detach(), dim=2)
                     W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
+                W_enc = None
+                if a.use_whole_pc and a.is_pc_train:     # the membership channel keeps its history: the sketch losses reach the backbone (:519-536)
+                    Wg = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2) if h is not None else torch.softmax(out["W_raw"], dim=2)
+                    W_enc = Wg[:, :, 0::2] + Wg[:, :, 1::2]
                 sk = step_sketch.sketch_branch_losses(pcs, X, W, W2K, out["match"], out["mask"], nrm, inst, bb, axes, cen, gt_sk, pn_encoder,
-                                                      loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2)
+                                                      loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2,
+                                                      use_whole_pc=a.use_whole_pc, W_encoder=W_enc)
                 total = (out["total"] + sk["im_loss"]) if a.is_pc_train else sk["im_loss"]                    # :690-693
                 sync.zero()
                 mom_fwd = step.get_batch_norm_decay(gstep, B, a.bn_decay_step)                                # :698-701 (reaches the next forward)

@@ -160,12 +160,18 @@ def test_config2_full_loss_step_graph_path_vs_oracle_fp32_and_fp64(B, N):
         a = np.abs(got - a64).max() / (3 * ref_err + 1e-6 * np.abs(a64).max())
         b = _relnorm(got, a64) / (3 * _relnorm(a32, a64) + 1e-6)
         ok &= _rec(tag + "grad[%s] min(max-abs ratio %.2f, relnorm ratio %.2f) vs 3x the fp32 oracle's distance from float64" % (name, a, b), min(a, b), 1.0)
+        # Adam's first update is -lr * g / (|g| + eps): (i) the optimiser applied exactly that to OUR gradient; (ii) where the gradient's
+        # sign is determined - |g64| above 10x the fp32 oracle's own max error on this tensor - the update equals the float64 run's.
+        # (Elsewhere the update is +-lr by the sign of rounding noise, for the fp32 oracle alike: one flipped element of a 256-vector
+        # is a relative norm of 0.125.)
         d_me = (after[name] - before[name]).cpu().double().numpy().reshape(a64.shape)
-        d32 = (r32["params_after"][name].double() - sd0[name].double()).numpy()
+        ok &= _rec(tag + "Adam delta[%s] max|delta + lr*g/(|g|+eps)| / lr (the optimiser on our gradient)" % name,
+                   float(np.abs(d_me + 1e-3 * got / (np.abs(got) + 1e-8)).max() / 1e-3), 2e-4)
         d64 = (r64["params_after"][name] - sd0[name].double()).numpy()
-        # Adam's first update is -lr * g / (|g| + eps): where |g| is not >> eps it amplifies any gradient difference, for the fp32 oracle alike
-        ok &= _rec(tag + "Adam delta[%s] relnorm vs float64 (bound 3x the fp32 oracle's %.2e + 1e-4)" % (name, _relnorm(d32, d64)),
-                   _relnorm(d_me, d64), 3 * _relnorm(d32, d64) + 1e-4)
+        det = np.abs(a64) > 10 * ref_err + 1e-12
+        if det.any():
+            ok &= _rec(tag + "Adam delta[%s] max|ours - float64| / lr where the sign is determined (%.1f %% of the elements)" % (name, 100.0 * det.mean()),
+                       float(np.abs(d_me - d64)[det].max() / 1e-3), 0.05)
     for k in ("sa1.mlp_bns.0.running_mean", "sa1.mlp_bns.2.running_var", "sa2.mlp_bns.2.running_var", "sa3.mlp_bns.1.running_var",
               "fp3.mlp_bns.0.running_mean", "fp1.mlp_bns.0.running_mean", "bn1.running_var"):
         a, b = m.state_dict()[k].cpu().numpy(), r32["buffers"][k].numpy()
@@ -213,16 +219,17 @@ def test_config4_sketch_branch_full_size_vs_oracle(B, with_f64):
     g_dec = {n: p.grad.detach().cpu() for n, p in dec.named_parameters() if p.grad is not None}
     lat_mine = out["latent_codes"].detach().cpu()
 
+    # the projections are integer sampling + one rotation per segment: evaluated once in fp32 (they feed every run the same way)
+    dk = lambda r: {(k, b): r[b, k] for k in range(K) for b in range(B)}
+    pP, pX, _, _ = R.sketch_implicit_projection(pcs, X, label, pbb, axes, cen, dk(r_pred), S)
+    _, _, gsc, _ = R.sketch_implicit_projection(pcs, nrm, seg, bb, axes, cen, dk(r_gt), S)
+    gpc = torch.cat(((pP / gsc.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2), pX.reshape(B * K, S, 2)), -1)
+
     def oracle(dtype):
         old = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         try:
             c = lambda v: v.to(dtype) if v.dtype.is_floating_point else v
-            dk = lambda r: {(k, b): r[b, k] for k in range(K) for b in range(B)}
-            # the projections are integer sampling + one rotation per segment: always evaluated in fp32 (they feed both sides the same way)
-            pP, pX, _, _ = R.sketch_implicit_projection(pcs, X, label, pbb, axes, cen, dk(r_pred), S)
-            _, _, gsc, _ = R.sketch_implicit_projection(pcs, nrm, seg, bb, axes, cen, dk(r_gt), S)
-            gpc = torch.cat(((pP / gsc.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2), pX.reshape(B * K, S, 2)), -1)
             e = {k: c(v.clone()) for k, v in sd_e.items()}
             gg = {k: c(v.clone()) for k, v in sd_g.items()}
             dd = {k: c(v.clone()) for k, v in sd_d.items()}
@@ -239,15 +246,15 @@ def test_config4_sketch_branch_full_size_vs_oracle(B, with_f64):
             (im + ll).backward()
             return (dict(im_loss=(im + ll).item(), latent_loss=ll.item(), mnfld_loss=mn.item(), grad_loss=ek.item(), normals_loss=nl.item()),
                     {k: v.grad.detach() for k, v in e.items() if v.requires_grad}, {k: v.grad.detach() for k, v in dd.items() if v.requires_grad and v.grad is not None},
-                    lat.detach(), gpc)
+                    lat.detach())
         finally:
             torch.set_default_dtype(old)
 
-    l32, ge32, gd32, lat32, gpc = oracle(torch.float32)
+    l32, ge32, gd32, lat32 = oracle(torch.float32)
     tag = "config4 sketch branch B=%d (%d sketches x %d) " % (B, B * K, S)
     ok = True
     if with_f64:
-        l64, ge64, gd64, lat64, _ = oracle(torch.float64)
+        l64, ge64, gd64, lat64 = oracle(torch.float64)
     for k in got:
         ok &= _rec(tag + "loss[%s] rel. diff vs fp32 oracle (ours %.7f, ref32 %.7f)" % (k, got[k], l32[k]), abs(got[k] - l32[k]) / abs(l32[k]), 2e-4)
         if with_f64:
@@ -255,8 +262,14 @@ def test_config4_sketch_branch_full_size_vs_oracle(B, with_f64):
                        abs(got[k] - l64[k]) / abs(l64[k]), 2e-4)
     ok &= _rec(tag + "latent codes max|ours - ref32| (unit vectors)", float((lat_mine - lat32).abs().max()), 1e-4)
     gmax = max(float(v.norm()) for v in ge32.values())
+    import re
     for n, gmine in g_enc.items():
         r = ge32[n].double().numpy()
+        if re.match(r"mlp[12]\.[036]\.bias$", n):
+            # a bias in front of a train-mode BatchNorm: analytically zero gradient - rounding noise in the oracle (1e-2 of gmax in fp32,
+            # 1e-11 in float64), zero or noise here
+            ok &= _rec(tag + "encoder grad[%s] (analytically zero) |ours| vs 10x the fp32 oracle's noise" % n, float(gmine.double().norm()), 10 * float(np.linalg.norm(r)) + 1e-12)
+            continue
         if with_f64:
             r64 = ge64[n].numpy()
             ok &= _rec(tag + "encoder grad[%s] relnorm vs float64 (bound 3x the fp32 oracle's %.2e + 1e-4)" % (n, _relnorm(r, r64)),

@@ -204,6 +204,13 @@ def _check_mlp_stack(tail, M, K0, widths, G, ns, xgrad):
     yref, rstats = _ref_stack(X0r, params, tail, G, ns, True, mask)
     go = torch.randn(yref.shape, generator=g)
     yref.backward(go)
+    ref64 = None
+    if M >= 8192 and (tail == "maxpool" or max(widths) >= 256):
+        # the same stack in float64: the yardstick for the gradients of the large max-pool / ReLU cases (see below)
+        p64 = [{k: (v.detach().double().requires_grad_(True) if k in ("W", "b", "gamma", "beta") else v.double()) for k, v in p.items()} for p in params]
+        y64, _ = _ref_stack(X0[:, :K0].double(), p64, tail, G, ns, True, None if mask is None else mask.double())
+        y64.backward(go.double())
+        ref64 = [p[k].grad.numpy() for p in p64 for k in ("W", "b", "gamma", "beta") if k in p]
     # device
     layers, dev_leaves = [], []
     for p in params:
@@ -235,7 +242,10 @@ def _check_mlp_stack(tail, M, K0, widths, G, ns, xgrad):
             # tens of thousands of max-pool winners / a million ReLU decisions: a handful of near-ties (candidates or pre-activations
             # within rounding of each other / of zero) resolve differently from the CPU reference and move single rows of gradient,
             # so compare in norm
-            assert np.linalg.norm(got - ref) <= 3e-3 * np.linalg.norm(ref), (i, np.linalg.norm(got - ref) / np.linalg.norm(ref))
+            # against float64: no further away than 3x the fp32 CPU reference is, or 3e-3 of the gradient's norm
+            r64 = ref64[i].reshape(ref.shape)
+            e_me, e_ref = np.linalg.norm(got - r64), np.linalg.norm(ref.astype(np.float64) - r64)
+            assert e_me <= max(3e-3 * np.linalg.norm(r64), 3 * e_ref), (i, e_me / np.linalg.norm(r64), e_ref / np.linalg.norm(r64))
             continue
         np.testing.assert_allclose(got, ref, rtol=2e-3, atol=tol)
     if not xgrad:
@@ -494,6 +504,9 @@ def test_train_step_golden():
     np.testing.assert_allclose(out["total"].item(), float(gb["total64"]), rtol=1e-4)
     grads = dict(zip([n for n, _ in m.named_parameters()], _GRADS_BEFORE_STEP))
     gmax64 = max(float(np.linalg.norm(gb["g64:" + str(n)])) for n in gb["kept"])
+    rels = [np.linalg.norm(gb["g32:" + str(n)].astype(np.float64) - gb["g64:" + str(n)]) / np.linalg.norm(gb["g64:" + str(n)]) for n in gb["kept"]
+            if np.linalg.norm(gb["g64:" + str(n)]) >= 1e-7 * gmax64]
+    rel_med = float(np.median(rels))
     for n in gb["kept"]:
         n = str(n)
         r32, r64 = gb["g32:" + n].astype(np.float64), gb["g64:" + n]
@@ -504,13 +517,17 @@ def test_train_step_golden():
         if np.linalg.norm(r64) < 1e-7 * gmax64:           # analytically zero at B=2 (SA3's last BatchNorm: two rows normalise to +-1): noise
             assert np.linalg.norm(got) <= 10 * np.linalg.norm(r32) + 1e-9 * gmax64, n
             continue
+        # yardstick per tensor: 3x the reference's own fp32 distance from float64 on THIS tensor, or the reference's MEDIAN relative
+        # distance over all tensors (B = 2: SA3 / FP3 normalise two rows per channel - a chain this ill-conditioned makes the per-tensor
+        # fp32 error of any implementation scatter by an order of magnitude; the reference's own spreads from 1e-3 to 1.2e-2)
         ref_err = np.abs(r32 - r64).max()
         a = np.abs(got - r64).max() / (3 * ref_err + 1e-6 * np.abs(r64).max())
-        b = (np.linalg.norm(got - r64) / np.linalg.norm(r64)) / (3 * np.linalg.norm(r32 - r64) / np.linalg.norm(r64) + 1e-6)
-        assert min(a, b) <= 1.0, (n, a, b)
+        rel_me, rel_ref = np.linalg.norm(got - r64) / np.linalg.norm(r64), np.linalg.norm(r32 - r64) / np.linalg.norm(r64)
+        b = rel_me / (max(3 * rel_ref, rel_med) + 1e-6)
+        assert min(a, b) <= 1.0, (n, a, b, rel_me, rel_ref, rel_med)
     for n, nrm64, rel32 in zip(gb["big_names"], gb["big_norm64"], gb["big_relerr32"]):
         got = float(grads[str(n)].double().norm())
-        assert abs(got - nrm64) <= (3 * rel32 + 1e-6) * nrm64, (str(n), got, nrm64)
+        assert abs(got - nrm64) <= (max(3 * rel32, rel_med) + 1e-6) * nrm64, (str(n), got, nrm64)
     # Adam's first update on those gradients is -lr * g / (|g| + 1e-8): checked against that formula on OUR gradients (the optimiser),
     # and against the reference's update where its gradient is not ~0
     for k in g:
@@ -974,6 +991,66 @@ def test_sketch_branch_step_vs_oracle():
     for n, p in enc.named_parameters():
         ref = sd_e[n].grad.numpy()
         assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 5e-3 * np.linalg.norm(ref) + 1e-5 * gmax, n
+
+
+def test_sketch_branch_whole_pc_vs_oracle():
+    """--use_whole_pc (train_Point2Cyl.py:268-276, :519-536): the encoder (4 input channels, no normals) sees [xyz | reordered soft
+    membership] of all N points per segment; the membership keeps its gradient, so the latent / decoder losses reach the segmentation
+    logits.  Losses, encoder gradients and the gradient w.r.t. the logits against the oracle's composition."""
+    from point2cyl_amd import synth, step_sketch
+    from point2cyl_amd.sketch import PointNetEncoder
+    from point2cyl_amd.implicit import ImplicitNet
+    B, N, K, S, E = 3, 1024, 8, 64, 24
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=78)
+    pcs, nrm, axes, cen = pcs.float(), nrm.float(), axes.float(), cen.float()
+    gen = torch.Generator().manual_seed(7)
+    X = F.normalize(nrm + 0.1 * torch.randn(B, N, 3, generator=gen), dim=-1)
+    logits = torch.randn(B, N, 2 * K, generator=gen) + 5 * F.one_hot(seg * 2 + bb, 2 * K)
+    W2K0 = torch.softmax(logits, -1)
+    W0 = W2K0[:, :, 0::2] + W2K0[:, :, 1::2]
+    match, mask = R.hungarian_matching(W0, seg)
+    torch.manual_seed(14)
+    enc, enc_gt = PointNetEncoder(E, 4, with_normals=False), PointNetEncoder(E, 2, with_normals=True).eval()
+    dec = ImplicitNet(d_in=2 + E, dims=[64] * 8, skip_in=[4])
+    sd_e = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    sd_g = {k: v.detach().clone() for k, v in enc_gt.state_dict().items()}
+    sd_d = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    gt_sk = torch.cat([torch.randn(B, K, S, 2, generator=gen) * 0.4, F.normalize(torch.randn(B, K, S, 2, generator=gen), dim=-1)], -1)
+    non = torch.cat([gt_sk[..., :2].reshape(B * K, S, 2) + 0.02 * torch.randn(B * K, S, 2, generator=gen), torch.rand(B * K, S // 8, 2, generator=gen) * 2 - 1], 1)
+    d = lambda x: x.to(DEV)
+    enc, enc_gt, dec = enc.to(DEV).train(), enc_gt.to(DEV), dec.to(DEV)
+    lg = d(logits).requires_grad_(True)
+    W2K = torch.softmax(lg, -1)
+    Wg = W2K[:, :, 0::2] + W2K[:, :, 1::2]
+    out = step_sketch.sketch_branch_losses(d(pcs), d(X), Wg.detach(), W2K.detach(), d(match), d(mask), d(nrm), d(seg), d(bb), d(axes), d(cen), d(gt_sk), enc, enc_gt,
+                                           dec, None, K, S, nonmnfld_pnts=d(non), use_whole_pc=True, W_encoder=Wg)
+    out["im_loss"].backward()
+    # the oracle's composition
+    lr = logits.clone().requires_grad_(True)
+    W2 = torch.softmax(lr, -1)
+    Wr = W2[:, :, 0::2] + W2[:, :, 1::2]
+    Wre = torch.gather(Wr, 2, match.unsqueeze(1).expand(B, N, K))
+    Wre = torch.where(mask.unsqueeze(1).expand(B, N, K), Wre, torch.zeros_like(Wre))
+    gpc = torch.cat((pcs.unsqueeze(1).repeat(1, K, 1, 1), Wre.permute(0, 2, 1).unsqueeze(-1)), -1).reshape(B * K, N, 4)
+    for k in sd_e:
+        if sd_e[k].dtype == torch.float32 and "running" not in k:
+            sd_e[k].requires_grad_(True)
+    lat = R.pointnet_encoder_forward(sd_e, gpc, training=True)
+    skp, skn = gt_sk[..., :2].reshape(B * K, S, 2), gt_sk[..., -2:].reshape(B * K, S, 2)
+    lat_gt = R.pointnet_encoder_forward(sd_g, torch.cat((skp, skn), -1), training=False)
+    mask_gt = R.get_mask_gt(seg, K)
+    im, mn, ek, nl = R.implicit_losses(sd_d, skp, skn, non, lat, mask_gt, B, K)
+    ll = R.reduce_mean_masked_instance(1.0 - (lat.reshape(B, K, -1) * lat_gt.reshape(B, K, -1)).sum(-1), mask_gt).mean()
+    (im + ll).backward()
+    got = [out[k].item() for k in ("im_loss", "latent_loss", "mnfld_loss", "grad_loss", "normals_loss")]
+    np.testing.assert_allclose(got, [(im + ll).item(), ll.item(), mn.item(), ek.item(), nl.item()], rtol=2e-4)
+    gmax = max(float(sd_e[n].grad.norm()) for n, _ in enc.named_parameters())
+    for n, p in enc.named_parameters():
+        ref = sd_e[n].grad.numpy()
+        assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 5e-3 * np.linalg.norm(ref) + 2e-2 * 1e-3 * gmax + 1e-5 * gmax, n
+    gl, gr = lg.grad.cpu().numpy(), lr.grad.numpy()
+    assert np.linalg.norm(gl - gr) <= 5e-3 * np.linalg.norm(gr), np.linalg.norm(gl - gr) / np.linalg.norm(gr)
+    assert np.linalg.norm(gr) > 0
 
 
 @pytest.mark.parametrize("n", [1, 3, 4, 1023, 4098, 300007])

@@ -201,20 +201,57 @@ def test_add_noise_golden():
     assert np.array_equal(out.numpy(), g["out"])
 
 
-def test_h5_reader_item_layout(tmp_path):
-    """dataloader.py:69-96 item logic on a tiny file written with the reference's schema (utils.py:1174-1188)."""
-    h5py = pytest.importorskip("h5py", reason="h5py is not installed in this image (no dataset on the box either)")
-    from point2cyl_amd.h5data import AutodeskH5
-    rng = np.random.default_rng(0)
-    n, P, K = 3, 40, 8
-    arrs = dict(point_cloud=rng.normal(size=(n, P, 3)), normals=rng.normal(size=(n, P, 3)), extrusion_labels=rng.integers(0, 3, (n, P)),
-                base_barrel_labels=rng.integers(0, 2, (n, P)), extrusion_axes=rng.normal(size=(n, K, 3)), extrusion_distances=rng.random((n, K)),
-                extrusion_centers=rng.normal(size=(n, K, 3)))
+def test_dataset_readers_match_the_reference_dataloader(tmp_path):
+    """G15 (oracle/make_golden_r3.py): items of the reference's AutodeskDataset_h5 and AutodeskDataset_h5_sketches on a small in-memory
+    file, for the flag combinations the scripts use and the full ones, under fixed seeds - h5data's readers must return the same tuples,
+    field for field (values, order, shapes), from the same arrays through the dict source, and through an .npz export of them."""
+    from tests.conftest import load_golden
+    from point2cyl_amd.h5data import AutodeskH5, AutodeskH5Sketches
+    g = load_golden("g15_dataloader")
+    f = {k[5:]: g[k] for k in g if k.startswith("file:")}
+    npz = str(tmp_path / "train.npz")
+    np.savez(npz, **f)
+    n_h5 = n_sk = 0
+    for row in g["cases"]:
+        kind, (op, center, scale, extent, seed, index, n_fields) = str(row[0]), [int(x) for x in row[1:]]
+        for src in (f, npz):
+            if kind == "h5":
+                ds = AutodeskH5(src, 32, 8, op=bool(op), center=bool(center), extent=bool(extent))
+                tag = "h5_%d" % n_h5
+            else:
+                ds = AutodeskH5Sketches(src, 32, 16, 8, op=bool(op), center=bool(center), with_scale=bool(scale), extent=bool(extent))
+                tag = "sk_%d" % n_sk
+            assert len(ds) == 3
+            torch.manual_seed(seed)
+            item = ds[index]
+            assert len(item) == n_fields, (tag, len(item), n_fields)
+            for j, v in enumerate(item):
+                ref = g["%s:%d" % (tag, j)]
+                assert np.asarray(v).shape == ref.shape and np.array_equal(np.asarray(v), ref), (tag, j)
+        if kind == "h5":
+            n_h5 += 1
+        else:
+            n_sk += 1
+    assert n_h5 == 4 and n_sk == 5
+    # whole-item mode (the device-resident trainers subsample on the GPU): no draw, every point
+    ds = AutodeskH5Sketches(f, None, 16, 8, center=True)
+    it = ds[0]
+    assert it[0].shape == (96, 3) and np.array_equal(it[0], f["point_cloud"][0]) and it[9].shape == (8, 16, 4)
+
+
+def test_h5py_file_source_when_available(tmp_path):
+    """The same readers on a real HDF5 file written with the reference's schema (utils.py:1174-1188) - only where h5py exists."""
+    h5py = pytest.importorskip("h5py", reason="h5py is not installed in this image (the readers are covered through the dict / .npz sources)")
+    from tests.conftest import load_golden
+    from point2cyl_amd.h5data import AutodeskH5Sketches
+    g = load_golden("g15_dataloader")
     path = str(tmp_path / "t.h5")
-    with h5py.File(path, "w") as f:
-        for k, v in arrs.items():
-            f.create_dataset(k, data=v)
-    ds = AutodeskH5(path, 16, K)
-    it = ds[1]
-    assert len(ds) == 3 and len(it) == 9 and it[0].shape == (16, 3) and it[2].dtype == np.int64 and it[6].shape == (K, 3)
-    assert np.allclose(it[4], arrs["extrusion_axes"][1][it[2]])
+    with h5py.File(path, "w") as fh:
+        for k in g:
+            if k.startswith("file:"):
+                fh.create_dataset(k[5:], data=g[k])
+    ds = AutodeskH5Sketches(path, 32, 16, 8, center=True)
+    torch.manual_seed(250)
+    item = ds[1]
+    for j, v in enumerate(item):
+        assert np.array_equal(np.asarray(v), g["sk_0:%d" % j])

@@ -1,5 +1,6 @@
 // Trace build of the persistent forward kernel: fwd_pp.hip + a plain C entry (the product entry lives in gemm.hip).
 #include "../point2cyl_amd/csrc/fwd_pp.hip"
+#include "../point2cyl_amd/csrc/fwd_pp3.hip"      // the bf16x3-split twin (selected at run time: P2C_MFMA=f32 runs the fp32-MFMA kernel)
 extern "C" int p2c_trace_fwd(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
                              const float *sc, const float *sh, double *partials, void *stream)
 {

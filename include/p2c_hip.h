@@ -43,7 +43,8 @@ const char *p2c_build_arch(void);     /* "gfx950" */
 /* farthest_point_sample, models/pointnet_util.py:63-84.
  * xyz [B,N,3]; start [B] int64 = the reference's torch.randint(0,N,(B,)) draw (:75), made by the caller on
  * the CPU generator exactly like the reference; idx_out [B,npoint]; new_xyz_out [B,npoint,3] (optional,
- * = index_points(xyz, idx), :127).  N <= 16384. */
+ * = index_points(xyz, idx), :127).  N <= 65536 (above 16384 the coordinates are re-read from memory every
+ * iteration; same indices). */
 int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start, int npoint, int32_t *idx_out,
                 float *new_xyz_out, void *stream);
 
@@ -191,6 +192,15 @@ int p2c_group_colsum_bn_f32(const float *dz, int lddz, const float *y, int ldy, 
 /* 1 if p2c_linear_fwd_f32 runs this shape on the persistent weight-stationary kernel (fwd_pp.hip: M >= 8192, N <= 256,
  * K <= 128 or the grouped K == 132, no byte mask); otherwise the tiled kernel is used.  Same results either way. */
 int p2c_linear_fwd_pp_supported(int M, int N, int K, int in_mode);
+
+/* Which matrix pipe the persistent kernels (p2c_linear_fwd_f32 / _pool / _fold0 on the fwd_pp path, p2c_linear_bwd_fused_f32) use.
+ *   1 (default): bf16x3 split - every fp32 operand is split into three bf16 pieces while its tile is staged and a 32x32x16 block is
+ *      accumulated from six v_mfma_f32_32x32x16_bf16 products in the fp32 accumulator (fwd_pp3.hip, bwd_fused3.hip): fp32-class
+ *      accuracy (the same parity tests pass in both modes) at 2.7x fewer matrix-pipe cycles.
+ *   0: v_mfma_f32_32x32x2_f32 (fwd_pp.hip, bwd_fused.hip).  Initial value from the environment: P2C_MFMA=f32 selects 0.
+ * p2c_set_mfma_mode returns the previous mode.  Not thread-safe against concurrent launches (a process-wide A/B switch). */
+int p2c_set_mfma_mode(int split);
+int p2c_get_mfma_mode(void);
 
 /* BatchNorm batch statistics -> affine.  training != 0: mean/var from the slots (biased var for the
  * normalisation, unbiased for running_var, torch semantics), running stats updated in place with

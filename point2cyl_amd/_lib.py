@@ -114,6 +114,10 @@ def lib():
     L.p2c_linear_bwd_fused_supported.restype = c_i
     L.p2c_linear_fwd_pp_supported.argtypes = [c_i, c_i, c_i, c_i]
     L.p2c_linear_fwd_pp_supported.restype = c_i
+    L.p2c_set_mfma_mode.argtypes = [c_i]
+    L.p2c_set_mfma_mode.restype = c_i
+    L.p2c_get_mfma_mode.argtypes = []
+    L.p2c_get_mfma_mode.restype = c_i
     L.p2c_linear_bwd_fused_parts.argtypes = [c_i, c_i]
     L.p2c_linear_bwd_fused_parts.restype = c_i
     L.p2c_linear_tile_m.restype = c_i

@@ -19,7 +19,14 @@
 //         Xr [2][BM][Ci+4]         raw X tile: B operand of dW after act_in on the fly (k = m, j = ci), and the
 //                                  y values the fused reduction needs in the dX epilogue
 #include "common.h"
+#include "fwd_pp.h"          // p2c_mfma_split()
 #include <stdlib.h>
+
+// bf16x3-split twin (bwd_fused3.hip): one wave per SIMD, W resident in registers; same arguments, fp32-accurate results
+int p2c_bwd_fused3_launch(const float *dZ, int lddz, const float *Yfwd, int ldy, int grad_mode, const float *coef, const int32_t *pool_arg,
+                          int pool_ns, const float *X, int ldx, int in_mode, const float *in_scale, const float *in_shift, const float *W, int ldw,
+                          float *dX, int lddx, float *dW, int lddw, long long dw_slot_stride, float *dbias, const float *prev_stat,
+                          double *bwd_partials, int M, int Co, int Ci, int coef_ld, int arg_ld, int dx_atomic, hipStream_t s);
 
 
 // Workgroup barrier that only drains the LDS queue.  __syncthreads() also waits for every outstanding global
@@ -735,6 +742,14 @@ extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *
         for (int h = 0; h < 2; ++h) {
             BwdFusedArgs b = a;
             const int c0 = 128 * h;
+            if (p2c_mfma_split()) {
+                const int rc3 = p2c_bwd_fused3_launch(dZ + c0, lddz, Yfwd ? Yfwd + c0 : nullptr, ldy, grad_mode, coef ? coef + c0 : nullptr,
+                                                      pool_arg ? pool_arg + c0 : nullptr, pool_ns, X, ldx, in_mode, in_scale, in_shift,
+                                                      W + (size_t)c0 * ldw, ldw, dX, lddx, dW + (size_t)c0 * lddw, lddw, dw_slot_stride, nullptr,
+                                                      prev_stat, bwd_partials, M, 128, 128, 256, 256, h, s);
+                if (rc3 != P2C_OK) return rc3;
+                continue;
+            }
             b.dz = dZ + c0; b.y = Yfwd ? Yfwd + c0 : nullptr; b.coef = coef ? coef + c0 : nullptr; b.arg = pool_arg ? pool_arg + c0 : nullptr;
             b.w = W + (size_t)c0 * ldw; b.dw = dW + (size_t)c0 * lddw;
             b.coef_ld = 256; b.arg_ld = 256; b.dx_atomic = h;
@@ -748,6 +763,9 @@ extern "C" int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *
         }
         return P2C_OK;
     }
+    if (!extra && p2c_mfma_split())
+        return p2c_bwd_fused3_launch(dZ, lddz, Yfwd, ldy, grad_mode, coef, pool_arg, pool_ns, X, ldx, in_mode, in_scale, in_shift, W, ldw, dX, lddx,
+                                     dW, lddw, dw_slot_stride, dbias, prev_stat, bwd_partials, M, Co, Ci, 0, 0, 0, s);
 #define P2C_F(G_, I_) return dispatch_shape<G_, I_>(Co, Ci, extra, a, s)
     if (grad_mode == 0) { if (in_mode == 0) P2C_F(0, 0); P2C_F(0, 1); }
     if (grad_mode == 1) { if (in_mode == 0) P2C_F(1, 0); P2C_F(1, 1); }

@@ -29,7 +29,9 @@ __device__ __forceinline__ float p2c_sqdist(float sx, float sy, float sz, float 
 // =============================================================================================
 // LDSXYZ: keep the SoA copy of the cloud in LDS for the centroid broadcast (N*12 B must fit in 160 KB);
 // otherwise the centroid is re-read from global memory each iteration (large-N fallback, slower).
-template <int PPT, bool LDSXYZ>
+// REGXYZ = false (clouds above 16384 points, PPT 32 / 64): only the running distances stay in registers, the coordinates are re-read
+// from memory (L2) in every iteration - the same arithmetic and tie rule, for sizes the reference's own (B, N) loop handles slowly too.
+template <int PPT, bool LDSXYZ, bool REGXYZ = true>
 __global__ void __launch_bounds__(1024) fps_kernel(const float *__restrict__ xyz, int N, const int64_t *__restrict__ start,
                                                    int npoint, int32_t *__restrict__ idx_out, float *__restrict__ new_xyz_out)
 {
@@ -51,14 +53,16 @@ __global__ void __launch_bounds__(1024) fps_kernel(const float *__restrict__ xyz
     if (tid < 64) { red[tid] = (tid & 1) ? 0 : (int)0xBF800000; }   // value slots = -1.0f, index slots = 0
     __syncthreads();
 
-    float px[PPT], py[PPT], pz[PPT], dist[PPT];
+    float px[REGXYZ ? PPT : 1], py[REGXYZ ? PPT : 1], pz[REGXYZ ? PPT : 1], dist[PPT];
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int n = tid * PPT + j;
         const bool ok = n < N;
-        px[j] = ok ? (LDSXYZ ? sx[n] : p[n * 3 + 0]) : 0.f;
-        py[j] = ok ? (LDSXYZ ? sy[n] : p[n * 3 + 1]) : 0.f;
-        pz[j] = ok ? (LDSXYZ ? sz[n] : p[n * 3 + 2]) : 0.f;
+        if (REGXYZ) {
+            px[j] = ok ? (LDSXYZ ? sx[n] : p[n * 3 + 0]) : 0.f;
+            py[j] = ok ? (LDSXYZ ? sy[n] : p[n * 3 + 1]) : 0.f;
+            pz[j] = ok ? (LDSXYZ ? sz[n] : p[n * 3 + 2]) : 0.f;
+        }
         dist[j] = ok ? 1e10f : -1.0f;     // :74; padded slots can never win the argmax
     }
     int far = (int)start[b];
@@ -76,7 +80,13 @@ __global__ void __launch_bounds__(1024) fps_kernel(const float *__restrict__ xyz
         int bj = 0;
 #pragma unroll
         for (int j = 0; j < PPT; ++j) {
-            const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+            float qx, qy, qz;
+            if (REGXYZ) { qx = px[j]; qy = py[j]; qz = pz[j]; }
+            else {
+                const int n = min(tid * PPT + j, N - 1);          // clamped: a padded slot's distance stays -1 (min with -1 below)
+                qx = p[n * 3 + 0]; qy = p[n * 3 + 1]; qz = p[n * 3 + 2];
+            }
+            const float dx = qx - cx, dy = qy - cy, dz = qz - cz;
             const float d = (dx * dx + dy * dy) + dz * dz;        // :80, no FMA
             const float nd = d < dist[j] ? d : dist[j];           // :81-82
             dist[j] = nd;
@@ -108,10 +118,11 @@ __global__ void __launch_bounds__(1024) fps_kernel(const float *__restrict__ xyz
 extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start, int npoint, int32_t *idx_out,
                            float *new_xyz_out, void *stream)
 {
-    if (!xyz || !start || !idx_out || B <= 0 || N <= 0 || npoint <= 0 || N > 16384) return P2C_EINVAL;
+    // up to 65536 points per cloud (64 running distances per thread of a 1024-thread workgroup); the reference's largest is 8192
+    if (!xyz || !start || !idx_out || B <= 0 || N <= 0 || npoint <= 0 || N > 65536) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     int ppt = 1;
-    while (ppt < 16 && (long long)ppt * 1024 < N) ppt *= 2;
+    while (ppt < 64 && (long long)ppt * 1024 < N) ppt *= 2;
     if (N <= 512) ppt = 8;                         // single wave per cloud: no barrier at all
     int threads = ((N + ppt - 1) / ppt + 63) & ~63;
     if (threads > 1024) return P2C_EINVAL;
@@ -136,6 +147,14 @@ extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start,
         P2C_FPS_CASE(4)
         P2C_FPS_CASE(8)
         P2C_FPS_CASE(16)
+    case 32:
+        (void)hipFuncSetAttribute((const void *)fps_kernel<32, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((fps_kernel<32, false, false>), dim3(B), dim3(threads), 64 * sizeof(float), s, xyz, N, start, npoint, idx_out, new_xyz_out);
+        break;
+    case 64:
+        (void)hipFuncSetAttribute((const void *)fps_kernel<64, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((fps_kernel<64, false, false>), dim3(B), dim3(threads), 64 * sizeof(float), s, xyz, N, start, npoint, idx_out, new_xyz_out);
+        break;
     default:
         return P2C_EINVAL;
     }

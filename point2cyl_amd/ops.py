@@ -478,8 +478,11 @@ class _MLPStack(torch.autograd.Function):
         X0, Ys, aff, Ws, arg, params = ctx.saved
         rep_grad = None
         arg, ywin = arg if isinstance(arg, tuple) else (arg, None)
-        if not cfg["training"]:
-            raise RuntimeError("point2cyl_amd: backward through an eval-mode (running-stats) stack is not implemented")
+        # Eval mode (running statistics, e.g. fine-tuning with frozen BatchNorm, train_Point2Cyl.py:354-357): y = scale * x + shift with a
+        # FIXED affine, so dY = scale * (dZ masked by the ReLU) - the batch-statistic terms q * Y + p of the train-mode backward vanish
+        # (coef rows 3, 4 zeroed after every finalize), dgamma / dbeta are the same sums taken with the running mean / invstd the forward
+        # saved, and the conv bias in front of the BatchNorm gets a real gradient: dbias = sum_m dY = gs * dbeta.
+        evalm = not cfg["training"]
         dev = X0.device
         pre = cfg.get("pre")
         Ms = X0.shape[0]
@@ -512,6 +515,8 @@ class _MLPStack(torch.autograd.Function):
             call("p2c_bn_relu_bwd_stats_f32", ptr(dZ), dZ.stride(0), ptr(Ys[i]), Co, ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]),
                  ptr(params[p0 + 2]), M, Co, ptr(dgamma), ptr(dbeta), ptr(coef), ptr(arena.f64(STAT_SLOTS, 2, Co)), stream())
             grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
+            if evalm:
+                coef[3:].zero_()
             return coef
 
         pool_ns = 0
@@ -526,6 +531,8 @@ class _MLPStack(torch.autograd.Function):
             call("p2c_maxpool_bn_bwd_stats_f32", ptr(dout), Cl, ptr(ywin), ptr(aff[-1]), ptr(params[p0 + 2]), G, pool_ns, Cl,
                  ptr(dgamma), ptr(dbeta), ptr(coef), ptr(arena.f64(STAT_SLOTS, 2, Cl)), stream())
             grads[p0 + 2], grads[p0 + 3] = dgamma, dbeta
+            if evalm:
+                coef[3:].zero_()
         elif tail == "bnrelu":
             dZ = dout
             grad_mode, coef = 1, standalone_stats(dZ, L - 1)
@@ -697,6 +704,15 @@ class _MLPStack(torch.autograd.Function):
                     call("p2c_bn_bwd_finalize_f32", ptr(part), Ci, M, ptr(aff[i - 1]), ptr(params[q0 + 2]), ptr(dgamma),
                          ptr(dbeta), ptr(coef), stream())
                     grads[q0 + 2], grads[q0 + 3] = dgamma, dbeta
+                    if evalm:
+                        coef[3:].zero_()
+        if evalm:
+            for i in range(L):
+                p0, has_bn = slots[i]
+                if has_bn and grads[p0 + 3] is not None:
+                    st, gamma = aff[i], params[p0 + 2]
+                    nb = params[p0 + 1].shape[0]
+                    grads[p0 + 1] = (gamma.detach().reshape(-1)[:nb] * st[3][:nb] * grads[p0 + 3][:nb]).reshape(params[p0 + 1].shape)
         dX0 = None
         if ctx.needs_input_grad[1]:
             dX0 = dZ

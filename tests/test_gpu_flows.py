@@ -283,15 +283,72 @@ def test_backbone_normal_channel_vs_oracle():
     for mine, r32, r64 in ((X, o32[0], o64[0]), (Wr, o32[1], o64[1])):
         ref_err = float((r32.double() - r64).abs().max())
         assert float((mine.detach().cpu().double() - r64).abs().max()) <= max(1e-4, 3 * ref_err)
+    rel_med = float(np.median([np.linalg.norm(g32[n].double().numpy() - g64[n].numpy()) / np.linalg.norm(g64[n].numpy()) for n, _ in m.named_parameters()
+                               if not (n.endswith(".bias") and ("mlp_convs" in n or n == "fc1.bias"))]))
     for name, p in m.named_parameters():
         r32, r64 = g32[name].double().numpy(), g64[name].numpy()
         got = p.grad.cpu().double().numpy().reshape(r64.shape)
         if name.endswith(".bias") and ("mlp_convs" in name or name == "fc1.bias"):
             assert np.abs(got).max() == 0.0
             continue
+        # per tensor: 3x the oracle's own fp32 distance from float64 on this tensor (max-abs OR norm: one max-pool winner that resolves
+        # differently moves max-abs alone), or the oracle's MEDIAN relative distance over all tensors (small batch: the per-tensor fp32
+        # error of any implementation scatters around that level)
         a = np.abs(got - r64).max() / (3 * np.abs(r32 - r64).max() + 1e-6 * np.abs(r64).max())
-        b = (np.linalg.norm(got - r64) / np.linalg.norm(r64)) / (3 * np.linalg.norm(r32 - r64) / np.linalg.norm(r64) + 1e-6)
-        assert min(a, b) <= 1.0, (name, a, b)          # max-abs OR norm: one max-pool winner that resolves differently moves max-abs alone
+        b = (np.linalg.norm(got - r64) / np.linalg.norm(r64)) / (max(3 * np.linalg.norm(r32 - r64) / np.linalg.norm(r64), rel_med) + 1e-6)
+        assert min(a, b) <= 1.0, (name, a, b)
+
+
+def test_backbone_eval_mode_backward_vs_oracle():
+    """Backward through the stack in EVAL mode (running statistics: fine-tuning with frozen BatchNorm, train_Point2Cyl.py:354-357; any
+    nn.Module differentiates in .eval()): forward and every parameter gradient - incl. the conv biases, which are no longer absorbed by
+    a batch mean - and the input gradient path against the oracle with training=False, fp32 and float64."""
+    B, N, K = 3, 1024, 8
+    pcs = synth.make_batch(B, N, K, seed=707)[0]
+    torch.manual_seed(78)
+    m = backbone(output_sizes=[3, 2 * K])
+    with torch.no_grad():                               # running statistics away from (0, 1), scales of both signs
+        for name, mod in m.named_modules():
+            if isinstance(mod, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                mod.running_mean.normal_(0, 0.3)
+                mod.running_var.uniform_(0.5, 2.0)
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.normal_(0, 0.2)
+        m.sa1.mlp_bns[1].weight[5] = -0.9
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(2)
+    s1, s2 = torch.randint(0, N, (B,), generator=g), torch.randint(0, 512, (B,), generator=g)
+    mask = (torch.rand(B, N, 128, generator=g) < 0.5).float()
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        sd = {k: (v.clone().to(dt) if v.dtype.is_floating_point else v.clone()) for k, v in sd0.items()}
+        leaves = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running" not in k}
+        outs = R.backbone_forward(sd, pcs.to(dt), [s1, s2], mask.to(dt), training=False, momentum=0.5, geom="c")
+        ((outs[0] ** 2).mean() + (outs[1] ** 2).mean() * 0.1 + outs[1][..., 0].mean()).backward()
+        res[dt] = ([o.detach() for o in outs], {k: v.grad for k, v in leaves.items()})
+    m = m.to(DEV).eval()
+    m.sa1.fps_start, m.sa2.fps_start = s1, s2
+    m.dropout_mask = mask
+    X, Wr = m(pcs.to(DEV))
+    ((X ** 2).mean() + (Wr ** 2).mean() * 0.1 + Wr[..., 0].mean()).backward()
+    (o32, g32), (o64, g64) = res[torch.float32], res[torch.float64]
+    for mine, r32, r64 in ((X, o32[0], o64[0]), (Wr, o32[1], o64[1])):
+        ref_err = float((r32.double() - r64).abs().max())
+        assert float((mine.detach().cpu().double() - r64).abs().max()) <= max(1e-4, 3 * ref_err)
+    for k in ("sa1.mlp_bns.0.running_mean", "bn1.running_var"):
+        assert torch.equal(m.state_dict()[k].cpu(), sd0[k]), "eval mode must not touch the running statistics"
+    nz_bias = 0
+    rel_med_e = float(np.median([np.linalg.norm(g32[n].double().numpy() - g64[n].numpy()) / max(np.linalg.norm(g64[n].numpy()), 1e-30) for n, _ in m.named_parameters()]))
+    for name, p in m.named_parameters():
+        r32, r64 = g32[name].double().numpy(), g64[name].numpy()
+        got = p.grad.cpu().double().numpy().reshape(r64.shape)
+        if name.endswith(".bias") and ("mlp_convs" in name or name == "fc1.bias"):
+            nz_bias += int(np.abs(r64).max() > 0)
+        a = np.abs(got - r64).max() / (3 * np.abs(r32 - r64).max() + 1e-6 * np.abs(r64).max() + 1e-12)
+        # (+ 2e-5: without train-mode BatchNorm the oracle's own fp32 distance from float64 is ~1e-6 - a floor well inside the 1e-4 bar)
+        b = (np.linalg.norm(got - r64) / max(np.linalg.norm(r64), 1e-30)) / (max(3 * np.linalg.norm(r32 - r64) / max(np.linalg.norm(r64), 1e-30), rel_med_e) + 2e-5)
+        assert min(a, b) <= 1.0, (name, a, b)
+    assert nz_bias >= 15, "the conv biases in front of an eval-mode BatchNorm have real gradients"
 
 
 def test_hungarian_rejects_out_of_range_labels():

@@ -35,7 +35,8 @@ def test_fps_golden(tag):
     assert np.array_equal(new_xyz.cpu().numpy(), ref_xyz)
 
 
-@pytest.mark.parametrize("B,N,npoint", [(3, 8192, 512), (2, 512, 128), (2, 1000, 77), (1, 16384, 64), (5, 100, 100), (2, 4096, 300)])
+@pytest.mark.parametrize("B,N,npoint", [(3, 8192, 512), (2, 512, 128), (2, 1000, 77), (1, 16384, 64), (5, 100, 100), (2, 4096, 300),
+                                          (2, 20000, 40), (1, 65536, 24), (1, 40001, 16)])       # > 16384: coordinates streamed, distances in registers
 def test_fps_vs_oracle(B, N, npoint):
     g = torch.Generator().manual_seed(N + npoint)
     xyz = torch.rand(B, N, 3, generator=g) * 2 - 1

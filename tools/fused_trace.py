@@ -10,15 +10,14 @@ FWD = "--fwd" in sys.argv             # trace fwd_pp.hip instead of bwd_fused.hi
 NODATA = "--nodata" in sys.argv       # MFMA phases only: no global traffic, no LDS staging (isolates the MFMA loops)
 LOCK = "--lockstep" in sys.argv       # both halves in the same phase (no one-phase offset)
 OLD = "--old" in sys.argv             # a library built by hand from an earlier revision of bwd_fused.hip (A/B runs)
-LIB = os.path.join(HERE, "libp2c_trace_fwd.so" if FWD else "libp2c_trace_nodata.so" if NODATA else "libp2c_trace_lock.so" if LOCK else "libp2c_trace_old.so" if OLD else "libp2c_trace.so")
+LIB = os.path.join(HERE, "libp2c_trace.so" if FWD else "libp2c_trace_nodata.so" if NODATA else "libp2c_trace_lock.so" if LOCK else "libp2c_trace_old.so" if OLD else "libp2c_trace.so")
 if "--build" in sys.argv:
+    shim = os.path.join(HERE, "trace_shim.hip")       # fwd_pp + fwd_pp3 + bwd_fused + bwd_fused3 in one library (they share the mode switch)
     for lib, extra in ((os.path.join(HERE, "libp2c_trace.so"), []), (os.path.join(HERE, "libp2c_trace_nodata.so"), ["-DP2C_TRACE_NODATA"]),
                        (os.path.join(HERE, "libp2c_trace_lock.so"), ["-DP2C_LOCKSTEP"])):
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_TRACE"] + extra +
-                              ["-shared", "-o", lib, os.path.join(ROOT, "point2cyl_amd", "csrc", "bwd_fused.hip")])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wno-unused-value", "-DP2C_TRACE"] + extra +
+                              ["-shared", "-o", lib, shim])
         print(lib)
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_TRACE",
-                           "-shared", "-o", os.path.join(HERE, "libp2c_trace_fwd.so"), os.path.join(HERE, "fwd_trace_shim.hip")])
     sys.exit(0)
 sys.path.insert(0, ROOT)
 import numpy as np
@@ -108,6 +107,13 @@ buf = np.zeros((2, 12, 8), dtype=np.uint64)
 assert L.p2c_trace_read(buf.ctypes.data_as(vp)) == 0
 t0 = buf[0, 2, 0]
 names = ["mfma0", "dW_end", "mfma_end", "bar1", "stage", "prefetch", "dx+sums", "bar2"]
+if L.p2c_get_mfma_mode():      # bwd_fused3.hip: one wave per SIMD, phases in program order (half 1 does not exist)
+    names = ["start", "dY staged", "X staged", "barrier1", "prefetch issued", "dW mfma", "dX mfma", "epilogue(+bar2 -> next start)"]
+    for it in range(2, 10):
+        row = buf[0, it].astype(np.int64) - int(t0)
+        d = np.diff(row)
+        print("it %d  start %8d | " % (it, row[0]) + "  ".join("%s %6d" % (n, v) for n, v in zip(names[1:], d)) + "  | to next start %6d" % (int(buf[0, it + 1, 0]) - int(buf[0, it, 7])))
+    sys.exit(0)
 for it in range(2, 10):
     for h in range(2):
         row = buf[h, it].astype(np.int64) - int(t0)

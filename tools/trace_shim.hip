@@ -1,6 +1,9 @@
-// Trace build of the persistent forward kernel: fwd_pp.hip + a plain C entry (the product entry lives in gemm.hip).
+// Trace build (-DP2C_TRACE) of the persistent kernels in ONE throw-away library: both forward kernels, both fused backward kernels and
+// the mode switch they share, plus the plain C entry the forward trace uses (the product entry lives in gemm.hip).
 #include "../point2cyl_amd/csrc/fwd_pp.hip"
-#include "../point2cyl_amd/csrc/fwd_pp3.hip"      // the bf16x3-split twin (selected at run time: P2C_MFMA=f32 runs the fp32-MFMA kernel)
+#include "../point2cyl_amd/csrc/fwd_pp3.hip"
+#include "../point2cyl_amd/csrc/bwd_fused.hip"
+#include "../point2cyl_amd/csrc/bwd_fused3.hip"
 extern "C" int p2c_trace_fwd(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K,
                              const float *sc, const float *sh, double *partials, void *stream)
 {

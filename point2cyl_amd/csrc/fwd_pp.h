@@ -18,6 +18,7 @@ struct FwdPPArgs {
     // and their rows: pool_max / pool_min [2*M/64][N] fp32, pool_idx [2*M/64][N] int32 = row_of_max | row_of_min << 16 (rows 0..63)
     float *pool_max, *pool_min;
     int32_t *pool_idx;
+    int lockstep;                         // fwd_pp3.hip: both halves in the same phase (set by its launcher; 0 elsewhere)
 };
 
 

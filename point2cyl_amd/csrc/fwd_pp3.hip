@@ -15,9 +15,16 @@
 //  * LDS rows are k-contiguous bf16 with a 16-byte pad: one ds_read_b128 per lane is the whole 8-deep operand of one MFMA
 //    (lane (i, h) holds k = 16q + 8h .. +7 of row i); per k-step 6 reads feed 6 MFMAs;
 //  * the split costs ~5.5 VALU per element at staging time (v_cvt_pk_bf16_f32 + shift/and + subtract, twice, + one more cvt), next
-//    to the act_in transform that already runs there.
+//    to the act_in transform that already runs there;
+//  * the two halves run IN THE SAME PHASE (no one-phase offset; P2C_FWD3_LOCKSTEP=0 restores it for A/B runs).  The phase trace of the
+//    offset form (tools/fused_trace.py --fwd, 128 -> 128, cycles per 32-row half tile): MFMA phase 2.1 k, wave-local phase 3.9 k, of which
+//    the first ~45 instructions take 2.0 k - the wave whose partner on the SIMD streams MFMAs is granted about one issue slot per MFMA,
+//    for the 32-cycle bf16 instruction as for the 64-cycle fp32 one - so the period was the SUM of the two phases (8.1 k per 64 rows).
+//    In lockstep both waves of a SIMD share the matrix pipe (3.5 k for the later one) and then run their vector work side by side,
+//    hiding each other's latencies: 6.8 k per 64 rows, the forward launches 5-13 % shorter, the step 4.34 -> 4.27 ms on one box.
 #include "common.h"
 #include "fwd_pp.h"
+#include <stdlib.h>
 
 #define P2C_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -202,7 +209,7 @@ __global__ void __launch_bounds__(512, 2) fwd_pp3_kernel(FwdPPArgs a)
     gload(tile_of(half + 2 < nk ? half + 2 : 0));
     __syncthreads();
     if (EX) we = *reinterpret_cast<const v4f *>(&We[(wn * 32 + l31) * 4]);
-    if (half == 1) P2C_LDS_BARRIER();                        // run one phase behind half 0
+    if (half == 1 && !a.lockstep) P2C_LDS_BARRIER();         // run one phase behind half 0 (lockstep: both halves in the same phase)
     for (int it = 0; it < niter; ++it) {
         const int k = 2 * it + half;
         const bool valid = k < nk;                           // uniform within the half
@@ -340,7 +347,7 @@ __global__ void __launch_bounds__(512, 2) fwd_pp3_kernel(FwdPPArgs a)
         P2C_LDS_BARRIER();                                   // the prefetch stays in flight across this barrier
         P2C_TR(7);
     }
-    if (half == 0) P2C_LDS_BARRIER();
+    if (half == 0 && !a.lockstep) P2C_LDS_BARRIER();
     // ---- BatchNorm sums: every (half, row block) parks its column sums in its own LDS slot, summed in a fixed order, then one fp64
     //      atomic per column into this workgroup's slot row
     if (a.partials) {
@@ -385,8 +392,11 @@ static int launch_pp3(const FwdPPArgs &a, hipStream_t s)
 }
 
 // same contract as p2c_fwd_pp_launch (fwd_pp.hip), which forwards here unless the fp32-MFMA path was asked for
-int p2c_fwd_pp3_launch(const FwdPPArgs &a, int in_mode, hipStream_t s)
+int p2c_fwd_pp3_launch(const FwdPPArgs &a_in, int in_mode, hipStream_t s)
 {
+    FwdPPArgs a = a_in;
+    static const int lock = getenv("P2C_FWD3_LOCKSTEP") ? atoi(getenv("P2C_FWD3_LOCKSTEP")) : 1;      // A/B switch; lockstep measured faster
+    a.lockstep = lock;
     const int K = a.K;          // EX columns already split off by the caller
     if (a.pool_max) {
         if (!a.pool_min || !a.pool_idx || !p2c_linear_fwd_pool_supported(a.M, a.N, K, in_mode, 64)) return P2C_EINVAL;

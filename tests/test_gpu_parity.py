@@ -167,6 +167,67 @@ def test_mlp_stack_forward_backward(tail, M, K0, widths, G, ns):
     _check_mlp_stack(tail, M, K0, widths, G, ns, True)
 
 
+@pytest.mark.parametrize("tail,M,K0,widths,G,ns,clamp", [
+    ("maxpool", 3 * 128, 259, (256, 512, 1024), 3, 128, 0.0),        # SA3's stack
+    ("maxpool", 3 * 128, 259, (256, 512, 1024), 3, 128, 1.5),        # ... with most pooled outputs clamped to zero by the ReLU
+    ("bnrelu", 1000, 384, (256, 128), None, None, 0.0),
+    ("maxpool", 40 * 16, 3, (16, 24, 40), 40, 16, 0.0),
+    ("maxpool", 300 * 32, 64, (64, 128), 300, 32, 0.0),              # >= 8192 rows: persistent forward, fused backward
+    ("linear", 9001, 128, (128, 128, 19), None, None, 0.0),
+])
+def test_mlp_stack_eval_mode_forward_backward(tail, M, K0, widths, G, ns, clamp):
+    """Backward through a stack in EVAL mode (running statistics; fine-tuning with frozen BatchNorm, train_Point2Cyl.py:354-357): y =
+    scale x + shift with a fixed affine, so the batch-statistic terms of the train-mode backward vanish, dgamma / dbeta are taken with
+    the running mean / invstd, and the conv bias in front of the BatchNorm has a real gradient.  Forward, every parameter gradient and
+    the input gradient against the torch layers in float64 (1e-5 of each tensor's norm)."""
+    g = torch.Generator().manual_seed(M + K0)
+    ld = (K0 + 3) // 4 * 4
+    X0 = torch.zeros(M, ld)
+    X0[:, :K0] = torch.randn(M, K0, generator=g)
+    params, cin = [], K0
+    for i, co in enumerate(widths):
+        p = dict(W=torch.randn(co, cin, generator=g) / cin ** 0.5, b=torch.randn(co, generator=g) * 0.1)
+        if not (tail == "linear" and i == len(widths) - 1):
+            p.update(gamma=torch.rand(co, generator=g) + 0.5, beta=torch.randn(co, generator=g) * 0.2, rm=torch.randn(co, generator=g) * 0.3,
+                     rv=torch.rand(co, generator=g) + 0.5)
+            if i == 0:
+                p["gamma"][0] = -0.7
+            if clamp and i >= len(widths) - 2:
+                p["beta"] = p["beta"] - clamp / (1 if i == len(widths) - 1 else 2)
+        params.append(p)
+        cin = co
+    ps = [{k: (v.double().clone().requires_grad_(True) if k in ("W", "b", "gamma", "beta") else v.double().clone()) for k, v in p.items()} for p in params]
+    xr = X0[:, :K0].double().clone().requires_grad_(True)
+    yr, _ = _ref_stack(xr, ps, tail, G, ns, False, None)
+    go = torch.randn(yr.shape, generator=g)
+    yr.backward(go.double())
+    ref = [p[k].grad for p in ps for k in ("W", "b", "gamma", "beta") if k in p]
+    layers, leaves = [], []
+    for p in params:
+        ly = {k: p[k].detach().to(DEV).requires_grad_(True) for k in ("W", "b", "gamma", "beta") if k in p}
+        leaves += [ly[k] for k in ("W", "b", "gamma", "beta") if k in ly]
+        if "gamma" in ly:
+            ly["bn"] = ops.BNState(p["rm"].clone().to(DEV), p["rv"].clone().to(DEV), torch.zeros((), dtype=torch.long, device=DEV), 0.1, 1e-5)
+        else:
+            ly.update(gamma=None, beta=None, bn=None)
+        layers.append(ly)
+    Xd = X0.to(DEV).requires_grad_(True)
+    y = ops.mlp_stack(Xd, K0, layers, tail, False, G=G, ns=ns)
+    scale = max(1.0, float(yr.abs().max()))
+    assert float((y.detach().cpu().double() - yr.detach()).abs().max()) <= 1e-5 * scale
+    if clamp:
+        assert float((yr == 0).double().mean()) > 0.3, "the clamped case must clamp"
+    y.backward(go.to(DEV))
+    for ly in layers:
+        if ly["bn"] is not None:
+            assert int(ly["bn"].nbt) == 0                    # eval mode leaves the running statistics alone
+    for i, (a, b) in enumerate(zip(leaves, ref)):
+        got, r = a.grad.cpu().double().numpy().reshape(b.shape), b.numpy()
+        assert np.linalg.norm(got - r) <= 1e-5 * np.linalg.norm(r) + 1e-12, (i, np.linalg.norm(got - r) / np.linalg.norm(r))
+    gx = Xd.grad.cpu().double()[:, :K0]
+    assert float((gx - xr.grad).norm()) <= 1e-5 * float(xr.grad.norm())
+
+
 @pytest.mark.parametrize("tail,M,K0,widths,G,ns", [
     ("maxpool", 300 * 32, 3, (64, 64, 128), 300, 32),
     ("maxpool", 130 * 64 + 0, 3, (64, 128, 128), 130, 64),

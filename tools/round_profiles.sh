@@ -34,6 +34,7 @@ with open("%s/%s_kernel_stats.md" % (out, tag), "w") as f:
     f.write("\ntotal kernel time %.3f ms over %d kernel names\n" % (tot / 1e6, len(rows)))
 EOF
 rm -rf "$OUT/trace"
+if [ "${QUICK:-0}" = "1" ]; then ls -la "$OUT"; exit 0; fi
 # 3. counters: HBM traffic and SQ counters of every kernel of the step (one group per pass)
 python tools/collect_pmc.py "$TAG" > "$OUT/pmc.log" 2>&1
 cp profiles/${TAG}_pmc_step.json profiles/${TAG}_pmc_step.md "$OUT/" 2>/dev/null

@@ -101,8 +101,13 @@ struct Unit3 {          // thread -> (4 rows x 4 channels) units of a [BM x C] t
     }
 };
 
-template <int Co, int Ci, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) bwd_fused3_kernel(BwdFused3Args a)
+// ROLES (512 threads, two waves per SIMD): the four waves of half 0 stage dY, run the dX MFMAs and the epilogue; the four waves of half 1
+// stage X and run the dW MFMAs - IN THE SAME PHASE.  Each SIMD then holds one wave of either kind: their vector work (the staging) runs
+// side by side and hides each other's latencies (a lone wave issues a dependent instruction chain at ~6 cycles per instruction), their
+// MFMA streams share the matrix pipe, and the register-resident state splits in two (W slab + dX accumulators | dW accumulators), so
+// both fit 256 registers.  Used for Ci = 128 (one staging unit per thread); the other shapes keep the one-wave-per-SIMD form.
+template <int Co, int Ci, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS, bool ROLES>
+__device__ __forceinline__ void bwd_fused3_body(const BwdFused3Args &a)
 {
     constexpr int WC = Ci / 32, WR = 4 / WC, BM = 32 * WR;
     constexpr int COT = Co / 64, CIT = Ci / 64;
@@ -121,8 +126,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     unsigned char *XR = XT + 3 * PLX;
     float *red = reinterpret_cast<float *>(XR + ((NEED_DX && HAS_STATS) ? Ci * LDXR : 0));      // [2][Ci] stats, [Co] dbias
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    [[maybe_unused]] constexpr int half = 0;                              // (P2C_TR: there is no second half here)
+    const int role = ROLES ? (int)(threadIdx.x >> 8) : 0;                 // ROLES: 0 = dY / dX / epilogue waves, 1 = X / dW waves
+    const bool doA = !ROLES || role == 0, doB = !ROLES || role == 1;
+    const int tid = ROLES ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    [[maybe_unused]] const int half = role;                               // (P2C_TR stamps: one row per role)
     P2C_TR_WG(0);
     const int l31 = lane & 31, lh = lane >> 5;
     const int wi = wave >> 1, wj = wave & 1;                              // dW wave grid
@@ -198,12 +205,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
     };
-    gload_y(tile_of(0), 3);                                               // in flight under the W set-up below
-    gload_x(tile_of(0));
+    if (doA) gload_y(tile_of(0), 3);                                      // in flight under the W set-up below
+    if (doB) gload_x(tile_of(0));
 
     // ---------------- this wave's slab of W^T as register-resident bf16 fragments: lane (i, h), k-step q holds W[16q + 8h + e][32 wc + i]
     bf16x8 wh[NEED_DX ? NQX : 1], wm[NEED_DX ? NQX : 1], wl[NEED_DX ? NQX : 1];
-    if (NEED_DX) {
+    if (NEED_DX && doA) {
         const float *wp = a.w + (size_t)(8 * lh) * a.ldw + wc * 32 + l31;
 #pragma unroll
         for (int q = 0; q < NQX; ++q) {
@@ -388,8 +395,125 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // the interleave spelled out with __builtin_amdgcn_sched_group_barrier - 13.5 k against 9.0 k for the plain order below: an
     // instruction placed between two MFMAs that share an accumulator costs tens of cycles (MI355X_MICROARCH.md, "one extra issue slot
     // between two MFMAs"), and the live packed pieces pushed the 128-wide shapes past 512 registers (48-156 B of scratch per lane).
-    asm volatile("" ::"v"(rx[UX::NU - 1][3]));            // both paths into the loop header see the prefetch registers settled (see below)
     P2C_TR_WG_MID(0);
+    if constexpr (ROLES) {
+        static_assert(!ROLES || (NEED_DX && UY::NU == 1 && UX::NU == 1), "");
+        if (role == 0) {
+            // ======================= role A: dY staging | dX MFMAs | sums + dX stores =======================
+            auto touch_y = [&]() {                                       // the youngest load of gload_y (see the vmcnt note in the plain loop)
+                if (GMODE >= 1) asm volatile("" ::"v"(ry[0][3])); else asm volatile("" ::"v"(rdz[0][3]));
+            };
+            touch_y();
+            for (int k = 0; k < nk; ++k) {
+                [[maybe_unused]] const int it = k;
+                const int t = tile_of(k), m0 = t * BM;
+                const int tn = tile_of(k + 1 < nk ? k + 1 : k);
+                const bool full = m0 + BM <= a.M;
+                P2C_TR(0);
+                make_py(t, !full);
+                P2C_TR(1);
+                P2C_LDS_BARRIER();
+                P2C_TR(2);
+                gload_y(tn, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x16 accX0, accX1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accX0[r] = accX1[r] = 0.f;
+#pragma unroll
+                for (int q = 0; q < NQX; q += 2) {
+                    bf16x8 f0[3], f1[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        f0[p] = *reinterpret_cast<const bf16x8 *>(DYR + adx + p * PLR + 32 * q);
+                        f1[p] = *reinterpret_cast<const bf16x8 *>(DYR + adx + p * PLR + 32 * (q + 1));
+                    }
+#define P2C_XR(ACC_, F_, Q_, PA_, WB_) ACC_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F_[PA_], WB_[Q_], ACC_, 0, 0, 0)
+                    P2C_XR(accX0, f0, q, 1, wm); P2C_XR(accX1, f1, q + 1, 1, wm);
+                    P2C_XR(accX0, f0, q, 0, wl); P2C_XR(accX1, f1, q + 1, 0, wl);
+                    P2C_XR(accX0, f0, q, 2, wh); P2C_XR(accX1, f1, q + 1, 2, wh);
+                    P2C_XR(accX0, f0, q, 0, wm); P2C_XR(accX1, f1, q + 1, 0, wm);
+                    P2C_XR(accX0, f0, q, 1, wh); P2C_XR(accX1, f1, q + 1, 1, wh);
+                    P2C_XR(accX0, f0, q, 0, wh); P2C_XR(accX1, f1, q + 1, 0, wh);
+#undef P2C_XR
+                }
+                P2C_TR(3);
+                float yp[16];
+                if (HAS_STATS) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const v4f v = *reinterpret_cast<const v4f *>(XR + ayp[g]);
+                        yp[4 * g] = v.x; yp[4 * g + 1] = v.y; yp[4 * g + 2] = v.z; yp[4 * g + 3] = v.w;
+                    }
+                }
+                touch_y();                                               // wait for the prefetch while only loads are outstanding
+                const uint32_t dxo = (uint32_t)((wr * 32 + 4 * lh) * a.lddx + xcol) * 4u;
+                float *dxp = a.dx + (size_t)(m0 + wr * 32 + 4 * lh) * a.lddx + xcol;
+                float vx[16];
+                float t1[4] = {0.f, 0.f, 0.f, 0.f}, t2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = accX0[r] + accX1[r];
+                    vx[r] = v;
+                    if (HAS_STATS) {
+                        const float g = (psc * yp[r] + psh > 0.f) ? v : 0.f;
+                        t1[r & 3] += g;
+                        t2[r & 3] = __builtin_fmaf(g, __builtin_fmaf(yp[r], pis, npm), t2[r & 3]);
+                    }
+                }
+                if (HAS_STATS) { s1 += (double)((t1[0] + t1[1]) + (t1[2] + t1[3])); s2 += (double)((t2[0] + t2[1]) + (t2[2] + t2[3])); }
+                if (full && !a.dx_atomic) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        *reinterpret_cast<float *>(reinterpret_cast<char *>(a.dx + (size_t)(m0 + (r & 3) + 8 * (r >> 2)) * a.lddx) + dxo) = vx[r];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = (r & 3) + 8 * (r >> 2);
+                        if (m0 + wr * 32 + 4 * lh + ro < a.M) {
+                            if (a.dx_atomic) atomicAdd(dxp + (size_t)ro * a.lddx, vx[r]);
+                            else dxp[(size_t)ro * a.lddx] = vx[r];
+                        }
+                    }
+                }
+                P2C_TR(7);
+                P2C_LDS_BARRIER();
+            }
+        } else {
+            // ======================= role B: X staging | dW MFMAs =======================
+            for (int k = 0; k < nk; ++k) {
+                [[maybe_unused]] const int it = k;
+                const int tn = tile_of(k + 1 < nk ? k + 1 : k);
+                P2C_TR(0);
+                stage_x();
+                P2C_TR(1);
+                P2C_LDS_BARRIER();
+                P2C_TR(2);
+                gload_x(tn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int sk = 0; sk < NKW; ++sk) {
+                    bf16x8 A[COT][3], B[CIT][3];
+#pragma unroll
+                    for (int i = 0; i < COT; ++i)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) A[i][p] = *reinterpret_cast<const bf16x8 *>(DYT + adw[i][sk] + p * PLY);
+#pragma unroll
+                    for (int j = 0; j < CIT; ++j)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) B[j][p] = *reinterpret_cast<const bf16x8 *>(XT + bdw[j][sk] + p * PLX);
+#define P2C_WR(PA_, PB_)                                                                                             \
+    _Pragma("unroll") for (int i = 0; i < COT; ++i) _Pragma("unroll") for (int j = 0; j < CIT; ++j)                  \
+        accW[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][PA_], B[j][PB_], accW[i][j], 0, 0, 0)
+                    P2C_WR(1, 1); P2C_WR(0, 2); P2C_WR(2, 0); P2C_WR(0, 1); P2C_WR(1, 0); P2C_WR(0, 0);
+#undef P2C_WR
+                }
+                P2C_TR(3);
+                P2C_TR(7);
+                P2C_LDS_BARRIER();
+            }
+        }
+    } else {
+    asm volatile("" ::"v"(rx[UX::NU - 1][3]));            // both paths into the loop header see the prefetch registers settled (see below)
     for (int k = 0; k < nk; ++k) {
         [[maybe_unused]] const int it = k;
         const int t = tile_of(k), m0 = t * BM;
@@ -535,10 +659,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         P2C_TR(7);
         P2C_LDS_BARRIER();                                               // every read of this tile's LDS image is done
     }
+    }
     P2C_TR_WG_MID(1);
 
     // ---------------- flush: dW into the slot of this workgroup's XCD, the statistics / dbias through LDS into fp64 slot rows
-    {
+    if (doB) {
         float *dws = a.dw + (size_t)(blockIdx.x & 7) * a.dw_slot_stride;
 #pragma unroll
         for (int i = 0; i < COT; ++i)
@@ -555,7 +680,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if ((NEED_DX && HAS_STATS) || want_db) {
         for (int u = tid; u < 2 * Ci + Co; u += 256) red[u] = 0.f;
         __syncthreads();
-        if (NEED_DX && HAS_STATS) {
+        if (NEED_DX && HAS_STATS && doA) {
             const double u1 = s1 + __shfl_xor(s1, 32), u2 = s2 + __shfl_xor(s2, 32);
             if (lh == 0) {                    // fp64 straight into this workgroup's slot row (one or two waves per column)
                 double *o = a.partials + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * Ci;
@@ -563,7 +688,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 atomicAdd(&o[Ci + xcol], u2);
             }
         }
-        if (want_db) {
+        if (want_db && doA) {
 #pragma unroll
             for (int u = 0; u < UY::NU; ++u) {
                 int c4, rg;
@@ -573,9 +698,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
         __syncthreads();
-        if (want_db && tid < Co) atomicAdd(&a.dbias[tid], red[2 * Ci + tid]);
+        if (want_db && doA && tid < Co) atomicAdd(&a.dbias[tid], red[2 * Ci + tid]);
     }
     P2C_TR_WG(1);
+}
+
+template <int Co, int Ci, int GMODE, int IMODE, bool NEED_DX, bool HAS_STATS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) bwd_fused3_kernel(BwdFused3Args a)
+{
+    bwd_fused3_body<Co, Ci, GMODE, IMODE, NEED_DX, HAS_STATS, false>(a);
+}
+
+template <int Co, int Ci, int GMODE, int IMODE, bool HAS_STATS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) bwd_fused3r_kernel(BwdFused3Args a)
+{
+    bwd_fused3_body<Co, Ci, GMODE, IMODE, true, HAS_STATS, true>(a);
 }
 
 template <int Co, int Ci, int GMODE, int IMODE>
@@ -593,6 +730,21 @@ static int launch_fused3(const BwdFused3Args &a, hipStream_t s)
                                   (int)lds);                                                                                          \
         hipLaunchKernelGGL((bwd_fused3_kernel<Co, Ci, GMODE, IMODE, DX_, ST_>), dim3(grid), dim3(256), lds, s, a);                    \
     } while (0)
+    static const bool roles_on = !(getenv("P2C_BWD3_ROLES") && atoi(getenv("P2C_BWD3_ROLES")) == 0);        // A/B switch
+    if constexpr (Ci == 128) {
+        if (a.dx && roles_on) {
+            const size_t lds = (size_t)3 * BM * LDR + 3 * Co * LDT + 3 * Ci * LDT + Ci * LDXR + (2 * Ci + Co) * 4;
+            if (a.pstat) {
+                (void)hipFuncSetAttribute((const void *)bwd_fused3r_kernel<Co, Ci, GMODE, IMODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((bwd_fused3r_kernel<Co, Ci, GMODE, IMODE, true>), dim3(grid), dim3(512), lds, s, a);
+            } else {
+                (void)hipFuncSetAttribute((const void *)bwd_fused3r_kernel<Co, Ci, GMODE, IMODE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                hipLaunchKernelGGL((bwd_fused3r_kernel<Co, Ci, GMODE, IMODE, false>), dim3(grid), dim3(512), lds, s, a);
+            }
+            P2C_LAUNCH_CHECK();
+            return P2C_OK;
+        }
+    }
     if (a.dx && a.pstat) P2C_FL3(true, true);
     else if (a.dx) P2C_FL3(true, false);
     else P2C_FL3(false, false);

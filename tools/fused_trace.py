@@ -108,6 +108,14 @@ assert L.p2c_trace_read(buf.ctypes.data_as(vp)) == 0
 t0 = buf[0, 2, 0]
 names = ["mfma0", "dW_end", "mfma_end", "bar1", "stage", "prefetch", "dx+sums", "bar2"]
 if L.p2c_get_mfma_mode():      # bwd_fused3.hip: one wave per SIMD, phases in program order (half 1 does not exist)
+    if Ci == 128 and os.environ.get("P2C_BWD3_ROLES", "1") != "0":      # role-split form: row 0 = dY/dX/epilogue waves, row 1 = X/dW waves
+        for it in range(2, 10):
+            for h in range(2):
+                r = buf[h, it].astype(np.int64) - int(t0)
+                print("it %d role %s start %8d | staged %6d  barrier1 %6d  prefetch+mfma %6d  %s %6d | barrier2 -> next start %6d"
+                      % (it, "AB"[h], r[0], r[1] - r[0], r[2] - r[1], r[3] - r[2], "epilogue" if h == 0 else "-       ", r[7] - r[3],
+                         int(buf[h, it + 1, 0]) - int(buf[h, it, 7])))
+        sys.exit(0)
     names = ["start", "dY staged", "X staged", "barrier1", "prefetch issued", "dW mfma", "dX mfma", "epilogue(+bar2 -> next start)"]
     for it in range(2, 10):
         row = buf[0, it].astype(np.int64) - int(t0)

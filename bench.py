@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16, dense (the 5 PF headline is 2:1 sparsity)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -45,7 +46,9 @@ def _newest_pmc():
     return best[1] if best else None
 
 
-_PMC_NAME = {"p2c_linear_bwd_fused_f32": "bwd_fused_pp_kernel", "p2c_linear_fwd_f32": "fwd_pp_kernel"}
+# entry point -> kernel name stems (fp32-MFMA kernel | bf16x3-split kernels: one wave per SIMD, role-split)
+_PMC_NAME = {"p2c_linear_bwd_fused_f32": ("bwd_fused_pp_kernel", "bwd_fused3_kernel", "bwd_fused3r_kernel"),
+             "p2c_linear_fwd_f32": ("fwd_pp_kernel", "fwd_pp3_kernel")}
 
 
 def _pmc_traffic(entry):
@@ -62,9 +65,10 @@ def _pmc_traffic(entry):
         from point2cyl_amd.build import source_hash
         shash = doc.get("source_hash")
         stale = (shash != source_hash()) if shash else None
-        sub = _PMC_NAME.get(entry)
+        subs = _PMC_NAME.get(entry, ())
         # (the IMODE-2 instantiation "<.., .., .., 2, ...>" belongs to p2c_linear_bwd_fused_fold0_f32, a different entry point)
-        sel = [v for k, v in ks.items() if sub and sub in k and not re.search(r"bwd_fused_pp_kernel<\d+, \d+, \d+, 2,", k)]
+        sel = [v for k, v in ks.items() if any(re.match(r"(void )?%s<" % sub, k) for sub in subs)
+               and not re.search(r"bwd_fused_pp_kernel<\d+, \d+, \d+, 2,", k)]
         n = sum(v["launches"] for v in sel)
         if not n:
             return None, None, None, None
@@ -259,9 +263,11 @@ def _bench(args, rank, world, local, dev):
     prof = ops.PROFILE.summary()           # per kernel family: launches, total ms (HIP events on the launch stream), flops, bytes
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
     roofline = None
+    from point2cyl_amd import _lib
+    split = bool(_lib.lib().p2c_get_mfma_mode())
     if dom[0] is not None:
         d = dom[1]
-        if d["flops"] > 0:
+        if d["flops"] > 0 and not split:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             traffic, tsrc, thash, tstale = _pmc_traffic(dom[0])
             roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
@@ -269,6 +275,27 @@ def _bench(args, rank, world, local, dev):
                             traffic_source=tsrc, traffic_source_hash=thash, traffic_stale=tstale, algorithmic_bytes_per_launch=round(d["bytes"] / max(1, d["launches"])),
                             launches_per_step=d["launches"] / prof_steps, avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
                             share_of_step=round(d["ms"] / prof_steps / ms, 3))
+        elif d["flops"] > 0:
+            # bf16x3-split: every fp32 product is six bf16 MFMA products, so the matrix pipe's ceiling for this arithmetic is
+            # 2500 / 6 = 417 fp32-equivalent TFLOP/s; the kernel then sits nearer its HBM bound than its matrix-pipe bound, and the line
+            # reports the tighter of the two as `bound` with the other beside it (and the fraction of the fp32-MFMA peak the
+            # round-2 line was priced against, for continuity).
+            tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+            traffic, tsrc, thash, tstale = _pmc_traffic(dom[0])
+            f_hbm, f_pipe = gbs / PEAK_HBM_GBS, 6.0 * tf / PEAK_BF16_MFMA_TFLOPS
+            common = dict(traffic=traffic, traffic_unit="bytes/launch (HBM read+write, PMC)", traffic_source=tsrc, traffic_source_hash=thash,
+                          traffic_stale=tstale, algorithmic_bytes_per_launch=round(d["bytes"] / max(1, d["launches"])),
+                          algorithmic_flops_per_launch=round(d["flops"] / max(1, d["launches"])),
+                          launches_per_step=d["launches"] / prof_steps, avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
+                          share_of_step=round(d["ms"] / prof_steps / ms, 3),
+                          hbm=dict(achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(f_hbm, 4)),
+                          mfma=dict(achieved_fp32_equivalent=round(tf, 2), issued_bf16=round(6.0 * tf, 1), peak_bf16=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
+                                    frac=round(f_pipe, 4), frac_of_fp32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4)))
+            if f_hbm >= f_pipe:
+                roofline = dict(bound="hbm", kernel=dom[0], achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(f_hbm, 4), **common)
+            else:
+                roofline = dict(bound="mfma", kernel=dom[0], achieved=round(6.0 * tf, 1), peak=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s", frac=round(f_pipe, 4), **common)
         else:
             ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             roofline = dict(bound="hbm", kernel=dom[0], achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
@@ -296,7 +323,7 @@ def _bench(args, rank, world, local, dev):
                                      "extrusion-cylinder clouds; step = fwd + losses + bwd + Adam" %
                                      (2 if args.full_losses else 1, B, N, K,
                                       "full loss set" if args.full_losses else "pred_seg+pred_normal+pred_bb"),
-                            batch_per_gpu=B, global_batch=B * world, num_point=N, parallelism="dp%d" % world, loss=round(loss, 5),
+                            mfma="bf16x3-split" if split else "f32", batch_per_gpu=B, global_batch=B * world, num_point=N, parallelism="dp%d" % world, loss=round(loss, 5),
                             launch=("hip_graph(fwd+bwd%s)+eager(allreduce,adam)" % ("" if args.no_prefetch else ", next batch's FPS/ball-query/3-NN on a forked stream")) if graphed is not None else "eager"),
                 roofline=roofline, cpu_baseline=cpu, multi_gpu=multi,
                 kernels={k: dict(ms_per_step=round(v["ms"] / prof_steps, 3), launches_per_step=v["launches"] / prof_steps)

@@ -114,6 +114,9 @@ def main():
     err_all = angle_error_deg(E_AX.cpu(), axes, seg, K)
     present = ((torch.nn.functional.one_hot(seg[:c].clamp_min(0), K) * (seg[:c] >= 0).unsqueeze(-1)).sum(1) > 0)
     axis_absdot = ((E_AX[:c].cpu() * E_cpu).sum(-1).abs())[present]
+    # the whole path (axis + centroids + extents): every input read once - normals, points, both membership matrices, both label arrays,
+    # the pre-drawn sample indices (they are an input of this boundary: data_utils.py:1690 draws them on the host)
+    path_bytes = points * (12 + 12 + 2 * K * 4 + seg.element_size() + bb.element_size()) + a.clouds * K * S * rand_idx.element_size()
     line = dict(metric="fitting-only cylinders/sec (axis + centroid + extent), 10k pre-segmented cylinders at N=8192",
                 value=round(a.clouds * K / dt, 1), unit="cylinders/s", n_gpus=1, steps=a.steps, ms_per_step=round(dt * 1e3, 3),
                 points_per_s=round(points / dt, 1), dtype="f32", data="synthetic",
@@ -121,11 +124,15 @@ def main():
                                      % (a.clouds, K, N, S)),
                 roofline=dict(bound="hbm", kernel="p2c_extrusion_axis_f32", achieved=round(axis_bytes / (axis_ms * 1e-3) / 1e9, 1) if axis_ms else None,
                               peak=8000.0, unit="GB/s", frac=round(axis_bytes / (axis_ms * 1e-3) / 1e9 / 8000.0, 4) if axis_ms else None,
-                              algorithmic_bytes_per_launch=axis_bytes, avg_launch_us=round(axis_ms * 1e3, 1), traffic=None),
+                              algorithmic_bytes_per_launch=axis_bytes, avg_launch_us=round(axis_ms * 1e3, 1), traffic=None,
+                              path=dict(algorithmic_bytes=path_bytes, ms=round(dt * 1e3, 3), achieved=round(path_bytes / dt / 1e9, 1),
+                                        frac=round(path_bytes / dt / 1e9 / 8000.0, 4))),
                 cpu_baseline=dict(value=round(c * K / cpu_dt, 1), unit="cylinders/s", cores=torch.get_num_threads(), kind="port",
                                   sample="oracle closed-form axis + hard centroids + extents on %d clouds, %.1f s" % (c, cpu_dt)),
                 parity=dict(axis_angle_error_deg_gpu=round(err_gpu, 5), axis_angle_error_deg_cpu=round(err_cpu, 5),
-                            rel_diff=round(abs(err_gpu - err_cpu) / max(err_cpu, 1e-12), 7), axis_angle_error_deg_all=round(err_all, 5),
+                            rel_diff=round(abs(err_gpu - err_cpu) / max(err_cpu, 1e-12), 7),
+                            rel_diff_vs_f64=round(abs(err_gpu - err_64) / max(err_64, 1e-12), 7),
+                            rel_diff_cpu32_vs_f64=round(abs(err_cpu - err_64) / max(err_64, 1e-12), 7), axis_angle_error_deg_all=round(err_all, 5),
                             axis_angle_error_deg_f64=round(err_64, 5),
                             max_axis_angle_deg_gpu_vs_f64=round(float(ang(E_AX[:c].cpu(), E_64)[present].max()), 5),
                             max_axis_angle_deg_cpu32_vs_f64=round(float(ang(E_cpu, E_64)[present].max()), 5),

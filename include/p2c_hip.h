@@ -346,6 +346,17 @@ int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, const int64_t 
                               const int64_t *rand_idx, int B, int N, int K, int S, float *extents_out, float *found_out,
                               void *ws, void *stream);
 
+/* The fitting-only chain of eval.py on pre-segmented clouds in one pass over each cloud (BASELINE configs[3]):
+ * estimate_extrusion_axis (eval.py:397 -> data_utils.py:99-177) -> hard per-segment centroids (eval.py:409-436) ->
+ * get_extrusion_extents (data_utils.py:1650-1730) on the axes and centroids just fitted.  Same outputs as the three entry points above
+ * called in that order: axis_out [B,K,3], centroids_out [B,K,3] + cfound_out [B,K], extents_out [K,B,2] + found_out [B,K].
+ * bb_gt / inst_gt are the per-point base-barrel and segment labels (both always read: the barrel lists and the centroids need them).
+ * p2c_fit_fused_supported(N, K, S) says whether the shape fits (K in {1,2,4,8}, the cloud within the LDS); ws as for the extents. */
+int p2c_fit_fused_supported(int N, int K, int S);
+int p2c_fit_fused_f32(const float *X, const float *Wb, const float *Wc, const int64_t *bb_gt, const int64_t *inst_gt, int normalize,
+                      const float *P, const int64_t *rand_idx, int B, int N, int K, int S, float *axis_out, float *centroids_out,
+                      float *cfound_out, float *extents_out, float *found_out, void *ws, void *stream);
+
 /* sketch_implicit_projection / sketch_implicit_projection2 (data_utils.py:1014-1146, :1149-1282) and, with all_points = 1
  * (S == N, seg / bb / rand_idx unused), sketch_implicit_projection3 (:1284-1417): the S sampled barrel points and normals
  * of every segment, turned by the matrix that takes the segment's axis onto z (the reference's construction through

@@ -66,6 +66,7 @@ _SIGS = {
     "p2c_extrusion_centers_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "p2c_segment_centroids_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "p2c_extrusion_extents_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+    "p2c_fit_fused_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_sketch_projection_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_softplus_fwd_f32": [c_p, c_p, c_ll, c_f, c_f, c_p],
     "p2c_softplus_bwd_f32": [c_p, c_p, c_p, c_ll, c_f, c_f, c_p],
@@ -123,6 +124,8 @@ def lib():
     L.p2c_linear_tile_m.restype = c_i
     L.p2c_hungarian_ws_bytes.argtypes = [c_i]
     L.p2c_hungarian_ws_bytes.restype = ctypes.c_size_t
+    L.p2c_fit_fused_supported.argtypes = [c_i, c_i, c_i]
+    L.p2c_fit_fused_supported.restype = c_i
     L.p2c_extents_ws_bytes.argtypes = [c_i, c_i]
     L.p2c_extents_ws_bytes.restype = ctypes.c_size_t
     _lib = L

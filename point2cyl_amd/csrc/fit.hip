@@ -381,8 +381,9 @@ extern "C" int p2c_extrusion_centers_bwd_f32(const float *dcenters, const float 
 #define EXT_MAXCH 8                       // 64-point chunks a wave keeps in registers per sweep: N <= EXT_WAVES*64*EXT_MAXCH per sweep
 
 // passes 1-2 of both kernels below: the K ascending lists of barrel points of cloud b -> list[start[k] .. start[k+1])
-__device__ __forceinline__ void ext_build_lists(const int64_t *__restrict__ sg, const int64_t *__restrict__ bl, int N, int K, int *list,
-                                                int (*wcnt)[FIT_MAXK], int *start)
+// key_of(n) -> segment of barrel point n, -1 for every other point
+template <class KeyF>
+__device__ __forceinline__ void ext_build_lists_by(KeyF key_of, int N, int K, int *list, int (*wcnt)[FIT_MAXK], int *start)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int per = ((N + EXT_WAVES - 1) / EXT_WAVES + 63) / 64 * 64;     // points per wave, a multiple of 64
@@ -398,10 +399,7 @@ __device__ __forceinline__ void ext_build_lists(const int64_t *__restrict__ sg, 
         for (int c = 0; c < EXT_MAXCH; ++c) {
             const int n = n_begin + (c0 + c) * 64 + lane;
             int kk = -1;
-            if (c0 + c < nch && n < n_end) {
-                const int64_t sv = sg[n];
-                kk = (bl[n] == 0 && sv >= 0 && sv < K) ? (int)sv : -1;
-            }
+            if (c0 + c < nch && n < n_end) kk = key_of(n);
             if (c0 == 0) key[c] = kk;                  // the first sweep stays in registers for pass 2
 #pragma unroll
             for (int k = 0; k < FIT_MAXK; ++k)
@@ -414,26 +412,30 @@ __device__ __forceinline__ void ext_build_lists(const int64_t *__restrict__ sg, 
             if (k < K) wcnt[wave][k] = cntk[k];
     }
     __syncthreads();
+    // counts -> offsets, in place and in parallel (a single thread walking the K x 16 table, then every thread its K x wave prefix,
+    // were two chains of dependent LDS reads: 10 us of the 80 a cloud takes in the one-pass kernel)
+    int mine = 0, before = 0;
+    const int pw = tid / K, pk = tid - pw * K;                 // thread (wave pw, segment pk) of the table
+    if (tid < EXT_WAVES * K) {
+        mine = wcnt[pw][pk];
+        for (int w = 0; w < pw; ++w) before += wcnt[w][pk];
+    }
+    __syncthreads();
+    if (tid < EXT_WAVES * K) {
+        wcnt[pw][pk] = before;                                 // now: barrel points of segment pk in the waves before pw
+        if (pw == EXT_WAVES - 1) start[pk + 1] = before + mine;    // segment totals, prefix-summed below
+    }
+    __syncthreads();
     if (tid == 0) {
         int run = 0;
-        for (int k = 0; k < K; ++k) {
-            start[k] = run;
-            for (int w = 0; w < EXT_WAVES; ++w) run += wcnt[w][k];
-        }
-        start[K] = run;
+        start[0] = 0;
+        for (int k = 0; k < K; ++k) { run += start[k + 1]; start[k + 1] = run; }
     }
     __syncthreads();
     // pass 2: ascending lists
     int base[FIT_MAXK];
 #pragma unroll
-    for (int k = 0; k < FIT_MAXK; ++k) {
-        int o = 0;
-        if (k < K) {
-            o = start[k];
-            for (int w = 0; w < wave; ++w) o += wcnt[w][k];
-        }
-        base[k] = o;
-    }
+    for (int k = 0; k < FIT_MAXK; ++k) base[k] = k < K ? start[k] + wcnt[wave][k] : 0;
     for (int c0 = 0; c0 < nch; c0 += EXT_MAXCH) {
 #pragma unroll
         for (int c = 0; c < EXT_MAXCH; ++c) {
@@ -442,8 +444,7 @@ __device__ __forceinline__ void ext_build_lists(const int64_t *__restrict__ sg, 
             if (c0 == 0) {
                 kk = key[c];
             } else if (c0 + c < nch && n < n_end) {
-                const int64_t sv = sg[n];
-                kk = (bl[n] == 0 && sv >= 0 && sv < K) ? (int)sv : -1;
+                kk = key_of(n);
             }
 #pragma unroll
             for (int k = 0; k < FIT_MAXK; ++k) {
@@ -456,6 +457,12 @@ __device__ __forceinline__ void ext_build_lists(const int64_t *__restrict__ sg, 
         }
     }
     __syncthreads();
+}
+
+__device__ __forceinline__ void ext_build_lists(const int64_t *__restrict__ sg, const int64_t *__restrict__ bl, int N, int K, int *list,
+                                                int (*wcnt)[FIT_MAXK], int *start)
+{
+    ext_build_lists_by([&](int n) { const int64_t sv = sg[n]; return (bl[n] == 0 && sv >= 0 && sv < K) ? (int)sv : -1; }, N, K, list, wcnt, start);
 }
 
 __global__ void __launch_bounds__(EXT_THREADS) extents_kernel(const float *__restrict__ P, const int64_t *__restrict__ seg,
@@ -484,16 +491,28 @@ __global__ void __launch_bounds__(EXT_THREADS) extents_kernel(const float *__res
             const int *lk = list + start[k];
             float lo = INFINITY, hi = -INFINITY;
             const int s_end = min(S, (ch + 1) * per_chunk);
-            for (int s = ch * per_chunk + lane; s < s_end; s += 64) {
-                float px = 0.f, py = 0.f, pz = 0.f;
-                if (cnt > 1) {
-                    const int n = lk[(int)ri[s]];
-                    const float *pp = P + ((size_t)b * N + n) * 3;
-                    px = pp[0]; py = pp[1]; pz = pp[2];
+            constexpr int RU = 8;                       // draws, then points, of 8 x 64 samples in flight (one dependent chain per 64 before)
+            for (int s0 = ch * per_chunk; s0 < s_end; s0 += 64 * RU) {
+                int r[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) { const int s = s0 + u * 64 + lane; r[u] = (s < s_end && cnt > 1) ? (int)ri[s] : 0; }
+                float px[RU], py[RU], pz[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    px[u] = py[u] = pz[u] = 0.f;
+                    if (cnt > 1 && s0 + u * 64 + lane < s_end) {
+                        const float *pp = P + ((size_t)b * N + lk[r[u]]) * 3;
+                        px[u] = pp[0]; py[u] = pp[1]; pz[u] = pp[2];
+                    }
                 }
-                const float dx = px - c0_, dy = py - c1_, dz = pz - c2_;
-                const float tt = __builtin_fmaf(dz, a2, __builtin_fmaf(dy, a1, dx * a0));
-                lo = fminf(lo, tt); hi = fmaxf(hi, tt);
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    if (s0 + u * 64 + lane < s_end) {
+                        const float dx = px[u] - c0_, dy = py[u] - c1_, dz = pz[u] - c2_;
+                        const float tt = __builtin_fmaf(dz, a2, __builtin_fmaf(dy, a1, dx * a0));
+                        lo = fminf(lo, tt); hi = fmaxf(hi, tt);
+                    }
+                }
             }
             for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
             if (lane == 0) { rmin[t] = lo; rmax[t] = hi; }
@@ -542,6 +561,227 @@ extern "C" int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, con
     const size_t lds = (size_t)N * sizeof(int);
     (void)hipFuncSetAttribute((const void *)extents_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(extents_kernel, dim3(B), dim3(EXT_THREADS), lds, s, P, seg, bb, axes, centers, rand_idx, N, K, S, ext_tmp, counts);
+    hipLaunchKernelGGL(extents_finish_kernel, dim3(K), dim3(256), 0, s, ext_tmp, counts, B, K, extents_out, found_out);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// The fitting-only path of eval.py in ONE pass over a cloud (BASELINE configs[3]: axis :397 -> hard centroids :409-436 -> extents
+// data_utils.py:1650-1730 on the fitted axes / centroids): the three kernels above read the same cloud three times (normals + weights,
+// points + labels, labels + points again).  One workgroup per cloud:
+//   phase 1  streams (X, Wb, Wc, P, seg, bb) once - thread (slice g, segment k) as in axis_kernel - into the 12 scatter sums, the 2 counts of
+//            the normalised variant and the centroid sums (3 + count) of segment k; the thread of segment 0 parks the point and its
+//            barrel key in LDS on the way (96 KB + 8 KB at N = 8192);
+//   phase 2  fp64 reduction (wave shuffles, then over the 16 waves), eigen-solve + centroid on K threads -> axes, centroids (global + LDS);
+//   phase 3  barrel lists from the LDS keys, projection of the S samples per segment from the LDS points -> min / max.
+// extents_finish_kernel applies the batch-level rules afterwards, as for the separate kernel.
+// K a power of two <= 8 and 3N floats + N bytes + N ints within the LDS: other shapes take the three separate kernels.
+// ------------------------------------------------------------------------------------------------
+#ifdef P2C_FIT_TRACE       // tools/fit_trace.py: shader-clock stamps of workgroup 0 at the phase boundaries
+__device__ unsigned long long p2c_fit_stamps[8];
+extern "C" int p2c_fit_trace_read(void *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_fit_stamps), sizeof(p2c_fit_stamps)) == hipSuccess ? 0 : 1; }
+#define FIT_TR(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) p2c_fit_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FIT_TR(i) do { } while (0)
+#endif
+
+template <int KK>
+__global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__restrict__ X, const float *__restrict__ Wb, const float *__restrict__ Wc,
+                                                                const float *__restrict__ P, const int64_t *__restrict__ seg,
+                                                                const int64_t *__restrict__ bb, const int64_t *__restrict__ rand_idx, int normalize,
+                                                                int N, int S, float *__restrict__ axis_out, float *__restrict__ cen_out,
+                                                                float *__restrict__ cfound_out, float *__restrict__ ext_tmp, int *__restrict__ counts)
+{
+    constexpr int NA = 18;                               // 12 scatter sums, 2 counts (normalize), centroid x y z, count
+    constexpr int G = EXT_THREADS / KK;                  // point slices
+    extern __shared__ int dyn[];
+    const int NL = max(N, EXT_WAVES * KK * NA * 2);      // ints: the lists of phase 3 / the per-wave fp64 sums of phase 2
+    int *list = dyn;
+    float *Ps = reinterpret_cast<float *>(dyn + NL);     // [3N]
+    signed char *keyb = reinterpret_cast<signed char *>(Ps + 3 * (size_t)N);    // [N]
+    __shared__ double tot[NA][KK];
+    __shared__ int wcnt[EXT_WAVES][FIT_MAXK];
+    __shared__ int start[FIT_MAXK + 1];
+    __shared__ float rmin[2 * EXT_WAVES], rmax[2 * EXT_WAVES];
+    __shared__ float axs[KK][3], cns[KK][3];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = tid / KK, k = tid % KK;
+    // ---------------- phase 1
+    FIT_TR(0);
+    float acc[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    {
+        const float *x = X + (size_t)b * N * 3, *pp = P + (size_t)b * N * 3;
+        const float *wb = Wb + (size_t)b * N * KK, *wc = Wc + (size_t)b * N * KK;
+        const int64_t *sg = seg + (size_t)b * N, *bl = bb + (size_t)b * N;
+#pragma unroll 4
+        for (int n = g; n < N; n += G) {
+            const float x0 = x[n * 3 + 0], x1 = x[n * 3 + 1], x2 = x[n * 3 + 2];
+            const float p0 = pp[n * 3 + 0], p1 = pp[n * 3 + 1], p2 = pp[n * 3 + 2];
+            const float b_ = wb[(size_t)n * KK + k], c_ = wc[(size_t)n * KK + k];
+            const int64_t sv = sg[n], bv = bl[n];
+            const float b2 = b_ * b_, c2 = c_ * c_;
+            const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
+            acc[0] += b2 * p00; acc[1] += b2 * p01; acc[2] += b2 * p02; acc[3] += b2 * p11; acc[4] += b2 * p12; acc[5] += b2 * p22;
+            acc[6] += c2 * p00; acc[7] += c2 * p01; acc[8] += c2 * p02; acc[9] += c2 * p11; acc[10] += c2 * p12; acc[11] += c2 * p22;
+            const bool mine = sv == k;
+            if (normalize) {
+                acc[12] += (mine && bv == 0) ? 1.f : 0.f;
+                acc[13] += (mine && bv == 1) ? 1.f : 0.f;
+            }
+            const float w = mine ? 1.f : 0.f;
+            acc[14] += w * p0; acc[15] += w * p1; acc[16] += w * p2; acc[17] += w;
+            if (k == 0) {
+                Ps[n * 3 + 0] = p0; Ps[n * 3 + 1] = p1; Ps[n * 3 + 2] = p2;
+                keyb[n] = (signed char)((bv == 0 && sv >= 0 && sv < KK) ? (int)sv : -1);
+            }
+        }
+    }
+    FIT_TR(1);
+    // the sample draws of this wave's first (segment, chunk) task: requested now, consumed after the reduction, the eigen-solve and the list
+    // build (one dependent global load per 64 samples inside the projection loop was a third of the separate kernel's time)
+    constexpr int nch = EXT_WAVES / KK, RU = 16;
+    const int per_chunk = (S + nch - 1) / nch;
+    int r0[RU];
+    {
+        const int kq = wave / nch, ch = wave - kq * nch;
+        const int64_t *ri = rand_idx + ((size_t)b * KK + kq) * S;
+        const int s_beg = ch * per_chunk, s_end = min(S, (ch + 1) * per_chunk);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) { const int s = s_beg + u * 64 + lane; r0[u] = s < s_end ? (int)ri[s] : 0; }
+    }
+    // ---------------- phase 2: the 64/K slices of a wave in fp32, fp64 from there on (see axis_kernel)
+    {
+        double *wsum = reinterpret_cast<double *>(list);                  // [EXT_WAVES][KK][NA]
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int o = KK; o < 64; o <<= 1) v += __shfl_xor(v, o);      // the lanes of segment k in this wave: lane % KK == k
+            if (lane < KK) wsum[(wave * KK + lane) * NA + i] = (double)v;
+        }
+        __syncthreads();
+        if (tid < KK * NA) {
+            const int rk = tid / NA, re = tid - rk * NA;
+            double rs = 0.0;
+            for (int w = 0; w < EXT_WAVES; ++w) rs += wsum[(w * KK + rk) * NA + re];
+            tot[re][rk] = rs;
+        }
+        __syncthreads();
+        FIT_TR(2);
+        if (tid < KK) {
+            double isb2 = 1.0, isc2 = 1.0;
+            if (normalize) {
+                const float sb = sqrtf((float)tot[12][tid]) + 1.0f, sc = sqrtf((float)tot[13][tid]) + 1.0f;   // data_utils.py:139-160
+                isb2 = 1.0 / ((double)sb * (double)sb);
+                isc2 = 1.0 / ((double)sc * (double)sc);
+            }
+            double a[6], lam[3], v[3][3];
+            for (int e = 0; e < 6; ++e) a[e] = tot[e][tid] * isb2 - tot[6 + e][tid] * isc2;
+            p2c_eigh3(a, lam, v);
+            int big = 0;
+            if (fabs(v[0][1]) > fabs(v[0][big])) big = 1;
+            if (fabs(v[0][2]) > fabs(v[0][big])) big = 2;
+            const double sgn = v[0][big] < 0 ? -1.0 : 1.0;
+            float *o = axis_out + ((size_t)b * KK + tid) * 3;
+            for (int e = 0; e < 3; ++e) { const float av = (float)(sgn * v[0][e]); o[e] = av; axs[tid][e] = av; }
+            const float c = (float)tot[17][tid];                          // hard centroid: as centroids_by_point_kernel
+            const bool ok = c > 1.f;
+            float *oc = cen_out + ((size_t)b * KK + tid) * 3;
+            for (int e = 0; e < 3; ++e) { const float cv = ok ? (float)tot[14 + e][tid] / c : 0.f; oc[e] = cv; cns[tid][e] = cv; }
+            cfound_out[(size_t)b * KK + tid] = ok ? 1.f : 0.f;
+        }
+        __syncthreads();
+    }
+    // ---------------- phase 3 (extents_kernel, on the LDS copies)
+    FIT_TR(3);
+    ext_build_lists_by([&](int n) { return (int)keyb[n]; }, N, KK, list, wcnt, start);
+    FIT_TR(4);
+    {
+        for (int t = wave; t < KK * nch; t += EXT_WAVES) {
+            const int kq = t / nch, ch = t - kq * nch;
+            const int cnt = start[kq + 1] - start[kq];
+            const float a0 = axs[kq][0], a1 = axs[kq][1], a2 = axs[kq][2], c0_ = cns[kq][0], c1_ = cns[kq][1], c2_ = cns[kq][2];
+            const int64_t *ri = rand_idx + ((size_t)b * KK + kq) * S;
+            const int *lk = list + start[kq];
+            float lo = INFINITY, hi = -INFINITY;
+            const int s_beg = ch * per_chunk, s_end = min(S, (ch + 1) * per_chunk);
+            for (int s0 = s_beg; s0 < s_end; s0 += 64 * RU) {
+                int r[RU];
+                if (t == wave && s0 == s_beg) {
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) r[u] = r0[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < RU; ++u) { const int s = s0 + u * 64 + lane; r[u] = s < s_end ? (int)ri[s] : 0; }
+                }
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    const int s = s0 + u * 64 + lane;
+                    if (s < s_end) {
+                        float px = 0.f, py = 0.f, pz = 0.f;
+                        if (cnt > 1) {
+                            const int n = lk[r[u]];
+                            px = Ps[n * 3 + 0]; py = Ps[n * 3 + 1]; pz = Ps[n * 3 + 2];
+                        }
+                        const float dx = px - c0_, dy = py - c1_, dz = pz - c2_;
+                        const float tt = __builtin_fmaf(dz, a2, __builtin_fmaf(dy, a1, dx * a0));
+                        lo = fminf(lo, tt); hi = fmaxf(hi, tt);
+                    }
+                }
+            }
+            for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+            if (lane == 0) { rmin[t] = lo; rmax[t] = hi; }
+        }
+        __syncthreads();
+        if (tid < KK) {
+            float l2 = rmin[tid * nch], h2 = rmax[tid * nch];
+            for (int ch = 1; ch < nch; ++ch) { l2 = fminf(l2, rmin[tid * nch + ch]); h2 = fmaxf(h2, rmax[tid * nch + ch]); }
+            ext_tmp[((size_t)b * KK + tid) * 2 + 0] = l2;
+            ext_tmp[((size_t)b * KK + tid) * 2 + 1] = h2;
+            counts[b * KK + tid] = start[tid + 1] - start[tid];
+        }
+        FIT_TR(5);
+    }
+}
+
+static size_t fit_fused_lds(int N, int K)
+{
+    const size_t nl = (size_t)N > (size_t)EXT_WAVES * K * 18 * 2 ? (size_t)N : (size_t)EXT_WAVES * K * 18 * 2;
+    return nl * sizeof(int) + (size_t)N * (3 * sizeof(float) + 1);
+}
+
+extern "C" int p2c_fit_fused_supported(int N, int K, int S)
+{
+    const bool kpow = K == 1 || K == 2 || K == 4 || K == 8;
+    return (kpow && S > 0 && N > 0 && (N % 4) == 0 && fit_fused_lds(N, K) <= 140 * 1024) ? 1 : 0;
+}
+
+// axes (B,K,3), centroids (B,K,3) + their found mask (B,K), extents (K,B,2) + found mask (B,K); ws: p2c_extents_ws_bytes(B, K)
+extern "C" int p2c_fit_fused_f32(const float *X, const float *Wb, const float *Wc, const int64_t *bb_gt, const int64_t *inst_gt, int normalize,
+                                 const float *P, const int64_t *rand_idx, int B, int N, int K, int S, float *axis_out, float *centroids_out,
+                                 float *cfound_out, float *extents_out, float *found_out, void *ws, void *stream)
+{
+    if (!X || !Wb || !Wc || !bb_gt || !inst_gt || !P || !rand_idx || !axis_out || !centroids_out || !cfound_out || !extents_out || !found_out || !ws ||
+        B <= 0 || !p2c_fit_fused_supported(N, K, S))
+        return P2C_EINVAL;
+    float *ext_tmp = (float *)ws;
+    int *counts = (int *)(ext_tmp + (size_t)B * K * 2);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = fit_fused_lds(N, K);
+#define P2C_FF(KK_)                                                                                                                     \
+    do {                                                                                                                                \
+        (void)hipFuncSetAttribute((const void *)fit_fused_kernel<KK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
+        hipLaunchKernelGGL(fit_fused_kernel<KK_>, dim3(B), dim3(EXT_THREADS), lds, s, X, Wb, Wc, P, inst_gt, bb_gt, rand_idx, normalize, N, S,  \
+                           axis_out, centroids_out, cfound_out, ext_tmp, counts);                                                      \
+    } while (0)
+    if (K == 8) P2C_FF(8);
+    else if (K == 4) P2C_FF(4);
+    else if (K == 2) P2C_FF(2);
+    else P2C_FF(1);
+#undef P2C_FF
     hipLaunchKernelGGL(extents_finish_kernel, dim3(K), dim3(256), 0, s, ext_tmp, counts, B, K, extents_out, found_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;

@@ -55,6 +55,25 @@ def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_cen
     return ops.extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, rand_idx.to(P.device))
 
 
+def fit_cylinders(X, W_barrel, W_base, gt_bb_labels, seg_label, P, num_points_to_sample=1024, rand_idx=None, normalize=False):
+    """The fitting-only chain on pre-segmented clouds (BASELINE configs[3]): estimate_extrusion_axis (eval.py:397) -> hard centroids
+    (eval.py:409-436) -> get_extrusion_extents on the fitted axes / centroids (data_utils.py:1650-1730), one pass per cloud where the
+    shape allows (ops.fit_fused), the three ops otherwise.  -> axes (B,K,3), centroids (B,K,3), centroid found (B,K), extents (K,B,2),
+    extent found (B,K).  Forward only."""
+    B, N, K = W_barrel.shape
+    S = num_points_to_sample if rand_idx is None else rand_idx.shape[2]
+    if rand_idx is None:
+        rand_idx = _barrel_draws(seg_label, gt_bb_labels, K, S)
+    rand_idx = rand_idx.to(P.device)
+    if ops.fit_fused_supported(N, K, S):
+        return ops.fit_fused(X, W_barrel, W_base, gt_bb_labels, seg_label, P, rand_idx, normalize=normalize)
+    with torch.no_grad():
+        axes = estimate_extrusion_axis(X, W_barrel, W_base, gt_bb_labels, seg_label, normalize=normalize)
+        cen, cfound = ops.segment_centroids(P, seg_label, K)
+        ext, found = ops.extrusion_extents(P, seg_label, gt_bb_labels, axes, cen, rand_idx)
+    return axes, cen, cfound, ext, found
+
+
 def _barrel_draws(seg_label, bb_labels, K, S):
     """The reference's torch.randint draws for its K x B sampling loops (data_utils.py:1064, :1696): k outer, b inner, only
     where the segment has > 1 barrel point in the batch and in the cloud, on the CPU generator."""

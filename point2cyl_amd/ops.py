@@ -832,6 +832,33 @@ def extrusion_extents(P, seg, bb, axes, centers, rand_idx):
     return ext, found
 
 
+def fit_fused_supported(N, K, S):
+    return bool(_lib.lib().p2c_fit_fused_supported(int(N), int(K), int(S)))
+
+
+def fit_fused(X, Wb, Wc, bb, seg, P, rand_idx, normalize=False):
+    """csrc/fit.hip fit_fused_kernel: axis -> hard centroids -> extents of pre-segmented clouds in one pass (eval.py:397, :409-436,
+    data_utils.py:1650-1730).  -> axes (B,K,3), centroids (B,K,3), centroid found (B,K), extents (K,B,2), extent found (B,K).  No gradient."""
+    _lib.require_device(X, Wb, Wc, bb, seg, P, rand_idx)
+    X, Wb, Wc, P = _f32c(X.detach()), _f32c(Wb.detach()), _f32c(Wc.detach()), _f32c(P)
+    B, N, K = Wb.shape
+    S = rand_idx.shape[2]
+    if not fit_fused_supported(N, K, S):
+        raise ValueError("fit_fused: shape N=%d K=%d S=%d is outside the fused kernel (K in {1,2,4,8}, cloud within the LDS); call the three ops" % (N, K, S))
+    seg, bb, rand_idx = seg.to(torch.int64).contiguous(), bb.to(torch.int64).contiguous(), rand_idx.to(torch.int64).contiguous()
+    dev = P.device
+    axes = torch.empty(B, K, 3, dtype=torch.float32, device=dev)
+    cen = torch.empty(B, K, 3, dtype=torch.float32, device=dev)
+    cfound = torch.empty(B, K, dtype=torch.float32, device=dev)
+    ext = torch.empty(K, B, 2, dtype=torch.float32, device=dev)
+    found = torch.empty(B, K, dtype=torch.float32, device=dev)
+    ws = torch.empty(_lib.lib().p2c_extents_ws_bytes(B, K) // 4 + 4, dtype=torch.float32, device=dev)
+    call("p2c_fit_fused_f32", ptr(X), ptr(Wb), ptr(Wc), ptr(bb), ptr(seg), 1 if normalize else 0, ptr(P), ptr(rand_idx), B, N, K, S,
+         ptr(axes), ptr(cen), ptr(cfound), ptr(ext), ptr(found), ptr(ws), stream(),
+         nbytes=float(B) * N * (12 + 12 + 2 * K * 4 + 16) + float(B) * K * S * 8)
+    return axes, cen, cfound, ext, found
+
+
 def sketch_projection(P, X, seg, bb, axes, centers, rand_idx, S, all_points=False):
     """data_utils.py:1014-1417 (csrc/fit.hip).  rand_idx (B,K,S) int64 or None with all_points ->
     P_projected (K,B,S,2), X_projected (K,B,S,2), scales (K,B), found (B,K).  No gradient (the reference's projection is built

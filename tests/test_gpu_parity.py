@@ -1235,6 +1235,51 @@ def test_fused_backward_256_wide_two_passes_equals_generic_kernels(grad_mode):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-6, name
 
 
+@pytest.mark.parametrize("B,N,K,S,normalize", [(6, 1024, 8, 256, False), (3, 2048, 4, 100, True), (2, 8192, 8, 2048, False), (5, 1000, 2, 64, True)])
+def test_fit_fused_equals_the_three_ops_and_the_oracle(B, N, K, S, normalize):
+    """fit_fused_kernel (axis -> hard centroids -> extents in one pass per cloud, eval.py:397 / :409-436 / data_utils.py:1650-1730) against
+    the three separate kernels called in that order, and against the oracle: centroids and found masks directly, extents on the SAME
+    axes / centroids (with its own fp32 axes the oracle's extents would mostly show eigenvector rounding), axes through the metric's dot."""
+    from point2cyl_amd import synth
+    pcs, nrm, seg, bb, _, _, axes_gt, _, _ = synth.make_batch(B, N, K, seed=100 + N + K)
+    pcs, nrm = pcs.float(), nrm.float()
+    g = torch.Generator().manual_seed(N + S)
+    nrm = F.normalize(nrm + 0.03 * torch.randn(nrm.shape, generator=g), dim=-1)
+    seg = seg.clone()
+    seg[0, :37] = -1                                        # unlabelled points
+    bb = bb.clone()
+    bb[-1][seg[-1] == 0] = 1                                # a segment without barrel points in one cloud
+    onehot = F.one_hot(seg.clamp_min(0), K).float() * (seg >= 0).unsqueeze(-1)
+    Wb, Wc = onehot * (bb == 0).unsqueeze(-1), onehot * (bb == 1).unsqueeze(-1)
+    cnt_barrel = Wb.sum(1).long()
+    ridx = torch.randint(0, 1 << 30, (B, K, S), generator=g) % cnt_barrel.clamp(min=1).unsqueeze(-1)
+    d = lambda t: t.to(DEV)
+    assert ops.fit_fused_supported(N, K, S)
+    A, C, CF, E, EF = fitting.fit_cylinders(d(nrm), d(Wb), d(Wc), d(bb), d(seg), d(pcs), rand_idx=ridx, normalize=normalize)
+    A3 = fitting.estimate_extrusion_axis(d(nrm), d(Wb), d(Wc), d(bb), d(seg), normalize=normalize)
+    C3, CF3 = ops.segment_centroids(d(pcs), d(seg), K)
+    E3, EF3 = ops.extrusion_extents(d(pcs), d(seg), d(bb), A, C, d(ridx))          # on the fused kernel's own axes / centroids
+    assert torch.equal(CF, CF3) and torch.equal(EF, EF3)
+    np.testing.assert_allclose(C.cpu().numpy(), C3.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_array_equal(E.cpu().numpy(), E3.cpu().numpy())                # same points, same axes, same arithmetic: bit-exact
+    well = (onehot.sum(1) > 0) & (Wb.sum(1) > 50) & (Wc.sum(1) > 50)               # isolated smallest eigenvalue
+    dots = (A.cpu() * A3.cpu()).sum(-1)
+    assert float(dots[well].min()) > 1 - 1e-6, float(dots[well].min())             # same canonical sign, same direction
+    # oracle
+    rc, rf = R.hard_centroids(onehot, pcs)
+    assert np.array_equal(CF.cpu().numpy(), rf.numpy())
+    np.testing.assert_allclose(C.cpu().numpy(), rc.numpy(), rtol=1e-5, atol=1e-6)
+    E_o = R.estimate_extrusion_axis(nrm.double(), Wb.double(), Wc.double(), bb if normalize else None, seg if normalize else None,
+                                    normalize=normalize, literal=False)
+    sin = torch.linalg.cross(A.cpu().double(), E_o.double()).norm(dim=-1)
+    assert float(sin[well].max()) < 3e-6, float(sin[well].max())
+    # (the oracle one-hots the labels: the unlabelled points go to segment 0 as BASE points there - no barrel list sees them either way)
+    seg_o, bb_o = seg.clamp_min(0), torch.where(seg < 0, torch.ones_like(bb), bb)
+    ext_o, found_o = R.get_extrusion_extents(pcs, seg_o, bb_o, A.cpu(), C.cpu(), {(k, b): ridx[b, k] for k in range(K) for b in range(B)})
+    assert np.array_equal(EF.cpu().numpy() > 0, found_o.numpy() > 0)
+    np.testing.assert_allclose(E.cpu().numpy(), ext_o.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_fitting_properties_at_config4_size():
     """BASELINE configs[3] size (1250 clouds x 8192 points would take the CPU oracle minutes): size-independent properties of the
     fitting kernels on 256 clouds x 8192 points instead.

@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--samples", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--cpu_clouds", type=int, default=64)
+    ap.add_argument("--unfused", action="store_true", help="the three separate kernels (axis, centroids, extents) instead of the one-pass kernel")
     a = ap.parse_args()
     from point2cyl_amd import fitting, ops
     from oracle import ref_torch as R
@@ -69,7 +70,12 @@ def main():
     d = lambda t: t.to(dev)
     pcs_d, X_d, seg_d, bb_d, Wb_d, Wc_d, oh_d, ri_d = d(pcs), d(X), d(seg), d(bb), d(Wb), d(Wc), d(onehot), d(rand_idx)
 
+    fused = (not a.unfused) and ops.fit_fused_supported(N, K, S)
+
     def fit():
+        if fused:
+            E_AX, cen, _, ext, _ = fitting.fit_cylinders(X_d, Wb_d, Wc_d, bb_d, seg_d, pcs_d, rand_idx=ri_d, normalize=False)
+            return E_AX, cen, ext
         with torch.no_grad():
             E_AX = fitting.estimate_extrusion_axis(X_d, Wb_d, Wc_d, bb_d, seg_d, normalize=False)
             cen, found = ops.segment_centroids(pcs_d, seg_d, K)
@@ -91,6 +97,7 @@ def main():
     points = a.clouds * N
     axis_ms = prof.get("p2c_extrusion_axis_f32", {}).get("ms", 0.0) / a.steps
     axis_bytes = points * (12 + 2 * K * 4)                     # X + W_barrel + W_base read once (76 B/point at K=8)
+    fused_ms = prof.get("p2c_fit_fused_f32", {}).get("ms", 0.0) / a.steps
 
     # ---- CPU side: the oracle's closed-form restatement on a subset, same inputs
     c = min(a.cpu_clouds, a.clouds)
@@ -117,14 +124,16 @@ def main():
     # the whole path (axis + centroids + extents): every input read once - normals, points, both membership matrices, both label arrays,
     # the pre-drawn sample indices (they are an input of this boundary: data_utils.py:1690 draws them on the host)
     path_bytes = points * (12 + 12 + 2 * K * 4 + seg.element_size() + bb.element_size()) + a.clouds * K * S * rand_idx.element_size()
+    kern_bytes, kern_ms = (path_bytes, fused_ms) if fused else (axis_bytes, axis_ms)
     line = dict(metric="fitting-only cylinders/sec (axis + centroid + extent), 10k pre-segmented cylinders at N=8192",
                 value=round(a.clouds * K / dt, 1), unit="cylinders/s", n_gpus=1, steps=a.steps, ms_per_step=round(dt * 1e3, 3),
                 points_per_s=round(points / dt, 1), dtype="f32", data="synthetic",
                 config=dict(workload="configs[3]: %d clouds x K=%d x N=%d, X = gt normals + 2 deg angular noise, one-hot W, S=%d"
-                                     % (a.clouds, K, N, S)),
-                roofline=dict(bound="hbm", kernel="p2c_extrusion_axis_f32", achieved=round(axis_bytes / (axis_ms * 1e-3) / 1e9, 1) if axis_ms else None,
-                              peak=8000.0, unit="GB/s", frac=round(axis_bytes / (axis_ms * 1e-3) / 1e9 / 8000.0, 4) if axis_ms else None,
-                              algorithmic_bytes_per_launch=axis_bytes, avg_launch_us=round(axis_ms * 1e3, 1), traffic=None,
+                                     % (a.clouds, K, N, S), kernels="one pass per cloud (fit_fused)" if fused else "axis, centroids, extents"),
+                roofline=dict(bound="hbm", kernel="p2c_fit_fused_f32" if fused else "p2c_extrusion_axis_f32",
+                              achieved=round(kern_bytes / (kern_ms * 1e-3) / 1e9, 1) if kern_ms else None,
+                              peak=8000.0, unit="GB/s", frac=round(kern_bytes / (kern_ms * 1e-3) / 1e9 / 8000.0, 4) if kern_ms else None,
+                              algorithmic_bytes_per_launch=kern_bytes, avg_launch_us=round(kern_ms * 1e3, 1), traffic=None,
                               path=dict(algorithmic_bytes=path_bytes, ms=round(dt * 1e3, 3), achieved=round(path_bytes / dt / 1e9, 1),
                                         frac=round(path_bytes / dt / 1e9 / 8000.0, 4))),
                 cpu_baseline=dict(value=round(c * K / cpu_dt, 1), unit="cylinders/s", cores=torch.get_num_threads(), kind="port",

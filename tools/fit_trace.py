@@ -1,0 +1,40 @@
+"""Phase stamps of fit_fused_kernel (csrc/fit.hip built with -DP2C_FIT_TRACE into a throw-away library).
+   Build here: python tools/fit_trace.py --build     Run on the GPU box: python tools/fit_trace.py"""
+import ctypes, os, subprocess, sys
+HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "libp2c_fit_trace.so")
+if "--build" in sys.argv:
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_FIT_TRACE", "-shared", "-o", LIB,
+                           os.path.join(ROOT, "point2cyl_amd", "csrc", "fit.hip")])
+    print(LIB); sys.exit(0)
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+sys.path.insert(0, HERE)
+from bench_config4 import make_inputs
+B, N, K, S = 1250, 8192, 8, 2048
+pcs, X, seg, bb, axes, Wb, Wc, onehot = make_inputs(B, N, K, 4321)
+g = torch.Generator().manual_seed(7)
+counts = ((seg.unsqueeze(-1) == torch.arange(K)) & (bb == 0).unsqueeze(-1)).sum(1)
+ri = torch.randint(0, 1 << 30, (B, K, S), generator=g) % counts.clamp_min(1).unsqueeze(-1)
+d = lambda t: t.cuda().contiguous()
+pcs, X, seg, bb, Wb, Wc, ri = d(pcs), d(X), d(seg), d(bb), d(Wb), d(Wc), d(ri)
+L = ctypes.CDLL(LIB)
+vp, ci = ctypes.c_void_p, ctypes.c_int
+L.p2c_fit_fused_f32.argtypes = [vp] * 5 + [ci] + [vp] * 2 + [ci] * 4 + [vp] * 7
+L.p2c_extents_ws_bytes.restype = ctypes.c_size_t
+ax = torch.empty(B, K, 3, device="cuda"); ce = torch.empty(B, K, 3, device="cuda"); cf = torch.empty(B, K, device="cuda")
+ex = torch.empty(K, B, 2, device="cuda"); ef = torch.empty(B, K, device="cuda"); ws = torch.empty(B * K * 3 + 16, device="cuda")
+def run():
+    assert L.p2c_fit_fused_f32(X.data_ptr(), Wb.data_ptr(), Wc.data_ptr(), bb.data_ptr(), seg.data_ptr(), 0, pcs.data_ptr(), ri.data_ptr(), B, N, K, S,
+                               ax.data_ptr(), ce.data_ptr(), cf.data_ptr(), ex.data_ptr(), ef.data_ptr(), ws.data_ptr(), None) == 0
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); run(); e1.record(); torch.cuda.synchronize()
+print("fit_fused + finish: %.1f us" % (e0.elapsed_time(e1) * 1e3))
+st = np.zeros(8, dtype=np.uint64)
+assert L.p2c_fit_trace_read(st.ctypes.data_as(vp)) == 0
+d_ = np.diff(st[:6].astype(np.int64))
+print("workgroup 0, shader cycles: stream %d | sums (shuffles + 16 waves) %d | eigen + centroid %d | lists %d | projection %d   (2.4 GHz: total %.1f us)"
+      % (d_[0], d_[1], d_[2], d_[3], d_[4], d_.sum() / 2400.0))

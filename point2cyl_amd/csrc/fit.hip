@@ -382,11 +382,11 @@ extern "C" int p2c_extrusion_centers_bwd_f32(const float *dcenters, const float 
 
 // passes 1-2 of both kernels below: the K ascending lists of barrel points of cloud b -> list[start[k] .. start[k+1])
 // key_of(n) -> segment of barrel point n, -1 for every other point
-template <class KeyF>
+template <int WAVES = EXT_WAVES, class KeyF>
 __device__ __forceinline__ void ext_build_lists_by(KeyF key_of, int N, int K, int *list, int (*wcnt)[FIT_MAXK], int *start)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = ((N + EXT_WAVES - 1) / EXT_WAVES + 63) / 64 * 64;     // points per wave, a multiple of 64
+    const int per = ((N + WAVES - 1) / WAVES + 63) / 64 * 64;     // points per wave, a multiple of 64
     const int n_begin = wave * per, n_end = min(N, n_begin + per);
     // pass 1: key of every point of this wave's range (-1 = not a barrel point of any segment); per-segment counts
     int key[EXT_MAXCH];
@@ -416,14 +416,14 @@ __device__ __forceinline__ void ext_build_lists_by(KeyF key_of, int N, int K, in
     // were two chains of dependent LDS reads: 10 us of the 80 a cloud takes in the one-pass kernel)
     int mine = 0, before = 0;
     const int pw = tid / K, pk = tid - pw * K;                 // thread (wave pw, segment pk) of the table
-    if (tid < EXT_WAVES * K) {
+    if (tid < WAVES * K) {
         mine = wcnt[pw][pk];
         for (int w = 0; w < pw; ++w) before += wcnt[w][pk];
     }
     __syncthreads();
-    if (tid < EXT_WAVES * K) {
+    if (tid < WAVES * K) {
         wcnt[pw][pk] = before;                                 // now: barrel points of segment pk in the waves before pw
-        if (pw == EXT_WAVES - 1) start[pk + 1] = before + mine;    // segment totals, prefix-summed below
+        if (pw == WAVES - 1) start[pk + 1] = before + mine;    // segment totals, prefix-summed below
     }
     __syncthreads();
     if (tid == 0) {
@@ -586,24 +586,26 @@ extern "C" int p2c_fit_trace_read(void *out) { return hipMemcpyFromSymbol(out, H
 #define FIT_TR(i) do { } while (0)
 #endif
 
-template <int KK>
-__global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__restrict__ X, const float *__restrict__ Wb, const float *__restrict__ Wc,
+// THREADS 1024 / PLDS: one workgroup per CU, the cloud's points parked in LDS.  THREADS 512 / !PLDS: two workgroups per CU (one streams
+// while the other is in its serial phases), the projection gathers its points from global memory (L2 / MALL: the workgroup has just read them).
+template <int KK, int THREADS, bool PLDS>
+__global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__restrict__ X, const float *__restrict__ Wb, const float *__restrict__ Wc,
                                                                 const float *__restrict__ P, const int64_t *__restrict__ seg,
                                                                 const int64_t *__restrict__ bb, const int64_t *__restrict__ rand_idx, int normalize,
                                                                 int N, int S, float *__restrict__ axis_out, float *__restrict__ cen_out,
                                                                 float *__restrict__ cfound_out, float *__restrict__ ext_tmp, int *__restrict__ counts)
 {
     constexpr int NA = 18;                               // 12 scatter sums, 2 counts (normalize), centroid x y z, count
-    constexpr int G = EXT_THREADS / KK;                  // point slices
+    constexpr int WAVES = THREADS / 64, G = THREADS / KK;                  // point slices
     extern __shared__ int dyn[];
-    const int NL = max(N, EXT_WAVES * KK * NA * 2);      // ints: the lists of phase 3 / the per-wave fp64 sums of phase 2
+    const int NL = max(N, WAVES * KK * NA * 2);      // ints: the lists of phase 3 / the per-wave fp64 sums of phase 2
     int *list = dyn;
-    float *Ps = reinterpret_cast<float *>(dyn + NL);     // [3N]
-    signed char *keyb = reinterpret_cast<signed char *>(Ps + 3 * (size_t)N);    // [N]
+    float *Ps = reinterpret_cast<float *>(dyn + NL);     // [3N] (PLDS)
+    signed char *keyb = reinterpret_cast<signed char *>(Ps + (PLDS ? 3 * (size_t)N : 0));    // [N]
     __shared__ double tot[NA][KK];
-    __shared__ int wcnt[EXT_WAVES][FIT_MAXK];
+    __shared__ int wcnt[WAVES][FIT_MAXK];
     __shared__ int start[FIT_MAXK + 1];
-    __shared__ float rmin[2 * EXT_WAVES], rmax[2 * EXT_WAVES];
+    __shared__ float rmin[2 * WAVES], rmax[2 * WAVES];
     __shared__ float axs[KK][3], cns[KK][3];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = tid / KK, k = tid % KK;
@@ -615,13 +617,15 @@ __global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__r
     {
         const float *x = X + (size_t)b * N * 3, *pp = P + (size_t)b * N * 3;
         const float *wb = Wb + (size_t)b * N * KK, *wc = Wc + (size_t)b * N * KK;
-        const int64_t *sg = seg + (size_t)b * N, *bl = bb + (size_t)b * N;
-#pragma unroll 4
+        // the labels' low words (little-endian int64 holding small non-negative values or -1): half the registers per point in flight, and
+        // a CU's streaming rate is set by the bytes it keeps in flight (16 waves x 8 points x 104 B per unrolled step)
+        const int *sg = reinterpret_cast<const int *>(seg + (size_t)b * N), *bl = reinterpret_cast<const int *>(bb + (size_t)b * N);
+#pragma unroll 8
         for (int n = g; n < N; n += G) {
             const float x0 = x[n * 3 + 0], x1 = x[n * 3 + 1], x2 = x[n * 3 + 2];
             const float p0 = pp[n * 3 + 0], p1 = pp[n * 3 + 1], p2 = pp[n * 3 + 2];
             const float b_ = wb[(size_t)n * KK + k], c_ = wc[(size_t)n * KK + k];
-            const int64_t sv = sg[n], bv = bl[n];
+            const int sv = sg[2 * n], bv = bl[2 * n];
             const float b2 = b_ * b_, c2 = c_ * c_;
             const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
             acc[0] += b2 * p00; acc[1] += b2 * p01; acc[2] += b2 * p02; acc[3] += b2 * p11; acc[4] += b2 * p12; acc[5] += b2 * p22;
@@ -634,7 +638,7 @@ __global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__r
             const float w = mine ? 1.f : 0.f;
             acc[14] += w * p0; acc[15] += w * p1; acc[16] += w * p2; acc[17] += w;
             if (k == 0) {
-                Ps[n * 3 + 0] = p0; Ps[n * 3 + 1] = p1; Ps[n * 3 + 2] = p2;
+                if (PLDS) { Ps[n * 3 + 0] = p0; Ps[n * 3 + 1] = p1; Ps[n * 3 + 2] = p2; }
                 keyb[n] = (signed char)((bv == 0 && sv >= 0 && sv < KK) ? (int)sv : -1);
             }
         }
@@ -642,7 +646,7 @@ __global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__r
     FIT_TR(1);
     // the sample draws of this wave's first (segment, chunk) task: requested now, consumed after the reduction, the eigen-solve and the list
     // build (one dependent global load per 64 samples inside the projection loop was a third of the separate kernel's time)
-    constexpr int nch = EXT_WAVES / KK, RU = 16;
+    constexpr int nch = WAVES / KK, RU = 16;
     const int per_chunk = (S + nch - 1) / nch;
     int r0[RU];
     {
@@ -654,7 +658,7 @@ __global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__r
     }
     // ---------------- phase 2: the 64/K slices of a wave in fp32, fp64 from there on (see axis_kernel)
     {
-        double *wsum = reinterpret_cast<double *>(list);                  // [EXT_WAVES][KK][NA]
+        double *wsum = reinterpret_cast<double *>(list);                  // [WAVES][KK][NA]
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             float v = acc[i];
@@ -666,7 +670,7 @@ __global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__r
         if (tid < KK * NA) {
             const int rk = tid / NA, re = tid - rk * NA;
             double rs = 0.0;
-            for (int w = 0; w < EXT_WAVES; ++w) rs += wsum[(w * KK + rk) * NA + re];
+            for (int w = 0; w < WAVES; ++w) rs += wsum[(w * KK + rk) * NA + re];
             tot[re][rk] = rs;
         }
         __syncthreads();
@@ -697,10 +701,10 @@ __global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__r
     }
     // ---------------- phase 3 (extents_kernel, on the LDS copies)
     FIT_TR(3);
-    ext_build_lists_by([&](int n) { return (int)keyb[n]; }, N, KK, list, wcnt, start);
+    ext_build_lists_by<WAVES>([&](int n) { return (int)keyb[n]; }, N, KK, list, wcnt, start);
     FIT_TR(4);
     {
-        for (int t = wave; t < KK * nch; t += EXT_WAVES) {
+        for (int t = wave; t < KK * nch; t += WAVES) {
             const int kq = t / nch, ch = t - kq * nch;
             const int cnt = start[kq + 1] - start[kq];
             const float a0 = axs[kq][0], a1 = axs[kq][1], a2 = axs[kq][2], c0_ = cns[kq][0], c1_ = cns[kq][1], c2_ = cns[kq][2];
@@ -717,15 +721,21 @@ __global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__r
 #pragma unroll
                     for (int u = 0; u < RU; ++u) { const int s = s0 + u * 64 + lane; r[u] = s < s_end ? (int)ri[s] : 0; }
                 }
+                float qx[RU], qy[RU], qz[RU];
+#pragma unroll
+                for (int u = 0; u < RU; ++u) {
+                    qx[u] = qy[u] = qz[u] = 0.f;
+                    if (cnt > 1 && s0 + u * 64 + lane < s_end) {
+                        const int n = lk[r[u]];
+                        const float *pg = PLDS ? Ps + n * 3 : P + ((size_t)b * N + n) * 3;
+                        qx[u] = pg[0]; qy[u] = pg[1]; qz[u] = pg[2];
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < RU; ++u) {
                     const int s = s0 + u * 64 + lane;
                     if (s < s_end) {
-                        float px = 0.f, py = 0.f, pz = 0.f;
-                        if (cnt > 1) {
-                            const int n = lk[r[u]];
-                            px = Ps[n * 3 + 0]; py = Ps[n * 3 + 1]; pz = Ps[n * 3 + 2];
-                        }
+                        const float px = qx[u], py = qy[u], pz = qz[u];
                         const float dx = px - c0_, dy = py - c1_, dz = pz - c2_;
                         const float tt = __builtin_fmaf(dz, a2, __builtin_fmaf(dy, a1, dx * a0));
                         lo = fminf(lo, tt); hi = fmaxf(hi, tt);
@@ -747,16 +757,16 @@ __global__ void __launch_bounds__(EXT_THREADS) fit_fused_kernel(const float *__r
     }
 }
 
-static size_t fit_fused_lds(int N, int K)
+static size_t fit_fused_lds(int N, int K, int waves, bool plds)
 {
-    const size_t nl = (size_t)N > (size_t)EXT_WAVES * K * 18 * 2 ? (size_t)N : (size_t)EXT_WAVES * K * 18 * 2;
-    return nl * sizeof(int) + (size_t)N * (3 * sizeof(float) + 1);
+    const size_t nl = (size_t)N > (size_t)waves * K * 18 * 2 ? (size_t)N : (size_t)waves * K * 18 * 2;
+    return nl * sizeof(int) + (size_t)N * ((plds ? 3 * sizeof(float) : 0) + 1);
 }
 
 extern "C" int p2c_fit_fused_supported(int N, int K, int S)
 {
     const bool kpow = K == 1 || K == 2 || K == 4 || K == 8;
-    return (kpow && S > 0 && N > 0 && (N % 4) == 0 && fit_fused_lds(N, K) <= 140 * 1024) ? 1 : 0;
+    return (kpow && S > 0 && N > 0 && (N % 4) == 0 && fit_fused_lds(N, K, EXT_WAVES, true) <= 140 * 1024) ? 1 : 0;
 }
 
 // axes (B,K,3), centroids (B,K,3) + their found mask (B,K), extents (K,B,2) + found mask (B,K); ws: p2c_extents_ws_bytes(B, K)
@@ -770,17 +780,23 @@ extern "C" int p2c_fit_fused_f32(const float *X, const float *Wb, const float *W
     float *ext_tmp = (float *)ws;
     int *counts = (int *)(ext_tmp + (size_t)B * K * 2);
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = fit_fused_lds(N, K);
-#define P2C_FF(KK_)                                                                                                                     \
+    // P2C_FIT_VARIANT=1: two half-size workgroups per CU, one's serial phases under the other's streaming, points gathered from global memory
+    const char *fv = getenv("P2C_FIT_VARIANT");
+    const int forced = fv ? atoi(fv) : -1;
+    const bool half = forced == 1;          // (measured at 1250 clouds: 0.45 ms against 0.40 for the one-workgroup form - the gathers cost what the overlap gains)
+#define P2C_FF(KK_, TH_, PLDS_)                                                                                                         \
     do {                                                                                                                                \
-        (void)hipFuncSetAttribute((const void *)fit_fused_kernel<KK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);           \
-        hipLaunchKernelGGL(fit_fused_kernel<KK_>, dim3(B), dim3(EXT_THREADS), lds, s, X, Wb, Wc, P, inst_gt, bb_gt, rand_idx, normalize, N, S,  \
+        const size_t lds = fit_fused_lds(N, K, TH_ / 64, PLDS_);                                                                        \
+        (void)hipFuncSetAttribute((const void *)fit_fused_kernel<KK_, TH_, PLDS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        hipLaunchKernelGGL((fit_fused_kernel<KK_, TH_, PLDS_>), dim3(B), dim3(TH_), lds, s, X, Wb, Wc, P, inst_gt, bb_gt, rand_idx, normalize, N, S,    \
                            axis_out, centroids_out, cfound_out, ext_tmp, counts);                                                      \
     } while (0)
-    if (K == 8) P2C_FF(8);
-    else if (K == 4) P2C_FF(4);
-    else if (K == 2) P2C_FF(2);
-    else P2C_FF(1);
+#define P2C_FFK(KK_) do { if (half) P2C_FF(KK_, 512, false); else P2C_FF(KK_, 1024, true); } while (0)
+    if (K == 8) P2C_FFK(8);
+    else if (K == 4) P2C_FFK(4);
+    else if (K == 2) P2C_FFK(2);
+    else P2C_FFK(1);
+#undef P2C_FFK
 #undef P2C_FF
     hipLaunchKernelGGL(extents_finish_kernel, dim3(K), dim3(256), 0, s, ext_tmp, counts, B, K, extents_out, found_out);
     P2C_LAUNCH_CHECK();

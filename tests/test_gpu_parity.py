@@ -1235,12 +1235,14 @@ def test_fused_backward_256_wide_two_passes_equals_generic_kernels(grad_mode):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-6, name
 
 
+@pytest.mark.parametrize("variant", ["0", "1"])          # 0: 1024 threads, points in LDS | 1: 512 threads, two workgroups per CU, points gathered
 @pytest.mark.parametrize("B,N,K,S,normalize", [(6, 1024, 8, 256, False), (3, 2048, 4, 100, True), (2, 8192, 8, 2048, False), (5, 1000, 2, 64, True)])
-def test_fit_fused_equals_the_three_ops_and_the_oracle(B, N, K, S, normalize):
+def test_fit_fused_equals_the_three_ops_and_the_oracle(B, N, K, S, normalize, variant, monkeypatch):
     """fit_fused_kernel (axis -> hard centroids -> extents in one pass per cloud, eval.py:397 / :409-436 / data_utils.py:1650-1730) against
     the three separate kernels called in that order, and against the oracle: centroids and found masks directly, extents on the SAME
     axes / centroids (with its own fp32 axes the oracle's extents would mostly show eigenvector rounding), axes through the metric's dot."""
     from point2cyl_amd import synth
+    monkeypatch.setenv("P2C_FIT_VARIANT", variant)
     pcs, nrm, seg, bb, _, _, axes_gt, _, _ = synth.make_batch(B, N, K, seed=100 + N + K)
     pcs, nrm = pcs.float(), nrm.float()
     g = torch.Generator().manual_seed(N + S)

@@ -277,6 +277,12 @@ int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Yfwd, int ld
 int p2c_bn_bwd_finalize_f32(const double *slots, int C, long long M, const float *stat, const float *gamma, float *dgamma,
                             float *dbeta, float *coef_out, void *stream);
 
+/* out[0..n) = sum over `copies` matrices src + c*stride (the per-XCD copies of a weight gradient the fused backward accumulates into),
+ * alone or in the same launch as p2c_bn_bwd_finalize_f32 (same arguments first). */
+int p2c_sum_copies_f32(const float *src, long long stride, int copies, float *out, long long n, void *stream);
+int p2c_bn_bwd_finalize_sum_f32(const double *slots, int C, long long M, const float *stat, const float *gamma, float *dgamma, float *dbeta,
+                                float *coef_out, const float *src, long long stride, int copies, float *out, long long n, void *stream);
+
 /* dW[co,ci] += sum_m dY[m,co] * act_in(X)[m,ci];  dbias[co] += sum_m dY[m,co] (dbias may be NULL).
  * dW / dbias must be zero-initialised by the caller (the kernel splits the row range over workgroups and
  * accumulates with fp32 atomics).  With dw_slot_stride != 0 the atomics are spread over 8 copies of dW

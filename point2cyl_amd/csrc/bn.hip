@@ -484,6 +484,81 @@ extern "C" int p2c_group_colsum_bn_f32(const float *dz, int lddz, const float *y
 
 extern "C" size_t p2c_stat_slots_bytes(int C) { return (size_t)P2C_STAT_SLOTS * 2 * (size_t)C * sizeof(double); }
 
+// The per-XCD copies of a weight gradient (csrc/bwd_fused3.hip flushes dW into the copy of the workgroup's XCD) summed into one matrix,
+// copy 0 first: out[i] = ((c0 + c1) + ... ) - alone, or as extra workgroups of the finalize launch that follows a fused backward kernel
+// anyway (a reduction launch of its own per layer was 8 x 6 us of a 4.2 ms step).
+__device__ __forceinline__ void p2c_sum_copies(const float *__restrict__ src, long long stride, int copies, float *__restrict__ out, long long n,
+                                               long long blk)
+{
+    const long long i = (blk * 256 + threadIdx.x) * 4;
+    if (i + 3 < n && ((stride | (long long)((uintptr_t)src >> 2) | (long long)((uintptr_t)out >> 2)) & 3) == 0) {
+        float4 a = *reinterpret_cast<const float4 *>(src + i);
+        for (int c = 1; c < copies; ++c) {
+            const float4 v = *reinterpret_cast<const float4 *>(src + c * stride + i);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(out + i) = a;
+    } else {
+        for (long long j = i; j < min(i + 4, n); ++j) {
+            float a = src[j];
+            for (int c = 1; c < copies; ++c) a += src[c * stride + j];
+            out[j] = a;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) sum_copies_kernel(const float *__restrict__ src, long long stride, int copies, float *__restrict__ out, long long n)
+{
+    p2c_sum_copies(src, stride, copies, out, n, blockIdx.x);
+}
+
+extern "C" int p2c_sum_copies_f32(const float *src, long long stride, int copies, float *out, long long n, void *stream)
+{
+    if (!src || !out || copies <= 0 || n <= 0) return P2C_EINVAL;
+    hipLaunchKernelGGL(sum_copies_kernel, dim3(p2c_cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, src, stride, copies, out, n);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_finalize_sum_kernel(const double *__restrict__ ws, int n_chunks, int C, long long M,
+                                                                 const float *__restrict__ stat, const float *__restrict__ gamma,
+                                                                 float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ coef,
+                                                                 int fin_blocks, const float *__restrict__ src, long long stride, int copies,
+                                                                 float *__restrict__ out, long long n)
+{
+    if ((int)blockIdx.x >= fin_blocks) {
+        p2c_sum_copies(src, stride, copies, out, n, (long long)blockIdx.x - fin_blocks);
+        return;
+    }
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    double s1 = 0.0, s2 = 0.0;
+    p2c_sum_slots(ws, n_chunks, C, c, true, s1, s2);
+    if (c >= C || threadIdx.x >= 64) return;
+    if (dgamma) dgamma[c] = (float)s2;
+    if (dbeta) dbeta[c] = (float)s1;
+    const double is = (double)stat[3 * C + c], gs = (double)gamma[c] * is;
+    const double q = -gs * is * s2 / (double)M;
+    const double p = -gs * s1 / (double)M - q * (double)stat[2 * C + c];
+    coef[c] = stat[c];
+    coef[C + c] = stat[C + c];
+    coef[2 * C + c] = (float)gs;
+    coef[3 * C + c] = (float)q;
+    coef[4 * C + c] = (float)p;
+}
+
+// p2c_bn_bwd_finalize_f32 + p2c_sum_copies_f32 in one launch
+extern "C" int p2c_bn_bwd_finalize_sum_f32(const double *slots, int C, long long M, const float *stat, const float *gamma, float *dgamma,
+                                           float *dbeta, float *coef_out, const float *src, long long stride, int copies, float *out, long long n,
+                                           void *stream)
+{
+    if (!slots || !stat || !gamma || !coef_out || C <= 0 || !src || !out || copies <= 0 || n <= 0) return P2C_EINVAL;
+    const int fin = p2c_cdiv(C, 64);
+    hipLaunchKernelGGL(bn_bwd_finalize_sum_kernel, dim3(fin + p2c_cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, slots, P2C_STAT_SLOTS, C, M, stat,
+                       gamma, dgamma, dbeta, coef_out, fin, src, stride, copies, out, n);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
 // finalize from per-tile partials produced elsewhere (the fused backward-data epilogue): stat = [scale|shift|mean|invstd] x C
 extern "C" int p2c_bn_bwd_finalize_f32(const double *slots, int C, long long M, const float *stat, const float *gamma, float *dgamma,
                                        float *dbeta, float *coef_out, void *stream)

@@ -649,6 +649,7 @@ class _MLPStack(torch.autograd.Function):
 
             grads[p0 + 1] = db[:co_t]
             dW_final = dW                     # replaced by the sum of the per-XCD copies where those are used
+            dW_copies = None                  # (the 8 copies, summed by the finalize launch below - or a launch of its own where there is none)
             need_dx = i > 0 or ctx.needs_input_grad[1]
             stats_below = i > 0                       # the layer below has a BatchNorm whose backward sums we produce here
             L_ = _lib.lib()
@@ -668,7 +669,7 @@ class _MLPStack(torch.autograd.Function):
                      ptr(db) if grad_mode == 0 else None, ptr(aff[i - 1]) if stats_below else None, ptr(part), M, Co, Ci, stream(),
                      flops=(4.0 if need_dx else 2.0) * M * Co * Ci,
                      nbytes=4.0 * M * ((1 if grad_mode == 2 else 2) * Co + (2 if need_dx else 1) * Ci))   # dZ (unless pooled), Y, X read once; dX written once
-                dW_final = dW8.sum(0)
+                dW_copies = dW8
             elif (USE_DUAL_BWD and need_dx and M <= 8192 and Co > 64 and Ci > 64 and grad_mode in (1, 2) and mode <= 1 and mptr is None):
                 # a few thousand rows: neither backward GEMM fills the chip -> both in one launch, side by side (csrc/gemm.hip)
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
@@ -684,7 +685,7 @@ class _MLPStack(torch.autograd.Function):
                      ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
                      flops=2.0 * M * Co * Ci)
                 if use_slots:
-                    dW_final = dWs.sum(0)
+                    dW_copies = dWs
                 dX = part = None
                 if need_dx:
                     dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
@@ -693,7 +694,8 @@ class _MLPStack(torch.autograd.Function):
                          mptr, omld, float(dscale),
                          ptr(Ys[i - 1]) if stats_below else None, Ci, ptr(aff[i - 1]) if stats_below else None, ptr(part),
                          ptr(arg) if grad_mode == 2 else None, pool_ns, stream(), flops=2.0 * M * Co * Ci)
-            grads[p0] = _to_param_layout(dW_final)       # after the kernels are enqueued (the permuted layout is a copy)
+            if dW_copies is not None:
+                dW_final = torch.empty(Co, Ci, dtype=torch.float32, device=dev)
             if need_dx:
                 dZ, grad_mode = dX, 1
                 if stats_below:
@@ -701,11 +703,19 @@ class _MLPStack(torch.autograd.Function):
                     coef = torch.empty(5, Ci, dtype=torch.float32, device=dev)
                     dgamma = torch.empty(Ci, dtype=torch.float32, device=dev)
                     dbeta = torch.empty(Ci, dtype=torch.float32, device=dev)
-                    call("p2c_bn_bwd_finalize_f32", ptr(part), Ci, M, ptr(aff[i - 1]), ptr(params[q0 + 2]), ptr(dgamma),
-                         ptr(dbeta), ptr(coef), stream())
+                    if dW_copies is not None:      # the copies are summed by extra workgroups of the same launch
+                        call("p2c_bn_bwd_finalize_sum_f32", ptr(part), Ci, M, ptr(aff[i - 1]), ptr(params[q0 + 2]), ptr(dgamma), ptr(dbeta),
+                             ptr(coef), ptr(dW_copies), Co * Ci, dW_copies.shape[0], ptr(dW_final), Co * Ci, stream())
+                        dW_copies = None
+                    else:
+                        call("p2c_bn_bwd_finalize_f32", ptr(part), Ci, M, ptr(aff[i - 1]), ptr(params[q0 + 2]), ptr(dgamma),
+                             ptr(dbeta), ptr(coef), stream())
                     grads[q0 + 2], grads[q0 + 3] = dgamma, dbeta
                     if evalm:
                         coef[3:].zero_()
+            if dW_copies is not None:
+                call("p2c_sum_copies_f32", ptr(dW_copies), Co * Ci, dW_copies.shape[0], ptr(dW_final), Co * Ci, stream())
+            grads[p0] = _to_param_layout(dW_final)       # after the kernels are enqueued (the permuted layout is a copy)
         if evalm:
             for i in range(L):
                 p0, has_bn = slots[i]

@@ -277,6 +277,16 @@ int p2c_linear_bwd_data_f32(const float *dZ, int lddz, const float *Yfwd, int ld
 int p2c_bn_bwd_finalize_f32(const double *slots, int C, long long M, const float *stat, const float *gamma, float *dgamma,
                             float *dbeta, float *coef_out, void *stream);
 
+/* Backward of a NARROW linear layer (Co <= 32 outputs, 128 inputs, >= 4096 rows: the per-point heads, models/pointnet_extrusion.py:56-61)
+ * whose input is dropout(relu(bn(Y))), in one pass over dZ and Y (csrc/heads.hip): dW into 8 per-XCD copies (accumulated, zero them),
+ * dbias (accumulated), dX, and the BatchNorm-backward sums of the layer below into `partials` (fp64 slot rows, accumulated).
+ * stat = [scale|shift|mean|invstd] x 128 of that BatchNorm; seed NULL: no dropout, else the int64 counter of the forward's hashed mask
+ * with keep-scale dscale.  Finish with p2c_bn_bwd_finalize_sum_f32.  p2c_linear_bwd_narrow_supported(M, Co, Ci, in_mode) -> 1/0. */
+int p2c_linear_bwd_narrow_supported(int M, int Co, int Ci, int in_mode);
+int p2c_linear_bwd_narrow_f32(const float *dZ, int lddz, const float *Y, int ldy, const float *stat, const void *seed, float dscale,
+                              const float *W, int ldw, float *dX, int lddx, float *dW8, int lddw, long long dw_slot_stride, float *dbias,
+                              double *partials, int M, int Co, int Ci, void *stream);
+
 /* out[0..n) = sum over `copies` matrices src + c*stride (the per-XCD copies of a weight gradient the fused backward accumulates into),
  * alone or in the same launch as p2c_bn_bwd_finalize_f32 (same arguments first). */
 int p2c_sum_copies_f32(const float *src, long long stride, int copies, float *out, long long n, void *stream);

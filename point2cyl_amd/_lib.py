@@ -46,6 +46,7 @@ _SIGS = {
     "p2c_bn_finalize_f32": [c_p, c_i, c_ll, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_bn_bwd_finalize_f32": [c_p, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_sum_copies_f32": [c_p, c_ll, c_i, c_p, c_ll, c_p],
+    "p2c_linear_bwd_narrow_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_i, c_p, c_i, c_p, c_i, c_ll, c_p, c_p, c_i, c_i, c_i, c_p],
     "p2c_bn_bwd_finalize_sum_f32": [c_p, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_p, c_ll, c_p],
     "p2c_bn_relu_apply_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_p, c_i, c_p],
     "p2c_maxpool_bnrelu_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p],
@@ -126,6 +127,8 @@ def lib():
     L.p2c_linear_tile_m.restype = c_i
     L.p2c_hungarian_ws_bytes.argtypes = [c_i]
     L.p2c_hungarian_ws_bytes.restype = ctypes.c_size_t
+    L.p2c_linear_bwd_narrow_supported.argtypes = [c_i, c_i, c_i, c_i]
+    L.p2c_linear_bwd_narrow_supported.restype = c_i
     L.p2c_fit_fused_supported.argtypes = [c_i, c_i, c_i]
     L.p2c_fit_fused_supported.restype = c_i
     L.p2c_extents_ws_bytes.argtypes = [c_i, c_i]

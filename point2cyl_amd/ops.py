@@ -19,6 +19,7 @@ USE_FUSED256 = os.environ.get("P2C_FUSED256", "1") != "0"   # 256-wide layers th
 USE_DUAL_BWD = os.environ.get("P2C_DUAL_BWD", "1") != "0"   # dX and dW of the small layers in one launch (gemm_dual_kernel)
 USE_FOLD0 = os.environ.get("P2C_FOLD0", "1") != "0"         # first layer with <= 4 input channels never materialised (bn.hip)
 USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated backward of the gathers (no atomics)
+USE_NARROW_BWD = os.environ.get("P2C_NARROW_BWD", "1") != "0"  # the per-point heads' backward in one pass (csrc/heads.hip)
 USE_POOL_EPI = os.environ.get("P2C_POOL_EPI", "1") != "0"    # max over 64 neighbours from extremes emitted by the last layer's GEMM epilogue
 
 
@@ -660,7 +661,18 @@ class _MLPStack(torch.autograd.Function):
                 fused_kind = 0           # kind 2 yields no dX for the 4 trailing input columns: fine for [feats | xyz | pad] only
             if fused_kind == 3 and (not need_dx or M < 8192 or not USE_FUSED256):
                 fused_kind = 0           # the two-pass form of a 256-wide layer accumulates dX across its passes: long layers with a dX only
-            if fused_kind:
+            narrow = (USE_NARROW_BWD and grad_mode == 0 and need_dx and stats_below and mode in (1, 3)
+                      and L_.p2c_linear_bwd_narrow_supported(M, Co, Ci, mode))
+            if narrow:
+                # a few outputs on many rows (the heads): dW, dbias, dX and the sums of the BatchNorm below from ONE read of dZ and the input
+                dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
+                part = arena.f64(STAT_SLOTS, 2, Ci)
+                dW8 = arena.f32(8, Co, Ci)
+                call("p2c_linear_bwd_narrow_f32", ptr(dZ), dZ.stride(0), ptr(Xin), ldxin, ptr(aff[i - 1]), mptr if mode == 3 else None, float(dscale),
+                     ptr(W2), Ci, ptr(dX), Ci, ptr(dW8), Ci, Co * Ci, ptr(db), ptr(part), M, Co, Ci, stream(),
+                     flops=4.0 * M * Co * Ci, nbytes=4.0 * M * (Co + 2 * Ci))
+                dW_copies = dW8
+            elif fused_kind:
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev) if need_dx else None
                 part = arena.f64(STAT_SLOTS, 2, Ci) if stats_below else None
                 dW8 = arena.f32(8, Co, Ci)     # one copy per XCD, summed below

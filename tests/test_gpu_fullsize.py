@@ -448,3 +448,36 @@ def test_b32_n8192_graph_replay_gradients_equal_eager(prefetch):
             assert ok, [mm for mm in _METRICS if not mm["ok"]]
     finally:
         bbmod.draw_fps_start = orig_draw
+
+
+@pytest.mark.parametrize("M,Co,drop", [(262144, 20, True), (5001, 20, False), (70000, 8, True), (4096, 32, False)])
+def test_narrow_backward_equals_generic_kernels(M, Co, drop):
+    """csrc/heads.hip (dW, dbias, dX and the sums of the BatchNorm below of the per-point heads from one read of dZ and the input) against
+    the two generic GEMM kernels it replaces, through the same stack (128 -> 128 + BN + ReLU [+ hashed dropout] -> Co), at the heads' own
+    size (B x N = 262,144 rows, 19 -> 20 outputs), a ragged row count, a narrower head and the 32-output limit."""
+    from point2cyl_amd import ops
+    g = torch.Generator().manual_seed(M + Co)
+    C = 128
+    X = torch.randn(M, C, generator=g).to(DEV)
+    W0, W1 = (torch.randn(C, C, generator=g) / 11).to(DEV), (torch.randn(Co, C, generator=g) / 11).to(DEV)
+    go = torch.randn(M, Co, generator=g).to(DEV)
+
+    def run(narrow):
+        ops.USE_NARROW_BWD = narrow
+        x = X.clone().requires_grad_(True)
+        layers = [dict(W=W0.clone().requires_grad_(True), b=torch.zeros(C, device=DEV, requires_grad=True),
+                       gamma=(torch.rand(C, generator=g).to(DEV) * 0 + 1.3).requires_grad_(True), beta=torch.full((C,), 0.1, device=DEV, requires_grad=True),
+                       bn=ops.BNState(torch.zeros(C, device=DEV), torch.ones(C, device=DEV), None, 0.1, 1e-5)),
+                  dict(W=W1.clone().requires_grad_(True), b=torch.zeros(Co, device=DEV, requires_grad=True), gamma=None, beta=None, bn=None)]
+        seed = torch.tensor([424242], dtype=torch.int64, device=DEV) if drop else None
+        out = ops.mlp_stack(x, C, layers, "linear", True, drop_scale=2.0 if drop else 1.0, drop_seed=seed)
+        out.backward(go)
+        return [out.detach(), x.grad, layers[1]["W"].grad, layers[1]["b"].grad, layers[0]["W"].grad, layers[0]["gamma"].grad, layers[0]["beta"].grad]
+
+    try:
+        a, b = run(True), run(False)
+    finally:
+        ops.USE_NARROW_BWD = True
+    for name, u, v in zip(("out", "dX0", "dW_heads", "db_heads", "dW0", "dgamma0", "dbeta0"), a, b):
+        assert u.shape == v.shape, name
+        assert float((u - v).abs().max()) <= 3e-6 * float(v.abs().max()) + 1e-7, (name, float((u - v).abs().max()), float(v.abs().max()))

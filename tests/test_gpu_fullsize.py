@@ -481,3 +481,38 @@ def test_narrow_backward_equals_generic_kernels(M, Co, drop):
     for name, u, v in zip(("out", "dX0", "dW_heads", "db_heads", "dW0", "dgamma0", "dbeta0"), a, b):
         assert u.shape == v.shape, name
         assert float((u - v).abs().max()) <= 3e-6 * float(v.abs().max()) + 1e-7, (name, float((u - v).abs().max()), float(v.abs().max()))
+
+
+def test_mfma_mode_switch_fp32_kernels_against_the_split_kernels():
+    """p2c_set_mfma_mode(0) routes the persistent forward and the fused backward back to the fp32-MFMA kernels (P2C_MFMA=f32 does the same
+    at load time): the A/B partner of the bf16x3-split kernels.  Same stack, both modes: outputs and every gradient agree to fp32 rounding."""
+    from point2cyl_amd import ops, _lib
+    L = _lib.lib()
+    M, C = 131072, 128
+    g = torch.Generator().manual_seed(77)
+    X = torch.randn(M, C, generator=g).to(DEV)
+    Ws = [(torch.randn(C, C, generator=g) / 11).to(DEV) for _ in range(3)]
+    go = torch.randn(M, C, generator=g).to(DEV)
+
+    def run():
+        x = X.clone().requires_grad_(True)
+        layers = [dict(W=w.clone().requires_grad_(True), b=torch.zeros(C, device=DEV, requires_grad=True),
+                       gamma=torch.full((C,), 1.1, device=DEV, requires_grad=True), beta=torch.full((C,), 0.05, device=DEV, requires_grad=True),
+                       bn=ops.BNState(torch.zeros(C, device=DEV), torch.ones(C, device=DEV), None, 0.1, 1e-5)) for w in Ws]
+        out = ops.mlp_stack(x, C, layers, "bnrelu", True)
+        out.backward(go)
+        return [out.detach(), x.grad] + [ly[k].grad for ly in layers for k in ("W", "gamma", "beta")]
+
+    assert L.p2c_get_mfma_mode() == 1                      # the split kernels are the default
+    try:
+        L.p2c_set_mfma_mode(0)
+        assert L.p2c_get_mfma_mode() == 0
+        a = run()
+    finally:
+        L.p2c_set_mfma_mode(1)
+    b = run()
+    for i, (u, v) in enumerate(zip(a, b)):
+        # ~10 of the 5e7 ReLU decisions of the stack resolve differently between two correct fp32 evaluations: compare in relative norm
+        rel = float((u - v).norm() / v.norm().clamp_min(1e-30))
+        assert (rel < 1e-5 if i == 0 else rel < 2e-3), (i, rel)
+

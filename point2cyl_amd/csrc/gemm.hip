@@ -165,6 +165,65 @@ struct Tile {
 };
 
 // ------------------------------------------------------------------------------------------------
+// bf16x3-split operand tiles (SPLIT = true): the same ROWS x GK tile as three bf16 planes [3][ROWS][LDK], k contiguous, so that one
+// ds_read_b128 per plane is the A / B fragment of a v_mfma_f32_32x32x16_bf16 (lane (i, h): k = 8h .. 8h+7 of row i).  Every fp32 element is
+// split once, here, into hi + mid + lo (round to nearest each: x = hi + mid + lo up to 2^-26 |x|); the six products mm, hl, lh, hm, mh, hh
+// into the fp32 accumulator give the fp32 product to 2-3e-7 of sum |a b| - what the fp32 MFMA gives (tools/ubench/split_bf16.hip) - at
+// 6 x 32 cycles per 32 x 32 x 16 block instead of 8 x 64.  Row stride 80 bytes: 16-byte aligned and conflict-free for the 16-lane
+// groups of ds_read_b128 (dword offsets 20 i mod 64 are distinct for i = 0..15).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float g_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t g_pk_bf16(float a, float b)
+{
+    const g_v2f v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, g_bf16x2));
+}
+__device__ __forceinline__ float g_bf_lo(uint32_t p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float g_bf_hi(uint32_t p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
+// (a, b) -> the three packed pairs
+__device__ __forceinline__ void g_split_pair(float a, float b, uint32_t &h, uint32_t &m, uint32_t &l)
+{
+    h = g_pk_bf16(a, b);
+    const float ra = a - g_bf_lo(h), rb = b - g_bf_hi(h);
+    m = g_pk_bf16(ra, rb);
+    l = g_pk_bf16(ra - g_bf_lo(m), rb - g_bf_hi(m));
+}
+
+template <int ROWS, bool KCONTIG>
+struct Tile3 {
+    static constexpr int LDK = GK + 8;                 // bf16 elements per row
+    static constexpr int PLANE = ROWS * LDK;           // elements per plane
+    static constexpr int UNITS = ROWS * GK / 4 / 256;
+    static __device__ __forceinline__ void store(uint16_t *s, const float4 (&regs)[UNITS])
+    {
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) {
+            const int u = threadIdx.x + 256 * i;
+            uint32_t h0, m0, l0, h1, m1, l1;
+            g_split_pair(regs[i].x, regs[i].y, h0, m0, l0);
+            g_split_pair(regs[i].z, regs[i].w, h1, m1, l1);
+            if (KCONTIG) {
+                const int nk = u >> 3, kq = u & 7;                      // 4 consecutive k of row nk: one 8-byte store per plane
+                uint16_t *o = s + nk * LDK + kq * 4;
+                *reinterpret_cast<uint2 *>(o) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(o + PLANE) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2 *>(o + 2 * PLANE) = make_uint2(l0, l1);
+            } else {
+                const int kr = u / (ROWS / 4), c4 = u % (ROWS / 4);     // 4 consecutive rows at k = kr: 2-byte stores
+                uint16_t *o = s + (c4 * 4) * LDK + kr;
+                o[0] = (uint16_t)h0; o[LDK] = (uint16_t)(h0 >> 16); o[2 * LDK] = (uint16_t)h1; o[3 * LDK] = (uint16_t)(h1 >> 16);
+                o += PLANE;
+                o[0] = (uint16_t)m0; o[LDK] = (uint16_t)(m0 >> 16); o[2 * LDK] = (uint16_t)m1; o[3 * LDK] = (uint16_t)(m1 >> 16);
+                o += PLANE;
+                o[0] = (uint16_t)l0; o[LDK] = (uint16_t)(l0 >> 16); o[2 * LDK] = (uint16_t)l1; o[3 * LDK] = (uint16_t)(l1 >> 16);
+            }
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 // Epilogues.  C/D fragment of mfma 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 // ------------------------------------------------------------------------------------------------
 struct EpiFwd {
@@ -189,26 +248,29 @@ struct EpiAtomic {
 };
 
 // shared-memory floats one workgroup of the GEMM body needs
-template <int TM, int TN, bool AK, bool BK_>
+template <int TM, int TN, bool AK, bool BK_, bool SPLIT = false>
 constexpr int gemm_smem_floats()
 {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int OPS = GK * Tile<BM, AK>::LD + GK * Tile<BN, BK_>::LD, OUT = BM * (BN + 4);
+    constexpr int OPS = SPLIT ? 3 * (BM + BN) * (GK + 8) / 2 : GK * Tile<BM, AK>::LD + GK * Tile<BN, BK_>::LD, OUT = BM * (BN + 4);
     return (OPS > OUT ? OPS : OUT) + 2 * BN + BM;
 }
 
 // The GEMM of one workgroup (256 threads) for tile (bx, by) of the output and k-split bz; smem: gemm_smem_floats<...>() floats.
 // A __device__ body so that one launch can run the workgroups of two different GEMMs side by side (gemm_dual_kernel below).
-template <int TM, int TN, bool AK, bool BK_, class OpA, class OpB, class Epi>
+template <int TM, int TN, bool AK, bool BK_, class OpA, class OpB, class Epi, bool SPLIT = false>
 __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB &opB, const Epi &epi, int I, int J, int K, int k_per_split,
                                           int bx, int by, int bz)
 {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     using TA = Tile<BM, AK>;
     using TB = Tile<BN, BK_>;
+    using TA3 = Tile3<BM, AK>;
+    using TB3 = Tile3<BN, BK_>;
     // operand tiles + [2][BN] stat scratch (+BM), or the BM x (BN+4) output tile the epilogue stages for full-row stores
-    constexpr int SMEM_OPS = GK * TA::LD + GK * TB::LD, SMEM_OUT = BM * (BN + 4);
+    constexpr int SMEM_OPS = SPLIT ? 3 * (BM + BN) * (GK + 8) / 2 : GK * TA::LD + GK * TB::LD, SMEM_OUT = BM * (BN + 4);
     float *As = smem, *Bs = smem + GK * TA::LD;
+    uint16_t *Ap = reinterpret_cast<uint16_t *>(smem), *Bp = Ap + 3 * TA3::PLANE;       // SPLIT: [3][BM][LDK], [3][BN][LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -230,8 +292,13 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
     TB::load(opB, j0, J, kbeg, kend, rb);
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         __syncthreads();              // previous tile fully consumed
-        TA::store(As, ra);
-        TB::store(Bs, rb);
+        if constexpr (SPLIT) {
+            TA3::store(Ap, ra);
+            TB3::store(Bp, rb);
+        } else {
+            TA::store(As, ra);
+            TB::store(Bs, rb);
+        }
         __syncthreads();
         if (k0 + GK < kend) {         // prefetch the next tile while the matrix pipe works
             TA::load(opA, i0, I, k0 + GK, kend, ra);
@@ -240,12 +307,45 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
         if constexpr (std::is_same<Epi, EpiAtomic>::value) {
             if (epi.dbias && by == 0 && tid < BM) {
                 float s = 0.f;
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+#pragma unroll
+                        for (int q = 0; q < GK / 8; ++q) {
+                            const g_bf16x8 v = *reinterpret_cast<const g_bf16x8 *>(Ap + p * TA3::PLANE + tid * TA3::LDK + q * 8);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) s += (float)v[e];
+                        }
+                } else {
 #pragma unroll 8
-                for (int kk = 0; kk < GK; ++kk) s += As[kk * TA::LD + tid];
+                    for (int kk = 0; kk < GK; ++kk) s += As[kk * TA::LD + tid];
+                }
                 dbias_acc += s;
             }
         }
         const int kl = lane >> 5, il = lane & 31;
+        if constexpr (SPLIT) {
+#pragma unroll
+            for (int kc = 0; kc < GK / 16; ++kc) {
+                g_bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        a[t][p] = *reinterpret_cast<const g_bf16x8 *>(Ap + p * TA3::PLANE + (wm * (TM * 32) + t * 32 + il) * TA3::LDK + kc * 16 + kl * 8);
+#pragma unroll
+                for (int t = 0; t < TN; ++t)
+#pragma unroll
+                    for (int p = 0; p < 3; ++p)
+                        b[t][p] = *reinterpret_cast<const g_bf16x8 *>(Bp + p * TB3::PLANE + (wn * (TN * 32) + t * 32 + il) * TB3::LDK + kc * 16 + kl * 8);
+                // smallest products first; consecutive MFMAs go to different accumulators where there are several
+#define P2C_G3(PA_, PB_)                                                                                             \
+    _Pragma("unroll") for (int ta = 0; ta < TM; ++ta) _Pragma("unroll") for (int tb = 0; tb < TN; ++tb)               \
+        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ta][PA_], b[tb][PB_], acc[ta][tb], 0, 0, 0)
+                P2C_G3(1, 1); P2C_G3(0, 2); P2C_G3(2, 0); P2C_G3(0, 1); P2C_G3(1, 0); P2C_G3(0, 0);
+#undef P2C_G3
+            }
+        } else
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 2) {
             float a[TM], b[TN];
@@ -482,30 +582,47 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
     }
 }
 
-template <int TM, int TN, bool AK, bool BK_, class OpA, class OpB, class Epi>
+template <int TM, int TN, bool AK, bool BK_, class OpA, class OpB, class Epi, bool SPLIT = false>
 __global__ void __launch_bounds__(256) gemm_kernel(OpA opA, OpB opB, Epi epi, int I, int J, int K, int k_per_split)
 {
-    __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<TM, TN, AK, BK_>()];
-    gemm_body<TM, TN, AK, BK_, OpA, OpB, Epi>(smem, opA, opB, epi, I, J, K, k_per_split, blockIdx.x, blockIdx.y, blockIdx.z);
+    __shared__ __attribute__((aligned(16))) float smem[gemm_smem_floats<TM, TN, AK, BK_, SPLIT>()];
+    gemm_body<TM, TN, AK, BK_, OpA, OpB, Epi, SPLIT>(smem, opA, opB, epi, I, J, K, k_per_split, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Both backward GEMMs of one layer in ONE launch: workgroups [0, nA) run the data gradient (64 x 64*TNA tiles), the rest the weight
 // gradient (TMB x TNB tiles, split over the rows).  For the 4 k - 16 k-row layers neither GEMM alone has enough workgroups to fill
 // the chip and each is a chain of latency-bound steps; side by side they overlap (two streams would do the same at the price of
 // fork / join events in the graph; one launch has no price).
-template <int TNA, int TMB, int TNB, class OpG, class OpI>
+template <int TNA, int TMB, int TNB, class OpG, class OpI, bool SPLIT = false>
 __global__ void __launch_bounds__(256) gemm_dual_kernel(OpG gA, OpPlain wA, EpiBwdData eA, int MA, int KA, int NA, int kpsA, int nAx, int nA,
                                                         OpG gB, OpI xB, EpiAtomic eB, int NB, int KB, int MB, int kpsB, int nBx, int nBy)
 {
-    constexpr int FA = gemm_smem_floats<1, TNA, true, false>(), FB = gemm_smem_floats<TMB, TNB, false, false>();
+    constexpr int FA = gemm_smem_floats<1, TNA, true, false, SPLIT>(), FB = gemm_smem_floats<TMB, TNB, false, false, SPLIT>();
     __shared__ __attribute__((aligned(16))) float smem[FA > FB ? FA : FB];
     const int b = blockIdx.x;
     if (b < nA) {
-        gemm_body<1, TNA, true, false, OpG, OpPlain, EpiBwdData>(smem, gA, wA, eA, MA, KA, NA, kpsA, b % nAx, b / nAx, 0);
+        gemm_body<1, TNA, true, false, OpG, OpPlain, EpiBwdData, SPLIT>(smem, gA, wA, eA, MA, KA, NA, kpsA, b % nAx, b / nAx, 0);
     } else {
         const int c = b - nA;
-        gemm_body<TMB, TNB, false, false, OpG, OpI, EpiAtomic>(smem, gB, xB, eB, NB, KB, MB, kpsB, c % nBx, (c / nBx) % nBy, c / (nBx * nBy));
+        gemm_body<TMB, TNB, false, false, OpG, OpI, EpiAtomic, SPLIT>(smem, gB, xB, eB, NB, KB, MB, kpsB, c % nBx, (c / nBx) % nBy, c / (nBx * nBy));
     }
+}
+
+// The tiled kernels follow the switch of the persistent ones (p2c_set_mfma_mode / P2C_MFMA=f32); P2C_GEMM_SPLIT=0 keeps just them on the
+// fp32 matrix instructions (A/B).
+static bool gemm_split()
+{
+    static const bool own = !(getenv("P2C_GEMM_SPLIT") && atoi(getenv("P2C_GEMM_SPLIT")) == 0);
+    return own && p2c_mfma_split();
+}
+
+// ... and the products with an operand whose k runs down the rows in memory (both backward products): their tiles are transposed on the way
+// into LDS with 2-byte stores, which costs more than the matrix pipe gains (measured: sa3.2 dW 70 -> 122 us) - fp32 kernels unless
+// P2C_GEMM_SPLIT=2 asks for the split form there too
+static bool gemm_split_t()
+{
+    static const bool on = getenv("P2C_GEMM_SPLIT") && atoi(getenv("P2C_GEMM_SPLIT")) == 2;
+    return on && p2c_mfma_split();
 }
 
 static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
@@ -582,12 +699,17 @@ static int launch_fwd(const float *X, int ldx, const float *W, int ldw, const fl
     OpPlain b{W, ldw};
     EpiFwd e{Y, ldy, bias, stat_partials, gbias, ldgb, rpg};
     const int kps = (K + GK - 1) / GK * GK;
-#define P2C_FW(TM_, TN_)                                                                                                          \
-    hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, true, OpActIn<MODE>, OpPlain, EpiFwd>), dim3(p2c_cdiv(M, 64 * TM_), p2c_cdiv(N, 64 * TN_), 1), \
+#define P2C_FW_(TM_, TN_, SP_)                                                                                                    \
+    hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, true, OpActIn<MODE>, OpPlain, EpiFwd, SP_>), dim3(p2c_cdiv(M, 64 * TM_), p2c_cdiv(N, 64 * TN_), 1), \
                        dim3(256), 0, s, a, b, e, M, N, K, kps)
+    // split form from 65,536 rows on (the implicit decoder's 512-wide products: 101 -> 125 TFLOP/s); the 4 k - 16 k-row levels of the
+    // backbone stay on the fp32 instructions - there the larger LDS / register footprint costs co-residency with the sampling kernel
+    // of the forked stream and the step got 0.03 ms slower
+#define P2C_FW(TM_, TN_) do { if (gemm_split() && M >= 65536) P2C_FW_(TM_, TN_, true); else P2C_FW_(TM_, TN_, false); } while (0)
     if (tile_m() == 128) { if (N > 64) P2C_FW(2, 2); else P2C_FW(2, 1); }
     else { if (N > 64 && !narrow_tiles(M, N)) P2C_FW(1, 2); else P2C_FW(1, 1); }
 #undef P2C_FW
+#undef P2C_FW_
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -686,12 +808,14 @@ static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy
     OpPlain b{W, ldw};
     EpiBwdData e{dX, lddx, out_mask, ldmask, out_mask_scale, p2c_drop_threshold(out_mask_scale), Yprev, ldyp, prev_stat, bwd_partials, spz, ldspz, sp_beta, sp_thr};
     const int kps = (N + GK - 1) / GK * GK;
-#define P2C_BDL(TM_, TN_)                                                                                                          \
-    hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, false, OpGrad<GMODE>, OpPlain, EpiBwdData>),                                    \
+#define P2C_BDL_(TM_, TN_, SP_)                                                                                                    \
+    hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, false, OpGrad<GMODE>, OpPlain, EpiBwdData, SP_>),                               \
                        dim3(p2c_cdiv(M, 64 * TM_), p2c_cdiv(K, 64 * TN_), 1), dim3(256), 0, s, a, b, e, M, K, N, kps)
+#define P2C_BDL(TM_, TN_) do { if (gemm_split_t()) P2C_BDL_(TM_, TN_, true); else P2C_BDL_(TM_, TN_, false); } while (0)
     if (tile_m() == 128) { if (K > 64) P2C_BDL(2, 2); else P2C_BDL(2, 1); }
     else { if (K > 64 && !narrow_tiles(M, K)) P2C_BDL(1, 2); else P2C_BDL(1, 1); }
 #undef P2C_BDL
+#undef P2C_BDL_
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -756,14 +880,16 @@ static int launch_bwd_weight(const float *dZ, int lddz, const float *Yfwd, int l
     const int kps = (ktiles + splits - 1) / splits * GK;
     splits = (M + kps - 1) / kps;
     dim3 grid(ti, tj, (unsigned)splits);
-#define P2C_BW(TM_, TN_)                                                                                                                  \
-    hipLaunchKernelGGL((gemm_kernel<TM_, TN_, false, false, OpGrad<GMODE>, OpActIn<IMODE>, EpiAtomic>), grid, dim3(256), 0, s, a, b, e, N, K, \
+#define P2C_BW_(TM_, TN_, SP_)                                                                                                            \
+    hipLaunchKernelGGL((gemm_kernel<TM_, TN_, false, false, OpGrad<GMODE>, OpActIn<IMODE>, EpiAtomic, SP_>), grid, dim3(256), 0, s, a, b, e, N, K, \
                        M, kps)
+#define P2C_BW(TM_, TN_) do { if (gemm_split_t()) P2C_BW_(TM_, TN_, true); else P2C_BW_(TM_, TN_, false); } while (0)
     if (N > 64 && K > 64) P2C_BW(2, 2);
     else if (N > 64) P2C_BW(2, 1);
     else if (K > 64) P2C_BW(1, 2);
     else P2C_BW(1, 1);
 #undef P2C_BW
+#undef P2C_BW_
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -828,8 +954,12 @@ static int launch_bwd_both(const float *dZ, int lddz, const float *Yfwd, int ldy
     if (splits > (ktiles + 3) / 4) splits = (ktiles + 3) / 4;
     const int kpsB = (ktiles + splits - 1) / splits * GK;
     splits = (M + kpsB - 1) / kpsB;
-    hipLaunchKernelGGL((gemm_dual_kernel<1, 2, 2, OpGrad<GMODE>, OpActIn<IMODE>>), dim3(nA + ti * tj * splits), dim3(256), 0, s, g, w, eA, M, K, N, kpsA,
-                       nAx, nA, g, x, eB, N, K, M, kpsB, ti, tj);
+    if (gemm_split_t())
+        hipLaunchKernelGGL((gemm_dual_kernel<1, 2, 2, OpGrad<GMODE>, OpActIn<IMODE>, true>), dim3(nA + ti * tj * splits), dim3(256), 0, s, g, w, eA, M, K, N,
+                           kpsA, nAx, nA, g, x, eB, N, K, M, kpsB, ti, tj);
+    else
+        hipLaunchKernelGGL((gemm_dual_kernel<1, 2, 2, OpGrad<GMODE>, OpActIn<IMODE>, false>), dim3(nA + ti * tj * splits), dim3(256), 0, s, g, w, eA, M, K, N,
+                           kpsA, nAx, nA, g, x, eB, N, K, M, kpsB, ti, tj);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

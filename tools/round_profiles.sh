@@ -7,9 +7,6 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-# 1. the bench line exactly as the driver runs it (with the CPU baseline), and configs[2]'s loss set
-python bench.py > "$OUT/${TAG}_bench.json.log" 2> "$OUT/bench.err"
-python bench.py --full_losses --no_cpu_baseline > "$OUT/${TAG}_bench_config2_full_losses.json.log" 2>> "$OUT/bench.err"
 # 2. kernel trace + stats of the same command (no counters in this pass)
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no_cpu_baseline > "$OUT/${TAG}_bench_under_rocprof.json.log" 2> "$OUT/trace.err"
 cp "$OUT/trace/r_kernel_stats.csv" "$OUT/${TAG}_rocprofv3_kernel_stats.csv"
@@ -39,6 +36,10 @@ if [ "${QUICK:-0}" = "1" ]; then ls -la "$OUT"; exit 0; fi
 python tools/collect_pmc.py "$TAG" > "$OUT/pmc.log" 2>&1
 cp profiles/${TAG}_pmc_step.json profiles/${TAG}_pmc_step.md "$OUT/" 2>/dev/null
 rm -rf gpurun_out/${TAG}_pmc_*
+# 3b. the bench line exactly as the driver runs it (with the CPU baseline), and configs[2]'s loss set - AFTER the counters, so that
+# roofline.traffic is read from the summary collected on this very tree (traffic_stale: false)
+python bench.py > "$OUT/${TAG}_bench.json.log" 2> "$OUT/bench.err"
+python bench.py --full_losses --no_cpu_baseline > "$OUT/${TAG}_bench_config2_full_losses.json.log" 2>> "$OUT/bench.err"
 # 4. the other configs / stages
 python tools/bench_config4.py > "$OUT/${TAG}_config4_fitting.json.log" 2> "$OUT/config4.err"
 python tools/bench_sa1_forward.py > "$OUT/${TAG}_sa1_forward_stage.json.log" 2> "$OUT/sa1.err"

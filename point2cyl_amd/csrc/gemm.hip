@@ -169,8 +169,7 @@ struct Tile {
 // ds_read_b128 per plane is the A / B fragment of a v_mfma_f32_32x32x16_bf16 (lane (i, h): k = 8h .. 8h+7 of row i).  Every fp32 element is
 // split once, here, into hi + mid + lo (round to nearest each: x = hi + mid + lo up to 2^-26 |x|); the six products mm, hl, lh, hm, mh, hh
 // into the fp32 accumulator give the fp32 product to 2-3e-7 of sum |a b| - what the fp32 MFMA gives (tools/ubench/split_bf16.hip) - at
-// 6 x 32 cycles per 32 x 32 x 16 block instead of 8 x 64.  Row stride 80 bytes: 16-byte aligned and conflict-free for the 16-lane
-// groups of ds_read_b128 (dword offsets 20 i mod 64 are distinct for i = 0..15).
+// 6 x 32 cycles per 32 x 32 x 16 block instead of 8 x 64.  Row stride 80 bytes: 16-byte aligned; see Tile3 for the row permutation.
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 g_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 g_bf16x2 __attribute__((ext_vector_type(2)));
@@ -194,30 +193,58 @@ __device__ __forceinline__ void g_split_pair(float a, float b, uint32_t &h, uint
 template <int ROWS, bool KCONTIG>
 struct Tile3 {
     static constexpr int LDK = GK + 8;                 // bf16 elements per row
-    static constexpr int PLANE = ROWS * LDK;           // elements per plane
+    // Rows are stored PERMUTED: row r lives at (r % 4) * RS + r / 4, RS = ROWS / 4 rounded up to 4 (mod 16).  A tile whose k runs down the
+    // memory rows (KCONTIG = false) arrives as float4s of 4 consecutive ROWS at one k; a thread takes 4 (2 for ROWS = 64) consecutive k of
+    // its row quad, splits, and writes for each of its 4 rows one 8-byte (4-byte) piece per plane - lanes with consecutive row quads then
+    // hit consecutive physical rows (80 bytes apart: conflict-free), instead of rows 320 bytes apart (16 lanes on 4 banks).  20 * RS = 16
+    // (mod 64 dwords) keeps the 16-lane groups of the fragment reads (rows r .. r + 15 -> 4 x 4 physical rows) on 16 distinct bank quads.
+    static constexpr int RS = ROWS == 64 ? 20 : 36;
+    static constexpr int PLANE = 4 * RS * LDK;         // elements per plane
     static constexpr int UNITS = ROWS * GK / 4 / 256;
+    static_assert(ROWS == 64 || ROWS == 128, "");
+    static __device__ __forceinline__ int prow(int r) { return (r & 3) * RS + (r >> 2); }
+    // KCONTIG = false only: consecutive k per thread (Tile<>::load deals k = kr, kr + 8, ...)
+    template <class Op>
+    static __device__ __forceinline__ void load_t(const Op &op, int o0, int Olim, int k0, int Klim, float4 (&regs)[UNITS])
+    {
+        const int c4 = threadIdx.x % (ROWS / 4), kg = threadIdx.x / (ROWS / 4);
+#pragma unroll
+        for (int i = 0; i < UNITS; ++i) regs[i] = op.load4(k0 + kg * UNITS + i, o0 + c4 * 4, Klim, Olim);
+    }
     static __device__ __forceinline__ void store(uint16_t *s, const float4 (&regs)[UNITS])
     {
+        if (KCONTIG) {
 #pragma unroll
-        for (int i = 0; i < UNITS; ++i) {
-            const int u = threadIdx.x + 256 * i;
-            uint32_t h0, m0, l0, h1, m1, l1;
-            g_split_pair(regs[i].x, regs[i].y, h0, m0, l0);
-            g_split_pair(regs[i].z, regs[i].w, h1, m1, l1);
-            if (KCONTIG) {
+            for (int i = 0; i < UNITS; ++i) {
+                const int u = threadIdx.x + 256 * i;
+                uint32_t h0, m0, l0, h1, m1, l1;
+                g_split_pair(regs[i].x, regs[i].y, h0, m0, l0);
+                g_split_pair(regs[i].z, regs[i].w, h1, m1, l1);
                 const int nk = u >> 3, kq = u & 7;                      // 4 consecutive k of row nk: one 8-byte store per plane
-                uint16_t *o = s + nk * LDK + kq * 4;
+                uint16_t *o = s + prow(nk) * LDK + kq * 4;
                 *reinterpret_cast<uint2 *>(o) = make_uint2(h0, h1);
                 *reinterpret_cast<uint2 *>(o + PLANE) = make_uint2(m0, m1);
                 *reinterpret_cast<uint2 *>(o + 2 * PLANE) = make_uint2(l0, l1);
-            } else {
-                const int kr = u / (ROWS / 4), c4 = u % (ROWS / 4);     // 4 consecutive rows at k = kr: 2-byte stores
-                uint16_t *o = s + (c4 * 4) * LDK + kr;
-                o[0] = (uint16_t)h0; o[LDK] = (uint16_t)(h0 >> 16); o[2 * LDK] = (uint16_t)h1; o[3 * LDK] = (uint16_t)(h1 >> 16);
-                o += PLANE;
-                o[0] = (uint16_t)m0; o[LDK] = (uint16_t)(m0 >> 16); o[2 * LDK] = (uint16_t)m1; o[3 * LDK] = (uint16_t)(m1 >> 16);
-                o += PLANE;
-                o[0] = (uint16_t)l0; o[LDK] = (uint16_t)(l0 >> 16); o[2 * LDK] = (uint16_t)l1; o[3 * LDK] = (uint16_t)(l1 >> 16);
+            }
+        } else {
+            const int c4 = threadIdx.x % (ROWS / 4), kg = threadIdx.x / (ROWS / 4);
+            const float *f = reinterpret_cast<const float *>(&regs[0]);   // f[4 * i + e]: k = kg * UNITS + i, row = 4 * c4 + e
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint16_t *o = s + (e * RS + c4) * LDK + kg * UNITS;
+                uint32_t h0, m0, l0;
+                g_split_pair(f[e], f[4 + e], h0, m0, l0);
+                if (UNITS == 4) {
+                    uint32_t h1, m1, l1;
+                    g_split_pair(f[8 + e], f[12 + e], h1, m1, l1);
+                    *reinterpret_cast<uint2 *>(o) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(o + PLANE) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2 *>(o + 2 * PLANE) = make_uint2(l0, l1);
+                } else {
+                    *reinterpret_cast<uint32_t *>(o) = h0;
+                    *reinterpret_cast<uint32_t *>(o + PLANE) = m0;
+                    *reinterpret_cast<uint32_t *>(o + 2 * PLANE) = l0;
+                }
             }
         }
     }
@@ -252,7 +279,7 @@ template <int TM, int TN, bool AK, bool BK_, bool SPLIT = false>
 constexpr int gemm_smem_floats()
 {
     constexpr int BM = 64 * TM, BN = 64 * TN;
-    constexpr int OPS = SPLIT ? 3 * (BM + BN) * (GK + 8) / 2 : GK * Tile<BM, AK>::LD + GK * Tile<BN, BK_>::LD, OUT = BM * (BN + 4);
+    constexpr int OPS = SPLIT ? 3 * (Tile3<BM, AK>::PLANE + Tile3<BN, BK_>::PLANE) / 2 : GK * Tile<BM, AK>::LD + GK * Tile<BN, BK_>::LD, OUT = BM * (BN + 4);
     return (OPS > OUT ? OPS : OUT) + 2 * BN + BM;
 }
 
@@ -268,7 +295,7 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
     using TA3 = Tile3<BM, AK>;
     using TB3 = Tile3<BN, BK_>;
     // operand tiles + [2][BN] stat scratch (+BM), or the BM x (BN+4) output tile the epilogue stages for full-row stores
-    constexpr int SMEM_OPS = SPLIT ? 3 * (BM + BN) * (GK + 8) / 2 : GK * TA::LD + GK * TB::LD, SMEM_OUT = BM * (BN + 4);
+    constexpr int SMEM_OPS = SPLIT ? 3 * (TA3::PLANE + TB3::PLANE) / 2 : GK * TA::LD + GK * TB::LD, SMEM_OUT = BM * (BN + 4);
     float *As = smem, *Bs = smem + GK * TA::LD;
     uint16_t *Ap = reinterpret_cast<uint16_t *>(smem), *Bp = Ap + 3 * TA3::PLANE;       // SPLIT: [3][BM][LDK], [3][BN][LDK]
 
@@ -288,8 +315,10 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
 
     float4 ra[TA::UNITS], rb[TB::UNITS];
     float dbias_acc = 0.f;
-    TA::load(opA, i0, I, kbeg, kend, ra);
-    TB::load(opB, j0, J, kbeg, kend, rb);
+    auto loadA = [&](int k0) { if constexpr (SPLIT && !AK) TA3::load_t(opA, i0, I, k0, kend, ra); else TA::load(opA, i0, I, k0, kend, ra); };
+    auto loadB = [&](int k0) { if constexpr (SPLIT && !BK_) TB3::load_t(opB, j0, J, k0, kend, rb); else TB::load(opB, j0, J, k0, kend, rb); };
+    loadA(kbeg);
+    loadB(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += GK) {
         __syncthreads();              // previous tile fully consumed
         if constexpr (SPLIT) {
@@ -301,8 +330,8 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
         }
         __syncthreads();
         if (k0 + GK < kend) {         // prefetch the next tile while the matrix pipe works
-            TA::load(opA, i0, I, k0 + GK, kend, ra);
-            TB::load(opB, j0, J, k0 + GK, kend, rb);
+            loadA(k0 + GK);
+            loadB(k0 + GK);
         }
         if constexpr (std::is_same<Epi, EpiAtomic>::value) {
             if (epi.dbias && by == 0 && tid < BM) {
@@ -312,7 +341,7 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
                     for (int p = 0; p < 3; ++p)
 #pragma unroll
                         for (int q = 0; q < GK / 8; ++q) {
-                            const g_bf16x8 v = *reinterpret_cast<const g_bf16x8 *>(Ap + p * TA3::PLANE + tid * TA3::LDK + q * 8);
+                            const g_bf16x8 v = *reinterpret_cast<const g_bf16x8 *>(Ap + p * TA3::PLANE + TA3::prow(tid) * TA3::LDK + q * 8);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) s += (float)v[e];
                         }
@@ -332,12 +361,12 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
                 for (int t = 0; t < TM; ++t)
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        a[t][p] = *reinterpret_cast<const g_bf16x8 *>(Ap + p * TA3::PLANE + (wm * (TM * 32) + t * 32 + il) * TA3::LDK + kc * 16 + kl * 8);
+                        a[t][p] = *reinterpret_cast<const g_bf16x8 *>(Ap + p * TA3::PLANE + TA3::prow(wm * (TM * 32) + t * 32 + il) * TA3::LDK + kc * 16 + kl * 8);
 #pragma unroll
                 for (int t = 0; t < TN; ++t)
 #pragma unroll
                     for (int p = 0; p < 3; ++p)
-                        b[t][p] = *reinterpret_cast<const g_bf16x8 *>(Bp + p * TB3::PLANE + (wn * (TN * 32) + t * 32 + il) * TB3::LDK + kc * 16 + kl * 8);
+                        b[t][p] = *reinterpret_cast<const g_bf16x8 *>(Bp + p * TB3::PLANE + TB3::prow(wn * (TN * 32) + t * 32 + il) * TB3::LDK + kc * 16 + kl * 8);
                 // smallest products first; consecutive MFMAs go to different accumulators where there are several
 #define P2C_G3(PA_, PB_)                                                                                             \
     _Pragma("unroll") for (int ta = 0; ta < TM; ++ta) _Pragma("unroll") for (int tb = 0; tb < TN; ++tb)               \
@@ -616,13 +645,13 @@ static bool gemm_split()
     return own && p2c_mfma_split();
 }
 
-// ... and the products with an operand whose k runs down the rows in memory (both backward products): their tiles are transposed on the way
-// into LDS with 2-byte stores, which costs more than the matrix pipe gains (measured: sa3.2 dW 70 -> 122 us) - fp32 kernels unless
-// P2C_GEMM_SPLIT=2 asks for the split form there too
+// ... and the products with an operand whose k runs down the rows in memory (both backward products: their tiles are transposed on the way
+// into LDS, Tile3's permuted rows make that conflict-free): sa3.2 dX 83 -> 59 us, dW 70 -> 56 us; step -0.06 ms.  P2C_GEMM_SPLIT=1 keeps
+// them on the fp32 instructions (A/B).
 static bool gemm_split_t()
 {
-    static const bool on = getenv("P2C_GEMM_SPLIT") && atoi(getenv("P2C_GEMM_SPLIT")) == 2;
-    return on && p2c_mfma_split();
+    static const bool off = getenv("P2C_GEMM_SPLIT") && atoi(getenv("P2C_GEMM_SPLIT")) == 1;
+    return !off && gemm_split();
 }
 
 static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }

@@ -110,8 +110,8 @@ def _self_launch(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch_size", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--num_point", type=int, default=8192)
     ap.add_argument("--K", type=int, default=8)

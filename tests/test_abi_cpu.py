@@ -52,6 +52,15 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_linear_sum_assignment_f64(one, 1, 8, 16, one, 1, None) == -1     # more than 15 columns
     assert L.p2c_sketch_projection_f32(one, one, None, None, one, one, None, 1, 16, 8, 4, 1, one, one, one, one, one, None) == -1   # all_points needs S == N
     assert L.p2c_linear_bwd_data_sig_f32(one, 4, one, 4, one, 4, 100.0, 20.0, one, 4, 8, 6, 4, None) == -2                          # N not a multiple of 4
+    # round 3 entries
+    assert L.p2c_fit_fused_f32(None, None, None, None, None, 0, None, None, 1, 8192, 8, 2048, None, None, None, None, None, None, None) == -1
+    assert L.p2c_fit_fused_f32(one, one, one, one, one, 0, one, one, 1, 8192, 3, 2048, one, one, one, one, one, one, None) == -1   # K not a power of two
+    assert L.p2c_fit_fused_f32(one, one, one, one, one, 0, one, one, 1, 65536, 8, 2048, one, one, one, one, one, one, None) == -1  # cloud larger than the LDS
+    assert L.p2c_linear_bwd_narrow_f32(None, 20, None, 128, None, None, 2.0, None, 128, None, 128, None, 128, 20 * 128, None, None, 262144, 20, 128, None) == -1
+    assert L.p2c_linear_bwd_narrow_f32(one, 20, one, 128, one, None, 1.0, one, 128, one, 128, one, 128, 40 * 128, None, one, 262144, 40, 128, None) == -1   # more than 32 outputs
+    assert L.p2c_linear_bwd_narrow_f32(one, 20, one, 130, one, None, 1.0, one, 128, one, 128, one, 128, 20 * 128, None, one, 262144, 20, 128, None) == -2   # row stride not 16-byte aligned
+    assert L.p2c_sum_copies_f32(None, 16, 8, None, 16, None) == -1
+    assert L.p2c_bn_bwd_finalize_sum_f32(None, 64, 10, None, None, None, None, None, None, 16, 8, None, 16, None) == -1
 
 
 def test_shape_queries_describe_the_kernel_coverage():
@@ -66,6 +75,19 @@ def test_shape_queries_describe_the_kernel_coverage():
     assert L.p2c_linear_bwd_fused_supported(128, 132, 0) == 2
     assert L.p2c_linear_bwd_fused_supported(256, 128, 1) == 3        # two passes over 128 output channels each
     assert L.p2c_linear_bwd_fused_supported(256, 256, 1) == 0
+    # one-pass heads backward: up to 32 outputs on 128 inputs, from 4096 rows, input = relu(bn) with or without the hashed dropout
+    assert L.p2c_linear_bwd_narrow_supported(262144, 20, 128, 3) == 1 and L.p2c_linear_bwd_narrow_supported(262144, 20, 128, 1) == 1
+    assert L.p2c_linear_bwd_narrow_supported(262144, 20, 128, 2) == 0 and L.p2c_linear_bwd_narrow_supported(262144, 20, 256, 1) == 0
+    assert L.p2c_linear_bwd_narrow_supported(1024, 20, 128, 1) == 0
+    # one-pass fitting: K a power of two <= 8, the cloud (points, keys, lists) within the LDS
+    assert L.p2c_fit_fused_supported(8192, 8, 2048) == 1 and L.p2c_fit_fused_supported(1024, 4, 100) == 1
+    assert L.p2c_fit_fused_supported(8192, 16, 2048) == 0 and L.p2c_fit_fused_supported(16384, 8, 2048) == 0 and L.p2c_fit_fused_supported(8192, 6, 64) == 0
+    # matrix-pipe mode switch (no device needed: it only selects kernels)
+    assert L.p2c_get_mfma_mode() in (0, 1)
+    old = L.p2c_set_mfma_mode(0)
+    assert L.p2c_get_mfma_mode() == 0
+    L.p2c_set_mfma_mode(old)
+    assert L.p2c_get_mfma_mode() == old
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

@@ -62,8 +62,10 @@ __device__ __forceinline__ float p2c_l0_preact(float wx, float wy, float wz, flo
     return __builtin_fmaf(wz, z, __builtin_fmaf(wy, y, wx * x)) + b;
 }
 
-// Counter-based dropout bits: keep(row, col) = hash(seed, row*C + col) >= threshold.  Stateless, so the forward
-// and the two backward kernels regenerate the same mask from (seed, element index) instead of storing M x C bytes.
+// Counter-based dropout bits.  Stateless, so the forward and the backward kernels regenerate the same mask from (seed, element index)
+// instead of storing M x C bytes.  Four consecutive elements share ONE hash (13 integer operations - as many as the bf16 split of an
+// element; hashing every element made the heads' forward and backward VALU-bound): element e = row*C + col keeps when byte (e & 3) of
+// hash(seed, e >> 2) >= the top byte of the threshold, i.e. the drop probability is taken in steps of 1/256 (exact for the reference's 0.5).
 __device__ __forceinline__ uint32_t p2c_hash32(uint32_t seed_lo, uint32_t seed_hi, uint32_t idx)
 {
     uint32_t x = idx * 0x9E3779B1u ^ seed_lo;
@@ -73,6 +75,11 @@ __device__ __forceinline__ uint32_t p2c_hash32(uint32_t seed_lo, uint32_t seed_h
     x ^= x >> 15; x *= 0x2C1B3C6Du;
     x ^= x >> 12;
     return x;
+}
+__device__ __forceinline__ bool p2c_keep4(uint32_t h, int j, uint32_t thr) { return ((h >> (8 * j)) & 0xFFu) >= (thr >> 24); }
+__device__ __forceinline__ bool p2c_keep(uint32_t seed_lo, uint32_t seed_hi, uint32_t e, uint32_t thr)
+{
+    return p2c_keep4(p2c_hash32(seed_lo, seed_hi, e >> 2), (int)(e & 3u), thr);
 }
 static inline uint32_t p2c_drop_threshold(float scale)     // scale = 1/(1-p)  ->  p * 2^32
 {

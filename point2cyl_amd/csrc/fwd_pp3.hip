@@ -174,10 +174,11 @@ __global__ void __launch_bounds__(512, 2) fwd_pp3_kernel(FwdPPArgs a)
             }
             if (MODE == 3) {
                 const uint32_t e = (uint32_t)min(m, a.M - 1) * (uint32_t)a.Kfull + (uint32_t)(4 * kq);
-                v.x = p2c_hash32(slo, shi, e + 0) >= a.thr ? v.x * a.dscale : 0.f;
-                v.y = p2c_hash32(slo, shi, e + 1) >= a.thr ? v.y * a.dscale : 0.f;
-                v.z = p2c_hash32(slo, shi, e + 2) >= a.thr ? v.z * a.dscale : 0.f;
-                v.w = p2c_hash32(slo, shi, e + 3) >= a.thr ? v.w * a.dscale : 0.f;
+                const uint32_t hq = p2c_hash32(slo, shi, e >> 2);            // e is a multiple of 4: one hash for the four elements
+                v.x = p2c_keep4(hq, 0, a.thr) ? v.x * a.dscale : 0.f;
+                v.y = p2c_keep4(hq, 1, a.thr) ? v.y * a.dscale : 0.f;
+                v.z = p2c_keep4(hq, 2, a.thr) ? v.z * a.dscale : 0.f;
+                v.w = p2c_keep4(hq, 3, a.thr) ? v.w * a.dscale : 0.f;
             }
             if (!full) v *= (m < a.M && kok) ? 1.f : 0.f;    // branch-free (the clamped loads only ever return finite data)
             v2u h, md, l;

@@ -78,10 +78,11 @@ struct OpActIn {
         if (MODE == 3) {
             const uint32_t *sd = reinterpret_cast<const uint32_t *>(mask);
             const uint32_t lo = sd[0], hi = sd[1], thr = (uint32_t)ldmask, e = (uint32_t)rr * (uint32_t)C + (uint32_t)cc;
-            v.x = p2c_hash32(lo, hi, e + 0) >= thr ? v.x * dscale : 0.f;
-            v.y = p2c_hash32(lo, hi, e + 1) >= thr ? v.y * dscale : 0.f;
-            v.z = p2c_hash32(lo, hi, e + 2) >= thr ? v.z * dscale : 0.f;
-            v.w = p2c_hash32(lo, hi, e + 3) >= thr ? v.w * dscale : 0.f;
+            const uint32_t hq = p2c_hash32(lo, hi, e >> 2);            // e is a multiple of 4: one hash for the four elements
+            v.x = p2c_keep4(hq, 0, thr) ? v.x * dscale : 0.f;
+            v.y = p2c_keep4(hq, 1, thr) ? v.y * dscale : 0.f;
+            v.z = p2c_keep4(hq, 2, thr) ? v.z * dscale : 0.f;
+            v.w = p2c_keep4(hq, 3, thr) ? v.w * dscale : 0.f;
         }
         return sel4(r < R && c < C, v);
     }
@@ -493,7 +494,7 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
                     const uint32_t *sd = reinterpret_cast<const uint32_t *>(epi.mask);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        vv[c] = p2c_hash32(sd[0], sd[1], (uint32_t)row * (uint32_t)J + (uint32_t)(col + c)) >= epi.thr ? vv[c] * epi.mscale : 0.f;
+                        vv[c] = p2c_keep(sd[0], sd[1], (uint32_t)row * (uint32_t)J + (uint32_t)(col + c), epi.thr) ? vv[c] * epi.mscale : 0.f;
                 }
                 if (epi.spz) {
                     const float4 z = *reinterpret_cast<const float4 *>(epi.spz + (size_t)row * epi.ldspz + col);
@@ -556,7 +557,7 @@ __device__ __forceinline__ void gemm_body(float *smem, const OpA &opA, const OpB
                             bool keep;
                             if (epi.ldmask < 0) {
                                 const uint32_t *sd = reinterpret_cast<const uint32_t *>(epi.mask);
-                                keep = p2c_hash32(sd[0], sd[1], (uint32_t)row * (uint32_t)J + (uint32_t)col) >= epi.thr;
+                                keep = p2c_keep(sd[0], sd[1], (uint32_t)row * (uint32_t)J + (uint32_t)col, epi.thr);
                             } else {
                                 keep = epi.mask[(size_t)row * epi.ldmask + col] != 0;
                             }

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256, 2) heads_bwd_kernel(HeadsBwdArgs a)
     __shared__ float Ys[HB_BM * HB_LDY];         // raw pre-BatchNorm rows
     __shared__ float Xs[HB_BM * HB_LDY];         // the layer's input
     __shared__ float Zs[HB_BM * HB_LDZ];         // dZ, columns Co..31 zero
-    __shared__ float red[2 * HB_CI + 32];
+    __shared__ unsigned char Kb[HB_BM * 32];     // dropout keep flags of the tile: bit j of byte [row][c / 4] = element (row, 4 * (c / 4) + j)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int il = lane & 31, kl = lane >> 5;
     const int cb = wave * 32;                                            // this wave's 32 input channels
@@ -85,10 +85,13 @@ __global__ void __launch_bounds__(256, 2) heads_bwd_kernel(HeadsBwdArgs a)
             x.z = fmaxf(lsc.z * v.z + lsh.z, 0.f); x.w = fmaxf(lsc.w * v.w + lsh.w, 0.f);
             if (a.seed) {
                 const uint32_t e = (uint32_t)(m0 + rl) * (uint32_t)HB_CI + (uint32_t)lc;
-                x.x = p2c_hash32(slo, shi, e + 0) >= a.thr ? x.x * a.dscale : 0.f;
-                x.y = p2c_hash32(slo, shi, e + 1) >= a.thr ? x.y * a.dscale : 0.f;
-                x.z = p2c_hash32(slo, shi, e + 2) >= a.thr ? x.z * a.dscale : 0.f;
-                x.w = p2c_hash32(slo, shi, e + 3) >= a.thr ? x.w * a.dscale : 0.f;
+                const uint32_t hq = p2c_hash32(slo, shi, e >> 2);            // e is a multiple of 4: one hash for the four elements
+                const bool k0 = p2c_keep4(hq, 0, a.thr), k1 = p2c_keep4(hq, 1, a.thr), k2 = p2c_keep4(hq, 2, a.thr), k3 = p2c_keep4(hq, 3, a.thr);
+                x.x = k0 ? x.x * a.dscale : 0.f;
+                x.y = k1 ? x.y * a.dscale : 0.f;
+                x.z = k2 ? x.z * a.dscale : 0.f;
+                x.w = k3 ? x.w * a.dscale : 0.f;
+                Kb[rl * 32 + (tid & 31)] = (unsigned char)((k0 ? 1 : 0) | (k1 ? 2 : 0) | (k2 ? 4 : 0) | (k3 ? 8 : 0));     // the dX epilogue reads it back
             }
             if (m0 + rl >= a.M) x = float4{0.f, 0.f, 0.f, 0.f};          // rows past M contribute nothing to dW
             *reinterpret_cast<float4 *>(&Ys[rl * HB_LDY + lc]) = v;
@@ -130,7 +133,7 @@ __global__ void __launch_bounds__(256, 2) heads_bwd_kernel(HeadsBwdArgs a)
                 const int rl = rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
                 const int row = m0 + rl;
                 float v = acc[r];
-                if (a.seed) v = p2c_hash32(slo, shi, (uint32_t)row * (uint32_t)HB_CI + (uint32_t)col) >= a.thr ? v * a.dscale : 0.f;
+                if (a.seed) v = ((Kb[rl * 32 + (col >> 2)] >> (col & 3)) & 1) ? v * a.dscale : 0.f;
                 if (row < a.M) {
                     a.dx[(size_t)row * a.lddx + col] = v;
                     const float yp = Ys[rl * HB_LDY + col];
@@ -161,7 +164,6 @@ __global__ void __launch_bounds__(256, 2) heads_bwd_kernel(HeadsBwdArgs a)
         }
     }
     if (a.dbias && tid < Co) atomicAdd(&a.dbias[tid], db);
-    (void)red;
 }
 
 extern "C" int p2c_linear_bwd_narrow_supported(int M, int Co, int Ci, int in_mode)

@@ -55,16 +55,19 @@ def _relnorm(a, b):
 
 
 def hashed_keep_mask(seed_i64, rows, cols=128, thr=1 << 31):
-    """Host restatement of the kernels' dropout bits (csrc/common.h p2c_hash32; fwd_pp.hip MODE 3): keep(row, col) = hash(seed, row*cols+col) >= thr."""
+    """Host restatement of the kernels' dropout bits (csrc/common.h p2c_hash32 / p2c_keep; fwd_pp3.hip MODE 3): element e = row*cols + col keeps
+    when byte (e & 3) of hash(seed, e >> 2) >= thr >> 24."""
     lo, hi = np.uint32(seed_i64 & 0xFFFFFFFF), np.uint32((seed_i64 >> 32) & 0xFFFFFFFF)
+    assert (rows * cols) % 4 == 0
     with np.errstate(over="ignore"):
-        x = np.arange(rows * cols, dtype=np.uint32) * np.uint32(0x9E3779B1) ^ lo
+        x = np.arange(rows * cols // 4, dtype=np.uint32) * np.uint32(0x9E3779B1) ^ lo
         x ^= x >> np.uint32(16); x *= np.uint32(0x85EBCA6B)
         x ^= x >> np.uint32(13); x *= np.uint32(0xC2B2AE35)
         x ^= x >> np.uint32(16); x += hi * np.uint32(0x27D4EB2F)
         x ^= x >> np.uint32(15); x *= np.uint32(0x2C1B3C6D)
         x ^= x >> np.uint32(12)
-    return (x >= np.uint32(thr)).reshape(rows, cols)
+    by = np.stack([(x >> np.uint32(8 * j)) & np.uint32(0xFF) for j in range(4)], axis=1).reshape(-1)
+    return (by >= np.uint32(thr >> 24)).reshape(rows, cols)
 
 
 # ------------------------------------------------------------------------------------------ configs[2], one rank's step

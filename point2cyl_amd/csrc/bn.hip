@@ -10,16 +10,18 @@
 // Block = 64 channels x 16 tile-lanes, fp64 accumulation.  torch semantics: biased variance normalises,
 // unbiased variance feeds running_var; running = (1-momentum)*running + momentum*batch.
 // ------------------------------------------------------------------------------------------------
-// Sum the P2C_STAT_SLOTS fp64 rows of one channel with 4 threads (16 independent loads each), combined through LDS.
-// Block = 64 channels x 4 slot-lanes; returns the totals to the slot-lane-0 thread of each channel.
+// Sum the P2C_STAT_SLOTS fp64 rows of one channel with 16 threads (4 rows each: 8 independent loads), combined through LDS.
+// Block = 16 channels x 16 slot-lanes (a finalisation is a latency chain of one small workgroup per 16 channels: with 64 channels x 4 lanes
+// a thread walked 16 rows); returns the totals to the slot-lane-0 thread of each channel (threadIdx.x < 16).
+#define FIN_CH 16
 __device__ __forceinline__ void p2c_sum_slots(const double *__restrict__ slots, int n_slots, int C, int c, bool active, double &s1, double &s2)
 {
-    __shared__ double red[2][4][64];
-    const int cx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    __shared__ double red[2][16][FIN_CH];
+    const int cx = threadIdx.x & (FIN_CH - 1), ty = threadIdx.x >> 4;
     double a = 0.0, b = 0.0;
     if (active && c < C) {
 #pragma unroll 4
-        for (int t = ty; t < n_slots; t += 4) {
+        for (int t = ty; t < n_slots; t += 16) {
             a += slots[(size_t)t * 2 * C + c];
             b += slots[(size_t)t * 2 * C + C + c];
         }
@@ -27,8 +29,14 @@ __device__ __forceinline__ void p2c_sum_slots(const double *__restrict__ slots, 
     red[0][ty][cx] = a;
     red[1][ty][cx] = b;
     __syncthreads();
-    s1 = (red[0][0][cx] + red[0][1][cx]) + (red[0][2][cx] + red[0][3][cx]);
-    s2 = (red[1][0][cx] + red[1][1][cx]) + (red[1][2][cx] + red[1][3][cx]);
+    s1 = s2 = 0.0;
+    if (ty == 0) {
+#pragma unroll
+        for (int t = 0; t < 16; t += 4) {
+            s1 += (red[0][t][cx] + red[0][t + 1][cx]) + (red[0][t + 2][cx] + red[0][t + 3][cx]);
+            s2 += (red[1][t][cx] + red[1][t + 1][cx]) + (red[1][t + 2][cx] + red[1][t + 3][cx]);
+        }
+    }
 }
 
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const double *__restrict__ partials, int n_tiles, int C, long long count,
@@ -38,10 +46,10 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const double *__restri
                                                            float *__restrict__ scale, float *__restrict__ shift,
                                                            float *__restrict__ mean_out, float *__restrict__ invstd_out)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
     double s1 = 0.0, s2 = 0.0;
     p2c_sum_slots(partials, n_tiles, C, c, training != 0, s1, s2);
-    if (c >= C || threadIdx.x >= 64) return;
+    if (c >= C || threadIdx.x >= FIN_CH) return;
     float mean, invstd;
     if (training) {
         const double m0 = s1 / (double)count;
@@ -74,7 +82,7 @@ extern "C" int p2c_bn_finalize_f32(const double *stat_slots, int C, long long co
     if (training && (!stat_slots || count <= 0)) return P2C_EINVAL;
     if (!training && (!running_mean || !running_var)) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, stat_slots, P2C_STAT_SLOTS, C, count, bias,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(p2c_cdiv(C, FIN_CH)), dim3(256), 0, s, stat_slots, P2C_STAT_SLOTS, C, count, bias,
                        gamma, beta, eps, momentum, training, running_mean, running_var, scale, shift, mean, invstd);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -254,10 +262,10 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const double *__re
                                                              const float *__restrict__ gamma, float *__restrict__ dgamma,
                                                              float *__restrict__ dbeta, float *__restrict__ coef)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
     double s1 = 0.0, s2 = 0.0;
     p2c_sum_slots(ws, n_chunks, C, c, true, s1, s2);
-    if (c >= C || threadIdx.x >= 64) return;
+    if (c >= C || threadIdx.x >= FIN_CH) return;
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
     const double is = (double)invstd[c], gs = (double)gamma[c] * is;
@@ -308,7 +316,7 @@ extern "C" int p2c_maxpool_bn_bwd_stats_f32(const float *dout, int ldo, const fl
     hipStream_t s = (hipStream_t)stream;
     const int chunks = p2c_cdiv(G, POOL_ROWS);
     hipLaunchKernelGGL(pool_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dout, ldo, ywin, stat, G, C, slots);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, (const double *)slots, P2C_STAT_SLOTS, C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, FIN_CH)), dim3(256), 0, s, (const double *)slots, P2C_STAT_SLOTS, C,
                        (long long)G * ns, stat, stat + C, stat + 2 * C, stat + 3 * C, gamma, dgamma, dbeta, coef_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -530,10 +538,10 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_sum_kernel(const double *
         p2c_sum_copies(src, stride, copies, out, n, (long long)blockIdx.x - fin_blocks);
         return;
     }
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x & (FIN_CH - 1));
     double s1 = 0.0, s2 = 0.0;
     p2c_sum_slots(ws, n_chunks, C, c, true, s1, s2);
-    if (c >= C || threadIdx.x >= 64) return;
+    if (c >= C || threadIdx.x >= FIN_CH) return;
     if (dgamma) dgamma[c] = (float)s2;
     if (dbeta) dbeta[c] = (float)s1;
     const double is = (double)stat[3 * C + c], gs = (double)gamma[c] * is;
@@ -552,7 +560,7 @@ extern "C" int p2c_bn_bwd_finalize_sum_f32(const double *slots, int C, long long
                                            void *stream)
 {
     if (!slots || !stat || !gamma || !coef_out || C <= 0 || !src || !out || copies <= 0 || n <= 0) return P2C_EINVAL;
-    const int fin = p2c_cdiv(C, 64);
+    const int fin = p2c_cdiv(C, FIN_CH);
     hipLaunchKernelGGL(bn_bwd_finalize_sum_kernel, dim3(fin + p2c_cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, slots, P2C_STAT_SLOTS, C, M, stat,
                        gamma, dgamma, dbeta, coef_out, fin, src, stride, copies, out, n);
     P2C_LAUNCH_CHECK();
@@ -565,7 +573,7 @@ extern "C" int p2c_bn_bwd_finalize_f32(const double *slots, int C, long long M, 
 {
     if (!slots || !stat || !gamma || !coef_out || C <= 0) return P2C_EINVAL;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, slots, P2C_STAT_SLOTS, C, M, stat, stat + C,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, FIN_CH)), dim3(256), 0, s, slots, P2C_STAT_SLOTS, C, M, stat, stat + C,
                        stat + 2 * C, stat + 3 * C, gamma, dgamma, dbeta, coef_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -584,7 +592,7 @@ extern "C" int p2c_bn_relu_bwd_stats_f32(const float *dZ, int lddz, const float 
     const int chunks = p2c_cdiv(M, rows);
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(chunks, p2c_cdiv(C, 64)), dim3(256), 0, s, dZ, lddz, Y, ldy, scale, shift, mean, invstd,
                        (long long)M, C, rows, slots);
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, 64)), dim3(256), 0, s, (const double *)slots, P2C_STAT_SLOTS, C, (long long)M, scale, shift,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(p2c_cdiv(C, FIN_CH)), dim3(256), 0, s, (const double *)slots, P2C_STAT_SLOTS, C, (long long)M, scale, shift,
                        mean, invstd, gamma, dgamma, dbeta, coef_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;

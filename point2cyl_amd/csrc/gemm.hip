@@ -735,7 +735,9 @@ static int launch_fwd(const float *X, int ldx, const float *W, int ldw, const fl
     // split form from 65,536 rows on (the implicit decoder's 512-wide products: 101 -> 125 TFLOP/s); the 4 k - 16 k-row levels of the
     // backbone stay on the fp32 instructions - there the larger LDS / register footprint costs co-residency with the sampling kernel
     // of the forked stream and the step got 0.03 ms slower
-#define P2C_FW(TM_, TN_) do { if (gemm_split() && M >= 65536) P2C_FW_(TM_, TN_, true); else P2C_FW_(TM_, TN_, false); } while (0)
+    // ... except the one product of those levels that is large enough to pay (SA3's 512 -> 1024 layer: K * N >= 400,000; -0.02 ms)
+    static const long long fw_kn = getenv("P2C_GEMM_FWD_KN") ? atoll(getenv("P2C_GEMM_FWD_KN")) : 400000;
+#define P2C_FW(TM_, TN_) do { if (gemm_split() && (M >= 65536 || (long long)K * N >= fw_kn)) P2C_FW_(TM_, TN_, true); else P2C_FW_(TM_, TN_, false); } while (0)
     if (tile_m() == 128) { if (N > 64) P2C_FW(2, 2); else P2C_FW(2, 1); }
     else { if (N > 64 && !narrow_tiles(M, N)) P2C_FW(1, 2); else P2C_FW(1, 1); }
 #undef P2C_FW

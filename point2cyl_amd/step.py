@@ -67,7 +67,7 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
     total = out4[0]
     zero = torch.zeros((), device=pcs.device)
     ext_loss = center_loss = zero
-    res = dict(normal=out4[1].detach(), miou=out4[2].detach(), bb=out4[3].detach(), match=match, mask=mask)
+    res = dict(normal=out4[1].detach(), miou=out4[2].detach(), bb=out4[3].detach(), match=match, mask=mask, E_AX=None)
     if fl.pred_extrusion or fl.pred_center:
         # normalised normals, softmax, barrel / base split and the reorder by the matching (train...:247-265, :319-325, :342-344) in
         # one kernel forward and one backward (ops.head_post) instead of ~25 torch launches over (B,N,2K) tensors
@@ -75,6 +75,7 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
         mask_gt = losses.get_mask_gt(gt_inst, K)
         if fl.pred_extrusion:
             E_AX = fitting.estimate_extrusion_axis(X, Wb_re, Wc_re, gt_bb, gt_inst, normalize=fl.norm_eig)
+            res["E_AX"] = E_AX                                   # (with its history: train_Point2Cyl.py:528 feeds it to the sketch encoder)
             ext = losses.compute_normal_loss(E_AX, gt_axes, angle_diff=False, collapse=False)
             ext_loss = losses.reduce_mean_masked_instance(ext, mask_gt).mean() * fl.weight_extrusion
         if fl.pred_center:
@@ -126,6 +127,7 @@ def compute_losses(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, 
         bb_loss = torch.zeros((), device=dev)
     total = total + (fl.weight_bb if fl.pred_bb else 0.0) * bb_loss
     mask_gt = losses.get_mask_gt(gt_inst, K)
+    E_AX = None
     if fl.pred_normal and fl.pred_bb and fl.pred_extrusion:                     # :319-332
         Wb_r, Wc_r = losses._reorder(W_barrel, match), losses._reorder(W_base, match)
         E_AX = fitting.estimate_extrusion_axis(X, Wb_r, Wc_r, gt_bb, gt_inst, normalize=fl.norm_eig)
@@ -142,7 +144,7 @@ def compute_losses(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, 
         center_loss = torch.zeros((), device=dev)
     total = total + center_loss
     return dict(total=total, normal=normal_loss, miou=miou_loss, bb=bb_loss, ext=ext_loss, center=center_loss,
-                match=match, mask=mask, X=X, W=W, W_raw=W_raw, X_head=X_head)
+                match=match, mask=mask, X=X, W=W, W_raw=W_raw, X_head=X_head, E_AX=E_AX)
 
 
 def train_step(model, optimizer, batch, fl: StepFlags, sync_grads=None, fused=False):

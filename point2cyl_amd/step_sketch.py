@@ -1,6 +1,7 @@
-"""The implicit-sketch part of one step of the with-sketch trainer (train_Point2Cyl.py:519-672): predicted labels (not --use_gt_im),
-projected sketches or - --use_whole_pc - the whole cloud with the soft segment membership as a fourth channel (:522-536; the membership
-keeps its gradient, so the latent and decoder losses reach the backbone through the encoder's input), angle or L2 latent loss, --with_im_loss.  Composition only - every piece is a kernel path of
+"""The implicit-sketch part of one step of the with-sketch trainer (train_Point2Cyl.py:519-672): predicted labels or - --use_gt_im, :566-600 -
+the ground-truth ones; projected sketches or - --use_whole_pc - the whole cloud with the (soft / one-hot) segment membership as a fourth
+channel (:522-536; the membership keeps its gradient, so the latent and decoder losses reach the backbone through the encoder's input) and,
+--use_extrusion_axis_feat, the segment's extrusion axis as channels 5-7 (:528-531, :577-580); angle or L2 latent loss, --with_im_loss.  Composition only - every piece is a kernel path of
 this package: fitting.sketch_implicit_projection (csrc/fit.hip), sketch.PointNetEncoder (MLP-stack kernels), implicit.ImplicitNet and
 its double backward (csrc/gemm.hip)."""
 import torch
@@ -27,11 +28,15 @@ def implicit_losses(implicit_net, sk_pnts, sk_normals, nonmnfld_pnts, latent_cod
 def sketch_branch_losses(pcs, X, W, W_2K, matching_indices, mask, gt_normals, gt_extrusion_instances, gt_bb_labels, gt_extrusion_axes,
                          gt_extrusion_centers, gt_sketches, pn_encoder, loaded_pn_encoder, implicit_net, sampler, K, num_sk_point,
                          with_im_loss=True, is_l2=False, rand_idx_pred=None, rand_idx_gt=None, nonmnfld_pnts=None, use_whole_pc=False,
-                         W_encoder=None):
+                         W_encoder=None, use_gt_im=False, axis_feat=None):
     """train_Point2Cyl.py:519-672.  pcs (B,N,3); X (B,N,3) predicted normals; W (B,N,K) and W_2K (B,N,2K) the softmaxed segmentation;
     matching_indices / mask from hungarian_matching; gt_sketches (B,K,S,4) = [point | normal] of the ground-truth profiles.
     use_whole_pc: the encoder (4 input channels) sees [xyz | W_reordered[:, :, k]] of all N points per segment instead of the projected
     sketch; W_encoder = the (B,N,K) segmentation WITH its autograd history (default: W as given).
+    axis_feat (B,K,3), with use_whole_pc: the segment's extrusion axis repeated over the points as channels 5-7 of the encoder input
+    (7 input channels; the fitted axes E_AX with their history, or the ground-truth axes under use_gt_im).
+    use_gt_im: the encoder input is built from the ground-truth labels (X, W, W_2K, matching_indices, mask are not read): the one-hot
+    membership for use_whole_pc, else the projection of the ground-truth barrels divided by its OWN scales (:591-593).
     -> dict(im_loss, latent_loss, mnfld_loss, grad_loss, normals_loss, latent_codes)."""
     B, N, _ = pcs.shape
     S = num_sk_point
@@ -40,11 +45,23 @@ def sketch_branch_losses(pcs, X, W, W_2K, matching_indices, mask, gt_normals, gt
         sk_pnts = gt_sketches[:, :, :, :2].reshape(B * K, S, 2)                                                          # :602-604
         sk_normals = gt_sketches[:, :, :, -2:].reshape(B * K, S, 2)
         latent_codes_gt = loaded_pn_encoder(torch.cat((sk_pnts, sk_normals), dim=-1))                                    # :605 (its parameters are frozen)
-    if use_whole_pc:                                                                                                     # :522-536
-        Wg = W if W_encoder is None else W_encoder
-        W_reordered = torch.gather(Wg, 2, matching_indices.unsqueeze(1).expand(B, N, K))                                 # :519
-        W_reordered = torch.where(mask.unsqueeze(1).expand(B, N, K) == 1, W_reordered, torch.zeros_like(W_reordered))   # :520
-        global_pc = torch.cat((pcs.unsqueeze(1).expand(B, K, N, 3), W_reordered.permute(0, 2, 1).unsqueeze(-1)), dim=-1).reshape(B * K, N, 4)
+    if use_whole_pc:                                                                                                     # :522-536, :569-586
+        if use_gt_im:
+            W_reordered = torch.nn.functional.one_hot(gt_extrusion_instances.reshape(-1), num_classes=K).view(B, N, K).float()  # :572-574
+        else:
+            Wg = W if W_encoder is None else W_encoder
+            W_reordered = torch.gather(Wg, 2, matching_indices.unsqueeze(1).expand(B, N, K))                             # :519
+            W_reordered = torch.where(mask.unsqueeze(1).expand(B, N, K) == 1, W_reordered, torch.zeros_like(W_reordered))   # :520
+        cols = [pcs.unsqueeze(1).expand(B, K, N, 3), W_reordered.permute(0, 2, 1).unsqueeze(-1)]
+        if axis_feat is not None:                                                                                        # :528-531, :577-580
+            cols.append(axis_feat.unsqueeze(-2).expand(B, K, N, 3))
+        global_pc = torch.cat(cols, dim=-1).reshape(B * K, N, 3 + 1 + (3 if axis_feat is not None else 0))
+    elif use_gt_im:                                                                                                      # :588-600
+        with torch.no_grad():
+            pred_pc, pred_nrm, pred_scales = fitting.sketch_implicit_projection(pcs, gt_normals, gt_extrusion_instances, gt_bb_labels,
+                                                                                gt_extrusion_axes, gt_extrusion_centers, S, rand_idx=rand_idx_gt)
+            pred_pc = pred_pc / pred_scales.unsqueeze(-1).unsqueeze(-1)
+            global_pc = torch.cat((pred_pc.reshape(B * K, S, 2), pred_nrm.reshape(B * K, S, 2)), dim=-1)
     else:
         with torch.no_grad():                                                          # labels: no gradient through the arg-max / sampling
             W_reordered = torch.gather(W, 2, matching_indices.unsqueeze(1).expand(B, N, K))                               # :519

@@ -1,7 +1,8 @@
 """Trainer counterpart of the reference's train_Point2Cyl.py (the with-sketch trainer: flags :33-90, networks and optimiser
 :256-321, checkpoint loading :327-350, loop :369-700, checkpoints :746-775) on the HIP kernels.
 
-Per step (default path: predicted labels, not --use_gt_im / --use_whole_pc, which are not built - DESIGN.md section 7):
+Per step (default path: predicted labels; --use_whole_pc, --use_extrusion_axis_feat and --use_gt_im select the reference's other encoder
+inputs, train_Point2Cyl.py:268-276, :519-600; --is_implicitnet_train is parsed and never read there (:75, :144) - accepted, no effect):
 backbone forward + segmentation / normal / base-barrel (+ axis, + centre) losses exactly as the without-sketch step
 (point2cyl_amd/step.py), then the sketch branch (point2cyl_amd/step_sketch.py, train_Point2Cyl.py:519-672): projection of the
 predicted and the ground-truth barrels, trainable sketch encoder vs the frozen pre-trained one (latent loss, angle or --is_L2),
@@ -98,9 +99,12 @@ def synthetic_sketches(data, K, S, dev, chunk=16):
 
 def main(argv=None):
     a = build_parser().parse_args(argv)
-    if a.use_gt_im or a.use_extrusion_axis_feat or a.is_implicitnet_train:
-        raise SystemExit("--use_gt_im / --use_extrusion_axis_feat / --is_implicitnet_train are variants of the reference "
-                         "trainer that this package does not build (DESIGN.md section 7)")
+    if a.use_extrusion_axis_feat and not a.use_whole_pc:
+        raise SystemExit("--use_extrusion_axis_feat only changes the --use_whole_pc encoder input (train_Point2Cyl.py:271-276, :528, :577)")
+    if a.use_extrusion_axis_feat and not (a.use_gt_im or a.pred_extrusion):
+        raise SystemExit("--use_extrusion_axis_feat feeds the FITTED axes to the encoder: it needs --pred_extrusion (train_Point2Cyl.py:446, :528) or --use_gt_im")
+    if a.use_gt_im and a.is_pc_train:
+        raise SystemExit("--use_gt_im skips the backbone (train_Point2Cyl.py:405, :566): there is nothing of it to train; drop --is_pc_train")
     if not (a.is_pc_train or a.is_im_train):
         raise SystemExit("nothing to train: pass --is_pc_train and/or --is_im_train (train_Point2Cyl.py:298-321)")
     rank, world, local = ddp.init_from_env()
@@ -118,12 +122,12 @@ def _main(a, rank, world, dev):
     fl = step.StepFlags(K=K, pred_seg=a.pred_seg, pred_normal=a.pred_normal, pred_bb=a.pred_bb, pred_extrusion=a.pred_extrusion,
                         pred_center=a.pred_center, norm_eig=a.norm_eig, weight_seg=a.weight_seg, weight_normal=a.weight_normal,
                         weight_bb=a.weight_bb, weight_extrusion=a.weight_extrusion, weight_center=a.weight_center)
-    if not (fl.pred_seg and fl.pred_bb and fl.pred_normal):
+    if not a.use_gt_im and not (fl.pred_seg and fl.pred_bb and fl.pred_normal):
         raise SystemExit("the sketch branch needs --pred_seg --pred_normal --pred_bb (labels, base/barrel split and normals feed the projection)")
     model = backbone(output_sizes=fl.pred_sizes()).to(dev)                                                   # train_Point2Cyl.py:256
     implicit_net = ImplicitNet(d_in=2 + 256, dims=[512] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100).to(dev)   # :268
-    if a.use_whole_pc:                                                                                       # :268-276: [xyz | membership] of the whole cloud
-        pn_encoder = PointNetEncoder(256, 4, with_normals=False).to(dev)
+    if a.use_whole_pc:                                                                                       # :268-276: [xyz | membership (| axis)] of the whole cloud
+        pn_encoder = PointNetEncoder(256, 7 if a.use_extrusion_axis_feat else 4, with_normals=False).to(dev)
     else:
         pn_encoder = PointNetEncoder(256, 2, with_normals=True).to(dev)                                      # :270
     loaded_pn_encoder = PointNetEncoder(256, 2, with_normals=True).to(dev)                                   # :280
@@ -235,22 +239,33 @@ def _main(a, rank, world, dev):
             step.update_momentum(model, mom_fwd)
             ops.step_done()
             with ops.step_arena(dev):
-                out = (step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses)(model, pcs, nrm, inst, bb, axes, cen, fl)
-                h = out["heads"].view(B, N, -1) if "heads" in out else None
-                with torch.no_grad():
-                    if h is not None:
-                        X = F.normalize(h[:, :, 0:3], p=2, dim=2, eps=1e-12)
-                        W2K = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2)
-                    else:
-                        X, W2K = out["X"].detach(), torch.softmax(out["W_raw"].detach(), dim=2)
-                    W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
-                W_enc = None
-                if a.use_whole_pc and a.is_pc_train:     # the membership channel keeps its history: the sketch losses reach the backbone (:519-536)
-                    Wg = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2) if h is not None else torch.softmax(out["W_raw"], dim=2)
-                    W_enc = Wg[:, :, 0::2] + Wg[:, :, 1::2]
-                sk = step_sketch.sketch_branch_losses(pcs, X, W, W2K, out["match"], out["mask"], nrm, inst, bb, axes, cen, gt_sk, pn_encoder,
-                                                      loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2,
-                                                      use_whole_pc=a.use_whole_pc, W_encoder=W_enc)
+                if a.use_gt_im:                                                # :405, :566-600: no backbone pass, ground-truth labels feed the encoder
+                    zero = torch.zeros((), device=dev)
+                    out = dict(total=zero, normal=zero, miou=zero, ext=zero, bb=zero, center=zero)
+                    sk = step_sketch.sketch_branch_losses(pcs, None, None, None, None, None, nrm, inst, bb, axes, cen, gt_sk, pn_encoder,
+                                                          loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2,
+                                                          use_whole_pc=a.use_whole_pc, use_gt_im=True,
+                                                          axis_feat=axes if a.use_extrusion_axis_feat else None)
+                else:
+                    out = (step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses)(model, pcs, nrm, inst, bb, axes, cen, fl)
+                    h = out["heads"].view(B, N, -1) if "heads" in out else None
+                    with torch.no_grad():
+                        if h is not None:
+                            X = F.normalize(h[:, :, 0:3], p=2, dim=2, eps=1e-12)
+                            W2K = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2)
+                        else:
+                            X, W2K = out["X"].detach(), torch.softmax(out["W_raw"].detach(), dim=2)
+                        W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
+                    W_enc = None
+                    if a.use_whole_pc and a.is_pc_train:     # the membership channel keeps its history: the sketch losses reach the backbone (:519-536)
+                        Wg = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2) if h is not None else torch.softmax(out["W_raw"], dim=2)
+                        W_enc = Wg[:, :, 0::2] + Wg[:, :, 1::2]
+                    ax_feat = None
+                    if a.use_extrusion_axis_feat:            # :528: the fitted axes, with their history when the backbone trains
+                        ax_feat = out["E_AX"] if a.is_pc_train else out["E_AX"].detach()
+                    sk = step_sketch.sketch_branch_losses(pcs, X, W, W2K, out["match"], out["mask"], nrm, inst, bb, axes, cen, gt_sk, pn_encoder,
+                                                          loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2,
+                                                          use_whole_pc=a.use_whole_pc, W_encoder=W_enc, axis_feat=ax_feat)
                 total = (out["total"] + sk["im_loss"]) if a.is_pc_train else sk["im_loss"]                    # :690-693
                 sync.zero()
                 mom_fwd = step.get_batch_norm_decay(gstep, B, a.bn_decay_step)                                # :698-701 (reaches the next forward)

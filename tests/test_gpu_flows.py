@@ -460,6 +460,31 @@ def test_with_sketch_trainer_cli(tmp_path):
     assert os.path.exists(os.path.join(logdir, "checkpoint_0001.pth"))
 
 
+@pytest.mark.parametrize("flags,enc_in", [(["--use_gt_im", "--is_im_train"], 4),
+                                          (["--use_gt_im", "--is_im_train", "--use_whole_pc", "--use_extrusion_axis_feat"], 7),
+                                          (["--is_pc_train", "--is_im_train", "--use_whole_pc", "--use_extrusion_axis_feat", "--pred_extrusion",
+                                            "--is_implicitnet_train"], 7)])
+def test_with_sketch_trainer_cli_variants(tmp_path, flags, enc_in):
+    """The reference trainer's other encoder inputs through the CLI (train_Point2Cyl.py:268-276, :519-600): --use_gt_im (no backbone pass),
+    --use_extrusion_axis_feat (7-channel encoder) and --is_implicitnet_train (parsed and never read by the reference: accepted, no effect);
+    two steps each, finite losses, the encoder of the checkpoint has the variant's input width."""
+    logdir = str(tmp_path / "sk")
+    out = _run(["-m", "point2cyl_amd.train_sketch", "--pred_seg", "--pred_normal", "--pred_bb", "--with_im_loss", "--synthetic", "4", "--batch_size", "2",
+                "--num_point", "1024", "--num_sk_point", "256", "--num_epochs", "1", "--save_every", "1", "--logdir", logdir,
+                "--im_logdir", str(tmp_path / "none")] + flags)
+    assert out.returncode == 0, out.stderr[-3000:]
+    im = [l for l in out.stdout.splitlines() if "latent loss" in l]
+    assert len(im) == 2
+    vals = np.array([float(x.split(":")[1]) for l in im for x in l.split("|")[2:]])
+    assert np.isfinite(vals).all() and vals[0] > 0
+    ck = torch.load(os.path.join(logdir, "model.pth"), map_location="cpu")
+    assert ck["pn_encoder"]["mlp1.0.weight"].shape[1] == enc_in
+    # inconsistent combinations are refused with the reference line that makes them meaningless
+    bad = _run(["-m", "point2cyl_amd.train_sketch", "--pred_seg", "--pred_normal", "--pred_bb", "--use_gt_im", "--is_pc_train", "--synthetic", "4",
+                "--logdir", logdir])
+    assert bad.returncode != 0 and "use_gt_im" in (bad.stderr + bad.stdout)
+
+
 def test_multi_tensor_adam_matches_torch():
     """point2cyl_amd.optim.Adam (one launch over all tensors) against torch.optim.Adam, five steps, odd sizes, two parameter groups
     with their own learning rates, a parameter without gradient."""

@@ -1115,6 +1115,87 @@ def test_sketch_branch_whole_pc_vs_oracle():
     assert np.linalg.norm(gr) > 0
 
 
+@pytest.mark.parametrize("variant", ["gt_whole", "gt_whole_axis", "gt_projection", "pred_whole_axis"])
+def test_sketch_branch_gt_im_and_axis_feat_vs_oracle(variant):
+    """The other encoder inputs of train_Point2Cyl.py: --use_gt_im (:566-600: one-hot ground-truth membership of the whole cloud, or the
+    projection of the ground-truth barrels divided by its own scales) and --use_extrusion_axis_feat (:528-531, :577-580: the segment's
+    axis as channels 5-7; with predicted labels the fitted axes keep their history).  Losses, encoder gradients and - for the predicted
+    variant - the gradient w.r.t. the axes against the oracle's composition."""
+    from point2cyl_amd import synth, step_sketch
+    from point2cyl_amd.sketch import PointNetEncoder
+    from point2cyl_amd.implicit import ImplicitNet
+    B, N, K, S, E = 3, 1024, 8, 64, 24
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=91)
+    pcs, nrm, axes, cen = pcs.float(), nrm.float(), axes.float(), cen.float()
+    gen = torch.Generator().manual_seed(17)
+    whole, gt, axis = "whole" in variant, variant.startswith("gt"), "axis" in variant
+    cin = (7 if axis else 4) if whole else 2
+    torch.manual_seed(23)
+    enc, enc_gt = PointNetEncoder(E, cin, with_normals=not whole), PointNetEncoder(E, 2, with_normals=True).eval()
+    dec = ImplicitNet(d_in=2 + E, dims=[64] * 8, skip_in=[4])
+    sd_e = {k: v.detach().clone() for k, v in enc.state_dict().items()}
+    sd_g = {k: v.detach().clone() for k, v in enc_gt.state_dict().items()}
+    sd_d = {k: v.detach().clone() for k, v in dec.state_dict().items()}
+    gt_sk = torch.cat([torch.randn(B, K, S, 2, generator=gen) * 0.4, F.normalize(torch.randn(B, K, S, 2, generator=gen), dim=-1)], -1)
+    non = torch.cat([gt_sk[..., :2].reshape(B * K, S, 2) + 0.02 * torch.randn(B * K, S, 2, generator=gen), torch.rand(B * K, S // 8, 2, generator=gen) * 2 - 1], 1)
+    d = lambda x: x.to(DEV)
+    enc, enc_gt, dec = enc.to(DEV).train(), enc_gt.to(DEV), dec.to(DEV)
+    # predicted side (only read by the "pred" variant)
+    logits = torch.randn(B, N, 2 * K, generator=gen) + 5 * F.one_hot(seg * 2 + bb, 2 * K)
+    W2K0 = torch.softmax(logits, -1)
+    W0 = W2K0[:, :, 0::2] + W2K0[:, :, 1::2]
+    match, mask = R.hungarian_matching(W0, seg)
+    E_AX0 = F.normalize(axes + 0.05 * torch.randn(B, K, 3, generator=gen), dim=-1)
+    torch.manual_seed(2); r_gt = fitting._barrel_draws(seg, bb, K, S)
+    ax_d = None
+    if axis:
+        ax_d = d(axes) if gt else d(E_AX0).requires_grad_(True)
+    if gt:
+        out = step_sketch.sketch_branch_losses(d(pcs), None, None, None, None, None, d(nrm), d(seg), d(bb), d(axes), d(cen), d(gt_sk), enc, enc_gt, dec, None,
+                                               K, S, rand_idx_gt=r_gt, nonmnfld_pnts=d(non), use_whole_pc=whole, use_gt_im=True, axis_feat=ax_d)
+    else:
+        out = step_sketch.sketch_branch_losses(d(pcs), None, d(W0), d(W2K0), d(match), d(mask), d(nrm), d(seg), d(bb), d(axes), d(cen), d(gt_sk), enc, enc_gt,
+                                               dec, None, K, S, nonmnfld_pnts=d(non), use_whole_pc=True, axis_feat=ax_d)
+    out["im_loss"].backward()
+    # the oracle's composition
+    ax_r = None
+    if whole:
+        if gt:
+            Wre = F.one_hot(seg.reshape(-1), K).view(B, N, K).float()                                  # train_Point2Cyl.py:572-574
+        else:
+            Wre = torch.gather(W0, 2, match.unsqueeze(1).expand(B, N, K))
+            Wre = torch.where(mask.unsqueeze(1).expand(B, N, K), Wre, torch.zeros_like(Wre))
+        cols = [pcs.unsqueeze(1).repeat(1, K, 1, 1), Wre.permute(0, 2, 1).unsqueeze(-1)]
+        if axis:
+            ax_r = axes.clone() if gt else E_AX0.clone().requires_grad_(True)
+            cols.append(ax_r.unsqueeze(-2).repeat(1, 1, N, 1))
+        gpc = torch.cat(cols, -1).reshape(B * K, N, cin)
+    else:
+        dk = lambda r: {(k, b): r[b, k] for k in range(K) for b in range(B)}
+        pP, pX, psc, _ = R.sketch_implicit_projection(pcs, nrm, seg, bb, axes, cen, dk(r_gt), S)
+        gpc = torch.cat(((pP / psc.unsqueeze(-1).unsqueeze(-1)).reshape(B * K, S, 2), pX.reshape(B * K, S, 2)), -1)      # :591-598
+    for k in sd_e:
+        if sd_e[k].dtype == torch.float32 and "running" not in k:
+            sd_e[k].requires_grad_(True)
+    lat = R.pointnet_encoder_forward(sd_e, gpc, training=True)
+    skp, skn = gt_sk[..., :2].reshape(B * K, S, 2), gt_sk[..., -2:].reshape(B * K, S, 2)
+    lat_gt = R.pointnet_encoder_forward(sd_g, torch.cat((skp, skn), -1), training=False)
+    mask_gt = R.get_mask_gt(seg, K)
+    im, mn, ek, nl = R.implicit_losses(sd_d, skp, skn, non, lat, mask_gt, B, K)
+    ll = R.reduce_mean_masked_instance(1.0 - (lat.reshape(B, K, -1) * lat_gt.reshape(B, K, -1)).sum(-1), mask_gt).mean()
+    (im + ll).backward()
+    got = [out[k].item() for k in ("im_loss", "latent_loss", "mnfld_loss", "grad_loss", "normals_loss")]
+    np.testing.assert_allclose(got, [(im + ll).item(), ll.item(), mn.item(), ek.item(), nl.item()], rtol=2e-4)
+    gmax = max(float(sd_e[n].grad.norm()) for n, _ in enc.named_parameters())
+    for n, p in enc.named_parameters():
+        ref = sd_e[n].grad.numpy()
+        assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 5e-3 * np.linalg.norm(ref) + 2e-2 * 1e-3 * gmax + 1e-5 * gmax, n
+    if axis and not gt:
+        ga, gr = ax_d.grad.cpu().numpy(), ax_r.grad.numpy()
+        assert np.linalg.norm(gr) > 0
+        assert np.linalg.norm(ga - gr) <= 5e-3 * np.linalg.norm(gr), np.linalg.norm(ga - gr) / np.linalg.norm(gr)
+
+
 @pytest.mark.parametrize("n", [1, 3, 4, 1023, 4098, 300007])
 def test_softplus_kernels_match_torch_double_backward(n):
     """softplus / its first and second derivative kernels (csrc/softplus.hip) against torch.nn.functional.softplus(beta=100) under

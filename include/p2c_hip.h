@@ -434,7 +434,7 @@ int p2c_hungarian_logits_f32(const float *heads, int ld, int woff, const int64_t
  * The training losses fused (losses.py:90-143, :317-351 with collapse=True; train…:247-307):
  * normal loss mean(1-|X.n_gt|), Hungarian-matched mIoU loss, base/barrel weighted cross-entropy, forward AND gradient
  * w.r.t. the head output in two passes.  heads [B*N, ld]: normals at columns [xoff,xoff+3), 2K logits at [woff,woff+2K).
- * out[4] = {total, normal, miou, bb}; dheads [B*N, ld] = d total / d heads.  ws: zeroed p2c_seg_losses_ws_bytes(B,K).  K == 8. */
+ * out[4] = {total, normal, miou, bb}; dheads [B*N, ld] = d total / d heads.  ws: zeroed p2c_seg_losses_ws_bytes(B,K).  K in {2, 4, 8}. */
 size_t p2c_seg_losses_ws_bytes(int B, int K);
 int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff, const float *normals_gt, const int64_t *I_gt,
                        const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,

@@ -208,20 +208,27 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(LossArgs a)
 extern "C" size_t p2c_seg_losses_ws_bytes(int B, int K) { return (size_t)B * (3 * K + 2) * sizeof(double) + (size_t)B * 2 * K * sizeof(float); }
 
 // losses.py:317-351 (compute_all_losses, collapse=True) + the base/barrel block of train…:283-307, forward AND gradient.
-// ws: zeroed p2c_seg_losses_ws_bytes(B,K).  out[4] = {total, normal, miou, bb}.  K must be 8.
+// ws: zeroed p2c_seg_losses_ws_bytes(B,K).  out[4] = {total, normal, miou, bb}.  K in {2, 4, 8} (the reference's default is 8).
 extern "C" int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff, const float *normals_gt, const int64_t *I_gt,
                                   const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
                                   float w_normal, float w_bb, float *out, float *dheads, void *ws, void *stream)
 {
     if (!heads || !normals_gt || !I_gt || !bb_gt || !match || !mask || !out || !dheads || !ws || B <= 0 || N <= 0) return P2C_EINVAL;
-    if (K != LOSS_MAXK) return P2C_EINVAL;
+    if (K != 2 && K != 4 && K != 8) return P2C_EINVAL;
     LossArgs a{heads, ld, xoff, woff, normals_gt, I_gt, bb_gt, match, mask, B, N, K, w_seg, w_normal, w_bb, (double *)ws, out,
                (float *)((char *)ws + (size_t)B * (3 * K + 2) * sizeof(double)), dheads};
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p2c_cdiv(N, 256), B);
-    hipLaunchKernelGGL(loss_reduce_kernel<LOSS_MAXK>, grid, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_finalize_kernel<LOSS_MAXK>, dim3(1), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(loss_grad_kernel<LOSS_MAXK>, grid, dim3(256), 0, s, a);
+#define P2C_LK(K_)                                                                       \
+    do {                                                                                 \
+        hipLaunchKernelGGL(loss_reduce_kernel<K_>, grid, dim3(256), 0, s, a);            \
+        hipLaunchKernelGGL(loss_finalize_kernel<K_>, dim3(1), dim3(256), 0, s, a);       \
+        hipLaunchKernelGGL(loss_grad_kernel<K_>, grid, dim3(256), 0, s, a);              \
+    } while (0)
+    if (K == 8) P2C_LK(8);
+    else if (K == 4) P2C_LK(4);
+    else P2C_LK(2);
+#undef P2C_LK
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

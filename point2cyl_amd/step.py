@@ -62,7 +62,7 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
     B, N, _ = pcs.shape
     K = fl.K
     heads, sizes = model.forward_heads(pcs, geom) if geom is not None else model.forward_heads(pcs)
-    assert sizes == [3, 2 * K] and fl.pred_seg and fl.pred_normal and fl.pred_bb and K == 8
+    assert sizes == [3, 2 * K] and fl.pred_seg and fl.pred_normal and fl.pred_bb and K in (2, 4, 8)
     out4, match, mask = ops.seg_losses(heads, gt_normals, gt_inst, gt_bb, B, N, K, 0, 3, fl.weight_seg, fl.weight_normal, fl.weight_bb)
     total = out4[0]
     zero = torch.zeros((), device=pcs.device)
@@ -88,7 +88,7 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
 
 
 def fused_loss_applicable(fl: StepFlags):
-    return fl.pred_seg and fl.pred_normal and fl.pred_bb and fl.K == 8
+    return fl.pred_seg and fl.pred_normal and fl.pred_bb and fl.K in (2, 4, 8)
 
 
 def compute_losses(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags, geom=None):

@@ -682,6 +682,48 @@ def test_fused_losses_match_the_torch_expressions(full):
     np.testing.assert_allclose(m2.h.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
 
 
+@pytest.mark.parametrize("K", [2, 4])
+@pytest.mark.parametrize("full", [False, True])
+def test_fused_losses_other_segment_counts(K, full):
+    """csrc/loss.hip for K = 2 and 4 (the reference's --K flag; its default 8 is the golden case above): matching from the logits, the three
+    losses (+ axis / centre terms) and the gradient w.r.t. the head output against the torch mirror of losses.py on synthetic clouds."""
+    from point2cyl_amd import synth
+    B, N = 3, 1024
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=40 + K)
+    gen = torch.Generator().manual_seed(K)
+    ld = (3 + 2 * K + 3) // 4 * 4
+    heads = torch.zeros(B * N, ld)
+    heads[:, 0:3] = (nrm.float() + 0.2 * torch.randn(B, N, 3, generator=gen)).reshape(-1, 3) * (0.5 + torch.rand(B * N, 1, generator=gen))
+    heads[:, 3:3 + 2 * K] = (torch.randn(B, N, 2 * K, generator=gen) + 3 * F.one_hot(seg * 2 + bb, 2 * K)).reshape(-1, 2 * K)
+    fl = step.StepFlags(K=K, pred_extrusion=full, pred_center=full, weight_seg=0.7, weight_normal=1.3, weight_bb=0.9)
+    assert step.fused_loss_applicable(fl)
+
+    class Head(torch.nn.Module):
+        def __init__(self, h):
+            super().__init__()
+            self.h = torch.nn.Parameter(h.to(DEV))
+
+        def forward_heads(self, x):
+            return self.h * 1.0, [3, 2 * K]
+
+        def forward(self, x):
+            h = self.h.view(B, N, ld)
+            return [h[:, :, 0:3], h[:, :, 3:3 + 2 * K]]
+
+    d = lambda x: x.to(DEV)
+    m1, m2 = Head(heads), Head(heads)
+    args = (d(pcs.float()), d(nrm.float()), d(seg), d(bb), d(axes.float()), d(cen.float()), fl)
+    o1 = step.compute_losses(m1, *args)
+    o2 = step.compute_losses_fused(m2, *args)
+    assert torch.equal(o1["match"], o2["match"]) and torch.equal(o1["mask"], o2["mask"])
+    for k in ("total", "normal", "miou", "bb", "ext", "center"):
+        np.testing.assert_allclose(float(o2[k]), float(o1[k]), rtol=2e-5, atol=1e-7)
+    o1["total"].backward()
+    o2["total"].backward()
+    ref = m1.h.grad.cpu().numpy()
+    np.testing.assert_allclose(m2.h.grad.cpu().numpy(), ref, rtol=2e-4, atol=2e-6 * np.abs(ref).max())
+
+
 def test_precomputed_geometry_gives_the_same_forward():
     """backbone.compute_geometry(x) (the parameter-free FPS / ball-query / 3-NN part) fed back through
     forward_heads(x, geom) must reproduce the inline forward bit for bit (same start indices, dropout off)."""

@@ -338,9 +338,11 @@ int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int l
  * X [B,N,3] normals, Wb/Wc [B,N,K]; bb_gt / inst_gt [B,N] int64 only when normalize != 0.
  * axis_out [B,K,3] (sign convention: largest-magnitude component positive);
  * eig_out [B,K,12] = {lambda0..2 ascending, v1 (3), v2 (3), 1/sb^2, 1/sc^2, sign} saved for backward (may be NULL).
+ * axis64_out [B,K,3] double (may be NULL): the same unit vector before its rounding to fp32 - the scatter sums and the Jacobi
+ * sweeps run in fp64, and eval.py's axis-angle metric (:398-405, acos next to its clamp) is evaluated on this copy.
  * K <= 16. */
 int p2c_extrusion_axis_f32(const float *X, const float *Wb, const float *Wc, const int64_t *bb_gt, const int64_t *inst_gt,
-                           int normalize, int B, int N, int K, float *axis_out, float *eig_out, void *stream);
+                           int normalize, int B, int N, int K, float *axis_out, float *eig_out, double *axis64_out, void *stream);
 /* backward: d axis [B,K,3] -> dX [B,N,3], dWb, dWc [B,N,K] */
 int p2c_extrusion_axis_bwd_f32(const float *daxis, const float *axis, const float *eig, const float *X, const float *Wb,
                                const float *Wc, int B, int N, int K, float *dX, float *dWb, float *dWc, void *stream);
@@ -365,13 +367,14 @@ int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, const int64_t 
 /* The fitting-only chain of eval.py on pre-segmented clouds in one pass over each cloud (BASELINE configs[3]):
  * estimate_extrusion_axis (eval.py:397 -> data_utils.py:99-177) -> hard per-segment centroids (eval.py:409-436) ->
  * get_extrusion_extents (data_utils.py:1650-1730) on the axes and centroids just fitted.  Same outputs as the three entry points above
- * called in that order: axis_out [B,K,3], centroids_out [B,K,3] + cfound_out [B,K], extents_out [K,B,2] + found_out [B,K].
+ * called in that order: axis_out [B,K,3], centroids_out [B,K,3] + cfound_out [B,K], extents_out [K,B,2] + found_out [B,K];
+ * axis64_out [B,K,3] double (may be NULL) as for p2c_extrusion_axis_f32 (the extents are taken along the fp32 axis_out).
  * bb_gt / inst_gt are the per-point base-barrel and segment labels (both always read: the barrel lists and the centroids need them).
  * p2c_fit_fused_supported(N, K, S) says whether the shape fits (K in {1,2,4,8}, the cloud within the LDS); ws as for the extents. */
 int p2c_fit_fused_supported(int N, int K, int S);
 int p2c_fit_fused_f32(const float *X, const float *Wb, const float *Wc, const int64_t *bb_gt, const int64_t *inst_gt, int normalize,
                       const float *P, const int64_t *rand_idx, int B, int N, int K, int S, float *axis_out, float *centroids_out,
-                      float *cfound_out, float *extents_out, float *found_out, void *ws, void *stream);
+                      float *cfound_out, float *extents_out, float *found_out, double *axis64_out, void *ws, void *stream);
 
 /* sketch_implicit_projection / sketch_implicit_projection2 (data_utils.py:1014-1146, :1149-1282) and, with all_points = 1
  * (S == N, seg / bb / rand_idx unused), sketch_implicit_projection3 (:1284-1417): the S sampled barrel points and normals

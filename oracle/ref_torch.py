@@ -342,7 +342,7 @@ def estimate_extrusion_axis(X, W_barrel, W_base, bb_gt=None, inst_gt=None, norma
     literal=True builds the N x N diag_embed like the reference (memory hungry); otherwise the
     same products are formed as (w*X)^T (w*X) (equal up to fp32 summation order)."""
     Bsz, N, K = W_barrel.shape
-    out = torch.zeros(Bsz, K, 3)
+    out = torch.zeros(Bsz, K, 3, dtype=X.dtype)       # (a float64 run keeps its float64 eigenvectors)
     for k in range(K):
         wb, wc = W_barrel[:, :, k], W_base[:, :, k]
         if literal:

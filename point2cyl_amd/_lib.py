@@ -63,13 +63,13 @@ _SIGS = {
                                   c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_linear_bwd_fused_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_ll,
                                  c_p, c_p, c_p, c_i, c_i, c_i, c_p],
-    "p2c_extrusion_axis_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p],
+    "p2c_extrusion_axis_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_extrusion_axis_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_extrusion_centers_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "p2c_extrusion_centers_bwd_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
     "p2c_segment_centroids_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "p2c_extrusion_extents_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
-    "p2c_fit_fused_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "p2c_fit_fused_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_sketch_projection_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_softplus_fwd_f32": [c_p, c_p, c_ll, c_f, c_f, c_p],
     "p2c_softplus_bwd_f32": [c_p, c_p, c_p, c_ll, c_f, c_f, c_p],

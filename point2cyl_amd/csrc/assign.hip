@@ -399,5 +399,5 @@ extern "C" int p2c_linear_sum_assignment_f64(const double *cost, int n_problems,
     return P2C_OK;
 }
 
-extern "C" int p2c_abi_version(void) { return 1; }
+extern "C" int p2c_abi_version(void) { return 2; }
 extern "C" const char *p2c_build_arch(void) { return "gfx950"; }

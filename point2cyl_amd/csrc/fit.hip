@@ -63,7 +63,8 @@ template <int THREADS>      // 1024: one workgroup per CU (few clouds: each gets
 __global__ void __launch_bounds__(THREADS) axis_kernel(const float *__restrict__ X, const float *__restrict__ Wb,
                                                            const float *__restrict__ Wc, const int64_t *__restrict__ bb_gt,
                                                            const int64_t *__restrict__ inst_gt, int normalize, int N, int K,
-                                                           float *__restrict__ axis_out, float *__restrict__ eig_out)
+                                                           float *__restrict__ axis_out, float *__restrict__ eig_out,
+                                                           double *__restrict__ axis64_out)
 {
     __shared__ float red[14][THREADS];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -123,6 +124,10 @@ __global__ void __launch_bounds__(THREADS) axis_kernel(const float *__restrict__
     const double sgn = v[0][big] < 0 ? -1.0 : 1.0;
     float *o = axis_out + ((size_t)b * K + tid) * 3;
     o[0] = (float)(sgn * v[0][0]); o[1] = (float)(sgn * v[0][1]); o[2] = (float)(sgn * v[0][2]);
+    if (axis64_out) {           // the unit eigenvector as the fp64 Jacobi left it: the eval metric (eval.py:398-405) is an acos next to its clamp
+        double *o64 = axis64_out + ((size_t)b * K + tid) * 3;
+        o64[0] = sgn * v[0][0]; o64[1] = sgn * v[0][1]; o64[2] = sgn * v[0][2];
+    }
     if (eig_out) {
         float *e = eig_out + ((size_t)b * K + tid) * 12;
         e[0] = (float)lam[0]; e[1] = (float)lam[1]; e[2] = (float)lam[2];
@@ -133,17 +138,17 @@ __global__ void __launch_bounds__(THREADS) axis_kernel(const float *__restrict__
 }
 
 extern "C" int p2c_extrusion_axis_f32(const float *X, const float *Wb, const float *Wc, const int64_t *bb_gt, const int64_t *inst_gt,
-                                      int normalize, int B, int N, int K, float *axis_out, float *eig_out, void *stream)
+                                      int normalize, int B, int N, int K, float *axis_out, float *eig_out, double *axis64_out, void *stream)
 {
     if (!X || !Wb || !Wc || !axis_out || B <= 0 || N <= 0 || K <= 0 || K > FIT_MAXK) return P2C_EINVAL;
     if (normalize && (!bb_gt || !inst_gt)) return P2C_EINVAL;
     if (B >= 1024)
-        hipLaunchKernelGGL(axis_kernel<256>, dim3(B), dim3(256), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K, axis_out, eig_out);
+        hipLaunchKernelGGL(axis_kernel<256>, dim3(B), dim3(256), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K, axis_out, eig_out, axis64_out);
     else if (B >= 512)
-        hipLaunchKernelGGL(axis_kernel<512>, dim3(B), dim3(512), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K, axis_out, eig_out);
+        hipLaunchKernelGGL(axis_kernel<512>, dim3(B), dim3(512), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K, axis_out, eig_out, axis64_out);
     else
         hipLaunchKernelGGL(axis_kernel<FIT_THREADS>, dim3(B), dim3(FIT_THREADS), 0, (hipStream_t)stream, X, Wb, Wc, bb_gt, inst_gt, normalize, N, K,
-                           axis_out, eig_out);
+                           axis_out, eig_out, axis64_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -593,11 +598,12 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
                                                                 const float *__restrict__ P, const int64_t *__restrict__ seg,
                                                                 const int64_t *__restrict__ bb, const int64_t *__restrict__ rand_idx, int normalize,
                                                                 int N, int S, float *__restrict__ axis_out, float *__restrict__ cen_out,
-                                                                float *__restrict__ cfound_out, float *__restrict__ ext_tmp, int *__restrict__ counts)
+                                                                float *__restrict__ cfound_out, float *__restrict__ ext_tmp, int *__restrict__ counts,
+                                                                double *__restrict__ axis64_out)
 {
     constexpr int NA = 18;                               // 12 scatter sums, 2 counts (normalize), centroid x y z, count
     constexpr int WAVES = THREADS / 64, G = THREADS / KK;                  // point slices
-    extern __shared__ int dyn[];
+    extern __shared__ __attribute__((aligned(16))) int dyn[];          // phase 2 views it as double[]
     const int NL = max(N, WAVES * KK * NA * 2);      // ints: the lists of phase 3 / the per-wave fp64 sums of phase 2
     int *list = dyn;
     float *Ps = reinterpret_cast<float *>(dyn + NL);     // [3N] (PLDS)
@@ -691,6 +697,8 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
             const double sgn = v[0][big] < 0 ? -1.0 : 1.0;
             float *o = axis_out + ((size_t)b * KK + tid) * 3;
             for (int e = 0; e < 3; ++e) { const float av = (float)(sgn * v[0][e]); o[e] = av; axs[tid][e] = av; }
+            if (axis64_out)
+                for (int e = 0; e < 3; ++e) axis64_out[((size_t)b * KK + tid) * 3 + e] = sgn * v[0][e];
             const float c = (float)tot[17][tid];                          // hard centroid: as centroids_by_point_kernel
             const bool ok = c > 1.f;
             float *oc = cen_out + ((size_t)b * KK + tid) * 3;
@@ -772,7 +780,7 @@ extern "C" int p2c_fit_fused_supported(int N, int K, int S)
 // axes (B,K,3), centroids (B,K,3) + their found mask (B,K), extents (K,B,2) + found mask (B,K); ws: p2c_extents_ws_bytes(B, K)
 extern "C" int p2c_fit_fused_f32(const float *X, const float *Wb, const float *Wc, const int64_t *bb_gt, const int64_t *inst_gt, int normalize,
                                  const float *P, const int64_t *rand_idx, int B, int N, int K, int S, float *axis_out, float *centroids_out,
-                                 float *cfound_out, float *extents_out, float *found_out, void *ws, void *stream)
+                                 float *cfound_out, float *extents_out, float *found_out, double *axis64_out, void *ws, void *stream)
 {
     if (!X || !Wb || !Wc || !bb_gt || !inst_gt || !P || !rand_idx || !axis_out || !centroids_out || !cfound_out || !extents_out || !found_out || !ws ||
         B <= 0 || !p2c_fit_fused_supported(N, K, S))
@@ -789,7 +797,7 @@ extern "C" int p2c_fit_fused_f32(const float *X, const float *Wb, const float *W
         const size_t lds = fit_fused_lds(N, K, TH_ / 64, PLDS_);                                                                        \
         (void)hipFuncSetAttribute((const void *)fit_fused_kernel<KK_, TH_, PLDS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
         hipLaunchKernelGGL((fit_fused_kernel<KK_, TH_, PLDS_>), dim3(B), dim3(TH_), lds, s, X, Wb, Wc, P, inst_gt, bb_gt, rand_idx, normalize, N, S,    \
-                           axis_out, centroids_out, cfound_out, ext_tmp, counts);                                                      \
+                           axis_out, centroids_out, cfound_out, ext_tmp, counts, axis64_out);                                          \
     } while (0)
 #define P2C_FFK(KK_) do { if (half) P2C_FF(KK_, 512, false); else P2C_FF(KK_, 1024, true); } while (0)
     if (K == 8) P2C_FFK(8);

@@ -108,12 +108,10 @@ def eval_metrics(X_head, W_raw, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
             Wc_re = torch.where((bbsel == 1).unsqueeze(-1), EA_W, torch.zeros_like(EA_W))
         else:
             Wb_re, Wc_re = _reorder_gather(W_barrel, matching_indices), _reorder_gather(W_base, matching_indices)
-        E_AX = fitting.estimate_extrusion_axis(EA_X, Wb_re, Wc_re, gt_bb_i, gt_inst, normalize=fl.norm_eig)        # :397
-        # :398, evaluated in float64 on the (B,K,3) axes: the angle of two nearly parallel unit vectors is an acos next to its clamp, where
-        # an fp32 dot product alone costs up to 1e-3 of the angle; the fp64 run of the reference is the yardstick
-        # (the fp32-stored axis is re-normalised in float64 first: |E| = 1 +- 3e-8 alone shifts a 0.3 degree angle by 1e-3 of itself)
-        E64 = E_AX.double()
-        E64 = E64 / E64.norm(dim=-1, keepdim=True).clamp(min=1e-30)
+        E_AX, E64 = fitting.estimate_extrusion_axis(EA_X, Wb_re, Wc_re, gt_bb_i, gt_inst, normalize=fl.norm_eig, return_float64=True)   # :397
+        # :398, evaluated in float64 on the axes as the kernel's fp64 eigen-solve left them (p2c_extrusion_axis_f32's axis64_out): the angle
+        # of two nearly parallel unit vectors is an acos next to its clamp, where an fp32 dot product alone costs up to 1e-3 of the angle and
+        # the |E| = 1 +- 3e-8 of an fp32-stored unit vector as much again; the fp64 run of the reference is the yardstick
         ext_diff = losses.compute_normal_difference(E64, gt_axes.double(), in_radians=False, collapse=False).float()
         out["extrusion_difference_uncollapsed"] = torch.where(mask_gt, ext_diff, torch.zeros_like(ext_diff))       # :403
         out["extrusion_difference"] = losses.reduce_mean_masked_instance(ext_diff, mask_gt)                       # :405

@@ -18,11 +18,19 @@ def add_noise(batch_xyz, batch_normal, sigma=0.01):
     return batch_xyz + torch.tensor(noise).unsqueeze(-1) * batch_normal
 
 
-def estimate_extrusion_axis(X, W_barrel, W_base, gt_bb_labels, gt_extrusion_instances, normalize=False):
+def estimate_extrusion_axis(X, W_barrel, W_base, gt_bb_labels, gt_extrusion_instances, normalize=False, return_float64=False):
     """data_utils.py:99-177 -> E_AX (B,K,3): eigenvector of the smallest eigenvalue of B^T B - C^T C.
     The sign is arbitrary in the reference (LAPACK); here the largest component is positive.  All
-    consumers take abs(dot) (losses.py:130, :149)."""
-    return ops.extrusion_axis(X, W_barrel, W_base, gt_bb_labels, gt_extrusion_instances, normalize)
+    consumers take abs(dot) (losses.py:130, :149).
+    return_float64 (not in the reference): also return the unit vector as the kernel's fp64 eigen-solve left it, (B,K,3) float64,
+    detached - what eval.py's axis-angle metric (:398-405) is evaluated on here (an acos next to its clamp: the 3e-8 of an fp32-stored
+    unit vector alone moves a 0.1 degree angle by more than the 1e-4 parity bar)."""
+    if not return_float64:
+        return ops.extrusion_axis(X, W_barrel, W_base, gt_bb_labels, gt_extrusion_instances, normalize)
+    B, _, K = W_barrel.shape
+    a64 = torch.empty(B, K, 3, dtype=torch.float64, device=X.device)
+    E = ops.extrusion_axis(X, W_barrel, W_base, gt_bb_labels, gt_extrusion_instances, normalize, axis64=a64)
+    return E, a64
 
 
 def estimate_extrusion_centers(W, pcs):
@@ -55,23 +63,30 @@ def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_cen
     return ops.extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, rand_idx.to(P.device))
 
 
-def fit_cylinders(X, W_barrel, W_base, gt_bb_labels, seg_label, P, num_points_to_sample=1024, rand_idx=None, normalize=False):
+def fit_cylinders(X, W_barrel, W_base, gt_bb_labels, seg_label, P, num_points_to_sample=1024, rand_idx=None, normalize=False,
+                  return_float64=False, validate=True):
     """The fitting-only chain on pre-segmented clouds (BASELINE configs[3]): estimate_extrusion_axis (eval.py:397) -> hard centroids
     (eval.py:409-436) -> get_extrusion_extents on the fitted axes / centroids (data_utils.py:1650-1730), one pass per cloud where the
     shape allows (ops.fit_fused), the three ops otherwise.  -> axes (B,K,3), centroids (B,K,3), centroid found (B,K), extents (K,B,2),
-    extent found (B,K).  Forward only."""
+    extent found (B,K) [, axes in float64 with return_float64, see estimate_extrusion_axis].  Forward only.
+    validate: the kernels read the labels' low words; labels outside [-1, K) / {0, 1} raise here instead of aliasing (one device->host
+    sync; a caller that loops over the same labels passes validate=False after its first call)."""
     B, N, K = W_barrel.shape
     S = num_points_to_sample if rand_idx is None else rand_idx.shape[2]
+    if validate:
+        ops.check_labels(seg_label, K)
+        ops.check_labels(gt_bb_labels, 2)
     if rand_idx is None:
         rand_idx = _barrel_draws(seg_label, gt_bb_labels, K, S)
     rand_idx = rand_idx.to(P.device)
     if ops.fit_fused_supported(N, K, S):
-        return ops.fit_fused(X, W_barrel, W_base, gt_bb_labels, seg_label, P, rand_idx, normalize=normalize)
+        return ops.fit_fused(X, W_barrel, W_base, gt_bb_labels, seg_label, P, rand_idx, normalize=normalize, axes64=return_float64)
     with torch.no_grad():
-        axes = estimate_extrusion_axis(X, W_barrel, W_base, gt_bb_labels, seg_label, normalize=normalize)
+        axes = estimate_extrusion_axis(X, W_barrel, W_base, gt_bb_labels, seg_label, normalize=normalize, return_float64=return_float64)
+        axes, a64 = axes if return_float64 else (axes, None)
         cen, cfound = ops.segment_centroids(P, seg_label, K)
         ext, found = ops.extrusion_extents(P, seg_label, gt_bb_labels, axes, cen, rand_idx)
-    return axes, cen, cfound, ext, found
+    return (axes, cen, cfound, ext, found, a64) if return_float64 else (axes, cen, cfound, ext, found)
 
 
 def _barrel_draws(seg_label, bb_labels, K, S):

@@ -1,0 +1,250 @@
+"""Stage-level measurements of the hot path on the device, shared by bench.py and tools/.
+
+Everything here times HIP-graph replays or back-to-back launches of the PRODUCT path with the inputs resident in HBM; nothing in this module
+touches the oracle (the CPU legs live in bench.py / tools/, which may import it).  Three measurements beside the training step:
+
+  * sa1_stage      the north-star stage "FPS + ball query + grouped MLP forward" (SA1: pointnet_util.py:63-143, :166-207) in train mode;
+  * forward_only   the whole backbone forward (pointnet_extrusion.py:37-66), train-mode BatchNorm, geometry included;
+  * fitting        BASELINE configs[3]: eval.py's fitting-only path on pre-segmented cylinders (fitting.fit_cylinders).
+
+and the per-stage roofline model of section 8(d) (path_roofline)."""
+import time
+
+import torch
+
+from . import fitting, ops, synth
+
+PEAK_F32_MFMA = 157.3e12          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA = 2500.0e12        # v_mfma_f32_32x32x16_bf16, dense
+PEAK_SPLIT = PEAK_BF16_MFMA / 6   # bf16x3 split: six bf16 products per fp32 product
+PEAK_HBM = 8.0e12
+
+# forward FLOPs and module-boundary bytes per SAMPLE (N = 8192 points, heads [3, 2K = 16])
+STAGES = (("sa1", 0.818e9, 366592), ("sa2", 1.080e9, 400896), ("sa3", 0.185e9, 136716), ("fp3", 0.101e9, 267776),
+          ("fp2", 0.134e9, 663040), ("fp1", 0.805e9, 4560896), ("head", 0.308e9, 4816896))
+FPS_ISSUE_US_PER_ITER = 8192 * 9 / 64.0 / 2.4e3   # 8192 points x ~9 VALU operations on the ONE CU a cloud occupies = 1150 issue cycles at 2.4 GHz
+                                                  # before any reduction: the issue-bound floor of one FPS iteration
+
+
+def path_roofline(B, ms, work_factor=1.0, N=8192):
+    """roofline.achieved = sum over stages of max(bytes / BW, flops / peak) divided by the measured time, per-stage terms
+    included.  work_factor 1 = forward; 3 = the training step (forward + two backward products and, to the same approximation, three
+    passes over the module-boundary tensors).  Two matrix peaks: the fp32-MFMA instruction and the bf16x3-split ceiling."""
+    scale = N / 8192.0
+    rows, t32, tsp, thbm = {}, 0.0, 0.0, 0.0
+    for name, fl, by in STAGES:
+        f, b = fl * B * work_factor * scale, by * B * work_factor * scale
+        a, s, h = f / PEAK_F32_MFMA, f / PEAK_SPLIT, b / PEAK_HBM
+        rows[name] = dict(gflop=round(f / 1e9, 2), mbytes=round(b / 1e6, 2), mfma_f32_us=round(a * 1e6, 1), mfma_split_us=round(s * 1e6, 1),
+                          hbm_us=round(h * 1e6, 1), bound="mfma" if a > h else "hbm")
+        t32 += max(a, h)
+        tsp += max(s, h)
+        thbm += h
+    return dict(model="sum over stages of max(bytes / 8 TB/s, flops / peak); module-boundary bytes and forward FLOPs of SURVEY 8(d) x %g" % work_factor,
+                floor_ms_f32_mfma=round(t32 * 1e3, 4), floor_ms_split=round(tsp * 1e3, 4), floor_ms_hbm_only=round(thbm * 1e3, 4),
+                frac_f32_mfma=round(t32 * 1e3 / ms, 4), frac_split=round(tsp * 1e3 / ms, 4), measured_ms=round(ms, 4), stages=rows)
+
+
+def capture(fn, warmup=2):
+    """fn() on static tensors -> (HIP graph, fn's captured outputs).  Warm-up + capture on a private stream."""
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        for _ in range(warmup):
+            fn()
+        cap.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=cap, capture_error_mode="thread_local"):
+            out = fn()
+    torch.cuda.current_stream().wait_stream(cap)
+    return gr, out
+
+
+def replay_ms(graphs, steps, warmup=3):
+    for _ in range(warmup):
+        for g in graphs:
+            g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        graphs[i % len(graphs)].replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3
+
+
+class _KeepBuffers:
+    """BatchNorm running statistics / counters and the dropout counter of `model` are restored on exit: measuring must not train."""
+
+    def __init__(self, model):
+        self.model = model
+
+    def __enter__(self):
+        self.keep = [(b, b.detach().clone()) for b in self.model.buffers()]
+        s = getattr(self.model, "_drop_seed", None)
+        self.seed = None if s is None else s.detach().clone()
+        return self
+
+    def __exit__(self, *exc):
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for b, v in self.keep:
+                b.copy_(v)
+            if self.seed is not None and getattr(self.model, "_drop_seed", None) is not None:
+                self.model._drop_seed.copy_(self.seed)
+        return False
+
+
+def sa1_stage(model, xyz, steps=30):
+    """The north-star stage at xyz's shape (B, N, 3): FPS(512) -> ball query(0.2, 64) -> grouped gather -> 3 shared-MLP layers with
+    train-mode BatchNorm -> max over the 64 neighbours, as HIP-graph replays (the way the training step launches it).
+    -> dict(ms serial, ms of the three parts alone, points/s, fractions of the stage's MFMA roofline and of the latency model
+    `512 dependent FPS iterations x the measured time per iteration + ball query + the MLP's MFMA floor`)."""
+    dev = xyz.device
+    B, N, _ = xyz.shape
+    sa1 = model.sa1
+    hook = sa1.fps_start
+    start = torch.randint(0, N, (B,)).to(dev)
+    sa1.fps_start = start
+    fl, by = STAGES[0][1] * B * N / 8192.0, STAGES[0][2] * B * N / 8192.0
+
+    def geometry():
+        g = sa1.geometry(xyz)
+        g["X0"] = ops.group_gather(xyz, None, g["new_xyz"], g["group_idx"], None)
+        return g
+
+    def mlp(g):
+        ops.step_done()
+        with torch.no_grad(), ops.step_arena(dev):
+            return sa1.forward_pm(xyz, None, g)
+
+    try:
+        with _KeepBuffers(model):
+            g0 = geometry()
+            gr_serial, _ = capture(lambda: mlp(geometry()))
+            gr_mlp, _ = capture(lambda: mlp(g0))
+            gr_fps, _ = capture(lambda: ops.fps(xyz, sa1.npoint, start))
+            gr_bq, _ = capture(lambda: ops.ball_query(sa1.radius, sa1.nsample, xyz, g0["new_xyz"]))
+            t_serial, t_mlp = replay_ms([gr_serial], steps), replay_ms([gr_mlp], steps)
+            t_fps, t_bq = replay_ms([gr_fps], steps), replay_ms([gr_bq], steps)
+            ops.step_done()
+    finally:
+        sa1.fps_start = hook
+    it_us = t_fps * 1e3 / sa1.npoint
+    mfma_floor_ms = fl / PEAK_F32_MFMA * 1e3
+    bq_floor_ms = (B * N * 12 + B * sa1.npoint * (12 + 4 * sa1.nsample)) / PEAK_HBM * 1e3
+    lat_model_ms = sa1.npoint * it_us * 1e-3 + bq_floor_ms + mfma_floor_ms
+    lat_issue_ms = sa1.npoint * FPS_ISSUE_US_PER_ITER * 1e-3 + bq_floor_ms + mfma_floor_ms
+    return dict(workload="SA1 forward: FPS(%d of %d) + ball query(r=%.1f, %d) + grouped MLP 3->64->64->128 + max-pool, B=%d, train-mode BatchNorm"
+                         % (sa1.npoint, N, sa1.radius, sa1.nsample, B),
+                graph_serial_ms=round(t_serial, 4), points_per_s=round(B * N / (t_serial * 1e-3), 1),
+                parts_ms=dict(fps=round(t_fps, 4), ball_query=round(t_bq, 4), grouped_mlp_with_pool=round(t_mlp, 4)),
+                gflop=round(fl / 1e9, 2), module_boundary_mbytes=round(by / 1e6, 2),
+                mfma_floor_ms=round(mfma_floor_ms, 4), hbm_floor_ms=round(by / PEAK_HBM * 1e3, 5), bound="mfma",
+                frac_of_mfma_roofline=round(mfma_floor_ms / t_serial, 4),
+                frac_of_split_roofline=round(fl / PEAK_SPLIT * 1e3 / t_serial, 4),
+                mlp_frac_of_mfma_roofline=round(mfma_floor_ms / t_mlp, 4),
+                fps_latency_model=dict(iterations=sa1.npoint, measured_us_per_iteration=round(it_us, 4),
+                                       issue_bound_us_per_iteration=round(FPS_ISSUE_US_PER_ITER, 4),
+                                       model_ms=round(lat_model_ms, 4), frac_of_model=round(lat_model_ms / t_serial, 4),
+                                       model_ms_issue_bound=round(lat_issue_ms, 4), frac_of_issue_bound_model=round(lat_issue_ms / t_serial, 4),
+                                       note="model = 512 dependent iterations x time per iteration (one workgroup = one CU per cloud) + ball-query "
+                                            "HBM floor + the MLP's fp32-MFMA floor; `measured` uses the FPS kernel's own time alone on the chip, "
+                                            "`issue_bound` the 1150 VALU issue cycles per iteration at 2.4 GHz"))
+
+
+def forward_only(model, pcs, steps=30):
+    """The whole backbone forward in train mode (batch statistics, always-on dropout), geometry included, no autograd: one HIP graph."""
+    dev = pcs.device
+    B, N, _ = pcs.shape
+    hooks = [(m, m.fps_start) for m in (model.sa1, model.sa2)]
+    model.sa1.fps_start = torch.randint(0, N, (B,)).to(dev)
+    model.sa2.fps_start = torch.randint(0, model.sa1.npoint, (B,)).to(dev)
+
+    def fwd():
+        ops.step_done()
+        with torch.no_grad(), ops.step_arena(dev):
+            return model.forward_heads(pcs)[0]
+
+    def fwd_geom(g):
+        ops.step_done()
+        with torch.no_grad(), ops.step_arena(dev):
+            return model.forward_heads(pcs, g)[0]
+
+    try:
+        with _KeepBuffers(model):
+            gr, _ = capture(fwd)
+            t = replay_ms([gr], steps)
+            with torch.no_grad():
+                g0 = model.compute_geometry(pcs)
+            gr2, _ = capture(lambda: fwd_geom(g0))
+            t2 = replay_ms([gr2], steps)
+            ops.step_done()
+    finally:
+        for m, h in hooks:
+            m.fps_start = h
+    return dict(workload="backbone forward, B=%d x N=%d, train-mode BatchNorm + dropout, FPS / ball query / 3-NN included, one HIP graph" % (B, N),
+                ms=round(t, 4), points_per_s=round(B * N / (t * 1e-3), 1),
+                ms_geometry_precomputed=round(t2, 4), points_per_s_geometry_precomputed=round(B * N / (t2 * 1e-3), 1),
+                path_roofline=path_roofline(B, t, 1.0, N))
+
+
+class FittingWorkload:
+    """BASELINE configs[3]: n_clouds x K segments x N points of pre-segmented synthetic cylinders (synth.make_fitting_inputs), S pre-drawn
+    samples per segment (the reference draws them on the host: data_utils.py:1696).  cpu: the host tensors; dev: their device copies."""
+
+    def __init__(self, n_clouds=1250, N=8192, K=8, S=2048, seed=4321, device="cuda:0"):
+        self.n, self.N, self.K, self.S = n_clouds, N, K, S
+        pcs, X, seg, bb, axes, Wb, Wc, onehot = synth.make_fitting_inputs(n_clouds, N, K, seed)
+        g = torch.Generator().manual_seed(7)
+        counts = Wb.sum(1).long()
+        ridx = torch.randint(0, 1 << 30, (n_clouds, K, S), generator=g) % counts.clamp_min(1).unsqueeze(-1)
+        self.cpu = dict(pcs=pcs, X=X, seg=seg, bb=bb, axes=axes, Wb=Wb, Wc=Wc, onehot=onehot, ridx=ridx)
+        self.dev = {k: v.to(device) for k, v in self.cpu.items()}
+        self.points = n_clouds * N
+        # every input read once: normals, points, both membership matrices, both label arrays, the pre-drawn sample indices
+        self.path_bytes = self.points * (12 + 12 + 2 * K * 4 + 8 + 8) + n_clouds * K * S * 8
+        self.survey_bytes = self.points * (12 + 2 * K * 4)        # X + W_barrel + W_base = 76 B/point at K = 8
+
+    def fit(self, fused=True, validate=False):
+        d = self.dev
+        if fused and ops.fit_fused_supported(self.N, self.K, self.S):
+            return fitting.fit_cylinders(d["X"], d["Wb"], d["Wc"], d["bb"], d["seg"], d["pcs"], rand_idx=d["ridx"], normalize=False,
+                                         return_float64=True, validate=validate)
+        with torch.no_grad():
+            E, E64 = fitting.estimate_extrusion_axis(d["X"], d["Wb"], d["Wc"], d["bb"], d["seg"], normalize=False, return_float64=True)
+            cen, cfound = ops.segment_centroids(d["pcs"], d["seg"], self.K)
+            ext, found = fitting.get_extrusion_extents(d["pcs"], d["seg"], d["bb"], E, cen, self.S, rand_idx=d["ridx"])
+        return E, cen, cfound, ext, found, E64
+
+    def time(self, steps=20, fused=True):
+        """-> (dict of timings and roofline fractions, the outputs of the last pass)."""
+        out = self.fit(fused, validate=True)
+        for _ in range(2):
+            out = self.fit(fused)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = self.fit(fused)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ops.PROFILE.reset(enabled=True)          # per-kernel times: HIP events around every launch, in passes of their own
+        for _ in range(steps):
+            self.fit(fused)
+        ops.PROFILE.enabled = False
+        prof = ops.PROFILE.summary()
+        ops.PROFILE.reset()
+        fused = fused and ops.fit_fused_supported(self.N, self.K, self.S)
+        kname = "p2c_fit_fused_f32" if fused else "p2c_extrusion_axis_f32"
+        kms = prof.get(kname, {}).get("ms", 0.0) / steps
+        kbytes = self.path_bytes if fused else self.survey_bytes
+        res = dict(workload="configs[3]: %d clouds x K=%d x N=%d = %d cylinders, X = gt normals + 2 deg angular noise, one-hot W, S=%d"
+                            % (self.n, self.K, self.N, self.n * self.K, self.S),
+                   kernels="one pass per cloud (fit_fused)" if fused else "axis, centroids, extents",
+                   ms=round(dt * 1e3, 4), cylinders_per_s=round(self.n * self.K / dt, 1), points_per_s=round(self.points / dt, 1),
+                   kernel=kname, kernel_us=round(kms * 1e3, 1),
+                   path_bytes=self.path_bytes, frac_hbm_path_bytes=round(self.path_bytes / dt / PEAK_HBM, 4),
+                   survey_bytes_76_per_point=self.survey_bytes, frac_hbm_76B_per_point=round(self.survey_bytes / dt / PEAK_HBM, 4),
+                   kernel_frac_hbm=round(kbytes / (kms * 1e-3) / PEAK_HBM, 4) if kms else None,
+                   per_kernel={k: dict(ms_per_pass=round(v["ms"] / steps, 4), launches_per_pass=v["launches"] / steps)
+                               for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])})
+        return res, out

@@ -772,7 +772,7 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
 # ------------------------------------------------------------------------------------------ fitting
 class _ExtrusionAxis(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, X, Wb, Wc, bb_gt, inst_gt, normalize):
+    def forward(ctx, X, Wb, Wc, bb_gt, inst_gt, normalize, axis64):
         X, Wb, Wc = _f32c(X), _f32c(Wb), _f32c(Wc)
         B, N, K = Wb.shape
         axis = torch.empty(B, K, 3, dtype=torch.float32, device=X.device)
@@ -781,7 +781,7 @@ class _ExtrusionAxis(torch.autograd.Function):
             bb_gt = bb_gt.to(torch.int64).contiguous()
             inst_gt = inst_gt.to(torch.int64).contiguous()
         call("p2c_extrusion_axis_f32", ptr(X), ptr(Wb), ptr(Wc), ptr(bb_gt) if normalize else None,
-             ptr(inst_gt) if normalize else None, 1 if normalize else 0, B, N, K, ptr(axis), ptr(eig), stream())
+             ptr(inst_gt) if normalize else None, 1 if normalize else 0, B, N, K, ptr(axis), ptr(eig), ptr(axis64), stream())
         ctx.save_for_backward(X, Wb, Wc, axis, eig)
         return axis
 
@@ -793,12 +793,15 @@ class _ExtrusionAxis(torch.autograd.Function):
         dX, dWb, dWc = torch.empty_like(X), torch.empty_like(Wb), torch.empty_like(Wc)
         call("p2c_extrusion_axis_bwd_f32", ptr(daxis), ptr(axis), ptr(eig), ptr(X), ptr(Wb), ptr(Wc), B, N, K, ptr(dX), ptr(dWb),
              ptr(dWc), stream())
-        return dX, dWb, dWc, None, None, None
+        return dX, dWb, dWc, None, None, None, None
 
 
-def extrusion_axis(X, Wb, Wc, bb_gt=None, inst_gt=None, normalize=False):
-    _lib.require_device(X, Wb, Wc)
-    return _ExtrusionAxis.apply(X, Wb, Wc, bb_gt, inst_gt, bool(normalize))
+def extrusion_axis(X, Wb, Wc, bb_gt=None, inst_gt=None, normalize=False, axis64=None):
+    """axis64: optional (B,K,3) float64 device tensor that receives the unit eigenvector before its rounding to fp32 (no gradient)."""
+    _lib.require_device(X, Wb, Wc, axis64)
+    if axis64 is not None and (axis64.dtype != torch.float64 or not axis64.is_contiguous() or tuple(axis64.shape) != (Wb.shape[0], Wb.shape[2], 3)):
+        raise ValueError("extrusion_axis: axis64 must be a contiguous float64 (B,K,3) tensor")
+    return _ExtrusionAxis.apply(X, Wb, Wc, bb_gt, inst_gt, bool(normalize), axis64)
 
 
 class _ExtrusionCenters(torch.autograd.Function):
@@ -858,9 +861,10 @@ def fit_fused_supported(N, K, S):
     return bool(_lib.lib().p2c_fit_fused_supported(int(N), int(K), int(S)))
 
 
-def fit_fused(X, Wb, Wc, bb, seg, P, rand_idx, normalize=False):
+def fit_fused(X, Wb, Wc, bb, seg, P, rand_idx, normalize=False, axes64=False):
     """csrc/fit.hip fit_fused_kernel: axis -> hard centroids -> extents of pre-segmented clouds in one pass (eval.py:397, :409-436,
-    data_utils.py:1650-1730).  -> axes (B,K,3), centroids (B,K,3), centroid found (B,K), extents (K,B,2), extent found (B,K).  No gradient."""
+    data_utils.py:1650-1730).  -> axes (B,K,3), centroids (B,K,3), centroid found (B,K), extents (K,B,2), extent found (B,K)
+    [, axes in float64 (B,K,3) with axes64=True].  No gradient."""
     _lib.require_device(X, Wb, Wc, bb, seg, P, rand_idx)
     X, Wb, Wc, P = _f32c(X.detach()), _f32c(Wb.detach()), _f32c(Wc.detach()), _f32c(P)
     B, N, K = Wb.shape
@@ -875,9 +879,12 @@ def fit_fused(X, Wb, Wc, bb, seg, P, rand_idx, normalize=False):
     ext = torch.empty(K, B, 2, dtype=torch.float32, device=dev)
     found = torch.empty(B, K, dtype=torch.float32, device=dev)
     ws = torch.empty(_lib.lib().p2c_extents_ws_bytes(B, K) // 4 + 4, dtype=torch.float32, device=dev)
+    a64 = torch.empty(B, K, 3, dtype=torch.float64, device=dev) if axes64 else None
     call("p2c_fit_fused_f32", ptr(X), ptr(Wb), ptr(Wc), ptr(bb), ptr(seg), 1 if normalize else 0, ptr(P), ptr(rand_idx), B, N, K, S,
-         ptr(axes), ptr(cen), ptr(cfound), ptr(ext), ptr(found), ptr(ws), stream(),
+         ptr(axes), ptr(cen), ptr(cfound), ptr(ext), ptr(found), ptr(a64), ptr(ws), stream(),
          nbytes=float(B) * N * (12 + 12 + 2 * K * 4 + 16) + float(B) * K * S * 8)
+    if axes64:
+        return axes, cen, cfound, ext, found, a64
     return axes, cen, cfound, ext, found
 
 

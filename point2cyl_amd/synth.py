@@ -134,3 +134,32 @@ class SyntheticExtrusionDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, i):
         return make_shape(np.random.default_rng(self.seed + i), self.num_point, self.K)
+
+
+def make_fitting_inputs(n_clouds, N=8192, K=8, seed=4321, distinct=64, noise_deg=2.0):
+    """BASELINE configs[3]'s workload: pre-segmented synthetic cylinders for the fitting-only path of eval.py.
+    `distinct` different clouds tiled to n_clouds; X = ground-truth normals turned by N(0, noise_deg) about a random perpendicular axis,
+    W_barrel / W_base one-hot from the labels.  -> pcs, X, seg, bb, gt axes (n,K,3), W_barrel, W_base, one-hot (all CPU, fp32 / int64)."""
+    pcs, nrm, seg, bb, _, _, axes, _, cen = make_batch(min(distinct, n_clouds), N, K, seed=seed)
+    pcs, nrm, axes = pcs.float(), nrm.float(), axes.float()
+    reps = (n_clouds + pcs.shape[0] - 1) // pcs.shape[0]
+    tile = lambda t: t.repeat((reps,) + (1,) * (t.dim() - 1))[:n_clouds].contiguous()
+    pcs, nrm, seg, bb, axes = tile(pcs), tile(nrm), tile(seg), tile(bb), tile(axes)
+    g = torch.Generator().manual_seed(seed + 1)
+    r = torch.randn(nrm.shape, generator=g)
+    perp = r - (r * nrm).sum(-1, keepdim=True) * nrm
+    perp = perp / perp.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    ang = torch.randn(nrm.shape[:2], generator=g).unsqueeze(-1) * (noise_deg * math.pi / 180.0)
+    X = torch.cos(ang) * nrm + torch.sin(ang) * perp
+    onehot = torch.nn.functional.one_hot(seg.clamp_min(0), K).float() * (seg >= 0).unsqueeze(-1)
+    Wb = onehot * (bb == 0).unsqueeze(-1)
+    Wc = onehot * (bb == 1).unsqueeze(-1)
+    return pcs, X.float(), seg, bb, axes, Wb, Wc, onehot
+
+
+def axis_angle_error_deg64(E, gt_axes, seg, K):
+    """eval.py:398-405 in float64: masked mean over the segments that exist of acos_safe(|a . a_gt|) in degrees (losses.py:123, :146-159)."""
+    dot = (E.double() * gt_axes.double()).sum(-1).abs().clamp(min=-1.0 + 1e-6, max=1.0 - 1e-6)
+    deg = torch.acos(dot) * 180.0 / math.pi
+    present = (torch.nn.functional.one_hot(seg.clamp_min(0), K) * (seg >= 0).unsqueeze(-1)).sum(1) > 0
+    return float((deg * present).sum() / present.sum())

@@ -53,9 +53,9 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_sketch_projection_f32(one, one, None, None, one, one, None, 1, 16, 8, 4, 1, one, one, one, one, one, None) == -1   # all_points needs S == N
     assert L.p2c_linear_bwd_data_sig_f32(one, 4, one, 4, one, 4, 100.0, 20.0, one, 4, 8, 6, 4, None) == -2                          # N not a multiple of 4
     # round 3 entries
-    assert L.p2c_fit_fused_f32(None, None, None, None, None, 0, None, None, 1, 8192, 8, 2048, None, None, None, None, None, None, None) == -1
-    assert L.p2c_fit_fused_f32(one, one, one, one, one, 0, one, one, 1, 8192, 3, 2048, one, one, one, one, one, one, None) == -1   # K not a power of two
-    assert L.p2c_fit_fused_f32(one, one, one, one, one, 0, one, one, 1, 65536, 8, 2048, one, one, one, one, one, one, None) == -1  # cloud larger than the LDS
+    assert L.p2c_fit_fused_f32(None, None, None, None, None, 0, None, None, 1, 8192, 8, 2048, None, None, None, None, None, None, None, None) == -1
+    assert L.p2c_fit_fused_f32(one, one, one, one, one, 0, one, one, 1, 8192, 3, 2048, one, one, one, one, one, None, one, None) == -1   # K not a power of two
+    assert L.p2c_fit_fused_f32(one, one, one, one, one, 0, one, one, 1, 65536, 8, 2048, one, one, one, one, one, None, one, None) == -1  # cloud larger than the LDS
     assert L.p2c_linear_bwd_narrow_f32(None, 20, None, 128, None, None, 2.0, None, 128, None, 128, None, 128, 20 * 128, None, None, 262144, 20, 128, None) == -1
     assert L.p2c_linear_bwd_narrow_f32(one, 20, one, 128, one, None, 1.0, one, 128, one, 128, one, 128, 40 * 128, None, one, 262144, 40, 128, None) == -1   # more than 32 outputs
     assert L.p2c_linear_bwd_narrow_f32(one, 20, one, 130, one, None, 1.0, one, 128, one, 128, one, 128, 20 * 128, None, one, 262144, 20, 128, None) == -2   # row stride not 16-byte aligned

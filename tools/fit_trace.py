@@ -20,13 +20,13 @@ d = lambda t: t.cuda().contiguous()
 pcs, X, seg, bb, Wb, Wc, ri = d(pcs), d(X), d(seg), d(bb), d(Wb), d(Wc), d(ri)
 L = ctypes.CDLL(LIB)
 vp, ci = ctypes.c_void_p, ctypes.c_int
-L.p2c_fit_fused_f32.argtypes = [vp] * 5 + [ci] + [vp] * 2 + [ci] * 4 + [vp] * 7
+L.p2c_fit_fused_f32.argtypes = [vp] * 5 + [ci] + [vp] * 2 + [ci] * 4 + [vp] * 8
 L.p2c_extents_ws_bytes.restype = ctypes.c_size_t
 ax = torch.empty(B, K, 3, device="cuda"); ce = torch.empty(B, K, 3, device="cuda"); cf = torch.empty(B, K, device="cuda")
 ex = torch.empty(K, B, 2, device="cuda"); ef = torch.empty(B, K, device="cuda"); ws = torch.empty(B * K * 3 + 16, device="cuda")
 def run():
     assert L.p2c_fit_fused_f32(X.data_ptr(), Wb.data_ptr(), Wc.data_ptr(), bb.data_ptr(), seg.data_ptr(), 0, pcs.data_ptr(), ri.data_ptr(), B, N, K, S,
-                               ax.data_ptr(), ce.data_ptr(), cf.data_ptr(), ex.data_ptr(), ef.data_ptr(), ws.data_ptr(), None) == 0
+                               ax.data_ptr(), ce.data_ptr(), cf.data_ptr(), ex.data_ptr(), ef.data_ptr(), None, ws.data_ptr(), None) == 0
 for _ in range(3):
     run()
 torch.cuda.synchronize()

@@ -88,6 +88,28 @@ def _cpu_model():
     return "unknown"
 
 
+def _cpu_all_threads_leg(cb, N, K, threads, limit_s):
+    """One CPU training step of the oracle at torch.set_num_threads(os.cpu_count()) in a child process, killed after limit_s seconds.
+    -> (points/s or None, seconds or None, note)."""
+    import subprocess
+    code = ("import sys, json, torch; sys.path.insert(0, %r)\n"
+            "from point2cyl_amd import synth\nfrom oracle import ref_step\n"
+            "b = synth.make_batch(%d, %d, %d, seed=1234)\n"
+            "pps, sec, thr, n = ref_step.time_cpu_baseline(tuple(x.contiguous() for x in b[:4]), threads=%d, steps=1)\n"
+            "print(json.dumps([pps, sec, thr]))\n" % (ROOT, cb, N, K, threads))
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=limit_s + 15.0)     # + import time
+        pps, sec, thr = json.loads(out.stdout.strip().splitlines()[-1])
+        return pps, sec, "one step on %d threads: %.1f s" % (thr, sec)
+    except subprocess.TimeoutExpired:
+        el = time.perf_counter() - t0
+        return None, None, ("one step of B=%d clouds on %d threads did not finish within %.0f s (< %.0f points/s): oversubscription, see DESIGN.md 5"
+                            % (cb, threads, el, cb * N / max(el - 5.0, 1.0)))
+    except Exception as e:
+        return None, None, "all-threads leg failed: %s: %s" % (type(e).__name__, e)
+
+
 def _self_launch(n):
     """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU) under torch.distributed.run on this node."""
     import socket
@@ -121,6 +143,9 @@ def main():
     ap.add_argument("--torch_losses", action="store_true", help="evaluate the losses with torch ops instead of csrc/loss.hip")
     ap.add_argument("--no_prefetch", action="store_true", help="compute FPS/ball-query/3-NN inline instead of one step ahead on a side stream")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
+    ap.add_argument("--no_extras", action="store_true", help="only the training-step line: skip stages / forward_only / config3_fitting / ab / dropin")
+    ap.add_argument("--dropin", action="store_true", help="make the DROP-IN step the timed one: the step composed as train_Point2Cyl_without_sketch.py:244-369 "
+                    "composes it through the reference's import names (model(pcs), compute_all_losses, inline BB block, torch.optim.Adam, six .item())")
     args = ap.parse_args()
 
     from point2cyl_amd import ddp, ops, step, synth
@@ -160,6 +185,20 @@ def _bench(args, rank, world, local, dev):
     fl = step.StepFlags(K=K, pred_extrusion=args.full_losses, pred_center=args.full_losses)
     pcs, normals, seg, bb, _, _, axes, _, centers = synth.make_batch(B, N, K, seed=1234 + 1000 * rank)
     batch = tuple(x.to(dev) for x in (pcs, normals, seg, bb, axes, centers))
+    if args.dropin:
+        if world != 1:
+            raise SystemExit("bench --dropin: the reference's trainer is single-process; run it with --gpus 1")
+        from point2cyl_amd import _lib
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = _dropin_leg(args, batch, fl, dev, B, N, K, native_ms=float("nan"), steps=args.steps)
+        res.pop("ratio_to_native_step", None)
+        print(json.dumps(dict(metric="training-step points/sec (BxN) at N=8192", value=res["points_per_s"], unit="points/s", n_gpus=1, steps=args.steps,
+                              warmup=3, ms_per_step=res["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
+                              data="synthetic", config=dict(workload="configs[%d] through the DROP-IN boundary: B=%d x N=%d, K=%d" % (2 if args.full_losses else 1, B, N, K),
+                                                            mfma="bf16x3-split" if _lib.lib().p2c_get_mfma_mode() else "f32", launch="reference trainer composition on the drop-in import names"),
+                              roofline=None, cpu_baseline=None, dropin=res)))
+        return
 
     torch.manual_seed(0)
     model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
@@ -307,14 +346,33 @@ def _bench(args, rank, world, local, dev):
         from oracle import ref_step
         cb = args.cpu_batch
         sample = tuple(x[:cb].contiguous() for x in (pcs, normals, seg, bb))
-        pps, sec, thr, nst = ref_step.time_cpu_baseline(sample, threads=min(32, os.cpu_count() or 1), budget_s=10.0)
+        host = os.cpu_count() or 1
+        pps, sec, thr, nst = ref_step.time_cpu_baseline(sample, threads=min(32, host), budget_s=10.0)
         one = tuple(x[:1].contiguous() for x in (pcs, normals, seg, bb))
         pps1, sec1, _, nst1 = ref_step.time_cpu_baseline(one, threads=1, budget_s=8.0)
-        cpu = dict(value=round(pps, 1), unit="points/s", cores=thr, kind="port", cpu_model=_cpu_model(), host_cores=os.cpu_count(),
-                   single_thread_value=round(pps1, 1),
+        # torch.set_num_threads(os.cpu_count()) as well - in a child process with a time limit: with every hardware thread in
+        # each of the step's thousands of small ops the run is slower, not faster (measured once without a limit on this pool's boxes:
+        # 183.6 s for ONE step at 256 threads = 178 points/s, profiles/r04_bench_all_threads_unbounded.json.log), and the default bench must
+        # finish within minutes
+        ppsa, seca, thra, all_note = None, None, host, None
+        if host > 32:
+            ppsa, seca, all_note = _cpu_all_threads_leg(cb, N, K, host, limit_s=25.0)
+        else:
+            ppsa, seca = pps, sec
+        torch.set_num_threads(min(32, host))
+        best = max(((pps, thr), (ppsa or 0.0, thra), (pps1, 1)), key=lambda t: t[0])
+        try:
+            affinity = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            affinity = None
+        cpu = dict(value=round(best[0], 1), unit="points/s", cores=best[1], kind="port", cpu_model=_cpu_model(), host_cores=host, sched_affinity=affinity,
+                   by_threads={str(thr): round(pps, 1), str(thra): None if ppsa is None else round(ppsa, 1), "1": round(pps1, 1)},
+                   single_thread_value=round(pps1, 1), all_threads_value=None if ppsa is None else round(ppsa, 1), all_threads_note=all_note,
                    sample="%d full training steps (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
-                          "points (same generator as the GPU batch) on %d threads, %.1f s of CPU work; single_thread_value: %d step(s) of the "
-                          "same on B=1 cloud with 1 thread, %.1f s" % (nst, cb, N, thr, sec * nst, nst1, sec1 * nst1))
+                          "points (same generator as the GPU batch) on %d threads, %.1f s of CPU work; all_threads_value: 1 step of the same on "
+                          "os.cpu_count() = %d threads in a child process limited to 25 s; single_thread_value: %d step(s) on B=1 cloud with 1 "
+                          "thread, %.1f s; `value` is the fastest (the step is thousands of small ops - a Python FPS loop, sorts, gathers: more "
+                          "threads than ~32 only add fork/join cost)" % (nst, cb, N, thr, sec * nst, host, nst1, sec1 * nst1))
     line = dict(metric="training-step points/sec (BxN) at N=8192", value=round(value, 1), unit="points/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                 vs_baseline=None, dtype="f32", data="synthetic",
@@ -328,9 +386,128 @@ def _bench(args, rank, world, local, dev):
                 roofline=roofline, cpu_baseline=cpu, multi_gpu=multi,
                 kernels={k: dict(ms_per_step=round(v["ms"] / prof_steps, 3), launches_per_step=v["launches"] / prof_steps)
                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])})
+    if world == 1 and not args.no_extras:
+        if graphed is not None:
+            graphed.release()
+        line.update(_extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt))
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+
+
+def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
+    """The measurements SURVEY 8(d) asks for beside the training-step number, in the same process after the timed region (rank 0, N = 1):
+    stages.sa1_forward, forward_only, path_roofline, config3_fitting, ab (fp32-MFMA kernels), dropin (the step through the import names).
+    Each leg is guarded: a failure is reported in the line instead of taking the training-step number down with it."""
+    from point2cyl_amd import _lib, measure, ops
+    out = {}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:
+            out[name] = dict(error="%s: %s" % (type(e).__name__, e))
+        try:
+            torch.cuda.synchronize()
+            ops.step_done()
+        except Exception:
+            pass
+
+    leg("path_roofline", lambda: measure.path_roofline(B, ms, 3.0, N))
+    leg("stages", lambda: dict(sa1_forward=measure.sa1_stage(model, batch[0], steps=30)))
+    leg("forward_only", lambda: measure.forward_only(model, batch[0], steps=30))
+
+    def ab():
+        from point2cyl_amd.graph import GraphedForwardBackward
+        cur = _lib.lib().p2c_get_mfma_mode()
+        res = {}
+        for mode, key in ((0, "f32_mfma_ms_per_step"), (1, "bf16x3_split_ms_per_step")):
+            _lib.lib().p2c_set_mfma_mode(mode)
+            try:
+                def fwd_bwd(geom=None):
+                    ops.step_done()
+                    with ops.step_arena(dev):
+                        o = loss_fn(model, *batch, fl, geom=geom)
+                        sync.zero()
+                        o["total"].backward()
+                        sync.pack()
+                    return {"total": o["total"].detach()}
+                g = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=None if args.no_prefetch else batch[0], stream=torch.cuda.current_stream())
+                try:
+                    def one():
+                        g()
+                        opt.step()
+                        ops.step_done()
+                    for _ in range(3):
+                        one()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(15):
+                        one()
+                    torch.cuda.synchronize()
+                    res[key] = round((time.perf_counter() - t0) / 15 * 1e3, 4)
+                finally:
+                    g.release()
+            finally:
+                _lib.lib().p2c_set_mfma_mode(cur)
+        res["note"] = "the SAME step, graph re-captured with p2c_set_mfma_mode(0) (v_mfma_f32_32x32x2_f32 kernels) and (1) (bf16x3 split), 15 replays each, alternating on this box"
+        return res
+
+    leg("ab", ab)
+
+    def config3():
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_config4
+        w = measure.FittingWorkload(1250, 8192, 8, 2048, device=dev)
+        res, (E, cen, cfound, ext, found, E64) = w.time(20)
+        cpu, parity = bench_config4.cpu_fitting_legs(w, E, cen, ext, E64, thread_counts=(min(32, os.cpu_count() or 1), 1))
+        res.update(cpu_baseline=cpu, parity=parity)
+        del w
+        return res
+
+    if not args.full_losses:
+        leg("config3_fitting", config3)
+
+    def dropin():
+        return _dropin_leg(args, batch, fl, dev, B, N, K, ms)
+
+    leg("dropin", dropin)
+    return out
+
+
+def _dropin_leg(args, batch, fl, dev, B, N, K, native_ms, steps=20):
+    """The step a user of the BOUNDARY gets: point2cyl_amd/dropin/trainer_step.py composes train_Point2Cyl_without_sketch.py:244-369 through
+    the reference's import names with torch.optim.Adam and six .item() reads.  Timed with the HIP graphs inside backbone.forward
+    (point2cyl_amd/autograph.py) and, for the A/B, with every kernel launched from Python."""
+    from point2cyl_amd import autograph
+    from point2cyl_amd.dropin.trainer_step import TrainerStep
+    res = {}
+    for label, on, n in (("ms_per_step", True, steps), ("eager_ms_per_step", False, max(5, steps // 4))):
+        old = autograph.ENABLED
+        autograph.ENABLED = on
+        try:
+            torch.manual_seed(0)
+            st = TrainerStep(K=K, batch_size=B, pred_extrusion=fl.pred_extrusion, pred_center=fl.pred_center, device=dev)
+            for _ in range(3):
+                logs = st(*batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                logs = st(*batch)
+            torch.cuda.synchronize()
+            res[label] = round((time.perf_counter() - t0) / n * 1e3, 4)
+            if on:
+                res["loss_after_%d_steps" % (n + 3)] = round(logs[0], 5)
+            autograph.reset(st.model)
+            del st
+        finally:
+            autograph.ENABLED = old
+    res["points_per_s"] = round(B * N / (res["ms_per_step"] * 1e-3), 1)
+    res["ratio_to_native_step"] = round(res["ms_per_step"] / native_ms, 3)
+    res["what"] = ("the reference trainer's own step composition (train_Point2Cyl_without_sketch.py:244-369) on the drop-in import names: model(pcs) "
+                   "[HIP graphs cached inside backbone.forward / its backward], F.normalize / softmax in torch, losses.compute_all_losses, the inline "
+                   "base/barrel block as torch ops, torch.optim.Adam, six .item() reads per step; FPS is on the critical path here (no next-batch prefetch)")
+    return res
 
 
 if __name__ == "__main__":

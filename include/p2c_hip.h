@@ -443,6 +443,14 @@ int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff, const flo
                        const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
                        float w_normal, float w_bb, float *out, float *dheads, void *ws, void *stream);
 
+/* compute_all_losses on its own inputs (losses.py:317-351, collapse=True): W [B,N,K] softmaxed membership and X [B,N,3] unit normals as the
+ * reference's trainer forms them in torch (train_Point2Cyl_without_sketch.py:246-271) - what the drop-in of that function is handed.
+ * match / mask [B,K] from p2c_hungarian_f32.  out2 = {mean normal loss, mean mIoU loss}; dW [B,N,K] = d out2[1] / d W and
+ * dX [B,N,3] = d out2[0] / d X (unweighted: the caller applies its multipliers).  ws: zeroed p2c_all_losses_ws_bytes(B,K).  K in {2,4,8}. */
+size_t p2c_all_losses_ws_bytes(int B, int K);
+int p2c_all_losses_f32(const float *W, const float *X, const float *normals_gt, const int64_t *I_gt, const int64_t *match,
+                       const uint8_t *mask, int B, int N, int K, float *out2, float *dW, float *dX, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

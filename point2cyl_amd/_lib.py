@@ -82,6 +82,7 @@ _SIGS = {
     "p2c_head_post_bwd_f32": [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p],
     "p2c_hungarian_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p],
     "p2c_hungarian_logits_f32": [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
+    "p2c_all_losses_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "p2c_seg_losses_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
 }
 
@@ -112,6 +113,8 @@ def lib():
     L.p2c_linear_stat_tiles.restype = c_i
     L.p2c_seg_losses_ws_bytes.argtypes = [c_i, c_i]
     L.p2c_seg_losses_ws_bytes.restype = ctypes.c_size_t
+    L.p2c_all_losses_ws_bytes.argtypes = [c_i, c_i]
+    L.p2c_all_losses_ws_bytes.restype = ctypes.c_size_t
     L.p2c_stat_slots_bytes.argtypes = [c_i]
     L.p2c_stat_slots_bytes.restype = ctypes.c_size_t
     L.p2c_linear_bwd_fused_supported.argtypes = [c_i, c_i, c_i]

@@ -1,0 +1,216 @@
+"""HIP graphs INSIDE `backbone.forward`: what makes an unchanged caller fast.
+
+The reference's trainer calls `model(pcs)` and later `total_loss.backward()` (train_Point2Cyl_without_sketch.py:244, :368).  Launched from
+Python the ~150 kernels of the backbone's forward + backward leave the GPU idle most of the time (13.8 ms per step against 4 ms of kernel
+time).  point2cyl_amd.step / graph.py solve that for OUR trainer by capturing the whole step; a caller that only knows the nn.Module interface
+gets the same effect here: per input shape the module captures TWO graphs - its forward, and the backward of that forward
+(torch.autograd.grad from the head outputs to the parameters, captured with a static upstream-gradient buffer) - and `forward` becomes one
+autograd node that replays the first in its forward and the second in its backward.  The caller's loss code, optimizer and `.item()`
+reads stay whatever they are.
+
+What is not static is handled like graph.py does: FPS start indices are drawn on the CPU generator per call (pointnet_util.py:75) and
+travel through pinned staging into static device tensors; the dropout counter and the BatchNorm running statistics are device state the
+captured kernels advance themselves; the BatchNorm momentum is a kernel argument, so a change of momentum (train...:357-360) is part of the
+cache key and triggers a new capture.  Parameter gradients: the backward graph leaves them in static tensors; `p.grad` is pointed at them
+when it is None (after `optimizer.zero_grad()`, whose default sets gradients to None) and added to otherwise.
+
+Contract (the same as torch.cuda.make_graphed_callables): the returned head tensors are views of a static buffer that the NEXT forward of
+the same shape overwrites; no double backward through the module; the input needs no gradient.  Anything outside the contract - test hooks
+(dropout_mask, fps_start), an input that requires grad, P2C_AUTOGRAPH=0, a capture that fails - takes the eager path."""
+import os
+import warnings
+import weakref
+
+import torch
+
+ENABLED = os.environ.get("P2C_AUTOGRAPH", "1") != "0"
+_MAX_CACHED = 4
+_STATE = weakref.WeakKeyDictionary()      # model -> dict(graphs, bns, params, failed): kept off the module so that deepcopy / pickling never meet a graph
+
+
+def _state(model):
+    st = _STATE.get(model)
+    if st is None:
+        st = _STATE[model] = dict(graphs={}, bns=_bn_modules(model), params=list(model.parameters()), failed=False)
+    return st
+
+
+def reset(model=None):
+    """Drop the cached graphs (of one model, or of all): after replacing parameters, or to free the graphs' memory pools."""
+    if model is None:
+        _STATE.clear()
+    else:
+        _STATE.pop(model, None)
+
+
+def _bn_modules(model):
+    return [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+
+
+class _Captured:
+    """Forward graph (+ backward graph when gradients are enabled) of `model.forward_heads` at one input shape."""
+
+    def __init__(self, model, x, want_grad):
+        from .graph import _PinnedStarts
+        from . import backbone as _bb
+        from torch.nn.utils import stateless
+        dev = x.device
+        named = list(model.named_parameters())
+        self.params = [p for _, p in named if p.requires_grad] if want_grad else []
+        self.want_grad = want_grad and len(self.params) > 0
+        # The capture never touches the caller's autograd leaves: the module runs on ALIASES of its parameters (same storage, fresh leaves).
+        # A parameter that has been through an eager backward owns an AccumulateGrad node bound to the stream of that backward (the
+        # default stream of an unchanged trainer); routing the captured backward towards it makes autograd order the capturing stream
+        # against that stream - work the capture never joins, which this ROCm ends with a segmentation fault in capture_end.
+        alias = {n: (p.detach().requires_grad_(True) if (self.want_grad and p.requires_grad) else p.detach()) for n, p in named}
+        leaves = [alias[n] for n, p in named if p.requires_grad] if self.want_grad else []
+        self.x = torch.empty_like(x).copy_(x)
+        self.starts = _PinnedStarts(dev)
+        hooked = [m for m in model.modules() if isinstance(m, _bb.PointNetSetAbstraction) and not m.group_all]
+        keep = [(b, b.detach().clone()) for b in model.buffers()]
+        seed = getattr(model, "_drop_seed", None)
+        keep_seed = None if seed is None else seed.detach().clone()
+        main = torch.cuda.current_stream()
+        cap = torch.cuda.Stream()
+        self.fwd = self.bwd = None
+
+        def fwd_body():
+            self.starts.cursor = 0
+            return model.forward_heads(self.x)
+
+        def restore():
+            with torch.no_grad():
+                for b, v in keep:
+                    b.copy_(v)
+                if keep_seed is not None and getattr(model, "_drop_seed", None) is not None:
+                    model._drop_seed.copy_(keep_seed)
+                elif keep_seed is None and getattr(model, "_drop_seed", None) is not None:
+                    model._drop_seed.sub_(2 * (0x9E3779B97F4A7C15 % (2 ** 62)))      # created by the first warm-up pass: take the two warm-up advances back
+
+        for m in hooked:
+            m.fps_start = self.starts
+        try:
+            import gc
+            gc.collect()
+            cap.wait_stream(main)
+            with torch.cuda.stream(cap), torch.set_grad_enabled(self.want_grad), stateless._reparametrize_module(model, alias):
+                for _ in range(2):                                         # warm-up: allocator, lazily created state, autograd accumulators
+                    heads, sizes = fwd_body()
+                    if self.want_grad:
+                        torch.autograd.grad((heads,), leaves, (torch.ones_like(heads),), allow_unused=True)
+                    del heads
+                cap.synchronize()
+                pool = torch.cuda.graph_pool_handle()
+                self.fwd = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.fwd, pool=pool, stream=cap, capture_error_mode="thread_local"):
+                    heads, sizes = fwd_body()
+                self.heads, self.sizes = heads.detach(), sizes
+                if self.want_grad:
+                    self.gout = torch.zeros_like(heads)
+                    self.bwd = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.bwd, pool=pool, stream=cap, capture_error_mode="thread_local"):
+                        grads = torch.autograd.grad((heads,), leaves, (self.gout,), allow_unused=True)
+                        # .grad in the parameter's own layout (a (64,3,1,1) weight's gradient arrives as a slice of the kernels' 4-padded
+                        # rows): one mismatch sends torch.optim's multi-tensor kernels down their one-launch-per-tensor path (measured:
+                        # Adam.step 0.35 -> 0.85 ms)
+                        grads = [g if (g is None or g.stride() == p.stride()) else g.contiguous().view_as(p) for g, p in zip(grads, self.params)]
+                    self.grads = [None if g is None else g.detach() for g in grads]
+            main.wait_stream(cap)
+            torch.cuda.synchronize()
+        finally:
+            for m in hooked:
+                if m.fps_start is self.starts:
+                    m.fps_start = None
+            try:
+                torch.cuda.synchronize()
+                restore()
+            except Exception:
+                pass
+        self.starts.cursor = 0
+        self._first = True
+
+    def replay_forward(self, x):
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x)
+        if not self._first:
+            self.starts.stage()          # fresh CPU draws for this call (the first replay consumes the pair drawn at construction)
+        self._first = False
+        self.fwd.replay()
+        return self.heads.detach()       # a fresh alias per call: autograd stamps its node on the object the Function returns
+
+
+class _Replay(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, cap, x, *params):
+        ctx.cap = cap
+        ctx.set_materialize_grads(False)
+        return cap.replay_forward(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        cap = ctx.cap
+        n = len(cap.params)
+        if gout is None:
+            return (None, None) + (None,) * n
+        # gradients of an earlier backward that nobody consumed or cleared (gradient accumulation): the static tensors are about to be
+        # overwritten, so .grad gets its own copy first
+        held = [p for p, g in zip(cap.params, cap.grads) if g is not None and p.grad is g]
+        if held:
+            for p in held:
+                p.grad = p.grad.clone()
+        if gout.data_ptr() != cap.gout.data_ptr():
+            cap.gout.copy_(gout)
+        cap.bwd.replay()
+        add_dst, add_src = [], []
+        for p, g in zip(cap.params, cap.grads):
+            if g is None:
+                continue
+            if p.grad is None:
+                p.grad = g
+            else:
+                add_dst.append(p.grad)
+                add_src.append(g)
+        if add_dst:
+            torch._foreach_add_(add_dst, add_src)
+        return (None, None) + (None,) * n
+
+
+def _key(model, x, want_grad):
+    st = _state(model)
+    bns, ps = st["bns"], st["params"]
+    return (tuple(x.shape), x.dtype, x.device.index, model.training, want_grad, tuple(b.momentum for b in bns),
+            ps[0].data_ptr(), ps[-1].data_ptr(), tuple(p.requires_grad for p in ps) if want_grad else None)
+
+
+def applicable(model, x):
+    if not ENABLED or not x.is_cuda or x.requires_grad or torch.cuda.is_current_stream_capturing():
+        return False
+    if model.dropout_mask is not None or model.sa1.fps_start is not None or model.sa2.fps_start is not None:
+        return False          # test hooks / an outer graph (graph.py) own these: eager path
+    return not _state(model)["failed"]
+
+
+def forward_heads(model, x):
+    """-> (heads, sizes) like backbone.forward_heads, through the cached graphs of x's shape (captured on first use)."""
+    st = _state(model)
+    want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in st["params"])
+    cache = st["graphs"]
+    key = _key(model, x, want_grad)
+    cap = cache.get(key)
+    if cap is None:
+        try:
+            cap = _Captured(model, x, want_grad)
+        except Exception as e:          # keep the caller alive: eager launches from here on
+            st["failed"] = True
+            warnings.warn("point2cyl_amd.autograph: HIP-graph capture of backbone.forward failed (%s: %s); continuing with eager launches"
+                          % (type(e).__name__, e))
+            return None
+        if len(cache) >= _MAX_CACHED:
+            cache.pop(next(iter(cache)))
+        cache[key] = cap
+    if cap.want_grad:
+        heads = _Replay.apply(cap, x, *cap.params)
+    else:
+        heads = cap.replay_forward(x)
+    return heads, cap.sizes

@@ -221,7 +221,9 @@ class backbone(nn.Module):
         return dict(sa1=g1, sa2=g2, fp2=nn_with_csr(g1["new_xyz"], g2["new_xyz"]), fp1=nn_with_csr(xyz, g1["new_xyz"]))
 
     def forward(self, x):
-        heads, sizes = self.forward_heads(x)
+        from . import autograph
+        r = autograph.forward_heads(self, x) if autograph.applicable(self, x) else None      # per-shape HIP graphs of this forward and its backward
+        heads, sizes = r if r is not None else self.forward_heads(x)
         B, N = x.shape[0], x.shape[1]
         heads = heads.view(B, N, heads.shape[-1])
         outs, o = [], 0

@@ -334,3 +334,140 @@ extern "C" int p2c_head_post_bwd_f32(const float *heads, int ld, int xoff, int w
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// compute_all_losses on its OWN inputs (losses.py:317-351 with collapse=True): the reference's trainer hands it the softmaxed membership
+// W [B,N,K] and the unit normals X [B,N,3] it has already formed in torch (train…:246-271, :280), so the drop-in of that function cannot
+// start from the logits like p2c_seg_losses_f32.  Same three steps on (W, X): per-cloud sums (dot, sumW, cnt, normal term), a small
+// finalisation (the two means, the per-(b,k) mIoU gradient coefficients), one pass that writes the UNWEIGHTED gradients
+// d miou / d W and d normal / d X (the caller scales them by its multipliers and the upstream gradient).
+// ------------------------------------------------------------------------------------------------
+struct AllLossArgs {
+    const float *W, *X, *ngt;                            // [B,N,K], [B,N,3], [B,N,3]
+    const int64_t *igt, *match; const uint8_t *mask;     // [B,N]; [B,K]; [B,K]
+    int B, N;
+    double *acc;                                         // [B][3K+1] zeroed: dot | sumW | cnt | normal
+    float *out;                                          // [2]: normal mean, miou mean
+    float *coef;                                         // [B][2K]
+    float *dW, *dX;
+};
+
+template <int K>
+__global__ void __launch_bounds__(256) all_losses_reduce_kernel(AllLossArgs a)
+{
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    float acc[3 * K + 1];
+#pragma unroll
+    for (int i = 0; i < 3 * K + 1; ++i) acc[i] = 0.f;
+    if (n < a.N) {
+        const size_t m = (size_t)b * a.N + n;
+        const int lab = (int)a.igt[m];
+        float w[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) w[j] = a.W[m * K + j];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int mk = (int)a.match[b * K + k];
+            float wr = 0.f;
+#pragma unroll
+            for (int j = 0; j < K; ++j) wr = (j == mk) ? w[j] : wr;
+            acc[k] = (lab == k) ? wr : 0.f;
+            acc[K + k] = wr;
+            acc[2 * K + k] = (lab == k) ? 1.f : 0.f;
+        }
+        const float *x = a.X + m * 3, *g = a.ngt + m * 3;
+        acc[3 * K] = 1.f - fabsf(x[0] * g[0] + x[1] * g[1] + x[2] * g[2]);
+    }
+    __shared__ float red[4][3 * K + 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 3 * K + 1; ++i) {
+        const float v = p2c_wave_sum_f32(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 * K + 1) {
+        const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        atomicAdd(&a.acc[(size_t)b * (3 * K + 1) + threadIdx.x], (double)v);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) all_losses_finalize_kernel(AllLossArgs a)
+{
+    __shared__ double sm[256], sn[256];
+    double miou = 0.0, nrm = 0.0;
+    for (int b = threadIdx.x; b < a.B; b += 256) {
+        const double *c = a.acc + (size_t)b * (3 * K + 1);
+        int nv = 0;
+        for (int k = 0; k < K; ++k) nv += a.mask[b * K + k] ? 1 : 0;
+        double s = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double dot = c[k], den = c[2 * K + k] + c[K + k] - dot + 1e-10;      // losses.py:99-101
+            const bool valid = a.mask[b * K + k] != 0;
+            if (valid) s += 1.0 - dot / den;
+            const double g = (valid && nv > 0) ? 1.0 / ((double)a.B * nv) : 0.0;
+            a.coef[(size_t)b * 2 * K + k] = (float)(-g * (den + dot) / (den * den));
+            a.coef[(size_t)b * 2 * K + K + k] = (float)(g * dot / (den * den));
+        }
+        miou += nv > 0 ? s / nv : 0.0;
+        nrm += c[3 * K] / a.N;
+    }
+    sm[threadIdx.x] = miou; sn[threadIdx.x] = nrm;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = 0, n = 0;
+        for (int i = 0; i < 256; ++i) { m += sm[i]; n += sn[i]; }
+        a.out[0] = (float)(n / a.B); a.out[1] = (float)(m / a.B);
+    }
+}
+
+template <int K>
+__global__ void __launch_bounds__(256) all_losses_grad_kernel(AllLossArgs a)
+{
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= a.N) return;
+    const size_t m = (size_t)b * a.N + n;
+    const int lab = (int)a.igt[m];
+    float dW[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) dW[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const int mk = (int)a.match[b * K + k];
+        const float d = a.coef[(size_t)b * 2 * K + K + k] + ((lab == k) ? a.coef[(size_t)b * 2 * K + k] : 0.f);
+#pragma unroll
+        for (int j = 0; j < K; ++j) dW[j] += (j == mk) ? d : 0.f;           // unmatched slots repeat a column: contributions add (gather's backward)
+    }
+#pragma unroll
+    for (int j = 0; j < K; ++j) a.dW[m * K + j] = dW[j];
+    const float *x = a.X + m * 3, *g = a.ngt + m * 3;
+    const float c = x[0] * g[0] + x[1] * g[1] + x[2] * g[2];
+    const float cn = -(c > 0.f ? 1.f : (c < 0.f ? -1.f : 0.f)) / ((float)a.B * (float)a.N);
+    a.dX[m * 3 + 0] = cn * g[0]; a.dX[m * 3 + 1] = cn * g[1]; a.dX[m * 3 + 2] = cn * g[2];
+}
+
+extern "C" size_t p2c_all_losses_ws_bytes(int B, int K) { return (size_t)B * (3 * K + 1) * sizeof(double) + (size_t)B * 2 * K * sizeof(float); }
+
+extern "C" int p2c_all_losses_f32(const float *W, const float *X, const float *normals_gt, const int64_t *I_gt, const int64_t *match,
+                                  const uint8_t *mask, int B, int N, int K, float *out2, float *dW, float *dX, void *ws, void *stream)
+{
+    if (!W || !X || !normals_gt || !I_gt || !match || !mask || !out2 || !dW || !dX || !ws || B <= 0 || N <= 0) return P2C_EINVAL;
+    if (K != 2 && K != 4 && K != 8) return P2C_EINVAL;
+    AllLossArgs a{W, X, normals_gt, I_gt, match, mask, B, N, (double *)ws, out2,
+                  (float *)((char *)ws + (size_t)B * (3 * K + 1) * sizeof(double)), dW, dX};
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(p2c_cdiv(N, 256), B);
+#define P2C_ALK(K_)                                                                          \
+    do {                                                                                     \
+        hipLaunchKernelGGL(all_losses_reduce_kernel<K_>, grid, dim3(256), 0, s, a);          \
+        hipLaunchKernelGGL(all_losses_finalize_kernel<K_>, dim3(1), dim3(256), 0, s, a);     \
+        hipLaunchKernelGGL(all_losses_grad_kernel<K_>, grid, dim3(256), 0, s, a);            \
+    } while (0)
+    if (K == 8) P2C_ALK(8);
+    else if (K == 4) P2C_ALK(4);
+    else P2C_ALK(2);
+#undef P2C_ALK
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

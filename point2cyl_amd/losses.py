@@ -9,6 +9,7 @@ import torch.nn.functional as F
 
 from . import ops
 
+FUSED_ALL_LOSSES = True                              # compute_all_losses through csrc/loss.hip where it applies (tests switch it off for the A/B)
 g_zero_tol = 1.0e-6                                  # global_variables.py:15
 TORCH_PI = torch.acos(torch.zeros(1)).item() * 2     # losses.py:17
 
@@ -95,8 +96,16 @@ def compute_normal_difference(X, X_gt, in_radians=True, collapse=True):
 
 def compute_all_losses(P, W, I_gt, X, X_gt, normal_loss_multiplier, miou_loss_multiplier, return_match_indices=False,
                        collapse=True):
-    """losses.py:317-351."""
+    """losses.py:317-351.  On the device with both multipliers > 0, collapse and K in {2, 4, 8} the matching, both reductions and their
+    gradient are three launches of csrc/loss.hip (ops.all_losses) instead of ~35 torch launches forward and as many backward; every
+    other call takes the torch expressions below (same values: tests/test_gpu_parity.py)."""
     B, _, K = W.shape
+    if (FUSED_ALL_LOSSES and W.is_cuda and collapse and K in (2, 4, 8) and normal_loss_multiplier > 0 and miou_loss_multiplier > 0
+            and W.dtype == torch.float32 and X.dtype == torch.float32):
+        out3, matching_indices, mask = ops.all_losses(W, X, X_gt, I_gt, normal_loss_multiplier, miou_loss_multiplier)
+        if return_match_indices:
+            return out3[0], out3[1], out3[2], matching_indices, mask
+        return out3[0], out3[1], out3[2]
     mask_gt = get_mask_gt(I_gt, K)
     if normal_loss_multiplier > 0:
         normal_loss = compute_normal_loss(X, X_gt, angle_diff=False)

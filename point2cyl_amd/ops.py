@@ -20,6 +20,7 @@ USE_DUAL_BWD = os.environ.get("P2C_DUAL_BWD", "1") != "0"   # dX and dW of the s
 USE_FOLD0 = os.environ.get("P2C_FOLD0", "1") != "0"         # first layer with <= 4 input channels never materialised (bn.hip)
 USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated backward of the gathers (no atomics)
 USE_NARROW_BWD = os.environ.get("P2C_NARROW_BWD", "1") != "0"  # the per-point heads' backward in one pass (csrc/heads.hip)
+STRICT_LABELS = os.environ.get("P2C_STRICT_LABELS", "0") == "1"   # validate labels with a device->host sync in every loss call instead of deferred
 USE_POOL_EPI = os.environ.get("P2C_POOL_EPI", "1") != "0"    # max over 64 neighbours from extremes emitted by the last layer's GEMM epilogue
 
 
@@ -933,6 +934,55 @@ def check_labels(I_gt, K):
         raise ValueError("instance labels must be in [-1, %d); got [%d, %d]" % (K, lo, hi))
 
 
+class _DeferredLabelCheck:
+    """Label validation WITHOUT a device->host sync in the step: the range test runs on the device, its verdict travels through a pinned
+    host word with an asynchronous copy, and the NEXT call (or flush_label_check()) raises if an earlier batch was out of range.  The
+    synchronous check costs the caller of compute_all_losses its whole launch-ahead: the host waits for the forward to finish before it
+    can enqueue the first loss kernel (measured on the drop-in step: 7.2 -> see DESIGN.md)."""
+
+    def __init__(self):
+        self.st = {}
+
+    def __call__(self, I_gt, K):
+        if torch.cuda.is_current_stream_capturing():
+            return
+        dev = I_gt.device
+        st = self.st.get(dev)
+        if st is None:
+            st = self.st[dev] = dict(acc=torch.zeros(1, dtype=torch.int32, device=dev), host=torch.zeros(1, dtype=torch.int32).pin_memory(),
+                                     ev=None, K=K)
+        self.poll(dev)
+        mn, mx = torch.aminmax(I_gt)
+        st["acc"] |= ((mx >= K) | (mn < -1)).to(torch.int32)
+        st["host"].copy_(st["acc"], non_blocking=True)
+        st["ev"] = torch.cuda.Event()
+        st["ev"].record()
+        st["K"] = K
+
+    def poll(self, dev, wait=False):
+        st = self.st.get(dev)
+        if st is None or st["ev"] is None:
+            return
+        if wait:
+            st["ev"].synchronize()
+        if st["ev"].query() and int(st["host"][0]) != 0:
+            st["acc"].zero_()
+            st["host"].zero_()
+            st["ev"] = None
+            raise ValueError("instance labels of an earlier batch were outside [-1, %d) (deferred check: losses.py:36-46 would have raised "
+                             "in that call)" % st["K"])
+
+
+check_labels_deferred = _DeferredLabelCheck()
+
+
+def flush_label_check(device=None):
+    """Wait for the outstanding deferred label checks and raise if one failed (end of an epoch, before a checkpoint)."""
+    for dev in list(check_labels_deferred.st):
+        if device is None or dev == torch.device(device):
+            check_labels_deferred.poll(dev, wait=True)
+
+
 def hungarian(W, I_gt):
     """losses.py:22-52 on the device -> matching_indices (B,K) int64, mask (B,K) bool.  No gradient."""
     _lib.require_device(W, I_gt)
@@ -1027,3 +1077,45 @@ def seg_losses(heads, normals_gt, I_gt, bb_gt, B, N, K, xoff, woff, w_seg=1.0, w
     """-> (out[4] = total, normal, miou, bb ; matching_indices (B,K) int64 ; mask (B,K) bool)."""
     out, match, mask = _SegLosses.apply(heads, normals_gt, I_gt, bb_gt, B, N, K, xoff, woff, w_seg, w_normal, w_bb)
     return out, match, mask.bool()
+
+
+class _AllLosses(torch.autograd.Function):
+    """losses.compute_all_losses (losses.py:317-351, collapse=True) on (W, X): matching + both means forward, the two unweighted gradients
+    kept for backward (csrc/loss.hip all_losses_*).  out3 = [w_seg * miou + w_normal * normal, normal, miou]."""
+
+    @staticmethod
+    def forward(ctx, W, X, normals_gt, I_gt, w_normal, w_seg):
+        dev = W.device
+        Wc, Xc = _f32c(W.detach()), _f32c(X.detach())
+        B, N, K = Wc.shape
+        I_gt = I_gt.to(torch.int64).contiguous()
+        (check_labels if STRICT_LABELS else check_labels_deferred)(I_gt, K)
+        match = torch.empty(B, K, dtype=torch.int64, device=dev)
+        mask = torch.empty(B, K, dtype=torch.uint8, device=dev)
+        call("p2c_hungarian_f32", ptr(Wc), ptr(I_gt), B, N, K, ptr(match), ptr(mask), stream())
+        out2 = torch.empty(2, dtype=torch.float32, device=dev)
+        dW, dX = torch.empty_like(Wc), torch.empty_like(Xc)
+        ws = STEP_ARENA.take(_lib.lib().p2c_all_losses_ws_bytes(B, K) // 8 + 8, dev)
+        call("p2c_all_losses_f32", ptr(Wc), ptr(Xc), ptr(_f32c(normals_gt)), ptr(I_gt), ptr(match), ptr(mask), B, N, K, ptr(out2), ptr(dW), ptr(dX),
+             ptr(ws), stream())
+        ctx.save_for_backward(dW, dX)
+        ctx.w = (float(w_normal), float(w_seg))
+        ctx.mark_non_differentiable(match, mask)
+        ctx.set_materialize_grads(False)
+        out3 = torch.stack([w_seg * out2[1] + w_normal * out2[0], out2[0], out2[1]])
+        return out3, match, mask
+
+    @staticmethod
+    def backward(ctx, gout, gmatch, gmask):
+        dW, dX = ctx.saved_tensors
+        if gout is None:
+            return (None,) * 6
+        w_normal, w_seg = ctx.w
+        return dW * (gout[0] * w_seg + gout[2]), dX * (gout[0] * w_normal + gout[1]), None, None, None, None
+
+
+def all_losses(W, X, normals_gt, I_gt, w_normal, w_seg):
+    """-> (out3 = [total, normal, miou], matching_indices (B,K) int64, mask (B,K) bool); K in {2, 4, 8}."""
+    _lib.require_device(W, X, normals_gt, I_gt)
+    out3, match, mask = _AllLosses.apply(W, X, normals_gt, I_gt, w_normal, w_seg)
+    return out3, match, mask.bool()

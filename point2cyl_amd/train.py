@@ -204,6 +204,9 @@ def _main(a, rank, world, local, dev, stream):
     B = min(a.batch_size, len(data))
     opt = optim.Adam(model.parameters(), lr=a.learning_rate)    # train…:204; one launch for all 123 tensors (point2cyl_amd/optim.py)
     sync = ddp.FlatGradSync(model.parameters(), world)
+    if a.no_graph:
+        from . import autograph
+        autograph.ENABLED = False                            # --no_graph means every kernel launched from Python, also inside backbone.forward
     run = Runner(model, opt, sync, fl, dev, B, a.num_point, a.K, use_graph=not a.no_graph, prefetch=not a.no_prefetch, stream=stream)
     log = None
     if rank == 0:

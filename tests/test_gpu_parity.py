@@ -1451,3 +1451,43 @@ def test_fitting_properties_at_config4_size():
     np.testing.assert_allclose(ext_f.cpu().numpy()[..., 0], -ext.cpu().numpy()[..., 1], rtol=0, atol=1e-6)
     np.testing.assert_allclose(ext_f.cpu().numpy()[..., 1], -ext.cpu().numpy()[..., 0], rtol=0, atol=1e-6)
     assert float((ext[..., 1] - ext[..., 0]).min()) >= 0.0
+
+
+@pytest.mark.parametrize("K", [2, 4, 8])
+def test_compute_all_losses_fused_equals_torch_expressions(K):
+    """losses.compute_all_losses (losses.py:317-351) on its own inputs (W softmaxed, X unit): the three-launch route of csrc/loss.hip
+    (ops.all_losses: what the drop-in hands an unchanged trainer) against the torch expressions of the same module and against the oracle:
+    matching bit-exact, the three scalars at 1e-6, d total / d W and d total / d X at 1e-6 of their largest element - also when the
+    caller differentiates the logged normal / mIoU scalars themselves, and with a cloud that has background points and missing labels."""
+    from point2cyl_amd import losses
+    torch.manual_seed(K)
+    B, N = 5, 1500
+    I = torch.randint(0, K, (B, N), device=DEV)
+    I[0, :200] = -1                                   # background points
+    I[1][I[1] == K - 1] = 0                            # a label that does not occur
+    if K > 2:
+        I[2][I[2] == 1] = 0                            # a hole below max(I_gt)
+    Xg = F.normalize(torch.randn(B, N, 3, device=DEV), dim=-1)
+
+    def run(fused, weights=(1.0, 1.0, 0.0, 0.0)):
+        losses.FUSED_ALL_LOSSES = fused
+        try:
+            torch.manual_seed(100 + K)
+            Wl = torch.randn(B, N, K, device=DEV, requires_grad=True)
+            Xr = torch.randn(B, N, 3, device=DEV, requires_grad=True)
+            W, X = torch.softmax(Wl, -1), F.normalize(Xr, dim=-1)
+            tot, ln, lm, match, mask = losses.compute_all_losses(None, W, I, X, Xg, 0.7, 1.3, return_match_indices=True)
+            (weights[0] * tot + weights[2] * ln + weights[3] * lm).backward()
+            return [float(tot), float(ln), float(lm)], match.cpu(), mask.cpu(), Wl.grad.clone(), Xr.grad.clone(), W.detach(), X.detach()
+        finally:
+            losses.FUSED_ALL_LOSSES = True
+
+    for weights in ((1.0, 1.0, 0.0, 0.0), (0.5, 0.0, 2.0, -1.5)):
+        a, b = run(True, weights), run(False, weights)
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        np.testing.assert_allclose(a[0], b[0], rtol=2e-6, atol=1e-7)
+        for ga, gb in ((a[3], b[3]), (a[4], b[4])):
+            assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max()) + 1e-12
+    ro = R.compute_all_losses(a[5].cpu(), I.cpu(), a[6].cpu(), Xg.cpu(), 0.7, 1.3)
+    np.testing.assert_allclose(a[0], [float(ro[0]), float(ro[1]), float(ro[2])], rtol=1e-5, atol=1e-7)
+    assert torch.equal(a[1], ro[3]) and torch.equal(a[2].bool(), ro[4].bool())

@@ -255,3 +255,45 @@ def test_h5py_file_source_when_available(tmp_path):
     item = ds[1]
     for j, v in enumerate(item):
         assert np.array_equal(np.asarray(v), g["sk_0:%d" % j])
+
+
+def test_dropin_falls_through_to_the_shadowed_reference_module(tmp_path):
+    """A drop-in `data_utils` / `losses` / `global_variables` shadows the whole reference module: names it does not override (eval.py
+    --is_visu needs visualize_segmentation_pc / visualize_segmentation_pc_bb_v2, eval.py:659-664; star-imports also leak the module's own
+    imports) must keep coming from the module it shadows, and the launcher must put the drop-ins IN FRONT of the script's directory
+    (python puts the script's directory before PYTHONPATH).  A fake reference tree stands in for /root/reference."""
+    ref = tmp_path / "fakeref"
+    ref.mkdir()
+    (ref / "global_variables.py").write_text("g_zero_tol = 123.0\nOTHER_CONSTANT = 7\n")
+    (ref / "data_utils.py").write_text(
+        "import json\nfrom global_variables import *\n"
+        "def estimate_extrusion_axis(*a, **k):\n    return 'reference axis'\n"
+        "def visualize_segmentation_pc(model_id, *a):\n    return 'reference visu ' + str(model_id) + ' ' + _helper()\n"
+        "def visualize_segmentation_pc_bb_v2(*a):\n    return 'reference visu v2'\n"
+        "def _helper():\n    return 'h%d' % OTHER_CONSTANT\n")
+    (ref / "losses.py").write_text(
+        "import numpy as np\nfrom global_variables import *\n"
+        "def hungarian_matching(*a, **k):\n    return 'reference matching'\n"
+        "def get_sketch_loss(a, b):\n    return 'reference sketch loss'\n")
+    (ref / "broken").mkdir()
+    (ref / "script.py").write_text(
+        "import sys\nfrom global_variables import *\nfrom data_utils import *\nfrom losses import *\n"
+        "import data_utils, losses\n"
+        "assert 'point2cyl_amd' in estimate_extrusion_axis.__module__, estimate_extrusion_axis.__module__\n"
+        "assert 'point2cyl_amd' in hungarian_matching.__module__\n"
+        "assert g_zero_tol == 1e-6 and OTHER_CONSTANT == 7\n"
+        "assert visualize_segmentation_pc('m', 1, 2) == 'reference visu m h7'\n"
+        "assert visualize_segmentation_pc_bb_v2() == 'reference visu v2' and get_sketch_loss(0, 0) == 'reference sketch loss'\n"
+        "assert json.dumps([1]) == '[1]' and np.zeros(1).shape == (1,)      # the shadowed modules' own imports leak through the star-import\n"
+        "assert data_utils.__p2c_shadowed__.endswith('fakeref/data_utils.py') and sys.argv[1:] == ['--flag', '3']\n"
+        "print('fallthrough ok')\n")
+    out = subprocess.run([sys.executable, "-m", "point2cyl_amd.dropin.run", str(ref / "script.py"), "--flag", "3"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and "fallthrough ok" in out.stdout, out.stderr + out.stdout
+    # a shadowed module whose out-of-scope dependency is missing: one warning, the hot-path names still resolve
+    (ref / "data_utils.py").write_text("import a_module_that_is_not_installed_anywhere\n")
+    (ref / "script2.py").write_text("import warnings\nwith warnings.catch_warnings(record=True) as w:\n    warnings.simplefilter('always')\n"
+                                    "    from data_utils import *\nassert any('could not be imported' in str(x.message) for x in w)\n"
+                                    "assert callable(estimate_extrusion_axis)\nprint('degraded ok')\n")
+    out = subprocess.run([sys.executable, "-m", "point2cyl_amd.dropin.run", str(ref / "script2.py")], cwd=ROOT, capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0 and "degraded ok" in out.stdout, out.stderr + out.stdout

@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 
-def cpu_fitting_legs(w, E_dev, cen_dev, ext_dev, E64_dev, literal_clouds=2):
+def cpu_fitting_legs(w, E_dev, cen_dev, ext_dev, E64_dev, literal_clouds=2, thread_counts=None):
     """The oracle side of configs[3] on workload `w` (measure.FittingWorkload): float64 closed form on all clouds (the parity yardstick),
     the fp32 closed form timed at three thread counts, the literal diag_embed form on a small subset.  -> (cpu_baseline dict, parity dict)."""
     from oracle import ref_torch as R
@@ -37,7 +37,7 @@ def cpu_fitting_legs(w, E_dev, cen_dev, ext_dev, E64_dev, literal_clouds=2):
     host = os.cpu_count() or 1
     timings = {}
     E_cpu = None
-    for thr in sorted({host, min(32, host), 1}, reverse=True):
+    for thr in sorted(set(thread_counts or (host, min(32, host), 1)) | {1}, reverse=True):
         torch.set_num_threads(thr)
         sl = slice(None) if thr > 1 else slice(0, max(1, n // 10))          # one thread: a tenth of the clouds, scaled
         t0 = time.perf_counter()

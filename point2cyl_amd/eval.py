@@ -233,7 +233,7 @@ def main(argv=None):
         ds = synth.SyntheticExtrusionDataset(a.synthetic, a.num_point, a.K, seed=99991)
     else:
         from .h5data import AutodeskH5, dataset_path
-        ds = AutodeskH5(dataset_path(a.data_dir, a.data_split), a.num_point, a.K)
+        ds = AutodeskH5(dataset_path(a.data_dir, a.data_split), a.num_point, a.K, center=True)
     lo, hi = ddp.shard_range(len(ds), rank, world)                               # clouds are independent: shard, no data-path collective
     loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=a.batch_size, num_workers=0, pin_memory=True,
                                          shuffle=a.data_split != "test")

@@ -9,7 +9,9 @@ on the file schema utils.py:1174-1188 / :1251-1268 writes (float32 `point_cloud`
 Same constructor flags, same item tuples in the same order for every flag combination, same RNG draws in the same order
 (`torch.randperm(P)` for the cloud, then `torch.randperm(S)` for the sketches), so a seeded reference run and a seeded run here see
 the same items.  The arrays come through a 3-line source protocol - anything with `keys()` and `obj[name][:]`:
-  * a path ending in .h5 / .hdf5  -> `h5py.File` (when h5py is importable; it is not in the build image, the authors' release is on no box),
+  * a path ending in .h5 / .hdf5  -> `h5py.File` when h5py is importable, else `point2cyl_amd.h5min.H5File`: a pure-numpy reader of the
+                                     format the reference writes (gzip-chunked datasets, utils.py:1174-1188), checked against files made by
+                                     the real library (tests/golden/autodesk_schema_*.h5),
   * a path ending in .npz         -> `numpy.load` (the same arrays exported once with numpy),
   * a dict of arrays              -> an in-memory "file" (tests; the fixture made from the imported reference dataloader).
 """
@@ -28,25 +30,22 @@ def open_arrays(source):
         return np.load(path)
     try:
         import h5py
-    except ImportError as e:
-        raise RuntimeError("reading %s needs h5py, which is not installed here; export the file's datasets with numpy.savez and pass the "
-                           ".npz instead (same names)" % path) from e
+    except ImportError:
+        from .h5min import H5File          # the pure-numpy reader of the file format the reference's preprocessing writes (gzip-chunked datasets)
+        return H5File(path)
     return h5py.File(path, "r")
 
 
 def dataset_path(data_dir, split):
-    """<data_dir>/<split>.h5 when h5py can read it, else <data_dir>/<split>.npz (the same arrays exported with numpy)."""
+    """<data_dir>/<split>.h5 (read through h5py when it is installed, through point2cyl_amd.h5min otherwise), else <data_dir>/<split>.npz
+    (the same arrays exported with numpy)."""
     import os
     h5, npz = os.path.join(data_dir, split + ".h5"), os.path.join(data_dir, split + ".npz")
-    try:
-        import h5py  # noqa: F401
-        if os.path.exists(h5):
-            return h5
-    except ImportError:
-        pass
+    if os.path.exists(h5):
+        return h5
     if os.path.exists(npz):
         return npz
-    raise SystemExit("no dataset at %s (needs h5py) or %s; use --synthetic N" % (h5, npz))
+    raise SystemExit("no dataset at %s or %s; use --synthetic N" % (h5, npz))
 
 
 def _load(source, op, center, extent, sketches):
@@ -99,7 +98,7 @@ class _Base(torch.utils.data.Dataset):
             sel = torch.arange(P)
         else:
             if P < self.npoints:
-                print("ERROR. Sampling more points than point cloud resolution.")
+                print("ERROR. Sampling more points than point cloud resolution.")       # dataloader.py:72-73 prints and goes on: the item is short
             sel = torch.randperm(P)[: self.npoints]
         lab = self.extrusion_labels[index][sel]
         head = (self.pcs[index][sel, :], self.normals[index][sel, :], lab, self.bb_labels[index][sel],
@@ -111,9 +110,10 @@ class _Base(torch.utils.data.Dataset):
 class AutodeskH5(_Base):
     """`AutodeskDataset_h5(filename, num_points, max_instances, op=False, center=False, extent=False)`.  Item = the 8 base fields
     [+ per-point operation] [+ centers (K,3)] [+ extents] in the reference's order (dataloader.py:87-123).
-    The trainers construct it with center=True (train_Point2Cyl_without_sketch.py:168): the 9-tuple synth.SyntheticExtrusionDataset mimics."""
+    Defaults as the reference's (center=False: 8 fields); the trainers pass center=True (train_Point2Cyl_without_sketch.py:168): the
+    9-tuple synth.SyntheticExtrusionDataset mimics."""
 
-    def __init__(self, source, num_points, max_instances, op=False, center=True, extent=False):
+    def __init__(self, source, num_points, max_instances, op=False, center=False, extent=False):
         self._common_init(_load(source, op, center, extent, False), num_points, max_instances, op, center, extent)
 
     def __getitem__(self, index):

@@ -97,7 +97,7 @@ def load_dataset(a, rank=0):
     if a.synthetic > 0:
         return synth.SyntheticExtrusionDataset(a.synthetic, a.num_point, a.K, seed=1234), False
     from .h5data import AutodeskH5, dataset_path
-    return AutodeskH5(dataset_path(a.data_dir, a.data_split), None, a.K), True
+    return AutodeskH5(dataset_path(a.data_dir, a.data_split), None, a.K, center=True), True
 
 
 class Runner:

@@ -657,3 +657,38 @@ def test_dropin_trainer_step_equals_native_step_and_trains():
         # it (train...:207, :357-360) and the momentum is a kernel argument
         assert len(autograph._state(st.model)["graphs"]) == 2
         autograph.reset(st.model)
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_reference_made_checkpoint_loads_and_evaluates(mode, tmp_path):
+    """SURVEY 8(f) rank 4 / eval.py:206-210: `tests/golden/ref_ckpt_3steps.pth` was written by the REFERENCE module (oracle/make_golden_ckpt.py:
+    pe.backbone trained for three Adam steps, saved as {"model": state_dict} like train...:405-410).  Loaded here the way eval.py loads it,
+    the backbone must reproduce the reference module's forward with that checkpoint (fixture G16: FPS starts and dropout mask recorded) -
+    eval mode (running statistics from the file) and train mode; then the evaluation CLI runs on it end to end (--ckpt)."""
+    g = load_golden("g16_ref_ckpt_forward")
+    ck = torch.load(os.path.join(ROOT, "tests", "golden", "ref_ckpt_3steps.pth"), map_location="cpu")
+    assert list(ck) == ["model"] and list(ck["model"].keys()) == [str(k) for k in g["keys"]] and len(ck["model"]) == 123
+    m = backbone(output_sizes=[3, 16]).to(DEV)
+    missing = m.load_state_dict(ck["model"])                                     # strict: same 123 keys and shapes
+    assert not missing.missing_keys and not missing.unexpected_keys
+    assert [int(v) for k, v in m.state_dict().items() if k.endswith("num_batches_tracked")] == [int(v) for v in g["nbt"]] and int(g["nbt"][0]) == 3
+    m.eval() if mode == "eval" else m.train()
+    B, N = g["pcs"].shape[:2]
+    dm = np.unpackbits(g["dropout_mask_bcn"])[:B * 128 * N].reshape(B, 128, N)
+    m.dropout_mask = torch.from_numpy(dm).permute(0, 2, 1).contiguous()
+    m.sa1.fps_start, m.sa2.fps_start = t(g[mode + ":start1"]), t(g[mode + ":start2"])
+    with torch.no_grad():
+        X, W_raw = m(cu(g["pcs"]))
+    np.testing.assert_allclose(X.cpu().numpy(), g[mode + ":X"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(W_raw.cpu().numpy(), g[mode + ":W_raw"], rtol=1e-4, atol=1e-4)
+    assert torch.equal(W_raw.argmax(-1).cpu(), t(g[mode + ":W_raw"]).argmax(-1))
+    if mode == "train":
+        return
+    # the evaluation script on the upstream-made file
+    import shutil
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "ref_ckpt_3steps.pth"), str(tmp_path / "model.pth"))
+    out = subprocess.run([sys.executable, "-m", "point2cyl_amd.eval", "--logdir", str(tmp_path), "--ckpt", "model.pth", "--synthetic", "8",
+                          "--batch_size", "4", "--num_point", "1024", "--dump_dir", str(tmp_path / "dump")], cwd=ROOT, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "mIoU" in out.stdout or "miou" in out.stdout.lower(), out.stdout[-1500:]

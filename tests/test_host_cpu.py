@@ -239,22 +239,57 @@ def test_dataset_readers_match_the_reference_dataloader(tmp_path):
     assert it[0].shape == (96, 3) and np.array_equal(it[0], f["point_cloud"][0]) and it[9].shape == (8, 16, 4)
 
 
-def test_h5py_file_source_when_available(tmp_path):
-    """The same readers on a real HDF5 file written with the reference's schema (utils.py:1174-1188) - only where h5py exists."""
-    h5py = pytest.importorskip("h5py", reason="h5py is not installed in this image (the readers are covered through the dict / .npz sources)")
-    from tests.conftest import load_golden
-    from point2cyl_amd.h5data import AutodeskH5Sketches
-    g = load_golden("g15_dataloader")
-    path = str(tmp_path / "t.h5")
-    with h5py.File(path, "w") as fh:
-        for k in g:
-            if k.startswith("file:"):
-                fh.create_dataset(k[5:], data=g[k])
-    ds = AutodeskH5Sketches(path, 32, 16, 8, center=True)
-    torch.manual_seed(250)
-    item = ds[1]
-    for j, v in enumerate(item):
-        assert np.array_equal(np.asarray(v), g["sk_0:%d" % j])
+def test_h5min_reads_files_written_by_the_real_hdf5_library():
+    """point2cyl_amd/h5min.py against HDF5 files made by the real library (oracle/make_golden_h5.py: h5py 3.3 / HDF5 1.10.6, the
+    create_dataset calls of utils.py:1174-1188 / :1251-1268 - gzip-chunked float32 / int datasets) and a file of other layouts (contiguous,
+    a chunk index with two B-tree levels, shuffle + gzip + fletcher32, ragged edge chunks, a group B-tree with several leaves, float64 /
+    int32 / uint8): every dataset name, shape, dtype and value."""
+    from point2cyl_amd.h5min import H5File
+    G = os.path.join(ROOT, "tests", "golden")
+    for stem, n in (("autodesk_schema_small", 10), ("autodesk_schema_sketches", 12), ("h5min_layouts", 47)):
+        ref = np.load(os.path.join(G, stem + "_arrays.npz"))
+        with H5File(os.path.join(G, stem + ".h5")) as f:
+            assert sorted(f.keys()) == sorted(ref.files) and len(ref.files) == n
+            for k in ref.files:
+                a = f[k][:]
+                assert a.shape == ref[k].shape and a.dtype == ref[k].dtype and np.array_equal(a, ref[k]), (stem, k)
+            assert "point_cloud" in f or stem == "h5min_layouts"
+    with pytest.raises(ValueError):
+        H5File(os.path.join(G, "autodesk_schema_small_arrays.npz"))
+
+
+def test_h5_file_source_through_the_dataset_classes(tmp_path):
+    """The `.h5` branch of h5data.open_arrays on REAL files of the reference's schema (h5py when importable, h5min otherwise): the dataset
+    classes return, item for item under the same seed, what they return on the same arrays through the dict source; dataset_path finds the
+    file; the trainers' center=True 9-tuple and the reference's default 8-tuple (AutodeskDataset_h5(f, n, K): center=False)."""
+    import shutil
+    from point2cyl_amd.h5data import AutodeskH5, AutodeskH5Sketches, dataset_path
+    G = os.path.join(ROOT, "tests", "golden")
+    shutil.copy(os.path.join(G, "autodesk_schema_small.h5"), str(tmp_path / "train.h5"))
+    path = dataset_path(str(tmp_path), "train")
+    assert path.endswith("train.h5")
+    arrays = dict(np.load(os.path.join(G, "autodesk_schema_small_arrays.npz")))
+    for kw in (dict(), dict(center=True), dict(op=True, center=True, extent=True)):
+        a, b = AutodeskH5(path, 64, 8, **kw), AutodeskH5(arrays, 64, 8, **kw)
+        assert len(a) == len(b) == 6
+        for idx in (0, 5):
+            torch.manual_seed(7 + idx)
+            ia = a[idx]
+            torch.manual_seed(7 + idx)
+            ib = b[idx]
+            assert len(ia) == len(ib) == 8 + len([k for k in ("op", "center", "extent") if kw.get(k)])
+            for u, v in zip(ia, ib):
+                assert np.array_equal(np.asarray(u), np.asarray(v))
+    sk_arrays = dict(np.load(os.path.join(G, "autodesk_schema_sketches_arrays.npz")))
+    a = AutodeskH5Sketches(os.path.join(G, "autodesk_schema_sketches.h5"), 64, 32, 8, center=True, with_scale=True)
+    b = AutodeskH5Sketches(sk_arrays, 64, 32, 8, center=True, with_scale=True)
+    torch.manual_seed(3)
+    ia = a[2]
+    torch.manual_seed(3)
+    ib = b[2]
+    assert len(ia) == 11 and ia[9].shape == (8, 32, 4)
+    for u, v in zip(ia, ib):
+        assert np.array_equal(np.asarray(u), np.asarray(v))
 
 
 def test_dropin_falls_through_to_the_shadowed_reference_module(tmp_path):

@@ -256,6 +256,9 @@ class backbone(nn.Module):
         else:   # F.dropout(p=0.5) is ALWAYS on in the reference, also in eval (pointnet_extrusion.py:60).
             # The keep-mask is never stored: the kernels regenerate it from (seed, element index); the seed is a
             # device counter drawn once from torch's generator and advanced per forward (HIP-graph safe).
+            if abs(self.dropout_p * 256.0 - round(self.dropout_p * 256.0)) > 1e-6:
+                raise ValueError("dropout_p = %r: the in-kernel hashed mask realises drop probabilities in steps of 1/256 only (csrc/common.h); "
+                                 "the reference's value is 0.5 (pointnet_extrusion.py:60)" % self.dropout_p)
             if self._drop_seed is None or self._drop_seed.device != x.device:
                 self._drop_seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(x.device)
             self._drop_seed += 0x9E3779B97F4A7C15 % (2 ** 62)

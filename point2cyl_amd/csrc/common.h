@@ -81,6 +81,16 @@ __device__ __forceinline__ bool p2c_keep(uint32_t seed_lo, uint32_t seed_hi, uin
 {
     return p2c_keep4(p2c_hash32(seed_lo, seed_hi, e >> 2), (int)(e & 3u), thr);
 }
+// The hashed mask compares ONE BYTE with the top byte of the threshold, so only drop probabilities that are multiples of 1/256 are realised
+// exactly; with any other p the keep-scale 1/(1-p) would no longer match the realised keep rate and the expectation would be biased.  The
+// entry points that take a hashed mask refuse such a scale (P2C_EINVAL) instead of training on a biased dropout.
+static inline bool p2c_drop_scale_representable(float scale)
+{
+    if (!(scale >= 1.0f)) return false;
+    const double p256 = (1.0 - 1.0 / (double)scale) * 256.0;
+    const double r = p256 - (double)(long long)(p256 + 0.5);
+    return (r < 0 ? -r : r) < 1e-4 && p256 < 255.5;
+}
 static inline uint32_t p2c_drop_threshold(float scale)     // scale = 1/(1-p)  ->  p * 2^32
 {
     double p = 1.0 - 1.0 / (double)scale;

@@ -753,7 +753,7 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
     if (!X || !W || !Y || M <= 0 || N <= 0 || K <= 0 || in_mode < 0 || in_mode > 3) return P2C_EINVAL;
     if (in_mode >= 1 && (!in_scale || !in_shift)) return P2C_EINVAL;
     if (in_mode == 2 && (!drop_mask || (ldmask & 3) || ((uintptr_t)drop_mask & 3))) return P2C_EINVAL;
-    if (in_mode == 3) { if (!drop_mask) return P2C_EINVAL; ldmask = (int)p2c_drop_threshold(drop_scale); }
+    if (in_mode == 3) { if (!drop_mask || !p2c_drop_scale_representable(drop_scale)) return P2C_EINVAL; ldmask = (int)p2c_drop_threshold(drop_scale); }
     if (K & 3) return P2C_EALIGN;
     P2C_REQ_ALIGNED(X, ldx);
     P2C_REQ_ALIGNED(W, ldw);
@@ -933,7 +933,7 @@ extern "C" int p2c_linear_bwd_weight_f32(const float *dZ, int lddz, const float 
                                          void *stream)
 {
     if (!dZ || !X || !dW || M <= 0 || N <= 0 || K <= 0 || grad_mode < 0 || grad_mode > 2 || in_mode < 0 || in_mode > 3) return P2C_EINVAL;
-    if (in_mode == 3) { if (!drop_mask) return P2C_EINVAL; ldmask = (int)p2c_drop_threshold(drop_scale); }
+    if (in_mode == 3) { if (!drop_mask || !p2c_drop_scale_representable(drop_scale)) return P2C_EINVAL; ldmask = (int)p2c_drop_threshold(drop_scale); }
     if (grad_mode >= 1 && (!Yfwd || !coef)) return P2C_EINVAL;
     if (grad_mode == 2 && (!pool_arg || pool_ns <= 0 || ((uintptr_t)pool_arg & 15))) return P2C_EINVAL;
     if (in_mode >= 1 && (!in_scale || !in_shift)) return P2C_EINVAL;

@@ -181,6 +181,7 @@ extern "C" int p2c_linear_bwd_narrow_f32(const float *dZ, int lddz, const float 
     if (!dZ || !Y || !stat || !W || !dX || !dW8 || !partials || M <= 0) return P2C_EINVAL;
     if (!p2c_linear_bwd_narrow_supported(M, Co, Ci, seed ? 3 : 1)) return P2C_EINVAL;
     if ((ldy & 3) || ((uintptr_t)Y & 15) || ((uintptr_t)stat & 15)) return P2C_EALIGN;
+    if (seed && !p2c_drop_scale_representable(dscale)) return P2C_EINVAL;      // hashed dropout: p must be a multiple of 1/256 (common.h)
     HeadsBwdArgs a{dZ, lddz, Y, ldy, stat, (const uint32_t *)seed, seed ? p2c_drop_threshold(dscale) : 0u, dscale, W, ldw, dX, lddx, dW8, lddw,
                    dw_slot_stride, dbias, partials, M, Co};
     const int ntiles = (M + HB_BM - 1) / HB_BM;

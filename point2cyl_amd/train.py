@@ -322,11 +322,26 @@ def _main(a, rank, world, local, dev, stream):
         cur = nxt
     torch.cuda.synchronize()
     report = None
+    multi = None
+    if world > 1:
+        # what a data-parallel run has to prove: the replicas hold the SAME parameters after the last step (sum of squares in float64,
+        # gathered), followed the schedule of the global batch, and the checkpoint's BatchNorm statistics are the replicas' mean
+        with torch.no_grad():
+            ck = sum(float((p.detach().double() ** 2).sum()) for p in model.parameters())
+            bk = sum(float(b_.detach().double().sum()) for b_ in model.buffers() if b_.dtype.is_floating_point)
+        mine = torch.tensor([ck, bk, old_lr, mom_fwd], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        multi = dict(backend=ddp.backend_name(), param_checksum=[float(v) for v in allr[:, 0]], params_identical=bool((allr[:, 0] == allr[0, 0]).all()),
+                     buffer_checksum_after_averaging=[float(v) for v in allr[:, 1]], buffers_identical=bool((allr[:, 1] == allr[0, 1]).all()),
+                     learning_rate=[float(v) for v in allr[:, 2]], next_bn_momentum=[float(v) for v in allr[:, 3]],
+                     samples_per_step=B * world, allreduce_bytes=int(sync.flat.numel() * 4) if sync.flat is not None else 0)
     if t_steady is not None and steps_steady > 0:
         dt = time.perf_counter() - t_steady
         report = dict(steps=gstep, steady_steps=steps_steady, ms_per_step=dt / steps_steady * 1e3, points_per_s=world * B * a.num_point * steps_steady / dt,
                       batch_per_gpu=B, num_point=a.num_point, world=world, graph=not a.no_graph, prefetch=run.prefetch, graph_captures=run.captures,
-                      per_step_log_sync=not a.quiet, epoch_means={k: v for k, v in scal.items()})
+                      per_step_log_sync=not a.quiet, epoch_means={k: v for k, v in scal.items()}, multi_gpu=multi)
         if rank == 0:
             print("trainer throughput: %.3f ms/step, %.1f points/s over %d steady steps (%d graph captures)" %
                   (report["ms_per_step"], report["points_per_s"], steps_steady, run.captures))

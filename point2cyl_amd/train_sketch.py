@@ -193,12 +193,19 @@ def _main(a, rank, world, dev):
         # train_Point2Cyl.py:215: AutodeskDataset_h5_sketches(H5_FILENAME, NUM_POINT, NUM_SK_POINT, K, op=False, center=True, extent=False).
         # The resident loader keeps every cloud whole (the per-step subsample is drawn on the device); the sketches come with it
         from .h5data import AutodeskH5Sketches, dataset_path
-        ds = AutodeskH5Sketches(dataset_path(a.data_dir, a.data_split), None, S, K, op=False, center=True, extent=False)
+        # and are kept WHOLE as well: the reference redraws its num_sk_point subset on every access (dataloader.py:211-214), so the
+        # subset is drawn per step on the device below, not frozen at load time
+        ds = AutodeskH5Sketches(dataset_path(a.data_dir, a.data_split), None, None, K, op=False, center=True, extent=False)
+        if ds.pcs.shape[1] < N:
+            raise SystemExit("--num_point %d exceeds the %d points per cloud of the dataset (the reference prints an error and returns short "
+                             "items, dataloader.py:72-73; the static-shape trainer refuses)" % (N, ds.pcs.shape[1]))
+        if ds.sketches.shape[2] < S:
+            raise SystemExit("--num_sk_point %d exceeds the %d points per sketch of the dataset" % (S, ds.sketches.shape[2]))
         file_sketches = True
     lo, hi = ddp.shard_range(len(ds), rank, world)
     if file_sketches:
         items = [ds[i] for i in range(lo, hi)]
-        file_sketches = torch.from_numpy(np.stack([np.asarray(it[9]) for it in items])).to(dev, torch.float)        # (n, K, S, 4)
+        file_sketches = torch.from_numpy(np.stack([np.asarray(it[9]) for it in items])).to(dev, torch.float)        # (n, K, S_all, 4)
 
         class _Nine(torch.utils.data.Dataset):          # the 9 fields of the sketch-free item (the sketch is item 9)
             def __len__(self):
@@ -234,6 +241,9 @@ def _main(a, rank, world, dev):
             it = data.gather(idx)
             pcs, nrm, inst, bb, axes, cen = it[0], it[1], it[2], it[3], it[6], it[8]
             gt_sk = sketches.index_select(0, idx)
+            if gt_sk.shape[2] != S:          # dataset sketches: a fresh num_sk_point subset per item and step (dataloader.py:211-214), drawn on the device
+                sel = torch.rand(B, gt_sk.shape[2], device=dev).argsort(dim=1)[:, :S]
+                gt_sk = torch.gather(gt_sk, 2, sel.view(B, 1, S, 1).expand(B, K, S, 4))
             if a.add_noise:
                 pcs = pcs + torch.randn(B, N, 1, device=dev) * a.noise_sigma * nrm
             step.update_momentum(model, mom_fwd)
@@ -268,8 +278,9 @@ def _main(a, rank, world, dev):
                                                           use_whole_pc=a.use_whole_pc, W_encoder=W_enc, axis_feat=ax_feat)
                 total = (out["total"] + sk["im_loss"]) if a.is_pc_train else sk["im_loss"]                    # :690-693
                 sync.zero()
-                mom_fwd = step.get_batch_norm_decay(gstep, B, a.bn_decay_step)                                # :698-701 (reaches the next forward)
-                lr = step.get_learning_rate(a.learning_rate, gstep, B, a.decay_step, a.decay_rate)             # :703-706: group 0 only
+                # the staircases count SAMPLES: under data parallelism a step consumes world * B of them (as point2cyl_amd.train does)
+                mom_fwd = step.get_batch_norm_decay(gstep, B * world, a.bn_decay_step)                        # :698-701 (reaches the next forward)
+                lr = step.get_learning_rate(a.learning_rate, gstep, B * world, a.decay_step, a.decay_rate)     # :703-706: group 0 only
                 if old_lr != lr:
                     opt.param_groups[0]["lr"] = lr
                     old_lr = lr

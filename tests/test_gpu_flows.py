@@ -679,9 +679,16 @@ def test_reference_made_checkpoint_loads_and_evaluates(mode, tmp_path):
     m.sa1.fps_start, m.sa2.fps_start = t(g[mode + ":start1"]), t(g[mode + ":start2"])
     with torch.no_grad():
         X, W_raw = m(cu(g["pcs"]))
-    np.testing.assert_allclose(X.cpu().numpy(), g[mode + ":X"], rtol=1e-4, atol=1e-4)
-    np.testing.assert_allclose(W_raw.cpu().numpy(), g[mode + ":W_raw"], rtol=1e-4, atol=1e-4)
-    assert torch.equal(W_raw.argmax(-1).cpu(), t(g[mode + ":W_raw"]).argmax(-1))
+    # eval mode (statistics from the file): 1e-4.  Train mode normalises 17 layers with the statistics of TWO clouds - the chain the G5
+    # fixture shows the reference's own fp32 run to be 1.0e-4 .. 1.6e-4 away from its float64 twin on: 3e-4 (measured here: 1.3e-4 on 4 of
+    # 6144 values), labels equal wherever the reference's two largest logits are more than 1e-3 apart
+    tol = 1e-4 if mode == "eval" else 3e-4
+    np.testing.assert_allclose(X.cpu().numpy(), g[mode + ":X"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(W_raw.cpu().numpy(), g[mode + ":W_raw"], rtol=tol, atol=tol)
+    ref_w = t(g[mode + ":W_raw"])
+    top2 = ref_w.topk(2, dim=-1).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-3
+    assert torch.equal(W_raw.argmax(-1).cpu()[clear], ref_w.argmax(-1)[clear]) and float(clear.float().mean()) > 0.99
     if mode == "train":
         return
     # the evaluation script on the upstream-made file
@@ -692,3 +699,36 @@ def test_reference_made_checkpoint_loads_and_evaluates(mode, tmp_path):
                          timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "mIoU" in out.stdout or "miou" in out.stdout.lower(), out.stdout[-1500:]
+
+
+def test_trainer_cli_two_ranks_on_one_gpu_over_gloo(tmp_path):
+    """point2cyl_amd.train as a data-parallel job: two ranks that share this GPU (P2C_ONE_GPU_RANKS: gloo instead of RCCL; the 8-GPU run uses
+    the same code with backend nccl), 16 synthetic shapes sharded 8 + 8, B = 2 per rank, 4 steps through the HIP-graph path.
+    After the last step: the replicas hold identical parameters (sum of squares in float64), both followed the schedules of the GLOBAL batch
+    (world * B samples per step: with --decay_step 8 / --bn_decay_step 8 the staircases move after every second step - a rank counting its
+    own B = 2 would be one stair behind), and the checkpoint rank 0 wrote carries the MEAN of the replicas' BatchNorm statistics."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(P2C_ONE_GPU_RANKS="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
+    rep = str(tmp_path / "report.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "point2cyl_amd.train", "--pred_seg", "--pred_normal", "--pred_bb", "--synthetic", "16", "--batch_size", "2", "--num_point", "1024",
+           "--num_epochs", "1", "--max_steps", "4", "--decay_step", "8", "--bn_decay_step", "8", "--logdir", str(tmp_path / "run"), "--report", rep, "--quiet"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.load(open(rep))
+    mg = r["multi_gpu"]
+    assert r["world"] == 2 and r["steps"] == 4 and r["graph"] and mg["backend"] == "gloo" and mg["samples_per_step"] == 4
+    assert mg["params_identical"] and mg["param_checksum"][0] == mg["param_checksum"][1] > 0
+    assert mg["buffers_identical"], "the BatchNorm statistics in the checkpoint are the mean over the replicas (ddp.average_buffers)"
+    # schedules of the global batch: after 4 steps of 4 samples gstep * B * world / 8 = floor(3 * 4 / 8) = 1 stair for the last lr set
+    # (get_learning_rate(gstep = 3)) and floor(3 * 4 / 8) = 1 for the momentum that reaches the next forward
+    assert mg["learning_rate"] == [pytest.approx(1e-3 * 0.7)] * 2, mg["learning_rate"]
+    assert mg["next_bn_momentum"] == [pytest.approx(0.25)] * 2, mg["next_bn_momentum"]
+    assert mg["allreduce_bytes"] == 4 * 1404243
+    ck = torch.load(str(tmp_path / "run" / "model.pth"), map_location="cpu")["model"]
+    assert len(ck) == 123 and int(ck["bn1.num_batches_tracked"]) == 4
+    assert all(torch.isfinite(v).all() for v in ck.values() if v.dtype.is_floating_point)

@@ -99,7 +99,7 @@ def _cpu_all_threads_leg(cb, N, K, threads, limit_s):
             "print(json.dumps([pps, sec, thr]))\n" % (ROOT, cb, N, K, threads))
     t0 = time.perf_counter()
     try:
-        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=limit_s + 15.0)     # + import time
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=limit_s + 8.0)     # + import time
         pps, sec, thr = json.loads(out.stdout.strip().splitlines()[-1])
         return pps, sec, "one step on %d threads: %.1f s" % (thr, sec)
     except subprocess.TimeoutExpired:
@@ -356,7 +356,7 @@ def _bench(args, rank, world, local, dev):
         # finish within minutes
         ppsa, seca, thra, all_note = None, None, host, None
         if host > 32:
-            ppsa, seca, all_note = _cpu_all_threads_leg(cb, N, K, host, limit_s=25.0)
+            ppsa, seca, all_note = _cpu_all_threads_leg(cb, N, K, host, limit_s=12.0)
         else:
             ppsa, seca = pps, sec
         torch.set_num_threads(min(32, host))
@@ -370,7 +370,7 @@ def _bench(args, rank, world, local, dev):
                    single_thread_value=round(pps1, 1), all_threads_value=None if ppsa is None else round(ppsa, 1), all_threads_note=all_note,
                    sample="%d full training steps (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
                           "points (same generator as the GPU batch) on %d threads, %.1f s of CPU work; all_threads_value: 1 step of the same on "
-                          "os.cpu_count() = %d threads in a child process limited to 25 s; single_thread_value: %d step(s) on B=1 cloud with 1 "
+                          "os.cpu_count() = %d threads in a child process limited to 20 s; single_thread_value: %d step(s) on B=1 cloud with 1 "
                           "thread, %.1f s; `value` is the fastest (the step is thousands of small ops - a Python FPS loop, sorts, gathers: more "
                           "threads than ~32 only add fork/join cost)" % (nst, cb, N, thr, sec * nst, host, nst1, sec1 * nst1))
     line = dict(metric="training-step points/sec (BxN) at N=8192", value=round(value, 1), unit="points/s", n_gpus=world,

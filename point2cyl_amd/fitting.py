@@ -89,6 +89,17 @@ def fit_cylinders(X, W_barrel, W_base, gt_bb_labels, seg_label, P, num_points_to
     return (axes, cen, cfound, ext, found, a64) if return_float64 else (axes, cen, cfound, ext, found)
 
 
+def barrel_draws_on_device(seg_label, bb_labels, K, S):
+    """The sampling draws of data_utils.py:1064 / :1696 made ON THE DEVICE: uniform integers in [0, n_barrel(b,k)) for every (b, k), from
+    torch's device generator - no device->host sync (the reference's CPU draws need the K x B barrel counts on the host), so a step that uses
+    them can be captured into a HIP graph.  Not the reference's random stream (its CPU generator draws only where a segment has > 1 barrel
+    point); the projection ignores the draws of segments it does not find, and tests that need the reference's draws pass rand_idx."""
+    barrel = (seg_label.unsqueeze(-1) == torch.arange(K, device=seg_label.device)) & (bb_labels == 0).unsqueeze(-1)
+    counts = barrel.sum(dim=1)                                                             # (B,K) on the device
+    u = torch.rand(seg_label.shape[0], K, S, device=seg_label.device)
+    return torch.minimum((u * counts.unsqueeze(-1)).long(), (counts - 1).clamp_min(0).unsqueeze(-1))
+
+
 def _barrel_draws(seg_label, bb_labels, K, S):
     """The reference's torch.randint draws for its K x B sampling loops (data_utils.py:1064, :1696): k outer, b inner, only
     where the segment has > 1 barrel point in the batch and in the cloud, on the CPU generator."""

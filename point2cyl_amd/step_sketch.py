@@ -28,7 +28,7 @@ def implicit_losses(implicit_net, sk_pnts, sk_normals, nonmnfld_pnts, latent_cod
 def sketch_branch_losses(pcs, X, W, W_2K, matching_indices, mask, gt_normals, gt_extrusion_instances, gt_bb_labels, gt_extrusion_axes,
                          gt_extrusion_centers, gt_sketches, pn_encoder, loaded_pn_encoder, implicit_net, sampler, K, num_sk_point,
                          with_im_loss=True, is_l2=False, rand_idx_pred=None, rand_idx_gt=None, nonmnfld_pnts=None, use_whole_pc=False,
-                         W_encoder=None, use_gt_im=False, axis_feat=None):
+                         W_encoder=None, use_gt_im=False, axis_feat=None, device_draws=False):
     """train_Point2Cyl.py:519-672.  pcs (B,N,3); X (B,N,3) predicted normals; W (B,N,K) and W_2K (B,N,2K) the softmaxed segmentation;
     matching_indices / mask from hungarian_matching; gt_sketches (B,K,S,4) = [point | normal] of the ground-truth profiles.
     use_whole_pc: the encoder (4 input channels) sees [xyz | W_reordered[:, :, k]] of all N points per segment instead of the projected
@@ -37,9 +37,15 @@ def sketch_branch_losses(pcs, X, W, W_2K, matching_indices, mask, gt_normals, gt
     (7 input channels; the fitted axes E_AX with their history, or the ground-truth axes under use_gt_im).
     use_gt_im: the encoder input is built from the ground-truth labels (X, W, W_2K, matching_indices, mask are not read): the one-hot
     membership for use_whole_pc, else the projection of the ground-truth barrels divided by its OWN scales (:591-593).
+    device_draws: the barrel-sample draws of the projections come from the device generator (fitting.barrel_draws_on_device) instead of
+    the reference's CPU draws: no device->host sync in the step, which makes it capturable into a HIP graph.
     -> dict(im_loss, latent_loss, mnfld_loss, grad_loss, normals_loss, latent_codes)."""
     B, N, _ = pcs.shape
     S = num_sk_point
+    if device_draws and not use_whole_pc:
+        with torch.no_grad():
+            if rand_idx_gt is None:
+                rand_idx_gt = fitting.barrel_draws_on_device(gt_extrusion_instances, gt_bb_labels, K, S)
     mask_gt = losses.get_mask_gt(gt_extrusion_instances, K)
     with torch.no_grad():
         sk_pnts = gt_sketches[:, :, :, :2].reshape(B * K, S, 2)                                                          # :602-604
@@ -69,6 +75,8 @@ def sketch_branch_losses(pcs, X, W, W_2K, matching_indices, mask, gt_normals, gt
             label = torch.argmax(W_reordered, dim=-1)                                                                    # :539
             BB = torch.stack([W_2K[:, :, 0::2].sum(-1), W_2K[:, :, 1::2].sum(-1)], -1)                                   # :542-546
             pred_bb_label = torch.argmax(BB, dim=-1)
+            if device_draws and rand_idx_pred is None:
+                rand_idx_pred = fitting.barrel_draws_on_device(label, pred_bb_label, K, S)
             pred_pc, pred_nrm, _ = fitting.sketch_implicit_projection(pcs, X, label, pred_bb_label, gt_extrusion_axes, gt_extrusion_centers, S,
                                                                       rand_idx=rand_idx_pred)                            # :548
             _, _, gt_scales = fitting.sketch_implicit_projection(pcs, gt_normals, gt_extrusion_instances, gt_bb_labels, gt_extrusion_axes,

@@ -21,7 +21,8 @@ PEAK_MFMA = 157.3e12
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
+    ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no_graph", action="store_true", help="launch the step from Python (with the reference's CPU sampling draws) instead of replaying a HIP graph")
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--train_decoder", action="store_true"); a = ap.parse_args()
     from point2cyl_amd import ddp, fitting, ops, step, step_sketch, synth
     import torch.distributed as dist
@@ -30,6 +31,7 @@ def main():
     from point2cyl_amd.sketch import PointNetEncoder
     rank, world, local = ddp.init_from_env()         # one process per GPU, clouds sharded by rank, one flat gradient all-reduce per step
     dev = torch.device("cuda", local); torch.cuda.set_device(dev)
+    torch.cuda.set_stream(torch.cuda.Stream(dev))      # everything on one non-default stream (a HIP graph cannot be captured on the default one)
     B, N, K, S = a.batch, 8192, 8, 2048
     fl = step.StepFlags(K=K)
     pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=1234 + 1000 * rank)
@@ -51,23 +53,46 @@ def main():
     sync = ddp.FlatGradSync(params, world)
     opt = torch.optim.Adam(params, lr=1e-3, fused=True)
 
-    def one_step():
+    def fwd_bwd(geom=None, device_draws=False):
+        ops.step_done()
         with ops.step_arena(dev):
-            out = step.compute_losses_fused(model, *batch, fl)
+            out = step.compute_losses_fused(model, *batch, fl, geom=geom)
             h = out["heads"].view(B, N, -1)
             with torch.no_grad():
                 X = F.normalize(h[:, :, 0:3], p=2, dim=2, eps=1e-12)
                 W2K = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2)
                 W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
             sk = step_sketch.sketch_branch_losses(batch[0], X, W, W2K, out["match"], out["mask"], batch[1], batch[2], batch[3], batch[4], batch[5], gt_sk,
-                                                  enc, enc_gt, dec, sampler, K, S)
+                                                  enc, enc_gt, dec, sampler, K, S, device_draws=device_draws)
             total = out["total"] + sk["im_loss"]
             sync.zero()
             total.backward()
+            sync.pack()
+        return dict(total=total.detach(), im_loss=sk["im_loss"].detach())
+
+    graphed, launch = None, "eager"
+    if not a.no_graph:
+        # the whole forward + losses + double backward as ONE HIP graph (point2cyl_amd/graph.py, as for the without-sketch step): the geometry
+        # of the next batch on the forked stream, the projections' sample draws from the device generator (no host sync inside the step)
+        from point2cyl_amd.graph import GraphedForwardBackward
+        try:
+            graphed = GraphedForwardBackward(model, lambda geom=None: fwd_bwd(geom, device_draws=True), prefetch_xyz=batch[0],
+                                             stream=torch.cuda.current_stream())
+            launch = "hip_graph(fwd + losses + double backward, next batch's geometry on a forked stream) + eager(allreduce, adam)"
+        except Exception as e:
+            sys.stderr.write("bench_config5: HIP graph capture failed (%s: %s); running eager\n" % (type(e).__name__, e))
+            torch.cuda.set_stream(torch.cuda.Stream(dev))
+            for m_ in model.modules():
+                if hasattr(m_, "fps_start"):
+                    m_.fps_start = None
+            graphed = None
+
+    def one_step():
+        out = graphed() if graphed is not None else fwd_bwd()
         sync.allreduce()
         opt.step()
         ops.step_done()
-        return total, sk
+        return out["total"], out
 
     def fence():
         if world > 1:
@@ -82,12 +107,17 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-    ops.PROFILE.reset(enabled=rank == 0); one_step(); prof = ops.PROFILE.summary(); ops.PROFILE.enabled = False      # every rank: the step has a collective
+    if graphed is not None:
+        graphed.starts.cursor = 0
+    ops.PROFILE.reset(enabled=rank == 0); fwd_bwd(); sync.allreduce(); opt.step(); ops.step_done()      # one EAGER step for the per-kernel HIP events
+    prof = ops.PROFILE.summary(); ops.PROFILE.enabled = False                                         # (every rank: the step has a collective)
     if world > 1:
         fence()
         dist.destroy_process_group()
     if rank != 0:
         return
+    from point2cyl_amd import _lib
+    split = bool(_lib.lib().p2c_get_mfma_mode())
     gemm = {k: v for k, v in prof.items() if v["flops"] > 0}
     fl_all, ms_all = sum(v["flops"] for v in gemm.values()), sum(v["ms"] for v in gemm.values())
     print(json.dumps(dict(
@@ -96,10 +126,14 @@ def main():
         config=dict(workload="configs[4]: B=%d clouds/GPU x N=%d, K=%d, %d points per sketch; backbone + seg/normal/bb losses + projection + sketch encoder "
                              "+ implicit decoder losses (decoder %s) + latent loss; fwd + bwd (double backward through the decoder) + Adam"
                              % (B, N, K, S, "trainable" if a.train_decoder else "frozen, as in the reference's optimiser"),
-                    loss=round(float(total), 5), im_loss=round(float(sk["im_loss"]), 5)),
-        roofline=dict(bound="mfma", kernel="gemm_kernel family (all matrix products of the step)", achieved=round(fl_all / ms_all / 1e9, 2), peak=157.3,
-                      unit="TFLOP/s", frac=round(fl_all / ms_all / 1e9 / 157.3, 4), gflop_per_step=round(fl_all / 1e9, 1), gemm_ms_per_step=round(ms_all, 2),
-                      share_of_step=round(ms_all / (dt * 1e3), 3), traffic=None),
+                    loss=round(float(total), 5), im_loss=round(float(sk["im_loss"]), 5), launch=launch),
+        roofline=dict(bound="mfma", kernel="gemm_kernel family (all matrix products of the step)", achieved=round(fl_all / ms_all / 1e9, 2),
+                      peak=round(2500.0 / 6, 1) if split else 157.3, unit="TFLOP/s (fp32-equivalent)",
+                      frac=round(fl_all / ms_all / 1e9 / (2500.0 / 6 if split else 157.3), 4),
+                      frac_of_f32_mfma_peak=round(fl_all / ms_all / 1e9 / 157.3, 4), frac_of_split_ceiling=round(fl_all / ms_all / 1e9 / (2500.0 / 6), 4),
+                      mfma="bf16x3-split: six bf16 products per fp32 product, ceiling 2500 / 6 = 417 TFLOP/s" if split else "f32",
+                      gflop_per_step=round(fl_all / 1e9, 1), gemm_ms_per_step=round(ms_all, 2),
+                      share_of_step=round(ms_all / (dt * 1e3), 3), whole_step_tflops=round(fl_all / dt / 1e12, 2), traffic=None),
         kernels={k: dict(ms_per_step=round(v["ms"], 3), launches=v["launches"]) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:12]})))
 
 

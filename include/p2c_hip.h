@@ -224,7 +224,8 @@ int p2c_maxpool_bnrelu_f32(const float *Y, int ldy, const float *scale, const fl
  *   p2c_linear_fwd_pool_f32: Y and stat slots exactly as p2c_linear_fwd_f32 with in_mode 1, plus - per 32-row half of every
  *     64-row neighbourhood and column - the largest / smallest pre-BN value and their rows: pool_max, pool_min [2*M/64, N] fp32,
  *     pool_idx [2*M/64, N] int32 (row_of_max | row_of_min << 16).  Requires p2c_linear_fwd_pool_supported(M, N, K, 1, 64)
- *     (groups of exactly 64 rows, K in {64,128}, N in {128,256}, M >= 8192, M % 64 == 0);
+ *     (groups of exactly 64 rows, K in {64,128}, N in {128,256}, M >= 8192, M % 64 == 0); Y may be NULL (not stored: the layer's
+ *     backward through p2c_linear_bwd_pool_alg_f32 needs no Y);
  *   p2c_pool_select_f32: once the layer's BatchNorm affine exists, out [G,C] = max over the group of relu(scale*y + shift)
  *     (the largest pre-BN value for scale >= 0, the smallest for scale < 0), arg / ywin as p2c_maxpool_bnrelu_f32.
  *     Ties: lowest row among equal PRE-BN values (models/pointnet_util.py:205 leaves ties to torch.max). */
@@ -327,6 +328,21 @@ int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int l
                              const float *in_shift, const float *W, int ldw, float *dX, int lddx, float *dW, int lddw,
                              long long dw_slot_stride, float *dbias, const float *prev_stat, double *bwd_partials, int M, int Co,
                              int Ci, void *stream);
+
+/* Backward of the LAST layer of a set-abstraction stack (conv -> train-mode BatchNorm -> ReLU -> max over ns neighbours,
+ * pointnet_util.py:201-205) without its pre-BatchNorm output: Y = A W^T + b is linear in the layer's input A = relu(in_scale * X + in_shift),
+ * so dX = dY W = A (W^T diag(q) W) + (q*b + p) W + (gs*G) W and dW = dY^T A = (gs*G)^T A + diag(q) (W A^T A + b 1^T A) + p 1^T A, with G
+ * the pooled gradient dout [M/ns, Co] at the winner rows (pool_arg, masked where coef_scale * ywin + coef_shift <= 0).  Same results as
+ * p2c_linear_bwd_fused_f32 with grad_mode 2 (dX [M, Ci], the ReLU + BatchNorm-backward sums of the layer below in bwd_partials, dW
+ * [Co, Ci]) from half the HBM traffic; the forward need not store Y for this layer.  coef [5][Co] as p2c_maxpool_bn_bwd_stats_f32 writes
+ * it; ws: 16-byte aligned scratch of p2c_linear_bwd_pool_alg_ws_bytes(Co, Ci) bytes (no initialisation needed).  Four launches: Q and r,
+ * the main kernel, the fp64 sum of the workgroups' partial sums, the assembly of dW.  Shapes: see p2c_linear_bwd_pool_alg_supported. */
+int p2c_linear_bwd_pool_alg_supported(int M, int Co, int Ci, int ns);
+size_t p2c_linear_bwd_pool_alg_ws_bytes(int Co, int Ci);
+int p2c_linear_bwd_pool_alg_f32(const float *dout, int lddo, const float *ywin, const int32_t *pool_arg, const float *coef, const float *X, int ldx,
+                                const float *in_scale, const float *in_shift, const float *W, int ldw, const float *bias, float *dX, int lddx,
+                                const float *prev_stat, double *bwd_partials, void *ws, float *dW, int lddw, int M, int Co, int Ci, int ns,
+                                void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Extrusion-cylinder fitting  (data_utils.py:99-177, :253-266, :1650-1730; eval.py:409-436)

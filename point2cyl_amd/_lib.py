@@ -63,6 +63,8 @@ _SIGS = {
                                   c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_linear_bwd_fused_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_ll,
                                  c_p, c_p, c_p, c_i, c_i, c_i, c_p],
+    "p2c_linear_bwd_pool_alg_f32": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i,
+                                    c_p],
     "p2c_extrusion_axis_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_extrusion_axis_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_extrusion_centers_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],
@@ -132,6 +134,10 @@ def lib():
     L.p2c_hungarian_ws_bytes.restype = ctypes.c_size_t
     L.p2c_linear_bwd_narrow_supported.argtypes = [c_i, c_i, c_i, c_i]
     L.p2c_linear_bwd_narrow_supported.restype = c_i
+    L.p2c_linear_bwd_pool_alg_supported.argtypes = [c_i, c_i, c_i, c_i]
+    L.p2c_linear_bwd_pool_alg_supported.restype = c_i
+    L.p2c_linear_bwd_pool_alg_ws_bytes.argtypes = [c_i, c_i]
+    L.p2c_linear_bwd_pool_alg_ws_bytes.restype = ctypes.c_size_t
     L.p2c_fit_fused_supported.argtypes = [c_i, c_i, c_i]
     L.p2c_fit_fused_supported.restype = c_i
     L.p2c_extents_ws_bytes.argtypes = [c_i, c_i]

@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(512, 2) fwd_pp_kernel(FwdPPArgs a)
 #pragma unroll
             for (int i = 0; i < NS; ++i) o[i] = *reinterpret_cast<const v4f *>(&out[(rf0 + i * (64 / V)) * (32 * NT) + 4 * c4]);
             P2C_TR(4);
-            if (col < a.N) {
+            if (a.y != nullptr && col < a.N) {          // (POOL: Y may be absent - its backward needs no Y, csrc/bwd_pool.hip)
                 float *yp = a.y + (size_t)(m0 + wm * 32 + rf0) * a.ldy + col;
                 if (m0 + BM <= a.M) {
 #pragma unroll

@@ -294,10 +294,12 @@ __global__ void __launch_bounds__(512, 2) fwd_pp3_kernel(FwdPPArgs a)
             const int c4 = lane & 7, rf0 = lane >> 3;        // 8 float4 per block row, 8 rows per instruction
             const int ocol = j0 + wn * 32 + 4 * c4;
             v4f o[4];
+            if (a.y != nullptr) {                            // (POOL: Y may be absent - its backward needs no Y, csrc/bwd_pool.hip)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = *reinterpret_cast<const v4f *>(&out[(rf0 + 8 * i) * 32 + 4 * c4]);
+                for (int i = 0; i < 4; ++i) o[i] = *reinterpret_cast<const v4f *>(&out[(rf0 + 8 * i) * 32 + 4 * c4]);
+            }
             P2C_TR(4);
-            if (ocol < a.N) {
+            if (a.y != nullptr && ocol < a.N) {
                 float *yp = a.y + (size_t)(m0 + wm * 32 + rf0) * a.ldy + ocol;
                 if (m0 + BMH <= a.M) {
 #pragma unroll

@@ -784,7 +784,9 @@ extern "C" int p2c_linear_fwd_pool_f32(const float *X, int ldx, const float *W, 
                                        int K, const float *in_scale, const float *in_shift, double *stat_partials, float *pool_max,
                                        float *pool_min, int32_t *pool_idx, void *stream)
 {
-    if (!X || !W || !Y || !in_scale || !in_shift || !pool_max || !pool_min || !pool_idx || M <= 0) return P2C_EINVAL;
+    // Y == NULL: the pre-BatchNorm output is not stored (the statistics and the extremes are all the pooled layer's forward AND its
+    // backward through p2c_linear_bwd_pool_alg_f32 need)
+    if (!X || !W || !in_scale || !in_shift || !pool_max || !pool_min || !pool_idx || M <= 0) return P2C_EINVAL;
     if (!p2c_linear_fwd_pool_supported(M, N, K, 1, 64)) return P2C_EINVAL;
     P2C_REQ_ALIGNED(X, ldx);
     P2C_REQ_ALIGNED(W, ldw);

@@ -21,6 +21,7 @@ USE_FOLD0 = os.environ.get("P2C_FOLD0", "1") != "0"         # first layer with <
 USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated backward of the gathers (no atomics)
 USE_NARROW_BWD = os.environ.get("P2C_NARROW_BWD", "1") != "0"  # the per-point heads' backward in one pass (csrc/heads.hip)
 STRICT_LABELS = os.environ.get("P2C_STRICT_LABELS", "0") == "1"   # validate labels with a device->host sync in every loss call instead of deferred
+USE_POOL_ALG = os.environ.get("P2C_POOL_ALG", "1") != "0"    # pooled last layer's backward without its pre-BN output (csrc/bwd_pool.hip)
 USE_POOL_EPI = os.environ.get("P2C_POOL_EPI", "1") != "0"    # max over 64 neighbours from extremes emitted by the last layer's GEMM epilogue
 
 
@@ -336,6 +337,7 @@ class _MLPStack(torch.autograd.Function):
                  and (L >= 3 or (L == 2 and tail == "bnrelu")) and params[0].shape[0] == 64 and params[4].shape[0] in (64, 128)
                  and bns[0] is not None and bns[1] is not None)
         mom = None
+        mptr_free = mask is None and seed is None
         for i in range(L):
             has_bn = not (tail == "linear" and i == L - 1)
             W, b = params[pi], params[pi + 1]
@@ -377,7 +379,11 @@ class _MLPStack(torch.autograd.Function):
                 sc, sh, in_mode = st[0], st[1], 1
                 K = Co
                 continue
-            Y = torch.empty(M, Co, dtype=torch.float32, device=dev)
+            # the pooled last layer of SA1: when its backward takes the Y-free route (csrc/bwd_pool.hip) the forward does not store Y either
+            no_y = (USE_POOL_ALG and USE_POOL_EPI and tail == "maxpool" and i == L - 1 and in_mode == 1 and mptr_free and training and ldx == K
+                    and L > 1 and _lib.lib().p2c_linear_fwd_pool_supported(M, Co, K, 1, cfg["ns"])
+                    and _lib.lib().p2c_linear_bwd_pool_alg_supported(M, Co, K, cfg["ns"]))
+            Y = torch.empty(0 if no_y else M, Co, dtype=torch.float32, device=dev)
             if fold0 and i == 1:
                 partials = arena.f64(STAT_SLOTS, 2, Co)
                 call("p2c_linear_fwd_fold0_f32", ptr(X0), ldx0, ptr(Ws[0]), ptr(fold_b0), ptr(sc), ptr(sh), K, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co,
@@ -428,7 +434,7 @@ class _MLPStack(torch.autograd.Function):
                 # last layer of a set-abstraction stack: the GEMM epilogue also emits the extremes the max over the 64 neighbours needs
                 pool = (torch.empty(2 * cfg["G"], Co, dtype=torch.float32, device=dev), torch.empty(2 * cfg["G"], Co, dtype=torch.float32, device=dev),
                         torch.empty(2 * cfg["G"], Co, dtype=I32, device=dev))
-                call("p2c_linear_fwd_pool_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, ptr(sc), ptr(sh), ptr(partials),
+                call("p2c_linear_fwd_pool_f32", ptr(X), ldx, ptr(W2), K, ptr(b), None if no_y else ptr(Y), Co, M, Co, K, ptr(sc), ptr(sh), ptr(partials),
                      ptr(pool[0]), ptr(pool[1]), ptr(pool[2]), stream(), flops=2.0 * M * Co * K)
             else:
                 call("p2c_linear_fwd_f32", ptr(X), ldx, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co, K, mode, ptr(sc), ptr(sh),
@@ -664,7 +670,22 @@ class _MLPStack(torch.autograd.Function):
                 fused_kind = 0           # the two-pass form of a 256-wide layer accumulates dX across its passes: long layers with a dX only
             narrow = (USE_NARROW_BWD and grad_mode == 0 and need_dx and stats_below and mode in (1, 3)
                       and L_.p2c_linear_bwd_narrow_supported(M, Co, Ci, mode))
-            if narrow:
+            pool_alg = (USE_POOL_ALG and grad_mode == 2 and i == L - 1 and need_dx and stats_below and mode == 1 and ldxin == Ci
+                        and ywin is not None and L_.p2c_linear_bwd_pool_alg_supported(M, Co, Ci, pool_ns))
+            if Y.shape[0] == 0 and not pool_alg:
+                raise RuntimeError("the pooled layer's forward did not store its pre-BatchNorm output (P2C_POOL_ALG route) but its backward "
+                                   "was asked to take the generic kernel; do not toggle ops.USE_POOL_ALG between a forward and its backward")
+            if pool_alg:
+                # SA1's last layer: dY = gs*G + q*Y + p with Y = A W^T + b linear in the staged input, so neither Y nor a dense dY exists
+                # (csrc/bwd_pool.hip): dX + the sums of the layer below from one read of X, dW assembled from Gs^T A, A^T A and 1^T A
+                dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
+                part = arena.f64(STAT_SLOTS, 2, Ci)
+                acc = torch.empty(L_.p2c_linear_bwd_pool_alg_ws_bytes(Co, Ci) // 4 + 4, dtype=torch.float32, device=dev)      # scratch, no zero-fill
+                dW_final = torch.empty(Co, Ci, dtype=torch.float32, device=dev)
+                call("p2c_linear_bwd_pool_alg_f32", ptr(dZ), dZ.stride(0), ptr(ywin), ptr(arg), ptr(coef), ptr(Xin), ldxin, ptr(sc), ptr(sh),
+                     ptr(W2), Ci, ptr(params[p0 + 1]), ptr(dX), Ci, ptr(aff[i - 1]), ptr(part), ptr(acc), ptr(dW_final), Ci, M, Co, Ci, pool_ns,
+                     stream(), flops=4.0 * M * Co * Ci, nbytes=4.0 * M * 2 * Ci)
+            elif narrow:
                 # a few outputs on many rows (the heads): dW, dbias, dX and the sums of the BatchNorm below from ONE read of dZ and the input
                 dX = torch.empty(M, Ci, dtype=torch.float32, device=dev)
                 part = arena.f64(STAT_SLOTS, 2, Ci)

@@ -516,3 +516,72 @@ def test_mfma_mode_switch_fp32_kernels_against_the_split_kernels():
         rel = float((u - v).norm() / v.norm().clamp_min(1e-30))
         assert (rel < 1e-5 if i == 0 else rel < 2e-3), (i, rel)
 
+
+
+@pytest.mark.parametrize("G", [256, 1031, 16384])
+def test_pool_alg_backward_equals_generic_pooled_backward_and_float64(G):
+    """csrc/bwd_pool.hip (p2c_linear_bwd_pool_alg_f32): the pooled last layer's backward WITHOUT its pre-BatchNorm output - dX = A Q + r +
+    Gs W, dW from Gs^T A, A^T A and 1^T A - against the generic pooled backward (p2c_linear_bwd_fused_f32, grad_mode 2, which rebuilds dY
+    from Y) on the same operands, and against the float64 evaluation of dY = gs*G + q*Y + p, dX = dY W, dW = dY^T A: SA1's shape
+    (Co, Ci, ns = 128, 64, 64) at 16 k, 66 k (a group count that is no multiple of the grid) and the full 1,048,576 rows of configs[1]."""
+    from point2cyl_amd._lib import call, lib, ptr, stream
+    torch.manual_seed(G)
+    Co, Ci, ns = 128, 64, 64
+    M = G * ns
+    assert lib().p2c_linear_bwd_pool_alg_supported(M, Co, Ci, ns)
+    X = torch.randn(M, Ci, device=DEV)
+    sc2, sh2 = torch.rand(Ci, device=DEV) + 0.5, torch.randn(Ci, device=DEV) * 0.3
+    sc2[::7] *= -1.0                                                       # negative BatchNorm scales of the layer below
+    W = torch.randn(Co, Ci, device=DEV) * 0.1
+    b = torch.randn(Co, device=DEV) * 0.1
+    A = torch.relu(sc2 * X + sh2)
+    Y = A @ W.t() + b
+    arg = torch.randint(0, ns, (G, Co), device=DEV, dtype=torch.int32)
+    ywin = torch.gather(Y.view(G, ns, Co), 1, arg.long().unsqueeze(1)).squeeze(1).contiguous()
+    dout = torch.randn(G, Co, device=DEV)
+    coef = torch.stack([torch.rand(Co, device=DEV) + 0.5, torch.randn(Co, device=DEV) * 0.2, torch.rand(Co, device=DEV) + 0.5,
+                        torch.randn(Co, device=DEV) * 0.01, torch.randn(Co, device=DEV) * 0.01]).contiguous()
+    coef[0, ::5] *= -1.0
+    pstat = torch.stack([sc2, sh2, torch.randn(Ci, device=DEV) * 0.1, torch.rand(Ci, device=DEV) + 0.5]).contiguous()
+
+    def alg():
+        dX = torch.empty(M, Ci, device=DEV); dW = torch.empty(Co, Ci, device=DEV)
+        parts = torch.zeros(64, 2, Ci, device=DEV, dtype=torch.float64)
+        acc = torch.empty(lib().p2c_linear_bwd_pool_alg_ws_bytes(Co, Ci) // 4 + 4, device=DEV)
+        call("p2c_linear_bwd_pool_alg_f32", ptr(dout), Co, ptr(ywin), ptr(arg), ptr(coef), ptr(X), Ci, ptr(sc2), ptr(sh2), ptr(W), Ci, ptr(b), ptr(dX), Ci,
+             ptr(pstat), ptr(parts), ptr(acc), ptr(dW), Ci, M, Co, Ci, ns, stream())
+        return dX, dW, parts.sum(0)
+
+    def generic():
+        dX = torch.empty(M, Ci, device=DEV); dW8 = torch.zeros(8, Co, Ci, device=DEV)
+        parts = torch.zeros(64, 2, Ci, device=DEV, dtype=torch.float64)
+        call("p2c_linear_bwd_fused_f32", ptr(dout), Co, ptr(Y), Co, 2, ptr(coef), ptr(arg), ns, ptr(X), Ci, 1, ptr(sc2), ptr(sh2), ptr(W), Ci, ptr(dX), Ci,
+             ptr(dW8), Ci, Co * Ci, None, ptr(pstat), ptr(parts), M, Co, Ci, stream())
+        return dX, dW8.sum(0), parts.sum(0)
+
+    a, g = alg(), generic()
+    torch.cuda.synchronize()
+    # float64: dY dense from its definition
+    d = lambda t: t.double()
+    Gd = torch.zeros(G, ns, Co, device=DEV, dtype=torch.float64)
+    m = (coef[0] * ywin + coef[1] > 0)
+    Gd.scatter_(1, arg.long().unsqueeze(1), (d(dout) * m).unsqueeze(1))
+    A64 = torch.relu(d(sc2) * d(X) + d(sh2))
+    Y64 = A64 @ d(W).t() + d(b)
+    dY = d(coef[2]) * Gd.view(M, Co) + d(coef[3]) * Y64 + d(coef[4])
+    dX64, dW64 = dY @ d(W), dY.t() @ A64
+    mask = (sc2 * X + sh2 > 0)
+    gm = dX64 * mask
+    s64 = torch.stack([gm.sum(0), (gm * ((d(X) - d(pstat[2])) * d(pstat[3]))).sum(0)])
+    sx = float(dX64.abs().max())
+    ex_a, ex_g = float((d(a[0]) - dX64).abs().max()) / sx, float((d(g[0]) - dX64).abs().max()) / sx
+    assert ex_a <= max(2.0 * ex_g, 4e-6), (ex_a, ex_g)
+    ew_a = float((d(a[1]) - dW64).norm() / dW64.norm())
+    ew_g = float((d(g[1]) - dW64).norm() / dW64.norm())
+    assert ew_a <= max(2.0 * ew_g, 5e-6), (ew_a, ew_g)
+    assert float((d(a[1]) - dW64).abs().max()) <= max(2.0 * float((d(g[1]) - dW64).abs().max()), 1e-5 * float(dW64.abs().max()))
+    es_a = float((a[2] - s64).abs().max() / s64.abs().max())
+    es_g = float((g[2] - s64).abs().max() / s64.abs().max())
+    assert es_a <= max(3.0 * es_g, 1e-5), (es_a, es_g)
+    _rec("pool_alg G=%d dX vs float64 (generic: %.2e)" % (G, ex_g), ex_a, max(2.0 * ex_g, 4e-6))
+    _rec("pool_alg G=%d dW rel norm vs float64 (generic: %.2e)" % (G, ew_g), ew_a, max(2.0 * ew_g, 5e-6))

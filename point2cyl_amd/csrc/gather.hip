@@ -390,10 +390,19 @@ template <int CPL>
 __global__ void __launch_bounds__(256) csr_gather_bn_kernel(const float *__restrict__ dz, int lddz, const float *__restrict__ y, int ldy,
                                                             const float *__restrict__ coef, const int32_t *__restrict__ offsets,
                                                             const int32_t *__restrict__ entries, const float *__restrict__ w, int E, int rows_b,
-                                                            int T, int C, long long total, float *__restrict__ out, int ldo)
+                                                            int T, int C, long long total, float *__restrict__ out, int ldo, int xcd_clouds)
 {
     const int lane = threadIdx.x & 63;
-    const long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // XCD-aware: workgroups go round the 8 XCDs (blockIdx.x % 8), and every dense row is read by ~3 target rows of the SAME cloud - with the
+    // targets of a cloud spread over all XCDs each of those reads missed its own L2 (742 MB fetched for a 268 MB stream).  xcd_clouds != 0:
+    // cloud b is served by XCD b % 8 only, all its targets resident there at about the same time, so the second and third read hit that L2.
+    long long wv;
+    if (xcd_clouds) {
+        const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3), bpc = T / 4;       // blocks per cloud
+        wv = ((long long)(xcd + 8 * (slot / bpc)) * bpc + (slot % bpc)) * 4 + (threadIdx.x >> 6);
+    } else {
+        wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    }
     if (wv >= total) return;
     const int b = (int)(wv / T), t = (int)(wv - (long long)b * T);
     const int k0 = offsets[(size_t)b * (T + 1) + t], k1 = offsets[(size_t)b * (T + 1) + t + 1];
@@ -458,7 +467,9 @@ extern "C" int p2c_csr_gather_bn_f32(const float *dz, int lddz, const float *y, 
     const long long total = (long long)B * T;
     dim3 grid(p2c_cdiv(total, 4));
     hipStream_t s = (hipStream_t)stream;
-#define P2C_CGB(CPL_) hipLaunchKernelGGL(csr_gather_bn_kernel<CPL_>, grid, dim3(256), 0, s, dz, lddz, y, ldy, coef, offsets, rows, wsorted, E, rows_b, T, C, total, out, ldo)
+    static const bool xcd_on = !(getenv("P2C_XCD_GATHER") && atoi(getenv("P2C_XCD_GATHER")) == 0);         // A/B switch
+    const int xcd_clouds = (xcd_on && B % 8 == 0 && T % 4 == 0) ? 1 : 0;
+#define P2C_CGB(CPL_) hipLaunchKernelGGL(csr_gather_bn_kernel<CPL_>, grid, dim3(256), 0, s, dz, lddz, y, ldy, coef, offsets, rows, wsorted, E, rows_b, T, C, total, out, ldo, xcd_clouds)
     if (C <= 64) P2C_CGB(1);
     else if (C <= 128) P2C_CGB(2);
     else P2C_CGB(4);

@@ -2,7 +2,7 @@
 
     python tools/collect_pmc.py <tag>          # writes profiles/<tag>_pmc_step.json and profiles/<tag>_pmc_step.md
 
-Each pass profiles `python bench.py --steps 2 --warmup 1 --no_graph --no_cpu_baseline` (configs[1], kernels launched one by one so
+Each pass profiles `python bench.py --steps 2 --warmup 1 --no_graph --no_cpu_baseline --no_extras` (configs[1], kernels launched one by one so
 that every dispatch is attributed) with `rocprofv3 --pmc ...` and nothing else but the kernel trace (MI355X_MICROARCH.md: counters
 in their own runs; FETCH_SIZE and WRITE_SIZE cannot share a pass; 8 SQ slots).  Units as the guide calibrates them:
 FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled (gfx950 tallies the 128-B requests of wide coalesced reads at 64 B);
@@ -29,7 +29,7 @@ PASSES = {
     "sq_lds": ["SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
                "SQ_ACTIVE_INST_MISC", "SQ_BUSY_CU_CYCLES"],
 }
-CMD = [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no_graph", "--no_cpu_baseline"]
+CMD = [sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no_graph", "--no_cpu_baseline", "--no_extras"]
 
 
 def short(n):
@@ -66,7 +66,7 @@ def main():
         if "WRITE_SIZE" in e:
             e["write_bytes_per_launch"] = e["WRITE_SIZE"] * 1024
         res[k] = e
-    note = ("rocprofv3 --pmc, one counter group per pass of `python bench.py --steps 2 --warmup 1 --no_graph --no_cpu_baseline` (configs[1]); "
+    note = ("rocprofv3 --pmc, one counter group per pass of `python bench.py --steps 2 --warmup 1 --no_graph --no_cpu_baseline --no_extras` (configs[1]); "
             "per-launch means over all launches of each kernel (3 steps + graph-less warm-up); FETCH_SIZE/WRITE_SIZE in KiB, fetch bytes = "
             "FETCH_SIZE x 1024 x 2 (MI355X_MICROARCH.md gfx950 correction), write bytes uncorrected")
     steps = 3

@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 # 2. kernel trace + stats of the same command (no counters in this pass)
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no_cpu_baseline > "$OUT/${TAG}_bench_under_rocprof.json.log" 2> "$OUT/trace.err"
+rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_extras > "$OUT/${TAG}_bench_under_rocprof.json.log" 2> "$OUT/trace.err"
 cp "$OUT/trace/r_kernel_stats.csv" "$OUT/${TAG}_rocprofv3_kernel_stats.csv"
 python tools/timeline.py "$OUT/trace/r_kernel_trace.csv" 7 > "$OUT/${TAG}_step_timeline.md" 2>> "$OUT/trace.err"
 python - "$OUT" "$TAG" <<'EOF'
@@ -20,7 +20,7 @@ steps = b["steps"] + b["warmup"] + 2 + 3
 rows = list(csv.DictReader(open("%s/trace/r_kernel_stats.csv" % out)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 with open("%s/%s_kernel_stats.md" % (out, tag), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats of `python bench.py --steps %d --warmup %d --no_cpu_baseline` (configs[1], 1 GPU)\n\n" % (b["steps"], b["warmup"]))
+    f.write("# rocprofv3 --kernel-trace --stats of `python bench.py --steps %d --warmup %d --no_cpu_baseline --no_extras` (configs[1], 1 GPU)\n\n" % (b["steps"], b["warmup"]))
     f.write("bench line of this run: %.1f points/s, %.3f ms/step.  The trace holds %d passes over the step (timed + warm-up + 2 capture warm-ups + the 3 "
             "eager steps bench.py uses for its HIP-event timing); 'us/step' = total / %d.  Kernels of the geometry prefetch (fps, ball_query, three_nn, "
             "build_csr, group_gather_xyz) run on the forked stream, concurrently with the rest.\n\n" % (b["value"], b["ms_per_step"], steps, steps))
@@ -39,11 +39,15 @@ rm -rf gpurun_out/${TAG}_pmc_*
 # 3b. the bench line exactly as the driver runs it (with the CPU baseline), and configs[2]'s loss set - AFTER the counters, so that
 # roofline.traffic is read from the summary collected on this very tree (traffic_stale: false)
 python bench.py > "$OUT/${TAG}_bench.json.log" 2> "$OUT/bench.err"
-python bench.py --full_losses --no_cpu_baseline > "$OUT/${TAG}_bench_config2_full_losses.json.log" 2>> "$OUT/bench.err"
+python bench.py --full_losses --no_cpu_baseline --no_extras > "$OUT/${TAG}_bench_config2_full_losses.json.log" 2>> "$OUT/bench.err"
+python bench.py --dropin --steps 40 > "$OUT/${TAG}_bench_dropin.json.log" 2>> "$OUT/bench.err"
 # 4. the other configs / stages
 python tools/bench_config4.py > "$OUT/${TAG}_config4_fitting.json.log" 2> "$OUT/config4.err"
 python tools/bench_sa1_forward.py > "$OUT/${TAG}_sa1_forward_stage.json.log" 2> "$OUT/sa1.err"
-python tools/bench_config5.py --steps 3 > "$OUT/${TAG}_config5_with_sketch_step.json.log" 2> "$OUT/config5.err"
+python tools/bench_config5.py --steps 10 > "$OUT/${TAG}_config5_with_sketch_step.json.log" 2> "$OUT/config5.err"
+python tools/bench_config5.py --steps 5 --no_graph > "$OUT/${TAG}_config5_with_sketch_step_eager.json.log" 2>> "$OUT/config5.err"
+python tools/bench_pool_alg.py --trace > "$OUT/${TAG}_pool_alg_backward.log" 2> "$OUT/pool.err"
+timeout 100 tools/ubench/grid_barrier.bin > "$OUT/${TAG}_grid_barrier_ubench.log" 2>&1
 # 5. the trainers and the evaluation script (throughput through the CLI, convergence log)
 python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 1024 --batch_size 32 --num_epochs 60 --quiet --logdir /tmp/${TAG}_tr \
     --report "$OUT/${TAG}_trainer_report.json" > "$OUT/${TAG}_train_convergence_synthetic.log" 2> "$OUT/train.err"

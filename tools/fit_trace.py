@@ -9,8 +9,7 @@ if "--build" in sys.argv:
     print(LIB); sys.exit(0)
 sys.path.insert(0, ROOT)
 import numpy as np, torch
-sys.path.insert(0, HERE)
-from bench_config4 import make_inputs
+from point2cyl_amd.synth import make_fitting_inputs as make_inputs
 B, N, K, S = 1250, 8192, 8, 2048
 pcs, X, seg, bb, axes, Wb, Wc, onehot = make_inputs(B, N, K, 4321)
 g = torch.Generator().manual_seed(7)

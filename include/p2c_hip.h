@@ -329,6 +329,11 @@ int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int l
                              long long dw_slot_stride, float *dbias, const float *prev_stat, double *bwd_partials, int M, int Co,
                              int Ci, void *stream);
 
+/* n independent 2-D fp32 copies in one launch.  table (device memory): n entries of
+ *   struct { const float *src; float *dst; int rows, cols, ld_src, ld_dst; }   (32 bytes each)
+ * The host mirror stages every padded / re-ordered / column-sliced weight operand of a step with it (point2cyl_amd/ops.py WeightStage). */
+int p2c_copy2d_batch_f32(const void *table, int n, void *stream);
+
 /* Backward of the LAST layer of a set-abstraction stack (conv -> train-mode BatchNorm -> ReLU -> max over ns neighbours,
  * pointnet_util.py:201-205) without its pre-BatchNorm output: Y = A W^T + b is linear in the layer's input A = relu(in_scale * X + in_shift),
  * so dX = dY W = A (W^T diag(q) W) + (q*b + p) W + (gs*G) W and dW = dY^T A = (gs*G)^T A + diag(q) (W A^T A + b 1^T A) + p 1^T A, with G

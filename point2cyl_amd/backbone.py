@@ -60,13 +60,18 @@ class PointNetSetAbstraction(nn.Module):
             g["csr"] = ops.build_csr(gidx, N)
         return g
 
-    def forward_pm(self, xyz, feats, geom=None):
-        """xyz (B,N,3), feats (B,N,D) or None -> new_xyz (B,S,3), new_feats (B,S,C')."""
+    def forward_pm(self, xyz, feats, geom=None, staged=None):
+        """xyz (B,N,3), feats (B,N,D) or None -> new_xyz (B,S,3), new_feats (B,S,C').
+        staged: operands derived from the first layer's weight, prepared by the backbone's WeightStage (keys W2 [, pre_wx]); used only on
+        the code path they were laid out for."""
         B, N, _ = xyz.shape
         layers = _layers(self.mlp_convs, self.mlp_bns)
         cin = self.mlp_convs[0].weight.shape[1]
         if self.group_all:
-            new_xyz = torch.zeros(B, 1, 3, device=xyz.device)
+            z = self.__dict__.get("_zero_xyz")
+            if z is None or z.shape[0] != B or z.device != xyz.device:
+                z = self.__dict__["_zero_xyz"] = torch.zeros(B, 1, 3, device=xyz.device)      # (constant: not re-filled every step)
+            new_xyz = z
             cols = ([] if feats is None else [feats.reshape(B * N, -1)]) + [xyz.reshape(B * N, 3)]
             pad = (-cin) % 4
             if pad:
@@ -86,10 +91,12 @@ class PointNetSetAbstraction(nn.Module):
                 pre = dict(kind="group", xyz=xyz.contiguous(), new_xyz=new_xyz.contiguous(), idx=gidx, csr=csr, B=B, N=N, S=self.npoint,
                            ns=ns, rows=G * ns)
                 F2 = feats.reshape(B * N, -1)
-                out = ops.mlp_stack(F2, F2.shape[1], layers, "maxpool", self.training, G=G, ns=ns, pre=pre)
+                out = ops.mlp_stack(F2, F2.shape[1], layers, "maxpool", self.training, G=G, ns=ns, pre=pre,
+                                    staged={0: staged} if (staged is not None and "pre_wx" in staged) else None)
                 return new_xyz, out.view(B, -1, out.shape[-1])
             X0 = geom["X0"] if (feats is None and "X0" in geom) else ops.group_gather(xyz, feats, new_xyz, gidx, geom.get("csr"))
-        out = ops.mlp_stack(X0, cin, layers, "maxpool", self.training, G=G, ns=ns, xyz_last=True)
+        use = staged is not None and "pre_wx" not in staged and tuple(staged["W2"].shape) == (self.mlp_convs[0].weight.shape[0], (cin + 3) // 4 * 4)
+        out = ops.mlp_stack(X0, cin, layers, "maxpool", self.training, G=G, ns=ns, xyz_last=True, staged={0: staged} if use else None)
         return new_xyz, out.view(B, -1, out.shape[-1])
 
     def forward(self, xyz, points):
@@ -122,8 +129,11 @@ class PointNetFeaturePropagation(nn.Module):
                 idx, w = ops.three_nn(xyz1, xyz2)
                 nn_ = (idx, w, ops.build_csr(idx, S, w, 3))
             idx, w, csr = nn_
-            interp = ops.three_interpolate(feats2, idx, w, csr)
             self.last_aux = dict(nn_idx=idx, nn_w=w)
+            if feats1 is not None:
+                # [skip | interpolated | pad] in one buffer: the interpolation writes its column block in place (no 25 MB cat at FP2)
+                return ops.skip_interp_cat(feats1.reshape(B * N, -1), feats2, idx, w, csr)
+            interp = ops.three_interpolate(feats2, idx, w, csr)
         if feats1 is not None:
             cols = [feats1.reshape(B * N, -1), interp]                            # [skip | interpolated] :312
             pad = (-(cols[0].shape[1] + cols[1].shape[1])) % 4                    # the kernels take 16-byte aligned rows (3 + 128 -> 132)
@@ -133,7 +143,7 @@ class PointNetFeaturePropagation(nn.Module):
         return interp
 
     def forward_pm(self, xyz1, xyz2, feats1, feats2, tail="bnrelu", extra_layers=(), drop_mask=None, drop_scale=1.0, drop_seed=None,
-                   keep_padding=False, nn_=None):
+                   keep_padding=False, nn_=None, staged=None):
         """xyz1 (B,N,3) dense, xyz2 (B,S,3) sparse, feats1 (B,N,D1)|None, feats2 (B,S,D2) -> (B,N,C')."""
         B, N, _ = xyz1.shape
         S = xyz2.shape[1]
@@ -149,7 +159,7 @@ class PointNetFeaturePropagation(nn.Module):
             pre = dict(kind="interp", idx=idx, w=w, csr=csr, B=B, N=N, S=S, rows=B * N)
             F2 = feats2.reshape(B * S, -1)
             out = ops.mlp_stack(F2, F2.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
-                                keep_padding=keep_padding, pre=pre)
+                                keep_padding=keep_padding, pre=pre, staged=staged if (staged and 0 not in staged) else None)
             return out.view(B, N, -1)
         if (S == 1 and feats1 is not None and ops.USE_PRE_LINEAR and N % 64 == 0 and feats1.shape[-1] % 4 == 0 and feats2.shape[-1] % 4 == 0
                 and self.training and self.mlp_convs[0].weight.shape[0] % 4 == 0):
@@ -158,7 +168,7 @@ class PointNetFeaturePropagation(nn.Module):
             pre = dict(kind="repeat", V=feats2.reshape(B, -1), rpg=N, rows=B * N)
             F1 = feats1.reshape(B * N, -1)
             out = ops.mlp_stack(F1, F1.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
-                                keep_padding=keep_padding, pre=pre)
+                                keep_padding=keep_padding, pre=pre, staged=staged if (staged and 0 in staged and "pre_wb" in staged[0]) else None)
             return out.view(B, N, -1)
         X0 = self._input_pm(xyz1, xyz2, feats1, feats2, nn_)
         out = ops.mlp_stack(X0, self.mlp_convs[0].weight.shape[1], layers, tail, self.training, drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed,
@@ -203,6 +213,38 @@ class backbone(nn.Module):
         self.dropout_mask = None   # test hook: (B,N,128) {0,1} mask to use instead of drawing one; "off" disables dropout
         self._drop_seed = None     # device int64 counter feeding the in-kernel dropout hash (advanced every forward)
 
+    def _weight_stage(self, device):
+        """The operands this forward derives from parameters alone, as one batched copy (ops.WeightStage).  Built lazily per device."""
+        ws = self.__dict__.get("_wstage")
+        if ws is not None and ws.device == device:
+            return ws
+        entries = []
+        if not self.normal_channel:
+            w = self.sa1.mlp_convs[0].weight                                              # (64, 3, 1, 1) -> (64, 4)
+            entries.append(("sa1_W", (w.shape[0], 4), [(w, 0, 3, 0, 0)]))
+        w = self.sa2.mlp_convs[0].weight                                                  # (128, 3 + 128): xyz part | feature part
+        co, ci = w.shape[0], w.shape[1]
+        entries.append(("sa2_wx", (co, 4), [(w, 0, 3, 0, 0)]))
+        entries.append(("sa2_W", (co, ci - 3), [(w, 3, ci - 3, 0, 0)]))
+        w = self.sa3.mlp_convs[0].weight                                                  # (256, 3 + 256) -> [features | xyz | pad] (256, 260)
+        co, ci = w.shape[0], w.shape[1]
+        entries.append(("sa3_W", (co, (ci + 3) // 4 * 4), [(w, 3, ci - 3, 0, 0), (w, 0, 3, 0, ci - 3)]))
+        w = self.fp3.mlp_convs[0].weight                                                  # (256, 256 skip + 1024 repeated): two column blocks
+        co, k = w.shape[0], self.sa2.mlp_convs[-1].weight.shape[0]
+        entries.append(("fp3_W", (co, k), [(w, 0, k, 0, 0)]))
+        entries.append(("fp3_wb", (co, w.shape[1] - k), [(w, k, w.shape[1] - k, 0, 0)]))
+        tot = sum(m.weight.shape[0] for m in self.fc2)
+        pad = (tot + 3) // 4 * 4
+        wparts, bparts, o = [], [], 0
+        for m in self.fc2:
+            wparts.append((m.weight, 0, m.weight.shape[1], o, 0))
+            bparts.append((m.bias, 0, m.bias.shape[0], 0, o))
+            o += m.weight.shape[0]
+        entries.append(("head_W", (pad, self.fc2[0].weight.shape[1]), wparts))
+        entries.append(("head_b", (pad,), bparts))
+        ws = self.__dict__["_wstage"] = ops.WeightStage(entries, device)
+        return ws
+
     def compute_geometry(self, x):
         """Everything in the forward pass that depends on the point coordinates only (no parameters): both FPS +
         ball-query levels, SA1's grouped relative coordinates and the two 3-NN interpolation stencils.  The result can be
@@ -242,10 +284,15 @@ class backbone(nn.Module):
         xyz = x[:, :, :3].contiguous()
         feats0 = x[:, :, 3:].contiguous() if C > 3 else None
         gm = geom or {}
-        l1_xyz, l1 = self.sa1.forward_pm(xyz, feats0, gm.get("sa1"))
-        l2_xyz, l2 = self.sa2.forward_pm(l1_xyz, l1, gm.get("sa2"))
-        l3_xyz, l3 = self.sa3.forward_pm(l2_xyz, l2)
-        l4 = self.fp3.forward_pm(l2_xyz, l3_xyz, l2, l3)
+        ws = None
+        if ops.USE_STAGED_WEIGHTS:
+            ws = self._weight_stage(x.device)
+            ws.run()                      # ONE launch: every padded / re-ordered / column-sliced weight operand of this forward
+        st = (lambda **kw: {k: ws[v] for k, v in kw.items()}) if ws is not None else (lambda **kw: None)
+        l1_xyz, l1 = self.sa1.forward_pm(xyz, feats0, gm.get("sa1"), staged=st(W2="sa1_W") if (ws is not None and feats0 is None) else None)
+        l2_xyz, l2 = self.sa2.forward_pm(l1_xyz, l1, gm.get("sa2"), staged=st(W2="sa2_W", pre_wx="sa2_wx"))
+        l3_xyz, l3 = self.sa3.forward_pm(l2_xyz, l2, staged=st(W2="sa3_W"))
+        l4 = self.fp3.forward_pm(l2_xyz, l3_xyz, l2, l3, staged={0: st(W2="fp3_W", pre_wb="fp3_wb")} if ws is not None else None)
         l5 = self.fp2.forward_pm(l1_xyz, l2_xyz, l1, l4, nn_=gm.get("fp2"))
         # FP1 -> fc1/bn1/relu -> dropout -> fc2 heads as ONE stack: l6 and the head activations stay out of HBM
         seed = None
@@ -264,14 +311,21 @@ class backbone(nn.Module):
             self._drop_seed += 0x9E3779B97F4A7C15 % (2 ** 62)
             mask, seed, dscale = None, self._drop_seed, 1.0 / (1.0 - self.dropout_p)
         sizes = [m.weight.shape[0] for m in self.fc2]
-        Wh = torch.cat([m.weight.reshape(m.weight.shape[0], 128) for m in self.fc2], 0)
-        bh = torch.cat([m.bias for m in self.fc2], 0)
+        head_staged = None
+        if ws is not None:
+            # the heads' stacked (and zero-padded) weight / bias already sit in the staged buffers; autograd sees their rows as a function
+            # of the fc2 parameters (ops._HeadParams: no launch either way)
+            Wh, bh = ops._HeadParams.apply(ws["head_W"], ws["head_b"], len(self.fc2), *[m.weight for m in self.fc2], *[m.bias for m in self.fc2])
+            head_staged = {len(self.fp1.mlp_convs) + 1: dict(W2=ws["head_W"], b=ws["head_b"])}
+        else:
+            Wh = torch.cat([m.weight.reshape(m.weight.shape[0], 128) for m in self.fc2], 0)
+            bh = torch.cat([m.bias for m in self.fc2], 0)
         extra = [dict(W=self.fc1.weight, b=self.fc1.bias, gamma=self.bn1.weight, beta=self.bn1.bias,
                       bn=ops.BNState(self.bn1.running_mean, self.bn1.running_var, self.bn1.num_batches_tracked,
                                      0.1 if self.bn1.momentum is None else self.bn1.momentum, self.bn1.eps)),
                  dict(W=Wh, b=bh, gamma=None, beta=None, bn=None)]
         heads = self.fp1.forward_pm(xyz, l1_xyz, feats0, l5, tail="linear", extra_layers=extra, drop_mask=mask, drop_scale=dscale,
-                                    drop_seed=seed, keep_padding=True, nn_=gm.get("fp1"))
+                                    drop_seed=seed, keep_padding=True, nn_=gm.get("fp1"), staged=head_staged)
         ops._DEFER_NBT[0] = False
         ops.flush_nbt()
         return heads.reshape(B * N, heads.shape[-1]), sizes

@@ -642,3 +642,27 @@ extern "C" int p2c_adam_multi_f32(const long long *table, const long long *numel
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Batched 2-D copies.  A training step prepares a dozen small operands from the parameters - 3 -> 4 / 259 -> 260 / 19 -> 20 zero-padded
+// weights, the [xyz | features] -> [features | xyz] column order of the grouped layers, the column blocks of a weight that multiply
+// different inputs - each with its own torch copy / cat launch (~4 us of the stream apiece, profiles/r04_torch_glue_ops.log).  The
+// sources and destinations never move, so ONE launch driven by a device-resident table does all of them.
+// table: n entries {src, dst, rows, cols, ld_src, ld_dst}; grid (n, row slices).
+// ------------------------------------------------------------------------------------------------
+struct P2cCopy2D { const float *src; float *dst; int rows, cols, lds, ldd; };
+__global__ void __launch_bounds__(256) copy2d_batch_kernel(const P2cCopy2D *__restrict__ tab)
+{
+    const P2cCopy2D d = tab[blockIdx.x];
+    for (int r = blockIdx.y; r < d.rows; r += gridDim.y)
+        for (int c = threadIdx.x; c < d.cols; c += 256) d.dst[(size_t)r * d.ldd + c] = d.src[(size_t)r * d.lds + c];
+}
+
+extern "C" int p2c_copy2d_batch_f32(const void *table, int n, void *stream)
+{
+    if (!table || n <= 0) return P2C_EINVAL;
+    hipLaunchKernelGGL(copy2d_batch_kernel, dim3(n, 32), dim3(256), 0, (hipStream_t)stream, (const P2cCopy2D *)table);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

@@ -337,30 +337,41 @@ class _MLPStack(torch.autograd.Function):
                  and (L >= 3 or (L == 2 and tail == "bnrelu")) and params[0].shape[0] == 64 and params[4].shape[0] in (64, 128)
                  and bns[0] is not None and bns[1] is not None)
         mom = None
+        staged = cfg.get("staged")
         mptr_free = mask is None and seed is None
         for i in range(L):
             has_bn = not (tail == "linear" and i == L - 1)
             W, b = params[pi], params[pi + 1]
             pi += 2
             Co_true = W.shape[0]
-            W2 = W.reshape(Co_true, -1)
-            if i == 0 and rep_v is not None:
-                # input = [X | V repeated over the rows of a group] (reference column order [points1 | interpolated]): V's product once
-                # per group, as a per-group additive term of the GEMM over X
-                pre_wb = W2[:, K:].contiguous()
-                W2 = W2[:, :K]
-            if i == 0 and pre is not None and pre["kind"] == "group":
-                # reference column order [xyz(3) | features]: the coordinate part goes to the gather, the feature part to the GEMM
-                pre_wx = _zero_padded(W2[:, :3], _pad4(Co_true), 4)
-                W2 = W2[:, 3:]
-            if i == 0 and cfg.get("xyz_last") and W2.shape[1] > 3:
-                W2 = torch.cat([W2[:, 3:], W2[:, :3]], 1)          # reference order [xyz(3) | feats] -> [feats | xyz(3)]
             Co = _pad4(Co_true)
-            if W2.shape[1] != K or Co != Co_true:
-                W2 = _zero_padded(W2, Co, K)
-                if Co != Co_true:
-                    b = _zero_padded(b, Co)
-            W2 = W2.contiguous()
+            st = staged.get(i) if staged else None
+            if st is not None:
+                # every operand derived from this layer's parameters was written by the step's ONE batched copy (WeightStage): same
+                # layouts as the branch below produces, persistent buffers, no launch here
+                W2 = st["W2"]
+                b = st.get("b", b)
+                pre_wb = st.get("pre_wb", pre_wb)
+                pre_wx = st.get("pre_wx", pre_wx)
+                assert tuple(W2.shape) == (Co, K), (tuple(W2.shape), Co, K)
+            else:
+                W2 = W.reshape(Co_true, -1)
+                if i == 0 and rep_v is not None:
+                    # input = [X | V repeated over the rows of a group] (reference column order [points1 | interpolated]): V's product once
+                    # per group, as a per-group additive term of the GEMM over X
+                    pre_wb = W2[:, K:].contiguous()
+                    W2 = W2[:, :K]
+                if i == 0 and pre is not None and pre["kind"] == "group":
+                    # reference column order [xyz(3) | features]: the coordinate part goes to the gather, the feature part to the GEMM
+                    pre_wx = _zero_padded(W2[:, :3], _pad4(Co_true), 4)
+                    W2 = W2[:, 3:]
+                if i == 0 and cfg.get("xyz_last") and W2.shape[1] > 3:
+                    W2 = torch.cat([W2[:, 3:], W2[:, :3]], 1)          # reference order [xyz(3) | feats] -> [feats | xyz(3)]
+                if W2.shape[1] != K or Co != Co_true:
+                    W2 = _zero_padded(W2, Co, K)
+                    if Co != Co_true:
+                        b = _zero_padded(b, Co)
+                W2 = W2.contiguous()
             if fold0 and i == 0:
                 gamma, beta = params[pi], params[pi + 1]
                 pi += 2
@@ -770,7 +781,7 @@ class _MLPStack(torch.autograd.Function):
 
 
 def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mask=None, drop_scale=1.0, drop_seed=None,
-              keep_padding=False, xyz_last=False, pre=None):
+              keep_padding=False, xyz_last=False, pre=None, staged=None):
     """layers: list of dicts {W, b, gamma, beta, bn: BNState} (gamma/beta/bn None for a BN-less last layer)."""
     params, bns = [], []
     for ly in layers:
@@ -779,7 +790,7 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
             params += [ly["gamma"], ly["beta"]]
         bns.append(ly.get("bn"))
     cfg = dict(in_channels=in_channels, n_layers=len(layers), tail=tail, training=training, bns=bns, G=G, ns=ns,
-               drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed, xyz_last=xyz_last, pre=pre)
+               drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed, xyz_last=xyz_last, pre=pre, staged=staged)
     if pre is not None and pre["kind"] == "repeat":
         params = [pre.pop("V")] + params
     out = _MLPStack.apply(cfg, X0, *params)
@@ -789,6 +800,116 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
     if tail == "linear" and out.shape[1] != co_last and not keep_padding:
         out = out[:, :co_last]          # the kernels work on 4-padded channel counts
     return out
+
+
+# ------------------------------------------------------------------------------------------ weight staging (one launch per step)
+USE_STAGED_WEIGHTS = os.environ.get("P2C_STAGE_WEIGHTS", "1") != "0"
+
+
+class WeightStage:
+    """Every operand a step derives from the PARAMETERS alone - zero-padded weights (3 -> 4, 259 -> 260 input channels, 19 -> 20 head
+    outputs), the grouped layers' [xyz | features] -> [features | xyz] column order, the column blocks of a first-layer weight that
+    multiply different inputs - prepared by ONE launch (p2c_copy2d_batch_f32) into persistent buffers instead of a dozen torch copy / cat
+    launches spread over the forward pass.  entries: (key, dst_shape, [(src tensor, src col0, ncols, dst row0, dst col0), ...]); padding
+    stays zero from the allocation.  The table is rebuilt when a source tensor moved (`.to()`, a re-created parameter)."""
+
+    def __init__(self, entries, device):
+        self.entries, self.device = entries, device
+        self.bufs = {key: torch.zeros(*shape, dtype=torch.float32, device=device) for key, shape, _ in entries}
+        self.table, self.n, self.src_ptrs = None, 0, None
+
+    def _build(self):
+        import struct
+        rows = []
+        for key, shape, parts in self.entries:
+            dst = self.bufs[key]
+            ldd = dst.shape[-1]
+            for src, c0, nc, r0, d0 in parts:
+                s2 = src.detach().reshape(src.shape[0], -1) if src.dim() > 1 else src.detach().reshape(1, -1)
+                assert s2.is_contiguous() and s2.dtype == torch.float32
+                rows.append(struct.pack("<QQiiii", s2.data_ptr() + 4 * c0, dst.data_ptr() + 4 * (r0 * ldd + d0), s2.shape[0], nc, s2.shape[1], ldd))
+        raw = b"".join(rows)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.n = len(rows)
+        self.src_ptrs = self._ptrs()
+
+    def _ptrs(self):
+        return tuple(src.data_ptr() for _, _, parts in self.entries for src, *_ in parts)
+
+    def run(self):
+        if self.table is None or self.src_ptrs != self._ptrs():
+            self._build()
+        call("p2c_copy2d_batch_f32", ptr(self.table), self.n, stream())
+
+    def __getitem__(self, key):
+        return self.bufs[key]
+
+
+class _HeadParams(torch.autograd.Function):
+    """The per-point heads share one GEMM: their weights stacked to (sum o_i, 128).  Forward returns the rows of the staged (zero-padded)
+    buffer the batched copy has filled - no launch; backward hands every head its rows of the stacked gradient - views, no launch."""
+
+    @staticmethod
+    def forward(ctx, Wbuf, bbuf, n_heads, *wb):
+        ctx.sizes = [w.shape[0] for w in wb[:n_heads]]
+        ctx.shapes = [tuple(t.shape) for t in wb]
+        tot = sum(ctx.sizes)
+        return Wbuf[:tot], bbuf[:tot]
+
+    @staticmethod
+    def backward(ctx, gW, gb):
+        outs_w, outs_b, o = [], [], 0
+        n = len(ctx.sizes)
+        for i, sz in enumerate(ctx.sizes):
+            outs_w.append(None if gW is None else gW[o:o + sz].reshape(ctx.shapes[i]))
+            outs_b.append(None if gb is None else gb[o:o + sz].reshape(ctx.shapes[n + i]))
+            o += sz
+        return (None, None, None) + tuple(outs_w) + tuple(outs_b)
+
+
+class _SkipInterpCat(torch.autograd.Function):
+    """[skip features | 3-NN interpolated features | zero pad] of a feature-propagation level (pointnet_util.py:308-312) as ONE buffer: the
+    interpolation kernel writes its column block in place (ldo), the skip features are one strided copy - instead of interpolating into a
+    tensor of its own and concatenating (a 25 MB cat at FP2)."""
+
+    @staticmethod
+    def forward(ctx, feats1, feats2, idx, w, csr, width):
+        B, S, C2 = feats2.shape
+        N = idx.shape[1]
+        C1 = feats1.shape[1]
+        feats2 = _f32c(feats2)
+        out = torch.empty(B * N, width, dtype=torch.float32, device=feats2.device)
+        out[:, :C1].copy_(feats1)
+        if width > C1 + C2:
+            out[:, C1 + C2:].zero_()
+        call("p2c_three_interp_f32", ptr(feats2), C2, ptr(idx), ptr(w), B, N, S, C2, out.data_ptr() + 4 * C1, width, stream())
+        ctx.save_for_backward(idx, w)
+        ctx.csr, ctx.dims = csr, (B, N, S, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, w = ctx.saved_tensors
+        B, N, S, C1, C2 = ctx.dims
+        if dout.stride(1) != 1:
+            dout = dout.contiguous()
+        d1 = dout[:, :C1] if ctx.needs_input_grad[0] else None
+        d2 = None
+        if ctx.needs_input_grad[1]:
+            dpart = dout[:, C1:C1 + C2]
+            d2 = torch.empty(B, S, C2, dtype=torch.float32, device=dout.device)
+            if USE_CSR_BWD and C2 <= 256:
+                offsets, rows, ws = ctx.csr if ctx.csr is not None else build_csr(idx, S, w, 3)
+                call("p2c_csr_gather_f32", ptr(dpart), dout.stride(0), 0, ptr(offsets), ptr(rows), ptr(ws), B, N * 3, N, S, C2, ptr(d2), C2, stream())
+            else:
+                d2.zero_()
+                call("p2c_three_interp_bwd_f32", ptr(dpart), dout.stride(0), ptr(idx), ptr(w), B, N, S, C2, ptr(d2), C2, stream())
+        return d1, d2, None, None, None, None
+
+
+def skip_interp_cat(feats1, feats2, idx, w, csr=None):
+    """feats1 (B*N, C1) skip features, feats2 (B,S,C2) -> (B*N, pad4(C1 + C2)) = [feats1 | interp(feats2) | 0]."""
+    return _SkipInterpCat.apply(feats1, feats2, idx, w, csr, _pad4(feats1.shape[1] + feats2.shape[2]))
 
 
 # ------------------------------------------------------------------------------------------ fitting

@@ -463,6 +463,11 @@ size_t p2c_seg_losses_ws_bytes(int B, int K);
 int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff, const float *normals_gt, const int64_t *I_gt,
                        const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
                        float w_normal, float w_bb, float *out, float *dheads, void *ws, void *stream);
+/* dheads may be NULL in p2c_seg_losses_f32 (forward launches only).  The gradient pass on its own, scaled by the upstream gradient
+ * *gscale (device scalar d / d total, NULL = 1), from what the forward call left in the same ws: */
+int p2c_seg_losses_grad_f32(const float *heads, int ld, int xoff, int woff, const float *normals_gt, const int64_t *I_gt,
+                            const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
+                            float w_normal, float w_bb, const float *gscale, float *dheads, void *ws, void *stream);
 
 /* compute_all_losses on its own inputs (losses.py:317-351, collapse=True): W [B,N,K] softmaxed membership and X [B,N,3] unit normals as the
  * reference's trainer forms them in torch (train_Point2Cyl_without_sketch.py:246-271) - what the drop-in of that function is handed.

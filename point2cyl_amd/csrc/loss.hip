@@ -26,6 +26,7 @@ struct LossArgs {
     float *out;                                          // [4]: total, normal, miou, bb
     float *coef;                                         // [B][2K]: a_bk (on the gt point) | c_bk (on every point)
     float *dheads;                                       // [M, ld]
+    const float *gscale;                                 // upstream d / d total (device scalar) the gradient is multiplied by; NULL = 1
 };
 
 struct PointEval {
@@ -164,7 +165,8 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(LossArgs a)
     const int lab = (int)a.igt[m], bb = (int)a.bbgt[m];
     PointEval e;
     eval_point<K>(a, m, b, bb, e);
-    const float cpt = 1.f / ((float)a.B * (float)a.N);
+    const float gsc = a.gscale ? a.gscale[0] : 1.f;
+    const float cpt = gsc / ((float)a.B * (float)a.N);      // the normal and base/barrel terms are linear in cpt, the mIoU term takes gsc itself
     // d total / d W[j]  (j = original column)
     float dW[K];
 #pragma unroll
@@ -178,7 +180,7 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(LossArgs a)
     for (int k = 0; k < K; ++k) {
         const int mk = (int)a.match[b * K + k];
         const float du = a.mask[b * K + k] ? cb * e.q[k] * (e.ce[k] - qd) : 0.f;
-        const float dmi = a.coef[(size_t)b * 2 * K + K + k] + ((lab == k) ? a.coef[(size_t)b * 2 * K + k] : 0.f);   // mIoU
+        const float dmi = gsc * (a.coef[(size_t)b * 2 * K + K + k] + ((lab == k) ? a.coef[(size_t)b * 2 * K + k] : 0.f));   // mIoU
 #pragma unroll
         for (int j = 0; j < K; ++j) dW[j] += (j == mk) ? (du + dmi) : 0.f;
     }
@@ -213,22 +215,43 @@ extern "C" int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff
                                   const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
                                   float w_normal, float w_bb, float *out, float *dheads, void *ws, void *stream)
 {
-    if (!heads || !normals_gt || !I_gt || !bb_gt || !match || !mask || !out || !dheads || !ws || B <= 0 || N <= 0) return P2C_EINVAL;
+    // dheads == NULL: the two forward launches only; the gradient then comes from p2c_seg_losses_grad_f32 with the same ws
+    if (!heads || !normals_gt || !I_gt || !bb_gt || !match || !mask || !out || !ws || B <= 0 || N <= 0) return P2C_EINVAL;
     if (K != 2 && K != 4 && K != 8) return P2C_EINVAL;
     LossArgs a{heads, ld, xoff, woff, normals_gt, I_gt, bb_gt, match, mask, B, N, K, w_seg, w_normal, w_bb, (double *)ws, out,
-               (float *)((char *)ws + (size_t)B * (3 * K + 2) * sizeof(double)), dheads};
+               (float *)((char *)ws + (size_t)B * (3 * K + 2) * sizeof(double)), dheads, nullptr};
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p2c_cdiv(N, 256), B);
 #define P2C_LK(K_)                                                                       \
     do {                                                                                 \
         hipLaunchKernelGGL(loss_reduce_kernel<K_>, grid, dim3(256), 0, s, a);            \
         hipLaunchKernelGGL(loss_finalize_kernel<K_>, dim3(1), dim3(256), 0, s, a);       \
-        hipLaunchKernelGGL(loss_grad_kernel<K_>, grid, dim3(256), 0, s, a);              \
+        if (dheads) hipLaunchKernelGGL(loss_grad_kernel<K_>, grid, dim3(256), 0, s, a);  \
     } while (0)
     if (K == 8) P2C_LK(8);
     else if (K == 4) P2C_LK(4);
     else P2C_LK(2);
 #undef P2C_LK
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// The gradient pass on its own: d total / d heads times the upstream gradient *gscale (a device scalar, NULL = 1), from the sums and
+// coefficients p2c_seg_losses_f32 left in ws.  Lets the caller's autograd node produce the scaled gradient in its backward in ONE launch
+// instead of keeping an unscaled copy from the forward and multiplying 21 MB by a scalar.
+extern "C" int p2c_seg_losses_grad_f32(const float *heads, int ld, int xoff, int woff, const float *normals_gt, const int64_t *I_gt,
+                                       const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
+                                       float w_normal, float w_bb, const float *gscale, float *dheads, void *ws, void *stream)
+{
+    if (!heads || !normals_gt || !I_gt || !bb_gt || !match || !mask || !dheads || !ws || B <= 0 || N <= 0) return P2C_EINVAL;
+    if (K != 2 && K != 4 && K != 8) return P2C_EINVAL;
+    LossArgs a{heads, ld, xoff, woff, normals_gt, I_gt, bb_gt, match, mask, B, N, K, w_seg, w_normal, w_bb, (double *)ws, nullptr,
+               (float *)((char *)ws + (size_t)B * (3 * K + 2) * sizeof(double)), dheads, gscale};
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(p2c_cdiv(N, 256), B);
+    if (K == 8) hipLaunchKernelGGL(loss_grad_kernel<8>, grid, dim3(256), 0, s, a);
+    else if (K == 4) hipLaunchKernelGGL(loss_grad_kernel<4>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(loss_grad_kernel<2>, grid, dim3(256), 0, s, a);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

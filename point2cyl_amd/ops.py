@@ -1163,21 +1163,34 @@ class _SegLosses(torch.autograd.Function):
         hd = heads.detach()
         call("p2c_hungarian_logits_f32", ptr(hd), ld, woff, ptr(I_gt), B, N, K, ptr(match), ptr(mask), ptr(_hungarian_ws(B, dev)), stream())
         out = torch.empty(4, dtype=torch.float32, device=dev)
-        dheads = torch.empty(M, ld, dtype=torch.float32, device=dev)
         ws = STEP_ARENA.take(_lib.lib().p2c_seg_losses_ws_bytes(B, K) // 8 + 8, dev)        # zeroed scratch: out of the step arena when one is active
-        call("p2c_seg_losses_f32", ptr(hd), ld, xoff, woff, ptr(_f32c(normals_gt)), ptr(I_gt), ptr(bb_gt), ptr(match), ptr(mask), B, N, K,
-             float(w_seg), float(w_normal), float(w_bb), ptr(out), ptr(dheads), ptr(ws), stream())
-        ctx.save_for_backward(dheads)
+        ngt = _f32c(normals_gt)
+        # forward launches only (dheads = NULL): the gradient is produced in backward, already multiplied by the upstream gradient
+        # (it used to be kept from the forward and scaled by a 21 MB torch multiply)
+        call("p2c_seg_losses_f32", ptr(hd), ld, xoff, woff, ptr(ngt), ptr(I_gt), ptr(bb_gt), ptr(match), ptr(mask), B, N, K,
+             float(w_seg), float(w_normal), float(w_bb), ptr(out), None, ptr(ws), stream())
+        ctx.save_for_backward(hd, ngt, I_gt, bb_gt, match, mask)
+        ctx.ws = ws                  # (a slice of the step arena shares the arena's version counter: every in-place write to ANY arena slice would
+        #                              trip save_for_backward's check; the slice itself is written by these two entry points only)
+        ctx.cfg = (B, N, K, xoff, woff, float(w_seg), float(w_normal), float(w_bb))
         ctx.mark_non_differentiable(match, mask)
         ctx.set_materialize_grads(False)       # no zero tensors (a fill launch each, ~5 us of the stream) for the outputs nobody differentiates
         return out, match, mask
 
     @staticmethod
     def backward(ctx, gout, gmatch, gmask):
-        (dheads,) = ctx.saved_tensors
         if gout is None:
             return (None,) * 12
-        return (dheads * gout[0],) + (None,) * 11      # only d/d total is propagated (the other three scalars are logging values)
+        hd, ngt, I_gt, bb_gt, match, mask = ctx.saved_tensors
+        ws = ctx.ws
+        B, N, K, xoff, woff, w_seg, w_normal, w_bb = ctx.cfg
+        M, ld = hd.shape
+        gout = _f32c(gout)
+        dheads = torch.empty(M, ld, dtype=torch.float32, device=hd.device)
+        # only d / d total is propagated (the other three scalars are logging values): gout[0] is the kernel's scale
+        call("p2c_seg_losses_grad_f32", ptr(hd), ld, xoff, woff, ptr(ngt), ptr(I_gt), ptr(bb_gt), ptr(match), ptr(mask), B, N, K,
+             w_seg, w_normal, w_bb, ptr(gout), ptr(dheads), ptr(ws), stream())
+        return (dheads,) + (None,) * 11
 
 
 class _HeadPost(torch.autograd.Function):
@@ -1218,7 +1231,7 @@ def head_post(heads, match, B, N, K, xoff=0, woff=3):
 def seg_losses(heads, normals_gt, I_gt, bb_gt, B, N, K, xoff, woff, w_seg=1.0, w_normal=1.0, w_bb=1.0):
     """-> (out[4] = total, normal, miou, bb ; matching_indices (B,K) int64 ; mask (B,K) bool)."""
     out, match, mask = _SegLosses.apply(heads, normals_gt, I_gt, bb_gt, B, N, K, xoff, woff, w_seg, w_normal, w_bb)
-    return out, match, mask.bool()
+    return out, match, mask.view(torch.bool)          # (0 / 1 bytes: a reinterpretation, not a conversion launch)
 
 
 class _AllLosses(torch.autograd.Function):

@@ -54,6 +54,9 @@ def get_learning_rate(init_lr, global_step, batch_size, decay_step, decay_rate, 
     return init_lr * (decay_rate ** p)
 
 
+_ZEROS = {}
+
+
 def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags, geom=None):
     """Same result as compute_losses for --pred_seg --pred_normal --pred_bb (K=8), with the head post-processing, the
     Hungarian matching and the three losses (forward + gradient) in csrc/loss.hip instead of ~60 torch launches.
@@ -65,7 +68,9 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
     assert sizes == [3, 2 * K] and fl.pred_seg and fl.pred_normal and fl.pred_bb and K in (2, 4, 8)
     out4, match, mask = ops.seg_losses(heads, gt_normals, gt_inst, gt_bb, B, N, K, 0, 3, fl.weight_seg, fl.weight_normal, fl.weight_bb)
     total = out4[0]
-    zero = torch.zeros((), device=pcs.device)
+    zero = _ZEROS.get(pcs.device)
+    if zero is None:
+        zero = _ZEROS[pcs.device] = torch.zeros((), device=pcs.device)      # a constant: not re-filled every step
     ext_loss = center_loss = zero
     res = dict(normal=out4[1].detach(), miou=out4[2].detach(), bb=out4[3].detach(), match=match, mask=mask, E_AX=None)
     if fl.pred_extrusion or fl.pred_center:

@@ -570,16 +570,17 @@ extern "C" int p2c_group_linear_bias_stats_f32(const float *G, int ldg, const fl
 // belongs to exactly one point) into dwx_slots [P2C_STAT_SLOTS][3][C] (fp64, zeroed by the caller).
 // Balanced over ENTRIES, not points: ball-query padding repeats the first neighbour, so a few points are read by hundreds of
 // grouped rows (one wave - or one workgroup - per point left a 0.3 - 1 ms tail).  Every wave takes EPW consecutive entries of
-// the point-sorted list, runs a segmented sum (the point changes where k reaches offsets[t+1]) and flushes each segment with
-// one atomicAdd per channel into dG (zeroed by the caller): ~2 segments per wave instead of one atomic per entry.
-template <int CPL>
+// the point-sorted list, runs a segmented sum (the point changes where k reaches offsets[t+1]) and flushes each segment into dG
+// (zeroed by the caller): plain stores for the points that lie wholly inside the wave's range, one atomicAdd per channel for the
+// (at most two) points its ends cut.
+template <int CPL, int EPW>
 __global__ void __launch_bounds__(256) group_linear_bwd_kernel(const float *__restrict__ dz, int lddz, const float *__restrict__ y, int ldy,
                                                                const float *__restrict__ coef, const int32_t *__restrict__ offsets,
                                                                const int32_t *__restrict__ entries, const float *__restrict__ xyz,
                                                                const float *__restrict__ new_xyz, int B, int N, int S, int ns, int C, int wpc,
                                                                float *__restrict__ dG, int ldo, double *__restrict__ dwx_slots)
 {
-    constexpr int EPW = 16, UB = 4;
+    constexpr int UB = 4;            // 64 entries per wave: ~4 whole points (plain stores) + 2 cut ones (atomics)
     __shared__ float red[3][4][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int E = S * ns;
@@ -597,26 +598,50 @@ __global__ void __launch_bounds__(256) group_linear_bwd_kernel(const float *__re
         const int32_t *eb = entries + (size_t)b * E;
         const int kb = (int)(gw - (long long)b * wpc) * EPW, kend = min(min(E, kb + EPW), off[N]);     // off[N] = number of valid entries
         if (kb < kend) {
-            int lo = 0, hi = N;                                 // point t with off[t] <= kb < off[t+1]
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= kb) lo = mid; else hi = mid; }
-            int t = lo, seg_end = off[t + 1];
-            int cur = -1;                                       // owner of acc[] (wave-uniform)
+            // Per-LANE prologue, so that the entry loop below carries no dependent scalar loads: lane l (and l + 64 when EPW = 128) owns
+            // entry kb + l - its grouped row, the point that reads it (binary search of the offsets, all lanes at once), that point's entry
+            // range and the relative coordinate.  The loop fetches them with v_readlane and has only the row loads left in flight.
+            constexpr int EL = (EPW + 63) / 64;
+            int le[EL], lt[EL], llo[EL], lhi[EL]; float rx[EL], ry[EL], rz[EL];
+#pragma unroll
+            for (int j = 0; j < EL; ++j) {
+                const int kk = min(kb + lane + 64 * j, kend - 1);
+                int lo = 0, hi = N;                             // point t with off[t] <= kk < off[t+1]
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (off[mid] <= kk) lo = mid; else hi = mid; }
+                const int e = eb[kk];
+                le[j] = e; lt[j] = lo; llo[j] = off[lo]; lhi[j] = off[lo + 1];
+                const float *pp = xyz + ((size_t)b * N + lo) * 3, *cc = new_xyz + ((size_t)b * S + e / ns) * 3;
+                rx[j] = pp[0] - cc[0]; ry[j] = pp[1] - cc[1]; rz[j] = pp[2] - cc[2];
+            }
+            int cur = -1, cur_lo = 0, cur_hi = 0;               // owner of acc[] (wave-uniform) and its entry range
             auto flush = [&]() {
                 float *o = dG + ((size_t)b * N + cur) * ldo;
+                // a point whose whole entry range lies inside this wave's range is nobody else's: plain stores.  Only the (at most two) points
+                // cut by the range's ends are shared with the neighbouring waves and need the atomic.  (With one atomic per channel and
+                // segment the kernel issued 4.2 M fp32 atomics per launch and ran at THEIR rate, not the memory system's.)
+                const bool whole = cur_lo >= kb && cur_hi <= kend;              // uniform
 #pragma unroll
-                for (int i = 0; i < CPL; ++i) { const int c = lane + 64 * i; if (c < C) atomicAdd(o + c, acc[i]); acc[i] = 0.f; }
+                for (int i = 0; i < CPL; ++i) {
+                    const int c = lane + 64 * i;
+                    if (c < C) { if (whole) o[c] = acc[i]; else atomicAdd(o + c, acc[i]); }
+                    acc[i] = 0.f;
+                }
             };
-            for (int k = kb; k < kend; k += UB) {
-                size_t ro[UB]; float dx[UB], dy[UB], dzz[UB]; int tt[UB];
+            auto pick_i = [&](const int (&v)[EL], int idx) { int r = __builtin_amdgcn_readlane(v[0], idx & 63);
+                                                             if (EL > 1 && idx >= 64) r = __builtin_amdgcn_readlane(v[EL - 1], idx & 63);
+                                                             return r; };
+            auto pick_f = [&](const float (&v)[EL], int idx) { int r = __builtin_amdgcn_readlane(__float_as_int(v[0]), idx & 63);
+                                                               if (EL > 1 && idx >= 64) r = __builtin_amdgcn_readlane(__float_as_int(v[EL - 1]), idx & 63);
+                                                               return __int_as_float(r); };
+            const int cnt = kend - kb;
+            for (int k = 0; k < cnt; k += UB) {
+                size_t ro[UB]; float dx[UB], dy[UB], dzz[UB]; int tt[UB], tlo[UB], thi[UB];
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
-                    const int kk = min(k + u, kend - 1);
-                    while (kk >= seg_end) { ++t; seg_end = off[t + 1]; }
-                    tt[u] = t;
-                    const int e = eb[kk];
-                    ro[u] = (size_t)b * E + e;
-                    const float *pp = xyz + ((size_t)b * N + t) * 3, *cc = new_xyz + ((size_t)b * S + e / ns) * 3;
-                    dx[u] = pp[0] - cc[0]; dy[u] = pp[1] - cc[1]; dzz[u] = pp[2] - cc[2];
+                    const int idx = min(k + u, cnt - 1);        // uniform
+                    tt[u] = pick_i(lt, idx); tlo[u] = pick_i(llo, idx); thi[u] = pick_i(lhi, idx);
+                    ro[u] = (size_t)b * E + pick_i(le, idx);
+                    dx[u] = pick_f(rx, idx); dy[u] = pick_f(ry, idx); dzz[u] = pick_f(rz, idx);
                 }
                 float d[UB][CPL];
 #pragma unroll
@@ -630,10 +655,10 @@ __global__ void __launch_bounds__(256) group_linear_bwd_kernel(const float *__re
                 }
 #pragma unroll
                 for (int u = 0; u < UB; ++u) {
-                    if (k + u < kend) {                         // uniform
+                    if (k + u < cnt) {                          // uniform
                         if (tt[u] != cur) {
                             if (cur >= 0) flush();
-                            cur = tt[u];
+                            cur = tt[u]; cur_lo = tlo[u]; cur_hi = thi[u];
                         }
 #pragma unroll
                         for (int i = 0; i < CPL; ++i) {
@@ -665,10 +690,11 @@ extern "C" int p2c_group_linear_bwd_f32(const float *dz, int lddz, const float *
     if (!dz || !y || !coef || !offsets || !rows || !xyz || !new_xyz || !dG || !dwx_slots || B <= 0 || N <= 0 || S <= 0 || nsample <= 0 ||
         C <= 0 || C > 256)
         return P2C_EINVAL;
-    const int wpc = p2c_cdiv((long long)S * nsample, 16);             // waves per cloud, 16 entries each
+    constexpr int EPW = 64;                                           // measured: 32 -> 69 us, 64 -> 57 us, 128 -> 88 us (SA2, 1M entries)
+    const int wpc = p2c_cdiv((long long)S * nsample, EPW);            // waves per cloud, EPW entries each
     const int blocks = p2c_cdiv((long long)B * wpc, 4);
     hipStream_t s = (hipStream_t)stream;
-#define P2C_GLB(CPL_) hipLaunchKernelGGL(group_linear_bwd_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, dz, lddz, y, ldy, coef, offsets, rows, xyz, new_xyz, B, N, S, nsample, C, wpc, dG, ldo, dwx_slots)
+#define P2C_GLB(CPL_) hipLaunchKernelGGL((group_linear_bwd_kernel<CPL_, EPW>), dim3(blocks), dim3(256), 0, s, dz, lddz, y, ldy, coef, offsets, rows, xyz, new_xyz, B, N, S, nsample, C, wpc, dG, ldo, dwx_slots)
     if (C <= 64) P2C_GLB(1);
     else if (C <= 128) P2C_GLB(2);
     else P2C_GLB(4);

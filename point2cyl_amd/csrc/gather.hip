@@ -390,72 +390,85 @@ template <int CPL>
 __global__ void __launch_bounds__(256) csr_gather_bn_kernel(const float *__restrict__ dz, int lddz, const float *__restrict__ y, int ldy,
                                                             const float *__restrict__ coef, const int32_t *__restrict__ offsets,
                                                             const int32_t *__restrict__ entries, const float *__restrict__ w, int E, int rows_b,
-                                                            int T, int C, long long total, float *__restrict__ out, int ldo, int xcd_clouds)
+                                                            int T, int C, long long total, float *__restrict__ out, int ldo, int xcd_clouds, int nsplit)
 {
     const int lane = threadIdx.x & 63;
     // XCD-aware: workgroups go round the 8 XCDs (blockIdx.x % 8), and every dense row is read by ~3 target rows of the SAME cloud - with the
     // targets of a cloud spread over all XCDs each of those reads missed its own L2 (742 MB fetched for a 268 MB stream).  xcd_clouds != 0:
     // cloud b is served by XCD b % 8 only, all its targets resident there at about the same time, so the second and third read hit that L2.
-    long long wv;
+    // nsplit = 2 (xcd_clouds only): the channels go in two halves, ALL targets of a cloud for the first half before any for the second, so the
+    // rows a cloud's targets share (dz + y of one cloud: 8.4 MB at 128 channels, twice an XCD's 4 MB L2) are a 4.2 MB working set per pass.
+    long long wv; int h = 0;
     if (xcd_clouds) {
-        const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3), bpc = T / 4;       // blocks per cloud
-        wv = ((long long)(xcd + 8 * (slot / bpc)) * bpc + (slot % bpc)) * 4 + (threadIdx.x >> 6);
+        const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3), bpc = T / 4;       // blocks per cloud (and channel half)
+        const int round = slot / (nsplit * bpc), r = slot - round * (nsplit * bpc);
+        h = r / bpc;
+        wv = ((long long)(xcd + 8 * round) * bpc + (r - h * bpc)) * 4 + (threadIdx.x >> 6);
     } else {
         wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     }
     if (wv >= total) return;
     const int b = (int)(wv / T), t = (int)(wv - (long long)b * T);
+    const int Cs = C / nsplit, c0 = h * Cs;                  // this wave's channels: [c0, c0 + Cs)
     const int k0 = offsets[(size_t)b * (T + 1) + t], k1 = offsets[(size_t)b * (T + 1) + t + 1];
     const int32_t *eb = entries + (size_t)b * E;
     const float *wb = w ? w + (size_t)b * E : nullptr;
     float acc[CPL], csc[CPL], csh[CPL], cgs[CPL], cq[CPL], cp[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
-        const int c = min(lane + 64 * i, C - 1);
+        const int c = c0 + min(lane + 64 * i, Cs - 1);
         acc[i] = 0.f;
         csc[i] = coef[c]; csh[i] = coef[C + c]; cgs[i] = coef[2 * C + c]; cq[i] = coef[3 * C + c]; cp[i] = coef[4 * C + c];
     }
     constexpr int UB = 8;                         // (dz, y) row pairs in flight per lane
-    int k = k0;
-    for (; k + UB <= k1; k += UB) {
-        float we[UB]; size_t ro[UB];
+    // 64 entries at a time: lane l fetches entry kc + l (row id and weight, one coalesced load each) and the loops below read them back with
+    // v_readlane - no scalar load sits between two batches of row loads (as in group_linear_bwd_kernel below).
+    for (int kc = k0; kc < k1; kc += 64) {
+        const int n = min(64, k1 - kc);
+        const int kl = kc + min(lane, n - 1);
+        const int le = eb[kl];
+        const float lw = wb ? wb[kl] : 1.f;
+        int k = 0;
+        for (; k + UB <= n; k += UB) {
+            float we[UB]; size_t ro[UB];
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-            we[u] = wb ? wb[k + u] : 1.f;
-            ro[u] = (size_t)b * rows_b + eb[k + u];
-        }
+            for (int u = 0; u < UB; ++u) {
+                we[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lw), k + u));
+                ro[u] = (size_t)b * rows_b + __builtin_amdgcn_readlane(le, k + u);
+            }
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int c = lane + 64 * i;
-            if (c < C) {
-                float g[UB], yy[UB];
+            for (int i = 0; i < CPL; ++i) {
+                const int c = c0 + lane + 64 * i;
+                if (c < c0 + Cs) {
+                    float g[UB], yy[UB];
 #pragma unroll
-                for (int u = 0; u < UB; ++u) { g[u] = dz[ro[u] * lddz + c]; yy[u] = y[ro[u] * ldy + c]; }
+                    for (int u = 0; u < UB; ++u) { g[u] = dz[ro[u] * lddz + c]; yy[u] = y[ro[u] * ldy + c]; }
 #pragma unroll
-                for (int u = 0; u < UB; ++u) {
-                    const float d = __builtin_fmaf(cgs[i], (csc[i] * yy[u] + csh[i] > 0.f) ? g[u] : 0.f, __builtin_fmaf(cq[i], yy[u], cp[i]));
-                    acc[i] += we[u] * d;
+                    for (int u = 0; u < UB; ++u) {
+                        const float d = __builtin_fmaf(cgs[i], (csc[i] * yy[u] + csh[i] > 0.f) ? g[u] : 0.f, __builtin_fmaf(cq[i], yy[u], cp[i]));
+                        acc[i] += we[u] * d;
+                    }
                 }
             }
         }
-    }
-    for (; k < k1; ++k) {
-        const float we = wb ? wb[k] : 1.f;
-        const size_t ro = (size_t)b * rows_b + eb[k];
+        for (; k < n; ++k) {
+            const float we = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lw), k));
+            const size_t ro = (size_t)b * rows_b + __builtin_amdgcn_readlane(le, k);
 #pragma unroll
-        for (int i = 0; i < CPL; ++i) {
-            const int c = lane + 64 * i;
-            if (c < C) {
-                const float g = dz[ro * lddz + c], yy = y[ro * ldy + c];
-                acc[i] += we * __builtin_fmaf(cgs[i], (csc[i] * yy + csh[i] > 0.f) ? g : 0.f, __builtin_fmaf(cq[i], yy, cp[i]));
+            for (int i = 0; i < CPL; ++i) {
+                const int c = c0 + lane + 64 * i;
+                if (c < c0 + Cs) {
+                    const float g = dz[ro * lddz + c], yy = y[ro * ldy + c];
+                    acc[i] += we * __builtin_fmaf(cgs[i], (csc[i] * yy + csh[i] > 0.f) ? g : 0.f, __builtin_fmaf(cq[i], yy, cp[i]));
+                }
             }
         }
     }
     float *o = out + ((size_t)b * T + t) * ldo;
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
-        const int c = lane + 64 * i;
-        if (c < C) o[c] = acc[i];
+        const int c = c0 + lane + 64 * i;
+        if (c < c0 + Cs) o[c] = acc[i];
     }
 }
 
@@ -465,13 +478,16 @@ extern "C" int p2c_csr_gather_bn_f32(const float *dz, int lddz, const float *y, 
 {
     if (!dz || !y || !coef || !offsets || !rows || !out || B <= 0 || E <= 0 || T <= 0 || C <= 0 || C > 256) return P2C_EINVAL;
     const long long total = (long long)B * T;
-    dim3 grid(p2c_cdiv(total, 4));
     hipStream_t s = (hipStream_t)stream;
-    static const bool xcd_on = !(getenv("P2C_XCD_GATHER") && atoi(getenv("P2C_XCD_GATHER")) == 0);         // A/B switch
+    static const bool xcd_on = !(getenv("P2C_XCD_GATHER") && atoi(getenv("P2C_XCD_GATHER")) == 0);         // A/B switches
+    static const bool split_on = !(getenv("P2C_GATHER_SPLIT") && atoi(getenv("P2C_GATHER_SPLIT")) == 0);
     const int xcd_clouds = (xcd_on && B % 8 == 0 && T % 4 == 0) ? 1 : 0;
-#define P2C_CGB(CPL_) hipLaunchKernelGGL(csr_gather_bn_kernel<CPL_>, grid, dim3(256), 0, s, dz, lddz, y, ldy, coef, offsets, rows, wsorted, E, rows_b, T, C, total, out, ldo, xcd_clouds)
-    if (C <= 64) P2C_CGB(1);
-    else if (C <= 128) P2C_CGB(2);
+    const int nsplit = (xcd_clouds && split_on && C == 128) ? 2 : 1;
+    dim3 grid(p2c_cdiv(total, 4) * nsplit);
+    const int Cs = C / nsplit;
+#define P2C_CGB(CPL_) hipLaunchKernelGGL(csr_gather_bn_kernel<CPL_>, grid, dim3(256), 0, s, dz, lddz, y, ldy, coef, offsets, rows, wsorted, E, rows_b, T, C, total, out, ldo, xcd_clouds, nsplit)
+    if (Cs <= 64) P2C_CGB(1);
+    else if (Cs <= 128) P2C_CGB(2);
     else P2C_CGB(4);
 #undef P2C_CGB
     P2C_LAUNCH_CHECK();

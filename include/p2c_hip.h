@@ -440,6 +440,19 @@ int p2c_linear_bwd_data_sig_f32(const float *dZ, int lddz, const float *W, int l
 int p2c_softplus_sig_bwd_f32(const float *g, const float *a, const float *z, float *t, float *dz, long long n, float beta, float threshold,
                              void *stream);
 
+/* The same two products for the decoder's LARGE shapes (p2c_linear_big_supported: M >= 16384 rows, N, K >= 128, multiples of 4) on 128 x 256
+ * tiles with W split into its three bf16 planes ONCE per call (csrc/gemm_big.hip) instead of once per workgroup: same operands, same results
+ * to the fp32 contract of the split products (section "bf16 x 3" above), plus a caller-provided workspace `ws` of
+ * p2c_linear_big_ws_bytes(N, K) bytes (16-byte aligned) that holds the split image.  p2c_linear_bwd_data_big_f32 with Z == NULL is the plain
+ * data gradient dX = dZ . W.  IGR/network.py:20-92 (the eight 512-wide layers), train_Point2Cyl.py:608-648 (evaluated forward, backward
+ * and backward-of-backward by the with-sketch step). */
+int p2c_linear_big_supported(int M, int N, int K);
+size_t p2c_linear_big_ws_bytes(int N, int K);
+int p2c_linear_fwd_big_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, float *Y, int ldy, int M, int N, int K, void *ws,
+                           void *stream);
+int p2c_linear_bwd_data_big_f32(const float *dZ, int lddz, const float *W, int ldw, const float *Z, int ldz, float beta, float threshold,
+                                float *dX, int lddx, int M, int N, int K, void *ws, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Hungarian matching on the device (losses.py:22-52; scipy.optimize.linear_sum_assignment restated)
  * W [B,N,K] soft or hard segmentation, I_gt [B,N] int64 (may contain -1).  match_out [B,K] int64,

@@ -79,6 +79,8 @@ _SIGS = {
     "p2c_softplus_bwd_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_p],
     "p2c_linear_bwd_data_sig_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p],
     "p2c_softplus_sig_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_ll, c_f, c_f, c_p],
+    "p2c_linear_fwd_big_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "p2c_linear_bwd_data_big_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "p2c_linear_sum_assignment_f64": [c_p, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_linear_bwd_both_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],
     "p2c_head_post_f32": [c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
@@ -144,6 +146,10 @@ def lib():
     L.p2c_fit_fused_supported.restype = c_i
     L.p2c_extents_ws_bytes.argtypes = [c_i, c_i]
     L.p2c_extents_ws_bytes.restype = ctypes.c_size_t
+    L.p2c_linear_big_supported.argtypes = [c_i, c_i, c_i]
+    L.p2c_linear_big_supported.restype = c_i
+    L.p2c_linear_big_ws_bytes.argtypes = [c_i, c_i]
+    L.p2c_linear_big_ws_bytes.restype = ctypes.c_size_t
     _lib = L
     return L
 

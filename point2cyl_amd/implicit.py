@@ -15,6 +15,8 @@ parameters keep the reference's shapes and names (lin0 .. lin8).  The bias is ad
 the double backward evaluates are one pass each (csrc/softplus.hip); moving them into the GEMM prologues / epilogues is the next
 step for this row.
 There is no CPU path."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -47,6 +49,16 @@ def _tn(A, X):
     return _TN.apply(_c(A), _c(X))
 
 
+USE_BIG = os.environ.get("P2C_GEMM_BIG", "1") != "0"      # A/B switch: the decoder's large products on csrc/gemm_big.hip
+
+
+def _big(M, N, K, dev):
+    """-> workspace for the split image of W if (M, N, K) is a shape of the big-tile kernels, else None."""
+    if not USE_BIG or not _lib.lib().p2c_linear_big_supported(M, N, K):
+        return None
+    return torch.empty(_lib.lib().p2c_linear_big_ws_bytes(N, K), dtype=torch.uint8, device=dev)
+
+
 def _check(*ts):
     _lib.require_device(*ts)
     for t in ts:
@@ -63,8 +75,12 @@ class _NT(torch.autograd.Function):
         M, K = X.shape
         N = W.shape[0]
         Y = torch.empty(M, N, dtype=torch.float32, device=X.device)
-        call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(),
-             flops=2.0 * M * N * K)
+        ws = _big(M, N, K, X.device)
+        if ws is not None:
+            call("p2c_linear_fwd_big_f32", ptr(X), K, ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, ptr(ws), stream(), flops=2.0 * M * N * K)
+        else:
+            call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(),
+                 flops=2.0 * M * N * K)
         ctx.save_for_backward(X, W)
         return Y
 
@@ -84,8 +100,12 @@ class _NN(torch.autograd.Function):
         M, N = A.shape
         K = W.shape[1]
         O = torch.empty(M, K, dtype=torch.float32, device=A.device)
-        call("p2c_linear_bwd_data_f32", ptr(A), N, None, 0, 0, None, ptr(W), K, ptr(O), K, M, N, K, None, 0, 1.0, None, 0, None, None, None, 0,
-             stream(), flops=2.0 * M * N * K)
+        ws = _big(M, N, K, A.device)
+        if ws is not None:
+            call("p2c_linear_bwd_data_big_f32", ptr(A), N, ptr(W), K, None, 0, 0.0, 0.0, ptr(O), K, M, N, K, ptr(ws), stream(), flops=2.0 * M * N * K)
+        else:
+            call("p2c_linear_bwd_data_f32", ptr(A), N, None, 0, 0, None, ptr(W), K, ptr(O), K, M, N, K, None, 0, 1.0, None, 0, None, None, None, 0,
+                 stream(), flops=2.0 * M * N * K)
         ctx.save_for_backward(A, W)
         return O
 
@@ -170,7 +190,11 @@ class _NNSig(torch.autograd.Function):
         M, N = A.shape
         K = W.shape[1]
         a = torch.empty(M, K, dtype=torch.float32, device=A.device)
-        call("p2c_linear_bwd_data_sig_f32", ptr(A), N, ptr(W), K, ptr(z), K, beta, thr, ptr(a), K, M, N, K, stream(), flops=2.0 * M * N * K)
+        ws = _big(M, N, K, A.device)
+        if ws is not None:
+            call("p2c_linear_bwd_data_big_f32", ptr(A), N, ptr(W), K, ptr(z), K, beta, thr, ptr(a), K, M, N, K, ptr(ws), stream(), flops=2.0 * M * N * K)
+        else:
+            call("p2c_linear_bwd_data_sig_f32", ptr(A), N, ptr(W), K, ptr(z), K, beta, thr, ptr(a), K, M, N, K, stream(), flops=2.0 * M * N * K)
         ctx.save_for_backward(A, W, z, a)
         ctx.bt = (beta, thr)
         return a
@@ -199,7 +223,11 @@ class _SpLinear(torch.autograd.Function):
         h = torch.empty_like(z)
         call("p2c_softplus_fwd_f32", ptr(z), ptr(h), z.numel(), beta, thr, stream(), nbytes=8.0 * z.numel())
         Y = torch.empty(M, N, dtype=torch.float32, device=z.device)
-        call("p2c_linear_fwd_f32", ptr(h), K, ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(), flops=2.0 * M * N * K)
+        ws = _big(M, N, K, z.device)
+        if ws is not None:
+            call("p2c_linear_fwd_big_f32", ptr(h), K, ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, ptr(ws), stream(), flops=2.0 * M * N * K)
+        else:
+            call("p2c_linear_fwd_f32", ptr(h), K, ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(), flops=2.0 * M * N * K)
         ctx.save_for_backward(z, W)
         ctx.bt = (beta, thr)
         ctx.has_bias = bias is not None

@@ -1041,6 +1041,93 @@ def test_implicit_decoder_vs_oracle_trainer_shapes():
         assert np.linalg.norm(p.grad.cpu().numpy() - ref) <= 2e-3 * np.linalg.norm(ref) + 1e-9, n
 
 
+@pytest.mark.parametrize("M,N,K", [(16384, 512, 512), (16500, 256, 260), (20001, 132, 516), (16384, 512, 128)])
+def test_big_tile_products_vs_float64(M, N, K):
+    """csrc/gemm_big.hip (the decoder's large products: W split once per call, 128 x 256 tiles) through the C ABI: forward with bias, plain data
+    gradient and data gradient with the softplus derivative in the epilogue, against float64 within the split products' fp32 contract
+    (4e-7 of sum |a||b| per element), ragged M / N / K included; and against the generic tiled route (same planes, same product order)."""
+    from point2cyl_amd import _lib
+    from point2cyl_amd._lib import call, ptr, stream
+    L = _lib.lib()
+    assert L.p2c_linear_big_supported(M, N, K) == 1 and L.p2c_linear_big_supported(1024, N, K) == 0
+    gen = torch.Generator().manual_seed(M + N + K)
+    X = torch.randn(M, K, generator=gen).to(DEV)
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=gen).to(DEV)
+    dZ = torch.randn(M, N, generator=gen).to(DEV)
+    Z = (torch.randn(M, K, generator=gen) * 0.02).to(DEV)
+    Z[::7, ::5] = 0.5                                            # beta * z > threshold: derivative exactly 1
+    ws = torch.empty(L.p2c_linear_big_ws_bytes(N, K), dtype=torch.uint8, device=DEV)
+    Y = torch.full((M, N), float("nan"), device=DEV)
+    call("p2c_linear_fwd_big_f32", ptr(X), K, ptr(W), K, ptr(b), ptr(Y), N, M, N, K, ptr(ws), stream())
+    ref = X.double() @ W.double().t() + b.double()
+    bound = 4e-7 * (X.double().abs() @ W.double().abs().t() + b.double().abs()) + 1e-30
+    assert bool(((Y.double() - ref).abs() <= bound).all()), float(((Y.double() - ref).abs() / bound).max())
+    Yg = torch.empty(M, N, device=DEV)
+    call("p2c_linear_fwd_f32", ptr(X), K, ptr(W), K, ptr(b), ptr(Yg), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream())
+    assert float((Y - Yg).abs().max()) <= 2e-6 * float(Yg.abs().max())
+    dX = torch.full((M, K), float("nan"), device=DEV)
+    call("p2c_linear_bwd_data_big_f32", ptr(dZ), N, ptr(W), K, None, 0, 0.0, 0.0, ptr(dX), K, M, N, K, ptr(ws), stream())
+    refd = dZ.double() @ W.double()
+    boundd = 4e-7 * (dZ.double().abs() @ W.double().abs()) + 1e-30
+    assert bool(((dX.double() - refd).abs() <= boundd).all()), float(((dX.double() - refd).abs() / boundd).max())
+    dXs = torch.full((M, K), float("nan"), device=DEV)
+    call("p2c_linear_bwd_data_big_f32", ptr(dZ), N, ptr(W), K, ptr(Z), K, 100.0, 20.0, ptr(dXs), K, M, N, K, ptr(ws), stream())
+    sg = torch.where(Z.double() * 100.0 > 20.0, torch.ones_like(Z, dtype=torch.float64), torch.sigmoid(Z.double() * 100.0))
+    err = (dXs.double() - refd * sg).abs()
+    tol = boundd * sg + 2e-6 * (refd * sg).abs() + 2e-7 * refd.abs()        # the last term: 1 - sigmoid in fp32 where sigmoid is ~1
+    assert bool((err <= tol).all()), float((err / tol).max())
+    dXg = torch.empty(M, K, device=DEV)
+    call("p2c_linear_bwd_data_sig_f32", ptr(dZ), N, ptr(W), K, ptr(Z), K, 100.0, 20.0, ptr(dXg), K, M, N, K, stream())
+    assert float((dXs - dXg).abs().max()) <= 2e-6 * float(dXg.abs().max())
+    # argument checks
+    assert L.p2c_linear_fwd_big_f32(ptr(X), K, ptr(W), K, ptr(b), ptr(Y), N, M, N, K, None, None) == -1
+    assert L.p2c_linear_fwd_big_f32(ptr(X), K + 1, ptr(W), K, ptr(b), ptr(Y), N, M, N, K, ptr(ws), None) == -2
+
+
+def test_implicit_decoder_big_tiles_vs_oracle_trainer_shapes():
+    """As test_implicit_decoder_vs_oracle_trainer_shapes, with enough rows (4 x 2 sketches of 2048 points: 16 384 and 18 432 rows) that every
+    512-wide product of the three passes takes the big-tile route; and the same losses / gradients with the route switched off."""
+    from point2cyl_amd import implicit
+    from point2cyl_amd.implicit import ImplicitNet
+    torch.manual_seed(9)
+    dec = ImplicitNet(d_in=258, dims=[512] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    dec = dec.to(DEV)
+    B, K, S = 4, 2, 2048
+    gen = torch.Generator().manual_seed(2)
+    sk = torch.randn(B * K, S, 2, generator=gen) * 0.4
+    nrm = F.normalize(torch.randn(B * K, S, 2, generator=gen), dim=-1)
+    non = torch.cat([sk + 0.05 * torch.randn(B * K, S, 2, generator=gen), torch.rand(B * K, S // 8, 2, generator=gen) * 2 - 1], 1)
+    lat0 = F.normalize(torch.randn(B * K, 256, generator=gen))
+    mask = torch.tensor([[True, True], [True, False], [True, True], [False, False]])
+    res = {}
+    for big in (True, False):
+        implicit.USE_BIG = big
+        try:
+            for p in dec.parameters():
+                p.grad = None
+            lat = lat0.to(DEV).requires_grad_(True)
+            im, mn, ek, nl, _, _ = _im_losses(dec, sk.to(DEV), nrm.to(DEV), non.to(DEV), lat, mask.to(DEV), B, K)
+            im.backward()
+            res[big] = ([im.item(), mn.item(), ek.item(), nl.item()], lat.grad.cpu().numpy(), {n: p.grad.cpu().numpy().copy() for n, p in dec.named_parameters()})
+        finally:
+            implicit.USE_BIG = True
+    latr = lat0.clone().requires_grad_(True)
+    imr, mnr, ekr, nlr = R.implicit_losses(sd, sk, nrm, non, latr, mask, B, K)
+    imr.backward()
+    for big in (True, False):
+        vals, lg, pg = res[big]
+        np.testing.assert_allclose(vals, [imr.item(), mnr.item(), ekr.item(), nlr.item()], rtol=1e-4)
+        assert np.linalg.norm(lg - latr.grad.numpy()) <= 2e-3 * np.linalg.norm(latr.grad.numpy())
+        for n in pg:
+            ref = sd[n].grad.numpy()
+            assert np.linalg.norm(pg[n] - ref) <= 2e-3 * np.linalg.norm(ref) + 1e-9, (big, n)
+    for n in res[True][2]:                                          # the two routes against each other: far inside the bar against the oracle
+        a, b = res[True][2][n], res[False][2][n]
+        assert np.linalg.norm(a - b) <= 2e-5 * np.linalg.norm(b) + 1e-9, n
+
+
 def test_sketch_branch_step_vs_oracle():
     """The composed implicit-sketch losses of one with-sketch training step (train_Point2Cyl.py:519-672: projection of the predicted
     and the ground-truth segmentation, encoder, frozen ground-truth encoder, decoder losses, latent loss) and the gradients they

@@ -148,7 +148,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
     for (int kt = 0; kt < KT; ++kt) {
         const bool more = kt + 1 < KT;
-        if (more) P2C_BIG_LOAD(kt + 1);                             // in flight under the MFMAs below
+        P2C_BIG_LOAD(more ? kt + 1 : kt);                           // in flight under the MFMAs below (unconditional: a load under a branch
+                                                                    // makes the 32 prefetch registers loop-carried copies, 32 v_mov per tile)
+        __builtin_amdgcn_s_setprio(0);
         {
             const uint16_t *As = Ap + (kt & 1) * STAGE, *Bs = As + 3 * A_PLANE;
             b_bf16x8 a[2][3], b[4][3];
@@ -171,9 +173,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             P2C_B3(1, 1); P2C_B3(0, 2); P2C_B3(2, 0); P2C_B3(0, 1); P2C_B3(1, 0); P2C_B3(0, 0);
 #undef P2C_B3
         }
-        if (more) P2C_BIG_STORE((kt + 1) & 1);
+        // The other workgroup's wave on this SIMD is (ideally) in its MFMA phase now, and an MFMA stream leaves its partner about one issue
+        // slot per MFMA: the split / store phase asks for priority so that its ~200 instructions do not take four MFMA phases.
+        __builtin_amdgcn_s_setprio(3);
+        P2C_BIG_STORE((kt + 1) & 1);                                // after the last tile: a harmless re-store into the idle stage
         __syncthreads();
     }
+    __builtin_amdgcn_s_setprio(0);
 #undef P2C_BIG_LOAD
 #undef P2C_BIG_STORE
 

@@ -28,11 +28,12 @@ def timed(fn, n=20):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--M", type=int, default=262144)
+    ap.add_argument("--one", action="store_true", help="the 512 x 512 shape only (profiling runs)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     L = _lib.lib()
     out = []
-    for (N, K) in [(512, 512), (512, 260), (256, 512), (512, 256)]:
+    for (N, K) in [(512, 512), (512, 260), (256, 512), (512, 256)][:1 if a.one else 4]:
         M = a.M
         X = torch.randn(M, K, device=dev)
         W = torch.randn(N, K, device=dev) / K ** 0.5

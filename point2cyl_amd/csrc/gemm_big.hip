@@ -4,12 +4,15 @@
 //
 // Why a second GEMM: gemm.hip's 64 x 128 tile re-splits its W tile in EVERY workgroup (4096 times per layer) and its A tile four times,
 // and on this chip VALU work does not hide behind the matrix pipe (a wave next to an MFMA stream gets about one issue slot per MFMA,
-// DESIGN 8): the split arithmetic is paid in full - 1.12 ms for 137 GFLOP, 29 % of the split ceiling.  Here
+// DESIGN 3 "issue model"): the split arithmetic is paid in full - 1.25 ms for 137 GFLOP, 26 % of the split ceiling.  Here
 //   * W is split ONCE per call by a 5 us pre-pass into three bf16 planes, tiled and swizzled exactly as the LDS image wants them
-//     ([k-tile][plane][row][32 k], 16-byte chunk c of row j stored at c ^ ((j >> 2) & 3)): a B tile is three contiguous 16 KB copies,
+//     ([k-tile][plane][row][16 k], the 16-byte half h of row r stored at h ^ ((r >> 3) & 1)): a B tile is three contiguous 8 KB copies,
 //     no arithmetic, no padding, conflict-free ds_read_b128 fragment reads;
 //   * the tile is 128 x 256 (wave tile 64 x 128, 8 accumulators): 48 MFMAs per 18 fragment reads, and the A split (the only VALU work
-//     left) is amortised over 256 columns instead of 128.
+//     left) is amortised over 256 columns instead of 128;
+//   * the k-tile is ONE MFMA k-step (16) with two LDS stages of 36.9 KB: two workgroups per CU (240 registers, 73.7 KB each), one barrier
+//     per tile; the other workgroup's MFMAs run while this one splits / stores / waits.
+// Measured: forward 1.25 -> 0.75 ms, data gradient with the softplus derivative 1.29 -> 0.88 ms at 262 144 x 512 x 512.
 // C[M, J] = A[M, Kd] . B[J, Kd]^T with B = W (forward: J = N, Kd = K) or B = W^T (data gradient: J = K, Kd = N).
 #include "common.h"
 #include <stdlib.h>

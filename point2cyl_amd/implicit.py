@@ -4,7 +4,7 @@
 The with-sketch trainer differentiates the decoder TWICE: the eikonal / normal losses are functions of d(output)/d(point)
 (`gradient`, torch.autograd.grad with create_graph=True), and the optimiser step needs their derivative w.r.t. the weights
 (train_Point2Cyl.py:608-648).  Every matrix product of all three passes runs on this package's GEMM kernels (csrc/gemm.hip through
-the C ABI): the three product shapes
+the C ABI; the 512-wide products of the trainer's shapes on csrc/gemm_big.hip, `_big`): the three product shapes
 
     NT(X, W) = X W^T        NN(A, W) = A W        TN(A, X) = A^T X
 

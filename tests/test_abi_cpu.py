@@ -61,6 +61,19 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_linear_bwd_narrow_f32(one, 20, one, 130, one, None, 1.0, one, 128, one, 128, one, 128, 20 * 128, None, one, 262144, 20, 128, None) == -2   # row stride not 16-byte aligned
     assert L.p2c_sum_copies_f32(None, 16, 8, None, 16, None) == -1
     assert L.p2c_bn_bwd_finalize_sum_f32(None, 64, 10, None, None, None, None, None, None, 16, 8, None, 16, None) == -1
+    # round 4 entries
+    assert L.p2c_all_losses_f32(None, None, None, None, None, None, 1, 8, 8, None, None, None, None, None) == -1
+    assert L.p2c_all_losses_f32(one, one, one, one, one, one, 1, 8, 6, one, one, one, one, None) == -1                              # K not 2, 4 or 8
+    assert L.p2c_seg_losses_grad_f32(None, 20, 0, 4, None, None, None, None, None, 1, 8, 8, 1.0, 1.0, 1.0, None, None, None, None) == -1
+    assert L.p2c_copy2d_batch_f32(None, 4, None) == -1 and L.p2c_copy2d_batch_f32(one, 0, None) == -1
+    assert L.p2c_linear_bwd_pool_alg_f32(None, 128, None, None, None, None, 64, None, None, None, 64, None, None, 64, None, None, None, None, 64, 1048576, 128, 64, 64, None) == -1
+    assert L.p2c_linear_bwd_pool_alg_supported(1048576, 128, 64, 64) == 1 and L.p2c_linear_bwd_pool_alg_supported(1048576, 128, 128, 64) == 0
+    assert L.p2c_linear_big_supported(262144, 512, 512) == 1 and L.p2c_linear_big_supported(2048, 512, 512) == 0 and L.p2c_linear_big_supported(262144, 510, 512) == 0
+    assert L.p2c_linear_big_ws_bytes(512, 512) == 3 * 2 * 512 * 512 and L.p2c_linear_big_ws_bytes(254 + 2, 260) == 3 * 2 * 512 * 256
+    assert L.p2c_linear_fwd_big_f32(None, 512, None, 512, None, None, 512, 262144, 512, 512, None, None) == -1
+    assert L.p2c_linear_fwd_big_f32(one, 512, one, 512, None, one, 512, 1024, 512, 512, one, None) == -1                            # too few rows for this route
+    assert L.p2c_linear_fwd_big_f32(one, 514, one, 512, None, one, 512, 262144, 512, 512, one, None) == -2                          # row stride not 16-byte aligned
+    assert L.p2c_linear_bwd_data_big_f32(one, 512, one, 512, one, 512, 0.0, 20.0, one, 512, 262144, 512, 512, one, None) == -1      # softplus derivative needs beta > 0
 
 
 def test_shape_queries_describe_the_kernel_coverage():

@@ -23,6 +23,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 b_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 b_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float b_v2f __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));       // a native vector: HIP's uint4 struct is copied by memcpy and stays in scratch
 
 constexpr int BM = 128, BN = 256, BK = 16;                                // one MFMA k-step per tile: two LDS stages fit twice per CU
@@ -194,8 +195,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int c = 0; c < 4; ++c) bv[c] = epi.bias[col + c];
     }
+    const bool has_z = EPI == 1 && epi.spz != nullptr;
 #pragma unroll
     for (int ta = 0; ta < 2; ++ta) {
+        // the pre-activations this pass multiplies by are requested BEFORE the tile goes through LDS, so their latency sits under the
+        // barrier pair and the 64 staging stores instead of in front of every row's arithmetic
+        f32x4 zr[16];
+        if (has_z) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int rl = (tid >> 6) + 4 * i;
+                const int row = i0 + (rl >> 5) * 64 + ta * 32 + (rl & 31);
+                zr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (row < M && col < J) zr[i] = *reinterpret_cast<const f32x4 *>(epi.spz + (size_t)row * epi.ldspz + col);
+            }
+        }
         __syncthreads();
 #pragma unroll
         for (int tb = 0; tb < 4; ++tb)
@@ -203,27 +217,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             for (int r = 0; r < 16; ++r)
                 so[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * rquad) * LDO + wn * 128 + tb * 32 + col_l] = acc[ta][tb][r];
         __syncthreads();
-        for (int rl = tid >> 6; rl < 64; rl += 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int rl = (tid >> 6) + 4 * i;
             const int row = i0 + (rl >> 5) * 64 + ta * 32 + (rl & 31);      // staged row rl = wm * 32 + r  ->  tile row wm * 64 + ta * 32 + r
             if (row >= M || col >= J) continue;
-            float4 v4 = *reinterpret_cast<const float4 *>(&so[rl * LDO + c4]);
-            float *vv = reinterpret_cast<float *>(&v4);
+            f32x4 v4 = *reinterpret_cast<const f32x4 *>(&so[rl * LDO + c4]);
             if (EPI == 0) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) vv[c] += bv[c];
-            } else if (epi.spz) {
-                const float4 z = *reinterpret_cast<const float4 *>(epi.spz + (size_t)row * epi.ldspz + col);
-                const float zz[4] = {z.x, z.y, z.z, z.w};
+                for (int c = 0; c < 4; ++c) v4[c] += bv[c];
+            } else if (has_z) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float bz = zz[c] * epi.beta;
+                    const float bz = zr[i][c] * epi.beta;
                     if (!(bz > epi.thr)) {                                  // linear region of softplus: derivative 1
                         const float e = __expf(-fabsf(bz)), sg = 1.f / (1.f + e);
-                        vv[c] *= bz >= 0.f ? sg : 1.f - sg;
+                        v4[c] *= bz >= 0.f ? sg : 1.f - sg;
                     }
                 }
             }
-            *reinterpret_cast<float4 *>(epi.out + (size_t)row * epi.ldo + col) = v4;
+            *reinterpret_cast<f32x4 *>(epi.out + (size_t)row * epi.ldo + col) = v4;
         }
     }
 }

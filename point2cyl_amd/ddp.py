@@ -5,7 +5,9 @@ cloud except the train-mode BatchNorm statistics (kept per replica, like running
 shard) and the final scalar means.  All 1,404,243 gradients (5.6 MB fp32) are exchanged as ONE flat buffer:
 after backward a single multi-tensor copy packs them into a persistent buffer (the copy is part of the captured
 HIP graph when the step is replayed), one RCCL all-reduce over xGMI averages it in place, and the parameters'
-.grad are views of that buffer from then on - nothing is allocated or unpacked per step.  With backend "gloo"
+.grad are views of that buffer from then on - nothing is allocated or unpacked per step.  The exchange is issued from a side stream
+gated on the replay that produced the gradients (`allreduce_async` / `wait`), so the step's tail - the copies of the next batch's
+prefetched geometry, a second small graph - runs under it.  With backend "gloo"
 the same code runs on CPU tensors for the tests.  With world_size 1 nothing is packed at all.
 
 BatchNorm buffers: per-replica running statistics during training (no SyncBN upstream either); `average_buffers`
@@ -54,6 +56,7 @@ class FlatGradSync:
         self.views = None
         self._src = None          # keeps the packed-from tensors of a captured step alive
         self._avg_ok = True
+        self._side, self._pending = None, False
 
     def zero(self):
         for p in self.params:
@@ -102,6 +105,28 @@ class FlatGradSync:
                     self._avg_ok = False
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.div_(self.world)
+
+
+    def allreduce_async(self):
+        """The exchange on a SIDE stream, gated on everything enqueued on the current stream so far (the replay that produced the gradients):
+        work the caller enqueues next on the current stream (graph.GraphedForwardBackward.tail) overlaps it.  `wait()` before the optimizer."""
+        if self.world <= 1:
+            return
+        if not self.params[0].is_cuda:
+            return self.allreduce()
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.params[0].device)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._side.wait_event(ev)
+        with torch.cuda.stream(self._side):
+            self.allreduce()
+        self._pending = True
+
+    def wait(self):
+        if self._pending:
+            torch.cuda.current_stream().wait_stream(self._side)
+            self._pending = False
 
 
 def broadcast_module(module, src=0):

@@ -89,9 +89,14 @@ class GraphedForwardBackward:
     loop keeps only B of the 256 CUs busy, so it disappears behind the GEMMs.
     At construction prefetch_xyz must hold the clouds of the FIRST batch to be trained on (its geometry is computed here).
 
-    draw_starts=False leaves the FPS start tensors alone between replays (callers that set them through `starts.set`)."""
+    draw_starts=False leaves the FPS start tensors alone between replays (callers that set them through `starts.set`).
 
-    def __init__(self, model, fn, warmup=2, prefetch_xyz=None, draw_starts=True, stream=None):
+    split_tail=True (data-parallel jobs): what follows the last gradient - the copies of the prefetched geometry into the 'current' buffers -
+    is captured as a SECOND graph, replayed by `tail()`.  Between `__call__` and `tail()` the caller records an event and starts the
+    gradient exchange on a side stream (ddp.FlatGradSync.allreduce_async): the exchange then overlaps the tail instead of waiting for it.
+    (An external event-record node inside one graph would do the same; torch refuses external events on ROCm.)"""
+
+    def __init__(self, model, fn, warmup=2, prefetch_xyz=None, draw_starts=True, stream=None, split_tail=False):
         import gc
         gc.collect()       # autograd graphs of earlier eager steps that only reference cycles keep alive: their AccumulateGrad nodes are
         # bound to the stream they were created on, and autograd would order the capture stream against that stream (work the capture
@@ -106,6 +111,9 @@ class GraphedForwardBackward:
                 self._hooked.append(m)
         self.fn = fn
         self.prefetch = prefetch_xyz is not None
+        self.split_tail = bool(split_tail) and self.prefetch
+        self.graph_tail = None
+        self._nxt = None
         main = torch.cuda.current_stream()
         # state the warm-up executions must not leave behind: BatchNorm running statistics / counters, the dropout counter
         keep = [(b, b.detach().clone()) for b in model.buffers()]
@@ -123,13 +131,18 @@ class GraphedForwardBackward:
                 nxt = model.compute_geometry(prefetch_xyz)
             out = fn(self.cur)
             cap.wait_stream(side)                                   # join
+            self._nxt = nxt
+            if not self.split_tail:
+                tail_body()
+            return out
+
+        def tail_body():
             by_dtype = {}
-            for dst, src in zip(_flatten(self.cur), _flatten(nxt)):
+            for dst, src in zip(_flatten(self.cur), _flatten(self._nxt)):
                 by_dtype.setdefault(dst.dtype, ([], []))[0].append(dst)
                 by_dtype[dst.dtype][1].append(src)
             for dsts, srcs in by_dtype.values():                    # one fused launch per dtype instead of ~25 copies
                 torch._foreach_copy_(dsts, srcs)
-            return out
 
         self._side = torch.cuda.Stream() if self.prefetch else None
 
@@ -153,6 +166,8 @@ class GraphedForwardBackward:
                 for _ in range(warmup):
                     self.starts.cursor = 0
                     body()
+                    if self.split_tail:
+                        tail_body()
             main.wait_stream(cap)
             torch.cuda.synchronize()
             self.starts.cursor = 0
@@ -161,6 +176,10 @@ class GraphedForwardBackward:
             # RCCL's watchdog polling its events in a multi-GPU job - invalidates the capture
             with torch.cuda.graph(self.graph, stream=cap, capture_error_mode="thread_local"):
                 self.out = body()
+            if self.split_tail:
+                self.graph_tail = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_tail, stream=cap, pool=self.graph.pool(), capture_error_mode="thread_local"):
+                    tail_body()
         except BaseException:
             # a failed warm-up / capture must not leave 1-2 extra BatchNorm updates and an advanced dropout counter behind: the caller
             # falls back to eager launches of the SAME batch
@@ -191,6 +210,12 @@ class GraphedForwardBackward:
             for p, g in self._grads:
                 p.grad = g
         return self.out
+
+    def tail(self):
+        """split_tail: the rest of the step (after the caller has gated its gradient exchange on the main replay).  Must be called once per
+        `__call__`, before the next one."""
+        if self.graph_tail is not None:
+            self.graph_tail.replay()
 
     def release(self):
         """Detach the FPS-start hook from the model (before building a replacement graph)."""

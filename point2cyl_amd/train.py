@@ -148,7 +148,7 @@ class Runner:
                 self.next_xyz.copy_(self.batch[0])
                 try:
                     self.graph = GraphedForwardBackward(self.model, self._fwd_bwd, prefetch_xyz=self.next_xyz if self.prefetch else None,
-                                                        stream=self.stream)
+                                                        stream=self.stream, split_tail=self.sync.world > 1)
                 except Exception as e:      # something in this configuration cannot be captured: train on, launched from Python
                     import sys
                     sys.stderr.write("point2cyl_amd.train: HIP graph capture failed (%s: %s); continuing without the graph\n" % (type(e).__name__, e))
@@ -165,7 +165,10 @@ class Runner:
                 self.graph_momentum = momentum
                 self.captures += 1
             out = self.graph()
-        self.sync.allreduce()
+        self.sync.allreduce_async()     # N > 1: the exchange on a side stream, gated on the replay ...
+        if not (eager or not self.use_graph) and self.graph is not None:
+            self.graph.tail()           # ... with the rest of the step (the prefetched geometry's copies) under it
+        self.sync.wait()
         self.opt.step()
         ops.step_done()
         return out["scalars"]

@@ -771,6 +771,57 @@ def test_hip_graph_replay_trains():
     assert losses_[-1] < losses_[0] + 0.05
 
 
+def test_hip_graph_split_tail_equals_single_graph():
+    """Data-parallel jobs capture the step's tail (the copies of the prefetched geometry) as a second graph so that the gradient exchange,
+    gated on the first, runs under it (graph.GraphedForwardBackward(split_tail=True), ddp.FlatGradSync.allreduce_async / wait).  Same
+    seeds, same FPS draws: after every tail the 'current' geometry buffers hold the prefetched geometry, and the loss trajectory stays as close
+    to a single-graph run as a second single-graph run does, with the exchange's side-stream plumbing called in between (world = 1: a no-op)."""
+    from point2cyl_amd import synth, ddp
+    from point2cyl_amd.graph import GraphedForwardBackward
+    B, N, K = 2, 1024, 8
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=3)
+    batch = tuple(v.to(DEV) for v in (pcs, nrm, seg, bb, axes, cen))
+    fl = step.StepFlags(K=K)
+    runs = []
+    for split in (False, False, True):
+        torch.manual_seed(0)
+        m = backbone(output_sizes=fl.pred_sizes()).to(DEV).train()
+        step.update_momentum(m, 0.5)
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        sync = ddp.FlatGradSync(m.parameters(), 1)
+
+        def fwd_bwd(geom=None):
+            out = step.compute_losses_fused(m, *batch, fl, geom=geom)
+            sync.zero()
+            out["total"].backward()
+            sync.pack()
+            return {"total": out["total"].detach()}
+
+        torch.manual_seed(11)                      # the FPS start draws
+        gr = GraphedForwardBackward(m, fwd_bwd, prefetch_xyz=batch[0], split_tail=split)
+        assert (gr.graph_tail is not None) == split
+        traj = []
+        for _ in range(5):
+            out = gr()
+            sync.allreduce_async()
+            gr.tail()
+            sync.wait()
+            opt.step()
+            traj.append(float(out["total"]))
+            from point2cyl_amd.graph import _flatten
+            assert all(torch.equal(a, b) for a, b in zip(_flatten(gr.cur), _flatten(gr._nxt)))      # the tail has run: 'current' = the prefetched geometry
+        torch.cuda.synchronize()
+        runs.append((traj, [p.detach().clone() for p in m.parameters()]))
+        gr.release()
+    # the kernels accumulate with fp32 atomics, so two runs of the SAME configuration agree only up to summation order, and Adam's first
+    # steps amplify that: the split run must sit as close to the first single-graph run as the second single-graph run does
+    t0, t1, t2 = (np.array(r[0]) for r in runs)
+    assert t0[0] == t1[0] == t2[0]                                  # the first replay: same geometry, same parameters
+    self_dev = np.abs(t1 - t0).max()
+    assert np.abs(t2 - t0).max() <= 3 * self_dev + 2e-5, (t0, t1, t2)
+    assert len(set(runs[2][0])) == 5
+
+
 def test_hip_graph_replay_feeds_the_gradient_exchange():
     """Data-parallel runs re-point every .grad at a view of the all-reduced flat buffer after each step (ddp.FlatGradSync); the
     graph keeps writing its own static gradient tensors.  Replays must hand the exchange the FRESH gradients: simulated here on

@@ -303,12 +303,20 @@ template <int CPL>
 __global__ void __launch_bounds__(256) three_interp_stats_kernel(const float *__restrict__ feats, int ldf, const int32_t *__restrict__ idx,
                                                                  const float *__restrict__ w, int N, int S, int C, long long rows,
                                                                  const float *__restrict__ bias, float *__restrict__ out, int ldo,
-                                                                 double *__restrict__ slots)
+                                                                 double *__restrict__ slots, int xcd_bpc)
 {
     constexpr int RPW = 16;                       // rows per wave
     __shared__ float red[2][4][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long r0 = ((long long)blockIdx.x * 4 + wave) * RPW;
+    // xcd_bpc != 0 (= workgroups per cloud): cloud b is served by XCD b % 8 only (workgroup ids go round the XCDs), so the 262 KB of sparse
+    // rows its 8192 dense rows read three at a time stay in ONE L2 - 4 clouds = 1 MB per XCD instead of all 32 = 8.4 MB in each of them
+    // (PMC: 152 MB fetched for 15 MB of sparse rows + indices).
+    int blk = blockIdx.x;
+    if (xcd_bpc) {
+        const int xcd = blk & 7, slot = blk >> 3, round = slot / xcd_bpc;
+        blk = (xcd + 8 * round) * xcd_bpc + (slot - round * xcd_bpc);
+    }
+    const long long r0 = ((long long)blk * 4 + wave) * RPW;
     float bv[CPL], s1[CPL], s2[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
@@ -361,7 +369,7 @@ __global__ void __launch_bounds__(256) three_interp_stats_kernel(const float *__
     for (int i = 0; i < CPL; ++i) { red[0][wave][lane + 64 * i] = s1[i]; red[1][wave][lane + 64 * i] = s2[i]; }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        double *o = slots + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * C;
+        double *o = slots + (size_t)(blk % P2C_STAT_SLOTS) * 2 * C;
         atomicAdd(&o[c], (double)((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])));
         atomicAdd(&o[C + c], (double)((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])));
     }
@@ -375,7 +383,9 @@ extern "C" int p2c_three_interp_bias_stats_f32(const float *feats, int ldf, cons
     const long long rows = (long long)B * N;
     const int blocks = p2c_cdiv(rows, 64);
     hipStream_t s = (hipStream_t)stream;
-#define P2C_TI(CPL_) hipLaunchKernelGGL(three_interp_stats_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, feats, ldf, idx, weight, N, S, C, rows, bias, out, ldo, stat_slots)
+    static const bool xcd_on = !(getenv("P2C_XCD_GATHER") && atoi(getenv("P2C_XCD_GATHER")) == 0);         // A/B switch
+    const int xcd_bpc = (xcd_on && B % 8 == 0 && N % 64 == 0) ? N / 64 : 0;
+#define P2C_TI(CPL_) hipLaunchKernelGGL(three_interp_stats_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, feats, ldf, idx, weight, N, S, C, rows, bias, out, ldo, stat_slots, xcd_bpc)
     if (C <= 64) P2C_TI(1);
     else if (C <= 128) P2C_TI(2);
     else P2C_TI(4);
@@ -502,12 +512,17 @@ __global__ void __launch_bounds__(256) group_linear_stats_kernel(const float *__
                                                                  const float *__restrict__ new_xyz, const int32_t *__restrict__ idx,
                                                                  const float *__restrict__ Wx, const float *__restrict__ bias, int N, int S, int ns,
                                                                  int C, long long rows, float *__restrict__ out, int ldo,
-                                                                 double *__restrict__ slots)
+                                                                 double *__restrict__ slots, int xcd_bpc)
 {
     constexpr int RPW = 16;
     __shared__ float red[2][4][64 * CPL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long r0 = ((long long)blockIdx.x * 4 + wave) * RPW;
+    int blk = blockIdx.x;                         // xcd_bpc != 0: cloud b on XCD b % 8, as in three_interp_stats_kernel
+    if (xcd_bpc) {
+        const int xcd = blk & 7, slot = blk >> 3, round = slot / xcd_bpc;
+        blk = (xcd + 8 * round) * xcd_bpc + (slot - round * xcd_bpc);
+    }
+    const long long r0 = ((long long)blk * 4 + wave) * RPW;
     float bv[CPL], s1[CPL], s2[CPL], wx0[CPL], wx1[CPL], wx2[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
@@ -558,7 +573,7 @@ __global__ void __launch_bounds__(256) group_linear_stats_kernel(const float *__
     for (int i = 0; i < CPL; ++i) { red[0][wave][lane + 64 * i] = s1[i]; red[1][wave][lane + 64 * i] = s2[i]; }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        double *o = slots + (size_t)(blockIdx.x % P2C_STAT_SLOTS) * 2 * C;
+        double *o = slots + (size_t)(blk % P2C_STAT_SLOTS) * 2 * C;
         atomicAdd(&o[c], (double)((red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c])));
         atomicAdd(&o[C + c], (double)((red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c])));
     }
@@ -572,7 +587,10 @@ extern "C" int p2c_group_linear_bias_stats_f32(const float *G, int ldg, const fl
     const long long rows = (long long)B * S * nsample;
     const int blocks = p2c_cdiv(rows, 64);
     hipStream_t s = (hipStream_t)stream;
-#define P2C_GL(CPL_) hipLaunchKernelGGL(group_linear_stats_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, G, ldg, xyz, new_xyz, idx, Wx, bias, N, S, nsample, C, rows, out, ldo, stat_slots)
+    static const bool xcd_on = !(getenv("P2C_XCD_GATHER") && atoi(getenv("P2C_XCD_GATHER")) == 0);         // A/B switch
+    const long long rows_b = (long long)S * nsample;
+    const int xcd_bpc = (xcd_on && B % 8 == 0 && rows_b % 64 == 0) ? (int)(rows_b / 64) : 0;
+#define P2C_GL(CPL_) hipLaunchKernelGGL(group_linear_stats_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, G, ldg, xyz, new_xyz, idx, Wx, bias, N, S, nsample, C, rows, out, ldo, stat_slots, xcd_bpc)
     if (C <= 64) P2C_GL(1);
     else if (C <= 128) P2C_GL(2);
     else P2C_GL(4);

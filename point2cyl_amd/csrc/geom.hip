@@ -240,10 +240,83 @@ __global__ void __launch_bounds__(256) ball_query_kernel(const float *__restrict
     }
 }
 
+// The same scan WITHOUT the shared staging: every wave walks the cloud on its own (the 96 KB of a cloud are L1 / L2 hits), next step's
+// points requested before the current ones are tested.  With the LDS chunks the 16 queries of a workgroup move in lockstep through two
+// barriers per 1024 points and all wait for the slowest of them (a centre in a sparse region scans the whole cloud while its neighbours
+// are done after a few hundred points); here a wave retires as soon as ITS queries are complete.
+template <int QPW>
+__global__ void __launch_bounds__(256) ball_query_direct_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz, int N,
+                                                                int S, float r2, int nsample, int32_t *__restrict__ idx_out)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * QPW;
+    if (q0 >= S) return;
+    const float *cloud = xyz + (size_t)b * N * 3;
+    float cx[QPW], cy[QPW], cz[QPW], cn[QPW];
+    int cnt[QPW], first[QPW];
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        const int s = q0 + q;
+        const float *c = new_xyz + ((size_t)b * S + (s < S ? s : 0)) * 3;
+        cx[q] = c[0]; cy[q] = c[1]; cz[q] = c[2];
+        cn[q] = p2c_norm2(cx[q], cy[q], cz[q]);
+        cnt[q] = s < S ? 0 : nsample;      // out-of-range queries are "done"
+        first[q] = N;
+    }
+    auto fetch = [&](int off, float &x, float &y, float &z) {
+        const int i = min(off + lane, N - 1);
+        x = cloud[(size_t)i * 3]; y = cloud[(size_t)i * 3 + 1]; z = cloud[(size_t)i * 3 + 2];
+    };
+    float nx, ny, nz;
+    fetch(0, nx, ny, nz);
+    for (int off = 0; off < N; off += 64) {
+        bool all_done = true;
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) all_done = all_done && (cnt[q] >= nsample);
+        if (all_done) break;                                     // wave-uniform
+        const float px = nx, py = ny, pz = nz;
+        if (off + 64 < N) fetch(off + 64, nx, ny, nz);
+        const int i = off + lane;
+        const bool ok = i < N;
+        const float pn = p2c_norm2(px, py, pz);
+#pragma unroll
+        for (int q = 0; q < QPW; ++q) {
+            if (cnt[q] >= nsample) continue;                     // wave-uniform
+            const float d = p2c_sqdist(cx[q], cy[q], cz[q], cn[q], px, py, pz, pn);
+            const bool in = ok && !(d > r2);                     // :102 excludes only d > r^2
+            const unsigned long long m = __ballot(in);
+            if (m) {
+                const int pos = cnt[q] + __popcll(m & ((1ull << lane) - 1ull));
+                if (in && pos < nsample) idx_out[((size_t)b * S + q0 + q) * nsample + pos] = i;
+                if (first[q] == N) first[q] = off + (__ffsll((long long)m) - 1);
+                cnt[q] += __popcll(m);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < QPW; ++q) {
+        if (q0 + q >= S) continue;
+        int32_t *o = idx_out + ((size_t)b * S + q0 + q) * nsample;
+        const int c = min(cnt[q], nsample);
+        for (int k = c + lane; k < nsample; k += 64) o[k] = first[q];      // :104-106
+    }
+}
+
 extern "C" int p2c_ball_query_f32(const float *xyz, const float *new_xyz, int B, int N, int S, float radius2, int nsample,
                                   int32_t *idx_out, void *stream)
 {
     if (!xyz || !new_xyz || !idx_out || B <= 0 || N <= 0 || S <= 0 || nsample <= 0) return P2C_EINVAL;
+    static const int direct = getenv("P2C_BQ_DIRECT") ? atoi(getenv("P2C_BQ_DIRECT")) : 2;                 // A/B: 0 = LDS chunks, 1 / 2 / 4 queries per wave
+    if (direct == 1 || direct == 2 || direct == 4) {
+        const int qpb = 4 * direct;
+        dim3 g(p2c_cdiv(S, qpb), B);
+        if (direct == 1) hipLaunchKernelGGL(ball_query_direct_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, radius2, nsample, idx_out);
+        else if (direct == 2) hipLaunchKernelGGL(ball_query_direct_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, radius2, nsample, idx_out);
+        else hipLaunchKernelGGL(ball_query_direct_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, radius2, nsample, idx_out);
+        P2C_LAUNCH_CHECK();
+        return P2C_OK;
+    }
     dim3 grid(p2c_cdiv(S, BQ_QPB), B);
     hipLaunchKernelGGL(ball_query_kernel, grid, dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, radius2, nsample, idx_out);
     P2C_LAUNCH_CHECK();

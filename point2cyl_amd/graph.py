@@ -120,8 +120,12 @@ class GraphedForwardBackward:
         seed = getattr(model, "_drop_seed", None)
         keep_seed = None if seed is None else seed.detach().clone()
 
+        executed = [0]                       # bodies run for real (warm-up), not captured
+
         def body():
             _ops.step_done()                 # warm-up / capture passes: the previous pass's gradients are discarded
+            if not torch.cuda.is_current_stream_capturing():
+                executed[0] += 1
             if not self.prefetch:
                 return fn(None)
             cap = torch.cuda.current_stream()
@@ -152,6 +156,9 @@ class GraphedForwardBackward:
                     b.copy_(v)
                 if keep_seed is not None and getattr(model, "_drop_seed", None) is not None:
                     model._drop_seed.copy_(keep_seed)
+                elif keep_seed is None and getattr(model, "_drop_seed", None) is not None:
+                    model._drop_seed.sub_(executed[0] * (0x9E3779B97F4A7C15 % (2 ** 62)))      # created by the first warm-up pass: take the warm-up
+                    executed[0] = 0                                                            # advances back (backbone.py:311)
 
         try:
             if self.prefetch:

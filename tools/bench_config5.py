@@ -23,6 +23,7 @@ PEAK_MFMA = 157.3e12
 def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--steps", type=int, default=10); ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no_graph", action="store_true", help="launch the step from Python (with the reference's CPU sampling draws) instead of replaying a HIP graph")
+    ap.add_argument("--glue", action="store_true", help="after the timing: one eager step under torch.profiler, every aten op that launched device work, by shape (stderr)")
     ap.add_argument("--batch", type=int, default=16); ap.add_argument("--train_decoder", action="store_true"); a = ap.parse_args()
     from point2cyl_amd import ddp, fitting, ops, step, step_sketch, synth
     import torch.distributed as dist
@@ -111,6 +112,23 @@ def main():
         graphed.starts.cursor = 0
     ops.PROFILE.reset(enabled=rank == 0); fwd_bwd(); sync.allreduce(); opt.step(); ops.step_done()      # one EAGER step for the per-kernel HIP events
     prof = ops.PROFILE.summary(); ops.PROFILE.enabled = False                                         # (every rank: the step has a collective)
+    if a.glue and rank == 0:
+        import collections
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as tp:
+            fwd_bwd(); sync.allreduce(); opt.step(); ops.step_done(); torch.cuda.synchronize()
+        rows = collections.defaultdict(lambda: [0, 0.0])
+        for e in tp.events():
+            if e.device_type.name != "CPU" or not e.name.startswith("aten::") or not e.kernels:
+                continue
+            rows[(e.name, str(e.input_shapes)[:70])][0] += len(e.kernels)
+            rows[(e.name, str(e.input_shapes)[:70])][1] += sum(k.duration for k in e.kernels)
+        tot_n = tot_us = 0
+        for (name, shp), (n, us) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+            if us >= 50.0:
+                sys.stderr.write("%-26s x%-3d %9.1f us  %s\n" % (name, n, us, shp))
+            tot_n += n; tot_us += us
+        sys.stderr.write("torch-side device launches of one eager with-sketch step: %d, %.2f ms\n" % (tot_n, tot_us / 1e3))
     if world > 1:
         fence()
         dist.destroy_process_group()

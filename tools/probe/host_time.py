@@ -1,12 +1,12 @@
 """How much HOST time does one replayed training step take, and where?  (Is the step host-bound?)
-    python tools/probe/host_time.py [--pingpong 0|1]"""
+    python tools/probe/host_time.py"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from point2cyl_amd import backbone as bb, ddp, optim, step as stepmod, synth, graph as G
 from point2cyl_amd.train import Runner
 
-ap = argparse.ArgumentParser(); ap.add_argument("--pingpong", type=int, default=1); a = ap.parse_args()
+ap = argparse.ArgumentParser(); a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.cuda.set_stream(torch.cuda.Stream(dev))
 B, N, K = 32, 8192, 8
@@ -17,12 +17,6 @@ opt = optim.Adam(model.parameters(), lr=1e-3)
 sync = ddp.FlatGradSync(model.parameters(), 1)
 pcs, nrm, inst, bbl, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=1234)
 cur = tuple(x.to(dev) for x in (pcs.float(), nrm.float(), inst, bbl, axes.float(), cen.float()))
-if not a.pingpong:
-    _orig = G.GraphedForwardBackward.__init__
-    def _init(self, *args, **kw):
-        kw["pingpong"] = False
-        _orig(self, *args, **kw)
-    G.GraphedForwardBackward.__init__ = _init
 r = Runner(model, opt, sync, fl, dev, B, N, K, stream=torch.cuda.current_stream())
 r.load(cur, cur[0])
 for _ in range(5):
@@ -35,11 +29,10 @@ orig_stage = g.starts.stage
 def stage():
     t0 = time.perf_counter(); orig_stage(); t["stage"] += time.perf_counter() - t0
 g.starts.stage = stage
-for gr_, _, _ in g._sets:
-    orig = gr_.replay
-    def rep(orig=orig):
-        t0 = time.perf_counter(); orig(); t["replay"] += time.perf_counter() - t0
-    gr_.replay = rep
+orig_replay = g.graph.replay
+def rep():
+    t0 = time.perf_counter(); orig_replay(); t["replay"] += time.perf_counter() - t0
+g.graph.replay = rep
 orig_step = opt.step
 def ostep(*aa, **kk):
     t0 = time.perf_counter(); out = orig_step(*aa, **kk); t["adam"] += time.perf_counter() - t0; return out
@@ -52,6 +45,6 @@ for _ in range(n):
 t_host = time.perf_counter() - t0
 torch.cuda.synchronize()
 t_all = time.perf_counter() - t0
-print("pingpong=%d: host time per step %.3f ms (graph launch %.3f, FPS-start staging %.3f, Adam %.3f, rest %.3f); wall per step with the final sync %.3f ms"
-      % (a.pingpong, t_host / n * 1e3, t["replay"] / n * 1e3, t["stage"] / n * 1e3, t["adam"] / n * 1e3,
+print("host time per step %.3f ms (graph launch %.3f, FPS-start staging %.3f, Adam %.3f, rest %.3f); wall per step with the final sync %.3f ms"
+      % (t_host / n * 1e3, t["replay"] / n * 1e3, t["stage"] / n * 1e3, t["adam"] / n * 1e3,
          (t_host - t["replay"] - t["stage"] - t["adam"]) / n * 1e3, t_all / n * 1e3))

@@ -300,36 +300,53 @@ class ImplicitNet(nn.Module):
         if not input.is_cuda:
             raise RuntimeError("point2cyl_amd.implicit.ImplicitNet runs on the HIP device only (got %s); there is no CPU path" % input.device)
         # x is kept as the PRE-activation of the previous layer where the next layer can take it that way (_SpLinear: softplus and its
-        # derivative ride on the GEMMs); the skip layer (needs the activation itself for the concat), odd widths and ReLU take the
-        # plain route
-        x, pending = input, False                       # pending: x still needs its softplus
+        # derivative ride on the GEMMs); the skip layer (needs the activation itself for the concat) and ReLU take the plain route.
+        # Widths: the GEMMs want multiples of 4 and the reference's are 258 (input), 254 (the layer in front of the skip), 1 (output).  x keeps
+        # its PADDED width from layer to layer - `segs` lists its column segments as (real, padded) - and every layer's weight is laid out
+        # to match (zero columns under x's pad columns, zero rows / bias entries for its own): a few small pads of 0.5 MB weights per
+        # evaluation instead of a slice + copy (forward), a zero-fill + copy (backward) and again (backward of backward) of 270 - 600 MB
+        # activations per odd-width layer.  A pad column of x holds 0 after a product and softplus(0) after the activation; it only ever meets
+        # zero weights.
+        d_in = input.shape[1]
+        inp = F.pad(input, (0, (-d_in) % 4)) if d_in % 4 else input
+        x, pending = inp, False                         # pending: x still needs its softplus
+        segs = [(d_in, inp.shape[1])]
+        N = Np = d_in
         for layer in range(0, self.num_layers - 1):
             lin = getattr(self, "lin" + str(layer))
             N, K = lin.weight.shape
-            fused = pending and layer not in self.skip_in and K % 4 == 0 and x.shape[1] == K
+            fused = pending and layer not in self.skip_in
             if pending and not fused:
                 x, pending = softplus(x, self.beta), False
-            wscale = None
+            w = lin.weight
             if layer in self.skip_in:
                 # IGR/network.py:75-76: x = cat([x, input]) / sqrt(2) in front of the layer.  The division is applied to the layer's WEIGHT
                 # instead ((c / s) W^T = c (W / s)^T): a 0.5 MB operand instead of three passes over the 537 MB activation (forward, backward
                 # and backward-of-backward each carried a scale kernel).
-                x = torch.cat([x, input], -1)
-                wscale = 1.0 / np.sqrt(2)
-            if fused:
-                npad = (-N) % 4
-                w = F.pad(lin.weight, (0, 0, 0, npad)) if npad else lin.weight
-                b = F.pad(lin.bias, (0, npad)) if npad else lin.bias
-                x = sp_linear(x, w, b, self.beta)
-                x = x[:, :N] if npad else x
-            else:
-                x = linear(x, lin.weight if wscale is None else lin.weight * wscale, lin.bias)
+                x = torch.cat([x, inp], -1)
+                segs = segs + [(d_in, inp.shape[1])]
+                w = w * (1.0 / np.sqrt(2))
+            if sum(r for r, _ in segs) != K:
+                raise RuntimeError("ImplicitNet: layer %d expects %d inputs, got %d" % (layer, K, sum(r for r, _ in segs)))
+            Np = N + (-N) % 4
+            b = lin.bias
+            if any(r != p_ for r, p_ in segs):
+                pieces, o = [], 0
+                for r, p_ in segs:
+                    pieces.append(F.pad(w[:, o:o + r], (0, p_ - r)) if p_ != r else w[:, o:o + r])
+                    o += r
+                w = torch.cat(pieces, 1) if len(pieces) > 1 else pieces[0]
+            if Np != N:
+                w = F.pad(w, (0, 0, 0, Np - N))
+                b = F.pad(b, (0, Np - N)) if b is not None else None
+            x = sp_linear(x, w, b, self.beta) if fused else _nt(x, w, b)
+            segs = [(N, Np)]
             if layer < self.num_layers - 2:
                 if self.beta > 0:
                     pending = True
                 else:
                     x = F.relu(x)
-        return x
+        return x[:, :N] if Np != N else x
 
 
 class NormalPerPoint:

@@ -11,7 +11,6 @@ Checked against files written by the real library (h5py 3.3 / HDF5 1.10.6: tests
 oracle/make_golden_h5.py).  Not supported (raises NotImplementedError with the feature's name): the "latest" file format (superblock 2/3,
 version-2 object headers and B-trees), variable-length / compound / string datasets, external storage, filters other than the three above.
 Format reference: the HDF5 File Format Specification, version 1.1 / 2.0 (sections III.A-III.D, IV.A.2)."""
-import struct
 import zlib
 
 import numpy as np

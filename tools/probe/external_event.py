@@ -1,6 +1,6 @@
 """Does an EXTERNAL event recorded inside a captured HIP graph release a side stream before the graph's tail has run?
 (the gate the data-parallel exchange needs to overlap the replay tail: ddp.FlatGradSync / graph.py)"""
-import time
+
 import torch
 
 dev = torch.device("cuda:0")

@@ -3,7 +3,7 @@
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
-from point2cyl_amd import backbone as bb, ddp, optim, step as stepmod, synth, graph as G
+from point2cyl_amd import backbone as bb, ddp, optim, step as stepmod, synth
 from point2cyl_amd.train import Runner
 
 ap = argparse.ArgumentParser(); a = ap.parse_args()

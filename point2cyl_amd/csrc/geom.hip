@@ -351,10 +351,36 @@ __global__ void __launch_bounds__(256) three_nn_kernel(const float *__restrict__
             sc[i] = make_float4(x, y, z, p2c_norm2(x, y, z));
         }
         __syncthreads();
-#pragma unroll 4
-        for (int i = 0; i < len; ++i) {
+        // eight candidates per step: their distances first (eight independent LDS reads and expressions in flight), ONE test whether any of
+        // them can enter the top 3, and only then - rarely - the insertions, in index order as before
+        constexpr int NNB = 8;               // 16: no further gain
+        int i = 0;
+        for (; i + NNB <= len; i += NNB) {
+            float d[NNB];
+#pragma unroll
+            for (int u = 0; u < NNB; ++u) {
+                const float4 c = sc[i + u];
+                d[u] = p2c_sqdist(qx, qy, qz, qn, c.x, c.y, c.z, c.w);       // src = xyz1, dst = xyz2 (:301)
+            }
+            float m = d[0];
+#pragma unroll
+            for (int u = 1; u < NNB; ++u) m = fminf(m, d[u]);
+            if (!(m < d2)) continue;
+#pragma unroll
+            for (int u = 0; u < NNB; ++u) {
+                const int s = base + i + u;
+                if (d[u] < d2) {
+                    if (d[u] < d1) {
+                        d2 = d1; i2 = i1;
+                        if (d[u] < d0) { d1 = d0; i1 = i0; d0 = d[u]; i0 = s; }
+                        else { d1 = d[u]; i1 = s; }
+                    } else { d2 = d[u]; i2 = s; }
+                }
+            }
+        }
+        for (; i < len; ++i) {
             const float4 c = sc[i];
-            const float d = p2c_sqdist(qx, qy, qz, qn, c.x, c.y, c.z, c.w);   // src = xyz1, dst = xyz2 (:301)
+            const float d = p2c_sqdist(qx, qy, qz, qn, c.x, c.y, c.z, c.w);
             const int s = base + i;
             if (d < d2) {
                 if (d < d1) {

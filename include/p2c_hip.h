@@ -334,6 +334,11 @@ int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int l
  * The host mirror stages every padded / re-ordered / column-sliced weight operand of a step with it (point2cyl_amd/ops.py WeightStage). */
 int p2c_copy2d_batch_f32(const void *table, int n, void *stream);
 
+/* n flat copies of contiguous buffers in one launch: srcs / dsts / nbytes are HOST arrays (device pointers 4-byte aligned, byte counts
+ * multiples of 4); the descriptors travel in the kernel arguments, so a captured graph node needs no device table.  The hand-over of the
+ * prefetched geometry between two replays of the step (point2cyl_amd/graph.py). */
+int p2c_copy_flat_batch(const void *const *srcs, void *const *dsts, const long long *nbytes, int n, void *stream);
+
 /* Backward of the LAST layer of a set-abstraction stack (conv -> train-mode BatchNorm -> ReLU -> max over ns neighbours,
  * pointnet_util.py:201-205) without its pre-BatchNorm output: Y = A W^T + b is linear in the layer's input A = relu(in_scale * X + in_shift),
  * so dX = dY W = A (W^T diag(q) W) + (q*b + p) W + (gs*G) W and dW = dY^T A = (gs*G)^T A + diag(q) (W A^T A + b 1^T A) + p 1^T A, with G

@@ -66,6 +66,7 @@ _SIGS = {
     "p2c_linear_bwd_pool_alg_f32": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i,
                                     c_p],
     "p2c_copy2d_batch_f32": [c_p, c_i, c_p],
+    "p2c_copy_flat_batch": [c_p, c_p, c_p, c_i, c_p],
     "p2c_extrusion_axis_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_extrusion_axis_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_extrusion_centers_f32": [c_p, c_p, c_i, c_i, c_i, c_p, c_p],

@@ -666,3 +666,61 @@ extern "C" int p2c_copy2d_batch_f32(const void *table, int n, void *stream)
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// n flat copies (contiguous buffers of 4-byte words) in ONE launch, the descriptors passed BY VALUE in the kernel arguments - a captured
+// graph node then holds them, no device table to keep in step with tensors that are re-allocated by every capture.  Used for the hand-over
+// of the prefetched geometry (graph.py): torch's multi-tensor copy moves those ~40 MB in two launches of ~21 us (one block per 64 K
+// elements of a tensor); here every block takes 4096-word chunks of whatever tensor its index falls into, 16 bytes per lane.
+// ------------------------------------------------------------------------------------------------
+#define P2C_FLAT_MAX 32
+struct P2cFlatBatch {
+    const uint32_t *src[P2C_FLAT_MAX];
+    uint32_t *dst[P2C_FLAT_MAX];
+    long long words[P2C_FLAT_MAX];
+    int chunk0[P2C_FLAT_MAX + 1];          // first chunk of entry e (4096 words per chunk), chunk0[n] = total
+    int n;
+};
+__global__ void __launch_bounds__(256) copy_flat_batch_kernel(P2cFlatBatch d)
+{
+    for (int blk = blockIdx.x; blk < d.chunk0[d.n]; blk += gridDim.x) {
+        int e = 0;
+        while (e + 1 < d.n && blk >= d.chunk0[e + 1]) ++e;                       // uniform, <= 32 steps over kernel-argument (scalar) memory
+        const long long w0 = (long long)(blk - d.chunk0[e]) * 4096, nw = min(4096LL, d.words[e] - w0);
+        const uint32_t *s = d.src[e] + w0;
+        uint32_t *o = d.dst[e] + w0;
+        if (((((uintptr_t)s) | ((uintptr_t)o)) & 15) == 0) {
+            const int nv = (int)(nw >> 2);
+            for (int i = threadIdx.x; i < nv; i += 256) reinterpret_cast<uint4 *>(o)[i] = reinterpret_cast<const uint4 *>(s)[i];
+            for (int i = (nv << 2) + threadIdx.x; i < nw; i += 256) o[i] = s[i];
+        } else {
+            for (int i = threadIdx.x; i < nw; i += 256) o[i] = s[i];
+        }
+    }
+}
+
+// srcs / dsts / nbytes: HOST arrays of n device pointers / byte counts (multiples of 4).  Any n (split into launches of 32).
+extern "C" int p2c_copy_flat_batch(const void *const *srcs, void *const *dsts, const long long *nbytes, int n, void *stream)
+{
+    if (!srcs || !dsts || !nbytes || n <= 0) return P2C_EINVAL;
+    for (int i = 0; i < n; ++i)
+        if (!srcs[i] || !dsts[i] || nbytes[i] < 0 || (nbytes[i] & 3) || (((uintptr_t)srcs[i] | (uintptr_t)dsts[i]) & 3)) return P2C_EINVAL;
+    for (int base = 0; base < n; base += P2C_FLAT_MAX) {
+        P2cFlatBatch d;
+        d.n = n - base < P2C_FLAT_MAX ? n - base : P2C_FLAT_MAX;
+        long long chunks = 0;
+        for (int i = 0; i < d.n; ++i) {
+            d.src[i] = (const uint32_t *)srcs[base + i]; d.dst[i] = (uint32_t *)dsts[base + i]; d.words[i] = nbytes[base + i] / 4;
+            d.chunk0[i] = (int)chunks;
+            chunks += (d.words[i] + 4095) / 4096;
+        }
+        if (chunks > 0x7fffffffLL) return P2C_EINVAL;
+        d.chunk0[d.n] = (int)chunks;
+        for (int i = d.n; i < P2C_FLAT_MAX; ++i) { d.src[i] = nullptr; d.dst[i] = nullptr; d.words[i] = 0; d.chunk0[i + 1] = (int)chunks; }
+        if (chunks == 0) continue;
+        const int grid = chunks < 4096 ? (int)chunks : 4096;
+        hipLaunchKernelGGL(copy_flat_batch_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
+    }
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

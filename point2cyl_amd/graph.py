@@ -141,12 +141,9 @@ class GraphedForwardBackward:
             return out
 
         def tail_body():
-            by_dtype = {}
-            for dst, src in zip(_flatten(self.cur), _flatten(self._nxt)):
-                by_dtype.setdefault(dst.dtype, ([], []))[0].append(dst)
-                by_dtype[dst.dtype][1].append(src)
-            for dsts, srcs in by_dtype.values():                    # one fused launch per dtype instead of ~25 copies
-                torch._foreach_copy_(dsts, srcs)
+            # ONE launch for the ~25 tensors (40 MB at B = 32 x 8192) instead of torch's two multi-tensor copies (21 us each: a block per 64 K
+            # elements); the descriptors are kernel arguments, so the node survives the re-allocation of `nxt` by every capture
+            _ops.copy_flat_batch(_flatten(self.cur), _flatten(self._nxt))
 
         self._side = torch.cuda.Stream() if self.prefetch else None
 

@@ -803,6 +803,30 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
 
 
 # ------------------------------------------------------------------------------------------ weight staging (one launch per step)
+def copy_flat_batch(dsts, srcs):
+    """dst_i.copy_(src_i) for lists of contiguous device tensors of equal shape and dtype, in ONE launch (p2c_copy_flat_batch: the descriptors
+    ride in the kernel arguments, so the call can be captured without a device table).  Tensors whose byte size is not a multiple of 4
+    fall back to torch's copy."""
+    import ctypes
+    fast_d, fast_s = [], []
+    for d, s_ in zip(dsts, srcs):
+        if d.shape != s_.shape or d.dtype != s_.dtype:
+            raise ValueError("copy_flat_batch: %s %s <- %s %s" % (tuple(d.shape), d.dtype, tuple(s_.shape), s_.dtype))
+        if d.is_contiguous() and s_.is_contiguous() and (d.numel() * d.element_size()) % 4 == 0 and d.data_ptr() % 4 == 0 and s_.data_ptr() % 4 == 0:
+            if d.numel():
+                fast_d.append(d); fast_s.append(s_)
+        else:
+            d.copy_(s_)
+    n = len(fast_d)
+    if n:
+        _lib.require_device(*fast_d, *fast_s)
+        sp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in fast_s])
+        dp = (ctypes.c_void_p * n)(*[t.data_ptr() for t in fast_d])
+        nb = (ctypes.c_longlong * n)(*[t.numel() * t.element_size() for t in fast_d])
+        call("p2c_copy_flat_batch", ctypes.cast(sp, ctypes.c_void_p), ctypes.cast(dp, ctypes.c_void_p), ctypes.cast(nb, ctypes.c_void_p), n, stream(),
+             nbytes=2.0 * sum(nb))
+
+
 USE_STAGED_WEIGHTS = os.environ.get("P2C_STAGE_WEIGHTS", "1") != "0"
 
 

@@ -117,7 +117,7 @@ class Runner:
 
     def load(self, cur, nxt_xyz):
         """cur = (pcs, normals, inst, bb, axes, centers) device tensors of the batch to train on; nxt_xyz = clouds of the batch after it."""
-        torch._foreach_copy_(list(self.batch), list(cur))
+        ops.copy_flat_batch(list(self.batch), [c.contiguous() for c in cur])      # one launch for the six tensors of a batch
         self.next_xyz.copy_(nxt_xyz if nxt_xyz is not None else cur[0])
 
     def _fwd_bwd(self, geom=None):

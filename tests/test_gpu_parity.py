@@ -740,6 +740,35 @@ def test_precomputed_geometry_gives_the_same_forward():
     assert torch.equal(geom["sa1"]["fps_idx"].cpu().long(), m.sa1.last_aux["fps_idx"].cpu().long())
 
 
+def test_copy_flat_batch_equals_torch_copies():
+    """p2c_copy_flat_batch (the hand-over of the prefetched geometry between two replays): 70 tensors of mixed 4- and 8-byte dtypes, sizes from
+    one word to 12 MB, some not a multiple of 16 bytes, misaligned views among them; one whose byte size is no multiple of 4 takes torch's
+    route.  Capturable: replayed from a HIP graph with fresh contents."""
+    g = torch.Generator().manual_seed(5)
+    srcs, dsts = [], []
+    for i in range(70):
+        n = int(torch.randint(1, 3_000_000 if i % 10 == 0 else 5000, (1,), generator=g))
+        dt = (torch.float32, torch.int32, torch.int64)[i % 3]
+        t = torch.randint(-1000, 1000, (n + 3,), generator=g).to(dt).to(DEV)
+        srcs.append(t[3:] if i % 7 == 0 else t[:n])                # every 7th: a view 12 / 24 bytes into its buffer
+        dsts.append(torch.zeros(n + 1, dtype=dt, device=DEV)[1:] if i % 11 == 0 else torch.zeros(n, dtype=dt, device=DEV))
+    srcs.append(torch.arange(7, dtype=torch.uint8, device=DEV)); dsts.append(torch.zeros(7, dtype=torch.uint8, device=DEV))
+    ops.copy_flat_batch(dsts, srcs)
+    assert all(torch.equal(d, s_) for d, s_ in zip(dsts, srcs))
+    with pytest.raises(ValueError):
+        ops.copy_flat_batch([torch.zeros(4, device=DEV)], [torch.zeros(5, device=DEV)])
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr, stream=st, capture_error_mode="thread_local"):
+            ops.copy_flat_batch(dsts[:40], srcs[:40])
+        for s_ in srcs[:40]:
+            s_.add_(1)
+        gr.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(d, s_) for d, s_ in zip(dsts[:40], srcs[:40]))
+
+
 def test_hip_graph_replay_trains():
     """Graph capture of forward+backward with the next batch's geometry on a forked stream: replays must keep producing
     finite, changing losses while Adam (outside the graph) updates the parameters the graph reads in place."""

@@ -264,33 +264,48 @@ __global__ void __launch_bounds__(256) ball_query_direct_kernel(const float *__r
         cnt[q] = s < S ? 0 : nsample;      // out-of-range queries are "done"
         first[q] = N;
     }
-    auto fetch = [&](int off, float &x, float &y, float &z) {
-        const int i = min(off + lane, N - 1);
-        x = cloud[(size_t)i * 3]; y = cloud[(size_t)i * 3 + 1]; z = cloud[(size_t)i * 3 + 2];
+    // Four 64-point steps per group; the NEXT group's 12 loads are issued before the current group is tested.  With one step of look-ahead a
+    // step cost a memory round trip (~0.5 us), and the kernel's length is set by its slowest wave - a centre in a sparse region that walks all
+    // N / 64 steps.
+    constexpr int G = 4;
+    auto fetch = [&](int off, float (&x)[G], float (&y)[G], float (&z)[G]) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int i = min(off + 64 * g + lane, N - 1);
+            x[g] = cloud[(size_t)i * 3]; y[g] = cloud[(size_t)i * 3 + 1]; z[g] = cloud[(size_t)i * 3 + 2];
+        }
     };
-    float nx, ny, nz;
+    float nx[G], ny[G], nz[G];
     fetch(0, nx, ny, nz);
-    for (int off = 0; off < N; off += 64) {
+    for (int off0 = 0; off0 < N; off0 += 64 * G) {
         bool all_done = true;
 #pragma unroll
         for (int q = 0; q < QPW; ++q) all_done = all_done && (cnt[q] >= nsample);
         if (all_done) break;                                     // wave-uniform
-        const float px = nx, py = ny, pz = nz;
-        if (off + 64 < N) fetch(off + 64, nx, ny, nz);
-        const int i = off + lane;
-        const bool ok = i < N;
-        const float pn = p2c_norm2(px, py, pz);
+        float cxs[G], cys[G], czs[G];
 #pragma unroll
-        for (int q = 0; q < QPW; ++q) {
-            if (cnt[q] >= nsample) continue;                     // wave-uniform
-            const float d = p2c_sqdist(cx[q], cy[q], cz[q], cn[q], px, py, pz, pn);
-            const bool in = ok && !(d > r2);                     // :102 excludes only d > r^2
-            const unsigned long long m = __ballot(in);
-            if (m) {
-                const int pos = cnt[q] + __popcll(m & ((1ull << lane) - 1ull));
-                if (in && pos < nsample) idx_out[((size_t)b * S + q0 + q) * nsample + pos] = i;
-                if (first[q] == N) first[q] = off + (__ffsll((long long)m) - 1);
-                cnt[q] += __popcll(m);
+        for (int g = 0; g < G; ++g) { cxs[g] = nx[g]; cys[g] = ny[g]; czs[g] = nz[g]; }
+        fetch(min(off0 + 64 * G, N - 1), nx, ny, nz);            // unconditional (clamped): no loop-carried copies
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int off = off0 + 64 * g;
+            if (off >= N) break;                                 // uniform
+            const float px = cxs[g], py = cys[g], pz = czs[g];
+            const int i = off + lane;
+            const bool ok = i < N;
+            const float pn = p2c_norm2(px, py, pz);
+#pragma unroll
+            for (int q = 0; q < QPW; ++q) {
+                if (cnt[q] >= nsample) continue;                 // wave-uniform
+                const float d = p2c_sqdist(cx[q], cy[q], cz[q], cn[q], px, py, pz, pn);
+                const bool in = ok && !(d > r2);                 // :102 excludes only d > r^2
+                const unsigned long long m = __ballot(in);
+                if (m) {
+                    const int pos = cnt[q] + __popcll(m & ((1ull << lane) - 1ull));
+                    if (in && pos < nsample) idx_out[((size_t)b * S + q0 + q) * nsample + pos] = i;
+                    if (first[q] == N) first[q] = off + (__ffsll((long long)m) - 1);
+                    cnt[q] += __popcll(m);
+                }
             }
         }
     }

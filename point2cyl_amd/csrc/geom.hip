@@ -14,7 +14,7 @@ __device__ __forceinline__ float p2c_norm2(float x, float y, float z) { return (
 __device__ __forceinline__ float p2c_sqdist(float sx, float sy, float sz, float sn, float dx, float dy, float dz, float dn)
 {
     const float dot = __builtin_fmaf(sz, dz, __builtin_fmaf(sy, dy, sx * dx));
-    return (-2.0f * dot + sn) + dn;
+    return __builtin_fmaf(-2.0f, dot, sn) + dn;      // = (-2 dot + sn) + dn bit for bit (the product by 2 is exact), one instruction instead of two
 }
 
 // =============================================================================================

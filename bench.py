@@ -143,6 +143,8 @@ def main():
     ap.add_argument("--torch_losses", action="store_true", help="evaluate the losses with torch ops instead of csrc/loss.hip")
     ap.add_argument("--no_prefetch", action="store_true", help="compute FPS/ball-query/3-NN inline instead of one step ahead on a side stream")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
+    ap.add_argument("--sync_exchange", action="store_true", help="N > 1, conservative form of the exchange: ONE graph per step (no split tail) and the "
+                    "all-reduce issued on the step's own stream right behind the replay (no side stream, no overlap); still all-HIP / RCCL")
     ap.add_argument("--no_extras", action="store_true", help="only the training-step line: skip stages / forward_only / config3_fitting / ab / dropin")
     ap.add_argument("--dropin", action="store_true", help="make the DROP-IN step the timed one: the step composed as train_Point2Cyl_without_sketch.py:244-369 "
                     "composes it through the reference's import names (model(pcs), compute_all_losses, inline BB block, torch.optim.Adam, six .item())")
@@ -203,6 +205,11 @@ def _bench(args, rank, world, local, dev):
     torch.manual_seed(0)
     model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
     ddp.broadcast_module(model)
+    try:
+        pre = ddp.preflight(model, dev)       # N > 1: one EAGER all-reduce + identical-replica proof before anything is captured
+    except RuntimeError as e:
+        sys.stderr.write("bench: %s\n" % e)
+        raise SystemExit(3)
     step.update_momentum(model, step.get_batch_norm_decay(0, B, 200000))
     sync = ddp.FlatGradSync(model.parameters(), world)
     opt = optim.Adam(model.parameters(), lr=1e-3)     # the reference's torch.optim.Adam update rule as ONE launch (point2cyl_amd/optim.py)
@@ -223,7 +230,7 @@ def _bench(args, rank, world, local, dev):
         from point2cyl_amd.graph import GraphedForwardBackward
         try:
             graphed = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=None if args.no_prefetch else batch[0], stream=torch.cuda.current_stream(),
-                                             split_tail=world > 1)
+                                             split_tail=world > 1 and not args.sync_exchange)
         except Exception as e:      # keep the bench alive: fall back to eager launches
             sys.stderr.write("bench: HIP graph capture failed (%s: %s); running eager\n" % (type(e).__name__, e))
             torch.cuda.set_stream(torch.cuda.Stream(dev))      # a failed capture can leave its stream in capture mode: continue on a fresh one
@@ -239,10 +246,13 @@ def _bench(args, rank, world, local, dev):
         if world > 1 and timed:         # events on the step's stream: from "gradients ready" to "exchange joined" (the graph's tail runs inside)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        sync.allreduce_async()          # N > 1: on a side stream, gated on the replay; N = 1: nothing
-        if graphed is not None:
-            graphed.tail()              # N > 1: the prefetched geometry's copies, a second graph, under the exchange
-        sync.wait()
+        if args.sync_exchange:
+            sync.allreduce()            # conservative: on the step's stream, nothing overlaps (the geometry copies are inside the one graph)
+        else:
+            sync.allreduce_async()      # N > 1: on a side stream, gated on the replay; N = 1: nothing
+            if graphed is not None:
+                graphed.tail()          # N > 1: the prefetched geometry's copies, a second graph, under the exchange
+            sync.wait()
         if world > 1 and timed:
             e1.record()
             ar_events.append((e0, e1))
@@ -290,7 +300,8 @@ def _bench(args, rank, world, local, dev):
         multi = dict(rank_ms_per_step=[round(float(v), 4) for v in allr[:, 0]], allreduce_ms=[round(float(v), 4) for v in allr[:, 1]],
                      allreduce_bytes=int(sync.flat.numel() * 4) if sync.flat is not None else 0,
                      param_checksum=[float(v) for v in allr[:, 2]], params_identical=bool((allr[:, 2] == allr[0, 2]).all()),
-                     recapture_count=1 if graphed is not None else 0,
+                     recapture_count=1 if graphed is not None else 0, preflight=pre,
+                     exchange="sync (step's stream, one graph)" if args.sync_exchange else "async (side stream under the split tail)",
                      allreduce_note="allreduce_ms: from 'gradients ready' to 'exchange joined' on the step's stream; the exchange runs on a side stream and the "
                                     "step's tail (the copies of the next batch's prefetched geometry, a second graph, ~0.04 ms) runs under it")
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)

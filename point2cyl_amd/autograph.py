@@ -11,12 +11,17 @@ reads stay whatever they are.
 What is not static is handled like graph.py does: FPS start indices are drawn on the CPU generator per call (pointnet_util.py:75) and
 travel through pinned staging into static device tensors; the dropout counter and the BatchNorm running statistics are device state the
 captured kernels advance themselves; the BatchNorm momentum is a kernel argument, so a change of momentum (train...:357-360) is part of the
-cache key and triggers a new capture.  Parameter gradients: the backward graph leaves them in static tensors; `p.grad` is pointed at them
-when it is None (after `optimizer.zero_grad()`, whose default sets gradients to None) and added to otherwise.
+cache key and triggers a new capture.  Parameter gradients are REAL autograd outputs: the backward graph packs them into one static flat
+buffer, `_Replay.backward` takes ONE copy of it (5.6 MB, one launch) and returns per-parameter views of that fresh copy - so
+`loss.backward()` (AccumulateGrad adopts the views without a further copy when `.grad` is None, adds otherwise), `torch.autograd.grad(loss,
+params)`, `backward(inputs=...)`, parameter hooks and torch's DistributedDataParallel all see them like any other node's gradients.
 
 Contract (the same as torch.cuda.make_graphed_callables): the returned head tensors are views of a static buffer that the NEXT forward of
-the same shape overwrites; no double backward through the module; the input needs no gradient.  Anything outside the contract - test hooks
-(dropout_mask, fps_start), an input that requires grad, P2C_AUTOGRAPH=0, a capture that fails - takes the eager path."""
+the same shape overwrites, and the saved activations live inside the graph: a backward through a forward that is no longer the LATEST
+replay of its graph (two forwards of one shape, then backward of the first: gradient accumulation over micro-batches is fine as long as
+each micro-batch does forward -> backward in turn) RAISES instead of differentiating the wrong activations; no double backward through the
+module; the input needs no gradient.  Anything outside the contract - test hooks (dropout_mask, fps_start), an input that requires grad,
+P2C_AUTOGRAPH=0, a capture that fails - takes the eager path."""
 import os
 import warnings
 import weakref
@@ -31,8 +36,16 @@ _STATE = weakref.WeakKeyDictionary()      # model -> dict(graphs, bns, params, f
 def _state(model):
     st = _STATE.get(model)
     if st is None:
-        st = _STATE[model] = dict(graphs={}, bns=_bn_modules(model), params=list(model.parameters()), failed=False)
+        slots = [(m._parameters, n) for m in model.modules() for n, p in m._parameters.items() if p is not None]
+        slots += [(m._buffers, n) for m in model.modules() for n, b in m._buffers.items() if b is not None]
+        st = _STATE[model] = dict(graphs={}, bns=_bn_modules(model), slots=slots, failed=False)
     return st
+
+
+def _live_ptrs(model):
+    """Storage addresses of the module's CURRENT parameters and buffers (the dict slots are read every call, ~20 us: `p.data = ...`,
+    `model.cpu(); model.cuda()`, load_state_dict(assign=True), a replaced nn.Parameter or buffer all show up here)."""
+    return tuple(d[n].data_ptr() for d, n in _state(model)["slots"])
 
 
 def reset(model=None):
@@ -113,8 +126,11 @@ class _Captured:
                         # .grad in the parameter's own layout (a (64,3,1,1) weight's gradient arrives as a slice of the kernels' 4-padded
                         # rows): one mismatch sends torch.optim's multi-tensor kernels down their one-launch-per-tensor path (measured:
                         # Adam.step 0.35 -> 0.85 ms)
-                        grads = [g if (g is None or g.stride() == p.stride()) else g.contiguous().view_as(p) for g, p in zip(grads, self.params)]
-                    self.grads = [None if g is None else g.detach() for g in grads]
+                        # (packed: element ranges of ONE flat buffer in the parameters' own contiguous layout)
+                        have = [(g, p) for g, p in zip(grads, self.params) if g is not None]
+                        self.flat = torch.cat([g.reshape(-1) for g, _ in have]) if have else None
+                    self.has_grad = [g is not None for g in grads]
+                    del grads, have
             main.wait_stream(cap)
             torch.cuda.synchronize()
         finally:
@@ -128,6 +144,7 @@ class _Captured:
                 pass
         self.starts.cursor = 0
         self._first = True
+        self.generation = 0          # number of forward replays: a backward checks that it differentiates the latest one
 
     def replay_forward(self, x):
         if x.data_ptr() != self.x.data_ptr():
@@ -135,6 +152,7 @@ class _Captured:
         if not self._first:
             self.starts.stage()          # fresh CPU draws for this call (the first replay consumes the pair drawn at construction)
         self._first = False
+        self.generation += 1
         self.fwd.replay()
         return self.heads.detach()       # a fresh alias per call: autograd stamps its node on the object the Function returns
 
@@ -144,7 +162,9 @@ class _Replay(torch.autograd.Function):
     def forward(ctx, cap, x, *params):
         ctx.cap = cap
         ctx.set_materialize_grads(False)
-        return cap.replay_forward(x)
+        out = cap.replay_forward(x)
+        ctx.generation = cap.generation
+        return out
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -153,34 +173,33 @@ class _Replay(torch.autograd.Function):
         n = len(cap.params)
         if gout is None:
             return (None, None) + (None,) * n
-        # gradients of an earlier backward that nobody consumed or cleared (gradient accumulation): the static tensors are about to be
-        # overwritten, so .grad gets its own copy first
-        held = [p for p, g in zip(cap.params, cap.grads) if g is not None and p.grad is g]
-        if held:
-            for p in held:
-                p.grad = p.grad.clone()
+        if ctx.generation != cap.generation:
+            raise RuntimeError("point2cyl_amd.autograph: backward through a forward pass that is not the latest one of its shape - the activations "
+                               "saved inside the HIP graph now belong to forward #%d, this backward belongs to #%d.  Run forward -> backward per "
+                               "(micro-)batch, or set P2C_AUTOGRAPH=0 for the eager path (INTEGRATION.md, 'autograd contract')"
+                               % (cap.generation, ctx.generation))
         if gout.data_ptr() != cap.gout.data_ptr():
             cap.gout.copy_(gout)
         cap.bwd.replay()
-        add_dst, add_src = [], []
-        for p, g in zip(cap.params, cap.grads):
-            if g is None:
+        if cap.flat is None:
+            return (None, None) + (None,) * n
+        fresh = cap.flat.clone()            # the static buffer is overwritten by the next replay; autograd gets tensors of its own (ONE launch)
+        outs, o = [], 0
+        for p, has in zip(cap.params, cap.has_grad):
+            if not has:
+                outs.append(None)
                 continue
-            if p.grad is None:
-                p.grad = g
-            else:
-                add_dst.append(p.grad)
-                add_src.append(g)
-        if add_dst:
-            torch._foreach_add_(add_dst, add_src)
-        return (None, None) + (None,) * n
+            k = p.numel()
+            outs.append(fresh[o:o + k].view(p.shape))
+            o += k
+        return (None, None) + tuple(outs)
 
 
 def _key(model, x, want_grad):
+    # the LIVE parameters and buffers: tensors that got new storage must not meet a graph captured on the old one
     st = _state(model)
-    bns, ps = st["bns"], st["params"]
-    return (tuple(x.shape), x.dtype, x.device.index, model.training, want_grad, tuple(b.momentum for b in bns),
-            ps[0].data_ptr(), ps[-1].data_ptr(), tuple(p.requires_grad for p in ps) if want_grad else None)
+    return (tuple(x.shape), x.dtype, x.device.index, model.training, want_grad, tuple(b.momentum for b in st["bns"]),
+            _live_ptrs(model), tuple(d[n].requires_grad for d, n in st["slots"]) if want_grad else None)
 
 
 def applicable(model, x):
@@ -194,7 +213,7 @@ def applicable(model, x):
 def forward_heads(model, x):
     """-> (heads, sizes) like backbone.forward_heads, through the cached graphs of x's shape (captured on first use)."""
     st = _state(model)
-    want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in st["params"])
+    want_grad = torch.is_grad_enabled() and any(d[n].requires_grad for d, n in st["slots"])
     cache = st["graphs"]
     key = _key(model, x, want_grad)
     cap = cache.get(key)

@@ -216,34 +216,44 @@ class backbone(nn.Module):
     def _weight_stage(self, device):
         """The operands this forward derives from parameters alone, as one batched copy (ops.WeightStage).  Built lazily per device."""
         ws = self.__dict__.get("_wstage")
-        if ws is not None and ws.device == device:
+        if ws is not None and ws.device == device and ws.owner_id == id(self):
             return ws
+        # sources are resolvers of the LIVE parameter (ops.WeightStage): never a tensor captured at build time
         entries = []
+        sa1w, sa2w, sa3w, fp3w = (lambda: self.sa1.mlp_convs[0].weight), (lambda: self.sa2.mlp_convs[0].weight), \
+            (lambda: self.sa3.mlp_convs[0].weight), (lambda: self.fp3.mlp_convs[0].weight)
         if not self.normal_channel:
-            w = self.sa1.mlp_convs[0].weight                                              # (64, 3, 1, 1) -> (64, 4)
-            entries.append(("sa1_W", (w.shape[0], 4), [(w, 0, 3, 0, 0)]))
-        w = self.sa2.mlp_convs[0].weight                                                  # (128, 3 + 128): xyz part | feature part
+            w = sa1w()                                                                    # (64, 3, 1, 1) -> (64, 4)
+            entries.append(("sa1_W", (w.shape[0], 4), [(sa1w, 0, 3, 0, 0)]))
+        w = sa2w()                                                                        # (128, 3 + 128): xyz part | feature part
         co, ci = w.shape[0], w.shape[1]
-        entries.append(("sa2_wx", (co, 4), [(w, 0, 3, 0, 0)]))
-        entries.append(("sa2_W", (co, ci - 3), [(w, 3, ci - 3, 0, 0)]))
-        w = self.sa3.mlp_convs[0].weight                                                  # (256, 3 + 256) -> [features | xyz | pad] (256, 260)
+        entries.append(("sa2_wx", (co, 4), [(sa2w, 0, 3, 0, 0)]))
+        entries.append(("sa2_W", (co, ci - 3), [(sa2w, 3, ci - 3, 0, 0)]))
+        w = sa3w()                                                                        # (256, 3 + 256) -> [features | xyz | pad] (256, 260)
         co, ci = w.shape[0], w.shape[1]
-        entries.append(("sa3_W", (co, (ci + 3) // 4 * 4), [(w, 3, ci - 3, 0, 0), (w, 0, 3, 0, ci - 3)]))
-        w = self.fp3.mlp_convs[0].weight                                                  # (256, 256 skip + 1024 repeated): two column blocks
+        entries.append(("sa3_W", (co, (ci + 3) // 4 * 4), [(sa3w, 3, ci - 3, 0, 0), (sa3w, 0, 3, 0, ci - 3)]))
+        w = fp3w()                                                                        # (256, 256 skip + 1024 repeated): two column blocks
         co, k = w.shape[0], self.sa2.mlp_convs[-1].weight.shape[0]
-        entries.append(("fp3_W", (co, k), [(w, 0, k, 0, 0)]))
-        entries.append(("fp3_wb", (co, w.shape[1] - k), [(w, k, w.shape[1] - k, 0, 0)]))
+        entries.append(("fp3_W", (co, k), [(fp3w, 0, k, 0, 0)]))
+        entries.append(("fp3_wb", (co, w.shape[1] - k), [(fp3w, k, w.shape[1] - k, 0, 0)]))
         tot = sum(m.weight.shape[0] for m in self.fc2)
         pad = (tot + 3) // 4 * 4
         wparts, bparts, o = [], [], 0
-        for m in self.fc2:
-            wparts.append((m.weight, 0, m.weight.shape[1], o, 0))
-            bparts.append((m.bias, 0, m.bias.shape[0], 0, o))
+        for i, m in enumerate(self.fc2):
+            wparts.append(((lambda i=i: self.fc2[i].weight), 0, m.weight.shape[1], o, 0))
+            bparts.append(((lambda i=i: self.fc2[i].bias), 0, m.bias.shape[0], 0, o))
             o += m.weight.shape[0]
         entries.append(("head_W", (pad, self.fc2[0].weight.shape[1]), wparts))
         entries.append(("head_b", (pad,), bparts))
         ws = self.__dict__["_wstage"] = ops.WeightStage(entries, device)
+        ws.owner_id = id(self)
         return ws
+
+    def __getstate__(self):
+        """copy.deepcopy / pickling of the module never carry the weight stage (its resolvers point at THIS object): the copy builds its own."""
+        d = self.__dict__.copy()
+        d.pop("_wstage", None)
+        return d
 
     def compute_geometry(self, x):
         """Everything in the forward pass that depends on the point coordinates only (no parameters): both FPS +

@@ -129,6 +129,43 @@ class FlatGradSync:
             self._pending = False
 
 
+def preflight(modules, device=None):
+    """Before anything is captured or timed in a job of several ranks: ONE eager all-reduce on the device (does the collective library work
+    on this node at all - xGMI / IPC / device visibility problems surface here, with the backend's own error text, not inside a graph
+    capture) and proof that the replicas start from the same parameters (float64 sum of squares, gathered).  Raises RuntimeError with
+    the backend's message; returns a dict for the bench / trainer report.  world_size 1: nothing."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return None
+    world, rank = dist.get_world_size(), dist.get_rank()
+    backend = dist.get_backend()
+    if isinstance(modules, torch.nn.Module):
+        modules = [modules]
+    params = [p for m in modules for p in m.parameters()]
+    dev = device if device is not None else params[0].device
+    try:
+        probe = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=dev)
+        dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+        if probe.is_cuda:
+            torch.cuda.synchronize(dev)
+        want = world * (world + 1) / 2.0
+        if not bool((probe == want).all()):
+            raise RuntimeError("all-reduce(SUM) of rank+1 over %d ranks returned %r, expected %r" % (world, float(probe[0]), want))
+        with torch.no_grad():
+            ck = torch.zeros(1, dtype=torch.float64, device=dev)
+            for p in params:
+                ck += (p.detach().double() ** 2).sum()
+        got = [torch.zeros_like(ck) for _ in range(world)]
+        dist.all_gather(got, ck)
+        sums = [float(g) for g in got]
+    except Exception as e:
+        raise RuntimeError("point2cyl_amd.ddp.preflight: the eager collective check failed on rank %d of %d (backend %s, device %s): %s: %s"
+                           % (rank, world, backend, dev, type(e).__name__, e)) from e
+    if any(s_ != sums[0] for s_ in sums):
+        raise RuntimeError("point2cyl_amd.ddp.preflight: replicas do not start from identical parameters (sum of squares per rank: %r); "
+                           "broadcast_module must run before the first step" % (sums,))
+    return dict(backend=backend, world_size=world, eager_allreduce_ok=True, param_checksum=sums[0], params_identical=True)
+
+
 def broadcast_module(module, src=0):
     """Same initial parameters and buffers on every rank."""
     if not dist.is_initialized() or dist.get_world_size() == 1:

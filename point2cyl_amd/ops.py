@@ -208,6 +208,7 @@ class _StepArena:
 
     def __init__(self):
         self.buf, self.off, self.need, self.run, self.active = None, 0, 0, 0, False
+        self.epoch = 0            # number of arena steps begun: a backward that reads an arena slice checks it is still the step that wrote it
         self.pending = False      # gradients handed out by the last arena step have not been consumed yet (see step_done)
 
     def take(self, n_f64, dev):
@@ -246,6 +247,7 @@ class step_arena:
         else:
             A.buf.zero_()
         A.off, A.run, A.active = 0, 0, True
+        A.epoch += 1
         return A
 
     def __exit__(self, *exc):
@@ -338,6 +340,12 @@ class _MLPStack(torch.autograd.Function):
                  and bns[0] is not None and bns[1] is not None)
         mom = None
         staged = cfg.get("staged")
+        stage_gen = None
+        if staged:
+            for sd_ in staged.values():
+                stg = getattr(sd_.get("W2"), "_p2c_stage", None) if sd_ else None
+                if stg is not None:
+                    stage_gen = (stg, stg.generation)
         mptr_free = mask is None and seed is None
         for i in range(L):
             has_bn = not (tail == "linear" and i == L - 1)
@@ -485,6 +493,7 @@ class _MLPStack(torch.autograd.Function):
         else:
             out = Ys[-1]
         ctx.cfg = cfg
+        ctx.stage_gen = stage_gen
         ctx.saved = (X0, Ys, aff, Ws, arg, params)      # params: the layer parameters (without a leading repeat vector)
         ctx.fold = (mom, fold_b0) if fold0 else None
         ctx.pre_wx = pre_wx
@@ -495,6 +504,10 @@ class _MLPStack(torch.autograd.Function):
     def backward(ctx, dout):
         cfg = ctx.cfg
         X0, Ys, aff, Ws, arg, params = ctx.saved
+        if ctx.stage_gen is not None and ctx.stage_gen[0].generation != ctx.stage_gen[1]:
+            raise RuntimeError("point2cyl_amd.ops.mlp_stack: backward after the staged weight operands were rewritten by a later forward "
+                               "(ops.WeightStage.run()): the persistent buffers no longer hold the weights this forward used.  Run forward -> "
+                               "backward in turn (no second forward of the module in between)")
         rep_grad = None
         arg, ywin = arg if isinstance(arg, tuple) else (arg, None)
         # Eval mode (running statistics, e.g. fine-tuning with frozen BatchNorm, train_Point2Cyl.py:354-357): y = scale * x + shift with a
@@ -834,13 +847,20 @@ class WeightStage:
     """Every operand a step derives from the PARAMETERS alone - zero-padded weights (3 -> 4, 259 -> 260 input channels, 19 -> 20 head
     outputs), the grouped layers' [xyz | features] -> [features | xyz] column order, the column blocks of a first-layer weight that
     multiply different inputs - prepared by ONE launch (p2c_copy2d_batch_f32) into persistent buffers instead of a dozen torch copy / cat
-    launches spread over the forward pass.  entries: (key, dst_shape, [(src tensor, src col0, ncols, dst row0, dst col0), ...]); padding
-    stays zero from the allocation.  The table is rebuilt when a source tensor moved (`.to()`, a re-created parameter)."""
+    launches spread over the forward pass.  entries: (key, dst_shape, [(src, src col0, ncols, dst row0, dst col0), ...]) where src is a
+    CALLABLE that returns the live source tensor (`lambda: conv.weight`): it is resolved on every run(), so a parameter that got new
+    storage (`p.data = ...`, `.cpu()` / `.cuda()`, load_state_dict(assign=True)) or was replaced is followed - a tensor captured once
+    would keep an alias of the old storage alive and the staged operands would silently go stale.  Padding stays zero from
+    the allocation; the device table is rebuilt when an address changed.  `generation` counts the runs (ops._MLPStack's backward
+    checks that the staged operands it reads are still the ones its forward used)."""
 
     def __init__(self, entries, device):
         self.entries, self.device = entries, device
         self.bufs = {key: torch.zeros(*shape, dtype=torch.float32, device=device) for key, shape, _ in entries}
+        for b in self.bufs.values():
+            b._p2c_stage = self          # (ops._MLPStack finds the stage of a staged operand through this tag)
         self.table, self.n, self.src_ptrs = None, 0, None
+        self.generation = 0
 
     def _build(self):
         import struct
@@ -848,7 +868,8 @@ class WeightStage:
         for key, shape, parts in self.entries:
             dst = self.bufs[key]
             ldd = dst.shape[-1]
-            for src, c0, nc, r0, d0 in parts:
+            for get, c0, nc, r0, d0 in parts:
+                src = get()
                 s2 = src.detach().reshape(src.shape[0], -1) if src.dim() > 1 else src.detach().reshape(1, -1)
                 assert s2.is_contiguous() and s2.dtype == torch.float32
                 rows.append(struct.pack("<QQiiii", s2.data_ptr() + 4 * c0, dst.data_ptr() + 4 * (r0 * ldd + d0), s2.shape[0], nc, s2.shape[1], ldd))
@@ -858,11 +879,12 @@ class WeightStage:
         self.src_ptrs = self._ptrs()
 
     def _ptrs(self):
-        return tuple(src.data_ptr() for _, _, parts in self.entries for src, *_ in parts)
+        return tuple(get().data_ptr() for _, _, parts in self.entries for get, *_ in parts)
 
     def run(self):
         if self.table is None or self.src_ptrs != self._ptrs():
             self._build()
+        self.generation += 1
         call("p2c_copy2d_batch_f32", ptr(self.table), self.n, stream())
 
     def __getitem__(self, key):
@@ -1106,12 +1128,19 @@ class _DeferredLabelCheck:
     synchronous check costs the caller of compute_all_losses its whole launch-ahead: the host waits for the forward to finish before it
     can enqueue the first loss kernel (measured on the drop-in step: 7.2 -> see DESIGN.md)."""
 
+    SYNC_FIRST = 3       # the first calls validate synchronously (the reference raises in the offending call: a mis-labelled dataset
+    #                      shows up at once); later batches are checked one call late, and at interpreter exit (atexit below)
+
     def __init__(self):
         self.st = {}
+        self.calls = 0
 
     def __call__(self, I_gt, K):
         if torch.cuda.is_current_stream_capturing():
             return
+        self.calls += 1
+        if self.calls <= self.SYNC_FIRST:
+            return check_labels(I_gt, K)
         dev = I_gt.device
         st = self.st.get(dev)
         if st is None:
@@ -1147,6 +1176,21 @@ def flush_label_check(device=None):
     for dev in list(check_labels_deferred.st):
         if device is None or dev == torch.device(device):
             check_labels_deferred.poll(dev, wait=True)
+
+
+def _flush_label_check_at_exit():
+    """The LAST batch of an unchanged caller (the reference's trainer never calls flush_label_check) is still reported: on stderr, at exit."""
+    import sys
+    try:
+        flush_label_check()
+    except ValueError as e:
+        sys.stderr.write("point2cyl_amd: %s\n" % e)
+    except Exception:
+        pass
+
+
+import atexit
+atexit.register(_flush_label_check_at_exit)
 
 
 def hungarian(W, I_gt):
@@ -1194,6 +1238,7 @@ class _SegLosses(torch.autograd.Function):
         call("p2c_seg_losses_f32", ptr(hd), ld, xoff, woff, ptr(ngt), ptr(I_gt), ptr(bb_gt), ptr(match), ptr(mask), B, N, K,
              float(w_seg), float(w_normal), float(w_bb), ptr(out), None, ptr(ws), stream())
         ctx.save_for_backward(hd, ngt, I_gt, bb_gt, match, mask)
+        ctx.epoch = STEP_ARENA.epoch if STEP_ARENA.active else None
         ctx.ws = ws                  # (a slice of the step arena shares the arena's version counter: every in-place write to ANY arena slice would
         #                              trip save_for_backward's check; the slice itself is written by these two entry points only)
         ctx.cfg = (B, N, K, xoff, woff, float(w_seg), float(w_normal), float(w_bb))
@@ -1207,6 +1252,9 @@ class _SegLosses(torch.autograd.Function):
             return (None,) * 12
         hd, ngt, I_gt, bb_gt, match, mask = ctx.saved_tensors
         ws = ctx.ws
+        if ctx.epoch is not None and ctx.epoch != STEP_ARENA.epoch:
+            raise RuntimeError("point2cyl_amd.ops.seg_losses: backward after the step arena it was recorded in has been cleared (a later "
+                               "`with ops.step_arena(...)` began): the matched sums it reads are gone.  Run backward inside the same arena step")
         B, N, K, xoff, woff, w_seg, w_normal, w_bb = ctx.cfg
         M, ld = hd.shape
         gout = _f32c(gout)

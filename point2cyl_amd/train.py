@@ -195,6 +195,7 @@ def _main(a, rank, world, local, dev, stream):
                         weight_bb=a.weight_bb, weight_extrusion=a.weight_extrusion, weight_center=a.weight_center)
     model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
     ddp.broadcast_module(model)
+    ddp.preflight(model, dev)          # world > 1: one eager all-reduce + identical replicas, before the first capture (raises with the backend's text)
     # everything random AFTER the parameters is per replica: data order / subsampling, noise, FPS starts, dropout
     np.random.seed(0 + rank)                                 # train…:135 (rank 0 reproduces the reference's stream)
     torch.manual_seed(a.seed + 7919 * rank)

@@ -133,6 +133,7 @@ def _main(a, rank, world, dev):
     loaded_pn_encoder = PointNetEncoder(256, 2, with_normals=True).to(dev)                                   # :280
     for m_ in (model, implicit_net, pn_encoder, loaded_pn_encoder):
         ddp.broadcast_module(m_)
+    ddp.preflight([model, implicit_net, pn_encoder, loaded_pn_encoder], dev)      # world > 1: eager collective + identical replicas (raises otherwise)
     groups = []
     if a.is_pc_train:
         groups.append({"params": list(model.parameters()), "lr": a.learning_rate})                           # :298-311
@@ -320,10 +321,25 @@ def _main(a, rank, world, dev):
         if last:
             break
     torch.cuda.synchronize()
+    multi = None
+    if world > 1:
+        # as point2cyl_amd.train: identical replicas after the last step (trained modules, float64 sum of squares, gathered), the schedules of
+        # the GLOBAL batch, the checkpoint's BatchNorm statistics = the replicas' mean, the size of the one exchange per step
+        with torch.no_grad():
+            ck = sum(float((p.detach().double() ** 2).sum()) for m_ in (model, pn_encoder) for p in m_.parameters())
+            bk = sum(float(b_.detach().double().sum()) for m_ in (model, pn_encoder) for b_ in m_.buffers() if b_.dtype.is_floating_point)
+        mine = torch.tensor([ck, bk, old_lr, mom_fwd], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        torch.distributed.all_gather(allr, mine)
+        allr = torch.stack(allr).cpu()
+        multi = dict(backend=ddp.backend_name(), param_checksum=[float(v) for v in allr[:, 0]], params_identical=bool((allr[:, 0] == allr[0, 0]).all()),
+                     buffer_checksum_after_averaging=[float(v) for v in allr[:, 1]], buffers_identical=bool((allr[:, 1] == allr[0, 1]).all()),
+                     learning_rate=[float(v) for v in allr[:, 2]], next_bn_momentum=[float(v) for v in allr[:, 3]], samples_per_step=B * world,
+                     allreduce_bytes=int(sync.flat.numel() * 4) if sync.flat is not None else 0, trainable_parameters=sum(p.numel() for p in trainable))
     if t0 is not None and steps_timed > 0 and rank == 0:
         dt = (time.perf_counter() - t0) / steps_timed
         rep = dict(steps=gstep, ms_per_step=dt * 1e3, points_per_s=world * B * N / dt, batch_per_gpu=B, num_point=N, num_sk_point=S, world=world,
-                   epoch_means={k: v for k, v in scal.items()})
+                   epoch_means={k: v for k, v in scal.items()}, multi_gpu=multi)
         print("with-sketch trainer throughput: %.2f ms/step, %.1f points/s" % (rep["ms_per_step"], rep["points_per_s"]))
         if a.report:
             with open(a.report, "w") as f:

@@ -366,6 +366,12 @@ def test_hungarian_rejects_out_of_range_labels():
     # the next call - or ops.flush_label_check() - raises
     X = F.normalize(torch.randn(2, 256, 3, device=DEV), dim=-1)
     Wn = torch.softmax(W, -1)
+    # (the first SYNC_FIRST calls of a process validate synchronously - the reference raises in the offending call - then deferred)
+    ops.check_labels_deferred.calls = 0
+    I[1, 5] = 9
+    with pytest.raises(ValueError):
+        losses.compute_all_losses(None, Wn, I, X, X, 1.0, 1.0)
+    ops.check_labels_deferred.calls = ops.check_labels_deferred.SYNC_FIRST
     I[1, 5] = 3
     ops.flush_label_check()
     losses.compute_all_losses(None, Wn, I, X, X, 1.0, 1.0)
@@ -620,6 +626,91 @@ def test_autograph_module_forward_backward_equals_eager_launches():
     autograph.reset()
 
 
+def test_autograph_is_an_autograd_citizen_and_follows_moved_parameters():
+    """ADVICE r4 (autograph.py:169, ops.py:862).  (a) the parameter gradients of the graphed module are real autograd outputs:
+    torch.autograd.grad(loss, params) returns them (and leaves .grad alone), a parameter hook sees them, and after loss.backward() every
+    .grad is a tensor of its own (not the graph's static buffer: the next backward does not overwrite it); (b) a backward through a
+    forward that is no longer the latest replay of its graph raises instead of differentiating the wrong activations; (c) parameters
+    whose STORAGE moved (`p.data = ...`, model.cpu(); model.cuda()) or that were replaced (load_state_dict(assign=True)) are followed:
+    the staged weight operands (ops.WeightStage: sa1/sa2/sa3 first layers, fp3, the heads) and the cached graphs are rebuilt, so the
+    forward equals the eager forward of the same module on the same draws."""
+    from point2cyl_amd import autograph
+    B, N = 2, 1024
+    pcs = synth.make_batch(B, N, 8, seed=78)[0].float().to(DEV)
+    m = _fresh_backbone(3)
+    params = [p for p in m.parameters()]
+    names = [k for k, _ in m.named_parameters()]
+    # (a) autograd.grad == backward, hooks fire, .grad survives the next backward
+    torch.manual_seed(1)
+    X, W = m(pcs)
+    loss = X.square().mean() + W.square().mean()
+    seen = {}
+    h = m.fc1.weight.register_hook(lambda g: seen.setdefault("fc1", g.detach().clone()))
+    got = torch.autograd.grad(loss, params, retain_graph=False, allow_unused=True)
+    h.remove()
+    assert all(p.grad is None for p in params), "autograd.grad must not touch .grad"
+    assert all(g is not None and torch.isfinite(g).all() for g in got)
+    assert "fc1" in seen and torch.equal(seen["fc1"], got[names.index("fc1.weight")])
+    st = autograph._state(m)
+    assert len(st["graphs"]) == 1 and not st["failed"]
+    m._drop_seed.sub_(0x9E3779B97F4A7C15 % (2 ** 62))          # same dropout bits and (seeded) FPS draws again
+    torch.manual_seed(1)
+    X, W = m(pcs)
+    (X.square().mean() + W.square().mean()).backward()
+    for k, p, g in zip(names, params, got):
+        assert float((p.grad - g).norm()) <= 1e-5 * float(g.norm()) + 1e-9, k      # (fp64 stat atomics: order noise only)
+    kept = {k: p.grad for k, p in zip(names, params)}
+    snap = {k: g.clone() for k, g in kept.items()}
+    for p in params:
+        p.grad = None
+    X, W = m(pcs)
+    (3.0 * X.square().mean()).backward()
+    for k in snap:
+        assert torch.equal(kept[k], snap[k]), "a gradient handed out earlier was overwritten by the next backward: %s" % k
+    # (b) stale backward raises
+    for p in params:
+        p.grad = None
+    X1, W1 = m(pcs)
+    l1 = X1.square().mean()
+    X2, W2 = m(pcs)
+    with pytest.raises(RuntimeError, match="not the latest"):
+        l1.backward()
+    (X2.square().mean()).backward()                              # the latest one still works
+    assert all(torch.isfinite(p.grad).all() for p in params if p.grad is not None)
+
+    # (c) moved / replaced parameters
+    def eager_and_graphed(seed):
+        for flag in (False, True):
+            autograph.ENABLED = flag
+            try:
+                m._drop_seed.fill_(12345)
+                torch.manual_seed(seed)
+                with torch.no_grad():
+                    yield torch.cat(m(pcs), -1).clone()
+            finally:
+                autograph.ENABLED = True
+
+    e0, g0 = eager_and_graphed(4)
+    assert float((e0 - g0).abs().max()) <= 2e-5 * float(e0.abs().max())
+    with torch.no_grad():
+        for mod in (m.sa1.mlp_convs[0], m.sa2.mlp_convs[0], m.sa3.mlp_convs[0], m.fp3.mlp_convs[0], m.fc2[1], m.fp1.mlp_convs[1]):
+            mod.weight.data = (mod.weight.data * 1.5 + 0.01).clone()          # NEW storage, new values
+    e1, g1 = eager_and_graphed(4)
+    assert float((e1 - e0).abs().max()) > 1e-3 * float(e0.abs().max()), "the perturbation must change the output"
+    assert float((e1 - g1).abs().max()) <= 2e-5 * float(e1.abs().max()), "graph / staged operands kept reading the old weights"
+    m.cpu(); m.to(DEV)
+    with torch.no_grad():
+        m.fc2[0].weight.mul_(0.5)
+    e2, g2 = eager_and_graphed(4)
+    assert float((e2 - g2).abs().max()) <= 2e-5 * float(e2.abs().max())
+    sd = {k: (v * 0.9 if v.dtype.is_floating_point and "running_var" not in k else v).clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd, assign=True)
+    e3, g3 = eager_and_graphed(4)
+    assert float((e3 - e2).abs().max()) > 1e-4 * float(e2.abs().max())
+    assert float((e3 - g3).abs().max()) <= 2e-5 * float(e3.abs().max())
+    autograph.reset()
+
+
 def test_dropin_trainer_step_equals_native_step_and_trains():
     """point2cyl_amd/dropin/trainer_step.py (train_Point2Cyl_without_sketch.py:244-369 composed on the drop-in import names, torch.optim.Adam,
     six .item()) against point2cyl_amd.step.train_step on the same seeds: the six logged scalars of step 0 at 1e-5, and the loss goes down
@@ -701,6 +792,38 @@ def test_reference_made_checkpoint_loads_and_evaluates(mode, tmp_path):
     assert "mIoU" in out.stdout or "miou" in out.stdout.lower(), out.stdout[-1500:]
 
 
+def test_with_sketch_trainer_two_ranks_on_one_gpu_over_gloo(tmp_path):
+    """configs[4] as a data-parallel job: point2cyl_amd.train_sketch with two ranks that share this GPU over gloo, backbone
+    + sketch encoder trained, 8 synthetic shapes sharded 4 + 4, B = 2 per rank, 4 steps.  The report's multi_gpu object: identical
+    parameters of the trained modules on both ranks after the last step, identical BatchNorm statistics after ddp.average_buffers (what
+    rank 0's checkpoint holds), ONE exchange of all trainable parameters per step (backbone 1,404,243 + encoder), the schedules of the
+    global batch (world * B samples per step)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(P2C_ONE_GPU_RANKS="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="8")
+    rep = str(tmp_path / "report.json")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "-m", "point2cyl_amd.train_sketch", "--pred_seg", "--pred_normal", "--pred_bb", "--is_pc_train", "--is_im_train", "--with_im_loss",
+           "--synthetic", "8", "--batch_size", "2", "--num_point", "1024", "--num_sk_point", "256", "--num_epochs", "2", "--max_steps", "4",
+           "--decay_step", "8", "--bn_decay_step", "8", "--logdir", str(tmp_path / "run"), "--im_logdir", str(tmp_path / "none"), "--report", rep]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.load(open(rep))
+    mg = r["multi_gpu"]
+    assert r["world"] == 2 and r["steps"] == 4 and mg["backend"] == "gloo" and mg["samples_per_step"] == 4
+    assert mg["params_identical"] and mg["param_checksum"][0] == mg["param_checksum"][1] > 0
+    assert mg["buffers_identical"]
+    assert mg["trainable_parameters"] > 1404243 and mg["allreduce_bytes"] == 4 * mg["trainable_parameters"]
+    assert mg["learning_rate"] == [pytest.approx(1e-3 * 0.7)] * 2, mg["learning_rate"]
+    assert mg["next_bn_momentum"] == [pytest.approx(0.25)] * 2, mg["next_bn_momentum"]
+    ck = torch.load(str(tmp_path / "run" / "model.pth"), map_location="cpu")
+    assert set(ck.keys()) == {"model", "implicit_net", "pn_encoder"} and len(ck["model"]) == 123
+    assert all(torch.isfinite(v).all() for v in ck["model"].values() if v.dtype.is_floating_point)
+
+
 def test_trainer_cli_two_ranks_on_one_gpu_over_gloo(tmp_path):
     """point2cyl_amd.train as a data-parallel job: two ranks that share this GPU (P2C_ONE_GPU_RANKS: gloo instead of RCCL; the 8-GPU run uses
     the same code with backend nccl), 16 synthetic shapes sharded 8 + 8, B = 2 per rank, 4 steps through the HIP-graph path.
@@ -728,7 +851,7 @@ def test_trainer_cli_two_ranks_on_one_gpu_over_gloo(tmp_path):
     # (get_learning_rate(gstep = 3)) and floor(3 * 4 / 8) = 1 for the momentum that reaches the next forward
     assert mg["learning_rate"] == [pytest.approx(1e-3 * 0.7)] * 2, mg["learning_rate"]
     assert mg["next_bn_momentum"] == [pytest.approx(0.25)] * 2, mg["next_bn_momentum"]
-    assert mg["allreduce_bytes"] == 4 * 1404243
+    assert mg["allreduce_bytes"] == 5616972 == 4 * 1404243
     ck = torch.load(str(tmp_path / "run" / "model.pth"), map_location="cpu")["model"]
     assert len(ck) == 123 and int(ck["bn1.num_batches_tracked"]) == 4
     assert all(torch.isfinite(v).all() for v in ck.values() if v.dtype.is_floating_point)

@@ -1424,8 +1424,10 @@ def test_softplus_kernels_match_torch_double_backward(n):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-6 * max(1.0, float(b.abs().max())))
 
 
-def test_bench_two_ranks_on_one_gpu_over_gloo():
-    """The multi-process flow of bench.py (one HIP graph per rank, flat gradient exchange, fused Adam, max-over-ranks timing, one
+@pytest.mark.parametrize("exchange", ["async", "sync"])
+def test_bench_two_ranks_on_one_gpu_over_gloo(exchange):
+    """[exchange = sync: `--sync_exchange`, the conservative fallback for the first run on a multi-GPU node - one graph per step, the all-reduce
+    on the step's own stream.]  The multi-process flow of bench.py (one HIP graph per rank, flat gradient exchange, fused Adam, max-over-ranks timing, one
     JSON line from rank 0) with two ranks that SHARE this GPU (test hook P2C_ONE_GPU_RANKS: RCCL refuses two ranks per device, so the
     exchange goes over gloo; the driver's 8-GPU run uses the same code with backend nccl)."""
     import json, os, subprocess, sys
@@ -1434,7 +1436,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     env.update(P2C_ONE_GPU_RANKS="1", MASTER_ADDR="127.0.0.1")
     # no launcher: `python bench.py --gpus 2` starts its two ranks itself (bench._self_launch)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--batch_size", "4", "--num_point", "2048", "--no_cpu_baseline"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+                          "--batch_size", "4", "--num_point", "2048", "--no_cpu_baseline"] + (["--sync_exchange"] if exchange == "sync" else []),
+                         env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -1445,7 +1448,10 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     # the diagnostics a scaling line needs: per-rank step time, the event-timed exchange, identical replicas after the Adam steps
     mg = d["multi_gpu"]
     assert len(mg["rank_ms_per_step"]) == 2 and len(mg["allreduce_ms"]) == 2 and min(mg["rank_ms_per_step"]) > 0 and min(mg["allreduce_ms"]) > 0
-    assert mg["allreduce_bytes"] == 4 * 1404243 and mg["recapture_count"] == 1
+    assert mg["allreduce_bytes"] == 5616972 == 4 * 1404243 and mg["recapture_count"] == 1
+    assert mg["exchange"].startswith(exchange)
+    pre = mg["preflight"]          # one eager all-reduce + identical replicas BEFORE the capture (ddp.preflight)
+    assert pre["eager_allreduce_ok"] and pre["params_identical"] and pre["world_size"] == 2 and pre["backend"] == "gloo"
     assert mg["params_identical"] and mg["param_checksum"][0] == mg["param_checksum"][1] and mg["param_checksum"][0] > 0
     assert abs(d["ms_per_step"] - max(mg["rank_ms_per_step"])) < 0.05 * d["ms_per_step"] + 0.5
 

@@ -88,6 +88,18 @@ w0 = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
 ref = [torch.zeros_like(w0) for _ in range(world)]
 dist.all_gather(ref, w0)
 assert all(torch.equal(ref[0], r) for r in ref), "broadcast_module must equalise the replicas"
+# the pre-flight of a multi-rank job (bench.py, both trainers): one eager all-reduce + identical-replica proof; raises when replicas differ
+pre = ddp.preflight(m)
+assert pre["eager_allreduce_ok"] and pre["params_identical"] and pre["world_size"] == world and pre["backend"] == "gloo"
+with torch.no_grad():
+    m[0].weight[0, 0] += float(rank)          # replicas drift apart
+try:
+    ddp.preflight(m)
+    raise SystemExit("preflight accepted replicas that differ")
+except RuntimeError as e:
+    assert "identical" in str(e)
+with torch.no_grad():
+    m[0].weight[0, 0] -= float(rank)
 sync = ddp.FlatGradSync(m.parameters(), world)
 x = torch.randn(4, 6)                      # different shard per rank (seeded by rank)
 sync.zero()

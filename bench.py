@@ -221,7 +221,7 @@ def _bench(args, rank, world, local, dev):
         with ops.step_arena(dev):          # every zero-initialised accumulator of the step out of one buffer, one fill
             out = loss_fn(model, *batch, fl, geom=geom)
             sync.zero()
-            out["total"].backward()
+            step.backward(out)
             sync.pack()                    # N > 1: one multi-tensor copy into the exchange's flat buffer (a node of the captured graph)
         return {"total": out["total"].detach()}
 
@@ -415,7 +415,7 @@ def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
     """The measurements SURVEY 8(d) asks for beside the training-step number, in the same process after the timed region (rank 0, N = 1):
     stages.sa1_forward, forward_only, path_roofline, config3_fitting, ab (fp32-MFMA kernels), dropin (the step through the import names).
     Each leg is guarded: a failure is reported in the line instead of taking the training-step number down with it."""
-    from point2cyl_amd import _lib, measure, ops
+    from point2cyl_amd import _lib, measure, ops, step
     out = {}
 
     def leg(name, fn):
@@ -445,7 +445,7 @@ def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
                     with ops.step_arena(dev):
                         o = loss_fn(model, *batch, fl, geom=geom)
                         sync.zero()
-                        o["total"].backward()
+                        step.backward(o)
                         sync.pack()
                     return {"total": o["total"].detach()}
                 g = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=None if args.no_prefetch else batch[0], stream=torch.cuda.current_stream())

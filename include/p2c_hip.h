@@ -82,6 +82,10 @@ int p2c_three_interp_f32(const float *feats, int ldf, const int32_t *idx, const 
                          float *out, int ldo, void *stream);
 int p2c_three_interp_bwd_f32(const float *dout, int ldo, const int32_t *idx, const float *weight, int B, int N, int S,
                              int C, float *dfeats, int ldf, void *stream);
+/* input of a feature-propagation level in one launch (pointnet_util.py:308-312: cat([points1, interpolated])):
+ * out[b*N+n, :] = [skip[b*N+n, :Cskip] | interpolated (C) | zeros up to width], width <= ldo */
+int p2c_three_interp_skip_f32(const float *feats, int ldf, const int32_t *idx, const float *weight, int B, int N, int S, int C,
+                              const float *skip, int ldskip, int Cskip, float *out, int ldo, int width, void *stream);
 
 /* Atomic-free backward of both gathers: the inverse map (target row -> entries reading it) depends only on the
  * geometry, so it is built once per batch and the backward becomes a gather.
@@ -176,6 +180,15 @@ int p2c_linear_bwd_fused_fold0_f32(const float *dZ, int lddz, const float *Yfwd,
                                    long long dw_slot_stride, double *partials5, int M, int Co, int C0, void *stream);
 int p2c_fold0_bwd_finalize_f32(const double *partials5, const double *moments, long long M, const float *W0, const float *b0,
                                const float *stat0, const float *gamma0, int C0, float *dgamma0, float *dbeta0, float *dW0, void *stream);
+/* the same with dW0 written [C0, lddw0] (lddw0 in 1..4; 3 = the (C0,3,1,1) parameter's own layout) and, by extra workgroups of the
+ * launch, the per-XCD copies of the consumer layer's dW summed: out[i] = sum_c src[c*stride + i], i < n (as p2c_sum_copies_f32) */
+int p2c_fold0_bwd_finalize_sum_f32(const double *partials5, const double *moments, long long M, const float *W0, const float *b0,
+                                   const float *stat0, const float *gamma0, int C0, float *dgamma0, float *dbeta0, float *dW0, int lddw0,
+                                   const float *src, long long stride, int copies, float *out, long long n, void *stream);
+/* weight gradient of a grouped first layer in the parameter's layout out [Co, 3 + Cf] = [coordinate part | feature part]
+ * (pointnet_util.py:137 column order): columns 0..2 = sum over the P2C_STAT_SLOTS fp64 rows of dwx_slots [slots][3][Cs]
+ * (p2c_group_linear_bwd_f32), columns 3.. = dW[:, :Cf] of the feature GEMM (dW [Co, lddw]). */
+int p2c_group_weight_grad_f32(const double *dwx_slots, int Cs, const float *dW, int lddw, int Co, int Cf, float *out, void *stream);
 
 /* Layer fed by [X | one vector per row group repeated over the group's rows] (FP3: the global feature repeated over the 128
  * points of a cloud, pointnet_util.py:298-299, :312).  The repeated part's product G = V . Wb^T is computed once per group by the
@@ -333,6 +346,9 @@ int p2c_linear_bwd_fused_f32(const float *dZ, int lddz, const float *Yfwd, int l
  *   struct { const float *src; float *dst; int rows, cols, ld_src, ld_dst; }   (32 bytes each)
  * The host mirror stages every padded / re-ordered / column-sliced weight operand of a step with it (point2cyl_amd/ops.py WeightStage). */
 int p2c_copy2d_batch_f32(const void *table, int n, void *stream);
+/* the same launch also advances device-resident 64-bit counters (BatchNorm num_batches_tracked += 1, the dropout hash seed += stride):
+ * counters (device memory): n_counters entries of struct { long long *ptr; long long inc; } (16 bytes each); n or n_counters may be 0. */
+int p2c_copy2d_batch_inc_f32(const void *table, int n, const void *counters, int n_counters, void *stream);
 
 /* n flat copies of contiguous buffers in one launch: srcs / dsts / nbytes are HOST arrays (device pointers 4-byte aligned, byte counts
  * multiples of 4); the descriptors travel in the kernel arguments, so a captured graph node needs no device table.  The hand-over of the

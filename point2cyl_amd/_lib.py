@@ -66,6 +66,11 @@ _SIGS = {
     "p2c_linear_bwd_pool_alg_f32": [c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i,
                                     c_p],
     "p2c_copy2d_batch_f32": [c_p, c_i, c_p],
+    "p2c_copy2d_batch_inc_f32": [c_p, c_i, c_p, c_i, c_p],
+    "p2c_three_interp_skip_f32": [c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_i, c_i, c_p],
+    "p2c_fold0_bwd_finalize_sum_f32": [c_p, c_p, ctypes.c_longlong, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, ctypes.c_longlong, c_i, c_p,
+                                       ctypes.c_longlong, c_p],
+    "p2c_group_weight_grad_f32": [c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p],
     "p2c_copy_flat_batch": [c_p, c_p, c_p, c_i, c_p],
     "p2c_extrusion_axis_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_extrusion_axis_bwd_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],

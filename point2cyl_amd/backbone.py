@@ -13,6 +13,9 @@ import torch.nn as nn
 from . import ops
 
 
+DROP_STRIDE = 0x9E3779B97F4A7C15 % (2 ** 62)      # the dropout hash seed advances by this much per forward
+
+
 def _layers(convs, bns):
     out = []
     for conv, bn in zip(convs, bns):
@@ -245,7 +248,12 @@ class backbone(nn.Module):
             o += m.weight.shape[0]
         entries.append(("head_W", (pad, self.fc2[0].weight.shape[1]), wparts))
         entries.append(("head_b", (pad,), bparts))
-        ws = self.__dict__["_wstage"] = ops.WeightStage(entries, device)
+        # device counters the same launch advances: every BatchNorm's num_batches_tracked (+1 per train-mode forward) and the dropout seed
+        bn_mods = [m for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        nbt = [((lambda m=m: m.num_batches_tracked), 1) for m in bn_mods]
+        seed = [((lambda: self._drop_seed), DROP_STRIDE)]
+        ws = self.__dict__["_wstage"] = ops.WeightStage(entries, device, counters=nbt + seed)
+        ws.nbt_counters, ws.seed_counter = nbt, seed
         ws.owner_id = id(self)
         return ws
 
@@ -295,9 +303,25 @@ class backbone(nn.Module):
         feats0 = x[:, :, 3:].contiguous() if C > 3 else None
         gm = geom or {}
         ws = None
+        hashed_dropout = self.dropout_mask is None          # (a mask tensor or "off" are test hooks)
+        if hashed_dropout:
+            # F.dropout(p=0.5) is ALWAYS on in the reference, also in eval (pointnet_extrusion.py:60).  The keep-mask is never stored: the
+            # kernels regenerate it from (seed, element index); the seed is a device counter drawn once from torch's generator and
+            # advanced per forward (HIP-graph safe).
+            if abs(self.dropout_p * 256.0 - round(self.dropout_p * 256.0)) > 1e-6:
+                raise ValueError("dropout_p = %r: the in-kernel hashed mask realises drop probabilities in steps of 1/256 only (csrc/common.h); "
+                                 "the reference's value is 0.5 (pointnet_extrusion.py:60)" % self.dropout_p)
+        # (the seed is created where it always was - AFTER this forward's FPS draws, so the CPU generator is consumed in the same order -
+        # and advanced by a torch add in that first forward; from then on the staging launch advances it)
+        have_seed = hashed_dropout and self._drop_seed is not None and self._drop_seed.device == x.device
+        seed_bumped = False
         if ops.USE_STAGED_WEIGHTS:
             ws = self._weight_stage(x.device)
-            ws.run()                      # ONE launch: every padded / re-ordered / column-sliced weight operand of this forward
+            # ONE launch: every padded / re-ordered / column-sliced weight operand of this forward, the 17 num_batches_tracked += 1 (train
+            # mode) and the dropout seed's advance
+            bumped = ws.run(bump=(ws.nbt_counters if self.training else []) + (ws.seed_counter if have_seed else []))
+            ops._NBT_BUMPED[0] = bumped and self.training
+            seed_bumped = bumped and have_seed
         st = (lambda **kw: {k: ws[v] for k, v in kw.items()}) if ws is not None else (lambda **kw: None)
         l1_xyz, l1 = self.sa1.forward_pm(xyz, feats0, gm.get("sa1"), staged=st(W2="sa1_W") if (ws is not None and feats0 is None) else None)
         l2_xyz, l2 = self.sa2.forward_pm(l1_xyz, l1, gm.get("sa2"), staged=st(W2="sa2_W", pre_wx="sa2_wx"))
@@ -310,15 +334,11 @@ class backbone(nn.Module):
             mask, dscale = None, 1.0
         elif self.dropout_mask is not None:
             mask, dscale = self.dropout_mask.reshape(B * N, 128).to(device=x.device, dtype=torch.uint8).contiguous(), 1.0 / (1.0 - self.dropout_p)
-        else:   # F.dropout(p=0.5) is ALWAYS on in the reference, also in eval (pointnet_extrusion.py:60).
-            # The keep-mask is never stored: the kernels regenerate it from (seed, element index); the seed is a
-            # device counter drawn once from torch's generator and advanced per forward (HIP-graph safe).
-            if abs(self.dropout_p * 256.0 - round(self.dropout_p * 256.0)) > 1e-6:
-                raise ValueError("dropout_p = %r: the in-kernel hashed mask realises drop probabilities in steps of 1/256 only (csrc/common.h); "
-                                 "the reference's value is 0.5 (pointnet_extrusion.py:60)" % self.dropout_p)
-            if self._drop_seed is None or self._drop_seed.device != x.device:
+        else:
+            if not have_seed:
                 self._drop_seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(x.device)
-            self._drop_seed += 0x9E3779B97F4A7C15 % (2 ** 62)
+            if not seed_bumped:
+                self._drop_seed += DROP_STRIDE
             mask, seed, dscale = None, self._drop_seed, 1.0 / (1.0 - self.dropout_p)
         sizes = [m.weight.shape[0] for m in self.fc2]
         head_staged = None
@@ -337,5 +357,6 @@ class backbone(nn.Module):
         heads = self.fp1.forward_pm(xyz, l1_xyz, feats0, l5, tail="linear", extra_layers=extra, drop_mask=mask, drop_scale=dscale,
                                     drop_seed=seed, keep_padding=True, nn_=gm.get("fp1"), staged=head_staged)
         ops._DEFER_NBT[0] = False
+        ops._NBT_BUMPED[0] = False
         ops.flush_nbt()
         return heads.reshape(B * N, heads.shape[-1]), sizes

@@ -416,13 +416,20 @@ extern "C" int p2c_bn_finalize_affine_f32(const double *moments, long long M, co
 //   dgamma = s2, dbeta = s1, and with dY0 = gs*g + q*Y0 + p (gs, q, p as in bn_bwd_finalize):
 //   dW0[c, e] = sum_m dY0[m,c] x0[m,e] = gs*G[c,e] + q*(sum_e' W0[c,e'] S2[e',e] + b0[c] S1[e]) + p*S1[e]
 // (S1, S2 = the input moments).  The bias in front of a train-mode BatchNorm has an exactly zero gradient.
-__global__ void fold0_bwd_finalize_kernel(const double *__restrict__ part, const double *__restrict__ mom, long long M,
+__device__ __forceinline__ void p2c_sum_copies(const float *__restrict__ src, long long stride, int copies, float *__restrict__ out, long long n,
+                                               long long blk);       // (defined below)
+__global__ void __launch_bounds__(256) fold0_bwd_finalize_kernel(const double *__restrict__ part, const double *__restrict__ mom, long long M,
                                           const float *__restrict__ W0, const float *__restrict__ b0, const float *__restrict__ stat,
                                           const float *__restrict__ gamma, int C, float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                          float *__restrict__ dW0)
+                                          float *__restrict__ dW0, int lddw0, int fin_blocks, const float *__restrict__ src, long long stride,
+                                          int copies, float *__restrict__ out, long long n)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    if ((int)blockIdx.x >= fin_blocks) {           // extra workgroups: the per-XCD copies of the NEXT layer's dW summed (p2c_sum_copies_f32)
+        p2c_sum_copies(src, stride, copies, out, n, (long long)blockIdx.x - fin_blocks);
+        return;
+    }
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C || threadIdx.x >= 64) return;
     double sv[5] = {0, 0, 0, 0, 0};
 #pragma unroll 16
     for (int t = 0; t < P2C_STAT_SLOTS; ++t)       // 80 independent loads in flight per round: one wave does all of this, latency is all it costs
@@ -443,7 +450,7 @@ __global__ void fold0_bwd_finalize_kernel(const double *__restrict__ part, const
         double yx = bb * mom[e];
         for (int k = 0; k < 4; ++k) yx += (double)W0[c * 4 + k] * S2[k][e];
         const double G = e < 3 ? sv[2 + e] : 0.0;
-        dW0[c * 4 + e] = (float)(gs * G + q * yx + p * mom[e]);
+        if (e < lddw0) dW0[c * lddw0 + e] = (float)(gs * G + q * yx + p * mom[e]);
     }
 }
 
@@ -453,7 +460,48 @@ extern "C" int p2c_fold0_bwd_finalize_f32(const double *partials5, const double 
 {
     if (!partials5 || !moments || !W0 || !stat0 || !gamma0 || !dgamma0 || !dbeta0 || !dW0 || C0 <= 0 || M <= 0) return P2C_EINVAL;
     hipLaunchKernelGGL(fold0_bwd_finalize_kernel, dim3(p2c_cdiv(C0, 64)), dim3(64), 0, (hipStream_t)stream, partials5, moments, M, W0, b0, stat0,
-                       gamma0, C0, dgamma0, dbeta0, dW0);
+                       gamma0, C0, dgamma0, dbeta0, dW0, 4, p2c_cdiv(C0, 64), (const float *)nullptr, 0LL, 0, (float *)nullptr, 0LL);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// The same with dW0 written [C0, lddw0] (lddw0 = 3: the parameter's own (C0, 3, 1, 1) layout, no slicing copy afterwards) and, as extra
+// workgroups of the launch, the per-XCD copies of the consumer layer's weight gradient summed: out[i] = sum_c src[c * stride + i], i < n.
+extern "C" int p2c_fold0_bwd_finalize_sum_f32(const double *partials5, const double *moments, long long M, const float *W0, const float *b0,
+                                              const float *stat0, const float *gamma0, int C0, float *dgamma0, float *dbeta0, float *dW0, int lddw0,
+                                              const float *src, long long stride, int copies, float *out, long long n, void *stream)
+{
+    if (!partials5 || !moments || !W0 || !stat0 || !gamma0 || !dgamma0 || !dbeta0 || !dW0 || C0 <= 0 || M <= 0 || lddw0 < 1 || lddw0 > 4)
+        return P2C_EINVAL;
+    if (!src || !out || copies <= 0 || n <= 0) return P2C_EINVAL;
+    const int fin = p2c_cdiv(C0, 64);
+    hipLaunchKernelGGL(fold0_bwd_finalize_kernel, dim3(fin + (int)p2c_cdiv(n, 1024)), dim3(256), 0, (hipStream_t)stream, partials5, moments, M, W0, b0,
+                       stat0, gamma0, C0, dgamma0, dbeta0, dW0, lddw0, fin, src, stride, copies, out, n);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// Weight gradient of a grouped first layer in the PARAMETER's layout [Co, 3 + Cf] = [coordinate part | feature part] (pointnet_util.py:137
+// column order): the coordinate part is the sum of the P2C_STAT_SLOTS fp64 rows p2c_group_linear_bwd_f32 accumulated (dwx [slots][3][Co]),
+// the feature part the first Cf columns of the GEMM's dW [Co, lddw] - one launch instead of a reduction, a transpose / cast and a concatenation.
+__global__ void __launch_bounds__(256) group_weight_grad_kernel(const double *__restrict__ dwx, int Cs, const float *__restrict__ dW, int lddw, int Co,
+                                                                int Cf, float *__restrict__ out)
+{
+    const int c = blockIdx.x;
+    const int ldo = 3 + Cf;
+    if (threadIdx.x < 3) {
+        double a = 0.0;
+#pragma unroll 8
+        for (int t = 0; t < P2C_STAT_SLOTS; ++t) a += dwx[((size_t)t * 3 + threadIdx.x) * Cs + c];
+        out[(size_t)c * ldo + threadIdx.x] = (float)a;
+    }
+    for (int k = threadIdx.x; k < Cf; k += 256) out[(size_t)c * ldo + 3 + k] = dW[(size_t)c * lddw + k];
+}
+
+extern "C" int p2c_group_weight_grad_f32(const double *dwx_slots, int Cs, const float *dW, int lddw, int Co, int Cf, float *out, void *stream)
+{
+    if (!dwx_slots || !dW || !out || Co <= 0 || Cf <= 0 || Cs < Co || lddw < Cf) return P2C_EINVAL;
+    hipLaunchKernelGGL(group_weight_grad_kernel, dim3(Co), dim3(256), 0, (hipStream_t)stream, dwx_slots, Cs, dW, lddw, Co, Cf, out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -663,6 +711,31 @@ extern "C" int p2c_copy2d_batch_f32(const void *table, int n, void *stream)
 {
     if (!table || n <= 0) return P2C_EINVAL;
     hipLaunchKernelGGL(copy2d_batch_kernel, dim3(n, 32), dim3(256), 0, (hipStream_t)stream, (const P2cCopy2D *)table);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// The same launch also advances the step's device-resident 64-bit counters (the 17 num_batches_tracked of the BatchNorms, += 1 each, and
+// the dropout hash's seed, += its golden-ratio stride): a multi-tensor add and a scalar add launch per forward otherwise (~5 us each).
+// counters (device memory): n_counters entries of struct { long long *ptr; long long inc; }; two's-complement wrap-around like torch's int64 add.
+struct P2cCounter { unsigned long long *ptr; unsigned long long inc; };
+__global__ void __launch_bounds__(256) copy2d_batch_inc_kernel(const P2cCopy2D *__restrict__ tab, int n, const P2cCounter *__restrict__ ctab, int nc)
+{
+    if ((int)blockIdx.x == n) {
+        if (blockIdx.y == 0)
+            for (int i = threadIdx.x; i < nc; i += 256) *ctab[i].ptr += ctab[i].inc;
+        return;
+    }
+    const P2cCopy2D d = tab[blockIdx.x];
+    for (int r = blockIdx.y; r < d.rows; r += gridDim.y)
+        for (int c = threadIdx.x; c < d.cols; c += 256) d.dst[(size_t)r * d.ldd + c] = d.src[(size_t)r * d.lds + c];
+}
+
+extern "C" int p2c_copy2d_batch_inc_f32(const void *table, int n, const void *counters, int n_counters, void *stream)
+{
+    if (n < 0 || n_counters < 0 || (n > 0 && !table) || (n_counters > 0 && !counters) || n + n_counters == 0) return P2C_EINVAL;
+    hipLaunchKernelGGL(copy2d_batch_inc_kernel, dim3(n + (n_counters > 0 ? 1 : 0), n > 0 ? 32 : 1), dim3(256), 0, (hipStream_t)stream,
+                       (const P2cCopy2D *)table, n, (const P2cCounter *)counters, n_counters);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

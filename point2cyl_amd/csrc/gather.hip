@@ -119,6 +119,42 @@ extern "C" int p2c_three_interp_f32(const float *feats, int ldf, const int32_t *
     return P2C_OK;
 }
 
+// The same with the row's skip features in front: out[r] = [skip[r, :Cs] | interpolated (C) | zeros up to width] - the input of a
+// feature-propagation level (pointnet_util.py:308-312) written by ONE kernel (the strided copy of the skip block was a launch of its own).
+__global__ void __launch_bounds__(256) three_interp_skip_kernel(const float *__restrict__ feats, int ldf, const int32_t *__restrict__ idx,
+                                                                const float *__restrict__ w, int N, int S, int C, long long rows,
+                                                                const float *__restrict__ skip, int ldskip, int Cs, float *__restrict__ out, int ldo,
+                                                                int width)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long r = wave; r < rows; r += nw) {
+        const int b = (int)(r / N);
+        const int i0 = idx[r * 3 + 0], i1 = idx[r * 3 + 1], i2 = idx[r * 3 + 2];
+        const float w0 = w[r * 3 + 0], w1 = w[r * 3 + 1], w2 = w[r * 3 + 2];
+        const float *f0 = feats + ((size_t)b * S + i0) * ldf, *f1 = feats + ((size_t)b * S + i1) * ldf,
+                    *f2 = feats + ((size_t)b * S + i2) * ldf;
+        const float *sk = skip + (size_t)r * ldskip;
+        float *o = out + (size_t)r * ldo;
+        for (int c = lane; c < Cs; c += 64) o[c] = sk[c];
+        for (int c = lane; c < C; c += 64) o[Cs + c] = (f0[c] * w0 + f1[c] * w1) + f2[c] * w2;
+        for (int c = Cs + C + lane; c < width; c += 64) o[c] = 0.f;
+    }
+}
+
+extern "C" int p2c_three_interp_skip_f32(const float *feats, int ldf, const int32_t *idx, const float *weight, int B, int N, int S, int C,
+                                         const float *skip, int ldskip, int Cskip, float *out, int ldo, int width, void *stream)
+{
+    if (!feats || !idx || !weight || !out || !skip || C <= 0 || Cskip <= 0 || width < Cskip + C || ldo < width) return P2C_EINVAL;
+    const long long rows = (long long)B * N;
+    const int blocks = (int)min((long long)p2c_cdiv(rows, 4), 16384LL);
+    hipLaunchKernelGGL(three_interp_skip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feats, ldf, idx, weight, N, S, C, rows, skip,
+                       ldskip, Cskip, out, ldo, width);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
 __global__ void __launch_bounds__(256) three_interp_bwd_kernel(const float *__restrict__ dout, int ldo, const int32_t *__restrict__ idx,
                                                                const float *__restrict__ w, int N, int S, int C, long long rows,
                                                                float *__restrict__ dfeats, int ldf)

@@ -160,6 +160,7 @@ def three_interpolate(feats, idx, w, csr=None):
 
 # ------------------------------------------------------------------------------------------ MLP stack
 _DEFER_NBT = [False]
+_NBT_BUMPED = [False]      # this forward's num_batches_tracked were advanced by the weight-staging launch (WeightStage.run(bump=...)): nothing to queue
 
 
 def flush_nbt():
@@ -389,7 +390,7 @@ class _MLPStack(torch.autograd.Function):
                 st = torch.empty(4, Co, dtype=torch.float32, device=dev)
                 call("p2c_bn_finalize_affine_f32", ptr(mom), M, ptr(W2), ptr(b), ptr(gamma), ptr(beta), float(bn.eps), float(bn.momentum),
                      ptr(bn.running_mean), ptr(bn.running_var), Co, ptr(st), stream())
-                if bn.nbt is not None:
+                if bn.nbt is not None and not _NBT_BUMPED[0]:
                     PENDING_NBT.append(bn.nbt)
                 Ys.append(None)
                 Ws.append(W2)
@@ -416,7 +417,7 @@ class _MLPStack(torch.autograd.Function):
                 call("p2c_bn_finalize_f32", ptr(partials), Co, M, ptr(b), ptr(gamma),
                      ptr(beta), float(bn.eps), float(bn.momentum), 1, ptr(bn.running_mean), ptr(bn.running_var),
                      ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
-                if bn.nbt is not None:
+                if bn.nbt is not None and not _NBT_BUMPED[0]:
                     PENDING_NBT.append(bn.nbt)
                 aff.append(st)
                 sc, sh, in_mode = st[0], st[1], 1
@@ -468,7 +469,7 @@ class _MLPStack(torch.autograd.Function):
                 call("p2c_bn_finalize_f32", ptr(partials), Co, M, ptr(b), ptr(gamma),
                      ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
                      ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
-                if training and bn.nbt is not None:
+                if training and bn.nbt is not None and not _NBT_BUMPED[0]:
                     PENDING_NBT.append(bn.nbt)
                 aff.append(st)
                 sc, sh, in_mode = st[0], st[1], 1
@@ -623,8 +624,10 @@ class _MLPStack(torch.autograd.Function):
                      None, Ms, Co, Ci, None, 0, stream(), flops=2.0 * Ms * Co * Ci)
                 Wp = params[p0]
                 if dwx is not None:
-                    dWx = dwx.sum(0).t().to(torch.float32)                                         # (Co, 3)
-                    grads[p0] = torch.cat([dWx[:Wp.shape[0]], dW[:Wp.shape[0], :Wp.numel() // Wp.shape[0] - 3]], 1).reshape(Wp.shape)
+                    # [coordinate part (slot sums) | feature part] in the parameter's own layout by one launch (was: reduction, transpose+cast, cat)
+                    gW = torch.empty(Wp.shape, dtype=torch.float32, device=dev)
+                    call("p2c_group_weight_grad_f32", ptr(dwx), Co, ptr(dW), Ci, Wp.shape[0], Wp.numel() // Wp.shape[0] - 3, ptr(gW), stream())
+                    grads[p0] = gW
                 else:
                     grads[p0] = dW[:Wp.shape[0], :Wp.numel() // Wp.shape[0]].reshape(Wp.shape)
                 grads[p0 + 1] = arena.f32(Co)[:Wp.shape[0]]          # bias in front of a train-mode BatchNorm: exactly zero
@@ -645,15 +648,19 @@ class _MLPStack(torch.autograd.Function):
                      ptr(st0), ptr(W2), Ci, ptr(dW8), Ci, Co * Ci, ptr(part5), M, Co, C0, stream(), flops=4.0 * M * Co * Ci,
                      nbytes=4.0 * M * (2 * Co + 4))
                 Wp = params[p0]
-                grads[p0] = dW8.sum(0)[:Wp.shape[0], :Wp.numel() // Wp.shape[0]].reshape(Wp.shape)
-                grads[p0 + 1] = arena.f32(Co)[:Wp.shape[0]]
-                dW0 = torch.empty(C0, 4, dtype=torch.float32, device=dev)
+                W0param = params[q0]
+                c0_in = W0param.numel() // W0param.shape[0]
+                # ONE launch: dgamma0 / dbeta0 / dW0 (in the parameter's own (C0, 3) layout) and, by extra workgroups, the sum of this layer's
+                # per-XCD dW copies (was: a torch reduction, the finalize, and a slicing copy)
+                dWsum = torch.empty(Co, Ci, dtype=torch.float32, device=dev)
+                dW0 = torch.empty(C0, c0_in, dtype=torch.float32, device=dev)
                 dgamma0 = torch.empty(C0, dtype=torch.float32, device=dev)
                 dbeta0 = torch.empty(C0, dtype=torch.float32, device=dev)
-                call("p2c_fold0_bwd_finalize_f32", ptr(part5), ptr(mom), M, ptr(W0p), ptr(b0), ptr(st0), ptr(params[q0 + 2]), C0, ptr(dgamma0),
-                     ptr(dbeta0), ptr(dW0), stream())
-                W0param = params[q0]
-                grads[q0] = dW0[:, :W0param.numel() // W0param.shape[0]].reshape(W0param.shape)
+                call("p2c_fold0_bwd_finalize_sum_f32", ptr(part5), ptr(mom), M, ptr(W0p), ptr(b0), ptr(st0), ptr(params[q0 + 2]), C0, ptr(dgamma0),
+                     ptr(dbeta0), ptr(dW0), c0_in, ptr(dW8), Co * Ci, 8, ptr(dWsum), Co * Ci, stream())
+                grads[p0] = dWsum[:Wp.shape[0], :Wp.numel() // Wp.shape[0]].reshape(Wp.shape)
+                grads[p0 + 1] = arena.f32(Co)[:Wp.shape[0]]
+                grads[q0] = dW0.reshape(W0param.shape)
                 grads[q0 + 1] = arena.f32(C0)
                 grads[q0 + 2], grads[q0 + 3] = dgamma0, dbeta0
                 continue
@@ -854,8 +861,12 @@ class WeightStage:
     the allocation; the device table is rebuilt when an address changed.  `generation` counts the runs (ops._MLPStack's backward
     checks that the staged operands it reads are still the ones its forward used)."""
 
-    def __init__(self, entries, device):
+    def __init__(self, entries, device, counters=()):
+        """counters: [(resolver of a device int64 scalar tensor, increment), ...] advanced by the same launch when run(bump=True): the BatchNorm
+        num_batches_tracked (+1 each) and the dropout hash seed (+ its stride) - otherwise a multi-tensor add and a scalar add launch per forward."""
         self.entries, self.device = entries, device
+        self.counters = list(counters)
+        self.ctable, self.cptrs = None, None
         self.bufs = {key: torch.zeros(*shape, dtype=torch.float32, device=device) for key, shape, _ in entries}
         for b in self.bufs.values():
             b._p2c_stage = self          # (ops._MLPStack finds the stage of a staged operand through this tag)
@@ -881,11 +892,31 @@ class WeightStage:
     def _ptrs(self):
         return tuple(get().data_ptr() for _, _, parts in self.entries for get, *_ in parts)
 
-    def run(self):
+    def _counter_table(self, which):
+        import struct
+        live = [(get(), inc) for get, inc in which]
+        live = [(t, inc) for t, inc in live if t is not None]
+        key = tuple((t.data_ptr(), inc) for t, inc in live)
+        if self.cptrs != key:
+            for t, _ in live:
+                assert t.dtype == torch.int64 and t.is_cuda and t.numel() == 1
+            raw = b"".join(struct.pack("<Qq", t.data_ptr(), inc) for t, inc in live)
+            self.ctable = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device) if live else None
+            self.cptrs = key
+        return self.ctable, len(live)
+
+    def run(self, bump=None):
+        """bump: None (copies only) or the subset of self.counters to advance in the same launch."""
         if self.table is None or self.src_ptrs != self._ptrs():
             self._build()
         self.generation += 1
+        if bump:
+            ctab, nc = self._counter_table(bump)
+            if nc:
+                call("p2c_copy2d_batch_inc_f32", ptr(self.table), self.n, ptr(ctab), nc, stream())
+                return True
         call("p2c_copy2d_batch_f32", ptr(self.table), self.n, stream())
+        return False
 
     def __getitem__(self, key):
         return self.bufs[key]
@@ -925,10 +956,15 @@ class _SkipInterpCat(torch.autograd.Function):
         C1 = feats1.shape[1]
         feats2 = _f32c(feats2)
         out = torch.empty(B * N, width, dtype=torch.float32, device=feats2.device)
-        out[:, :C1].copy_(feats1)
-        if width > C1 + C2:
-            out[:, C1 + C2:].zero_()
-        call("p2c_three_interp_f32", ptr(feats2), C2, ptr(idx), ptr(w), B, N, S, C2, out.data_ptr() + 4 * C1, width, stream())
+        if feats1.dtype == torch.float32 and feats1.stride(1) == 1:
+            # skip block, interpolated block and the zero pad of every row by ONE kernel
+            call("p2c_three_interp_skip_f32", ptr(feats2), C2, ptr(idx), ptr(w), B, N, S, C2, ptr(feats1), feats1.stride(0), C1, ptr(out), width, width,
+                 stream())
+        else:
+            out[:, :C1].copy_(feats1)
+            if width > C1 + C2:
+                out[:, C1 + C2:].zero_()
+            call("p2c_three_interp_f32", ptr(feats2), C2, ptr(idx), ptr(w), B, N, S, C2, out.data_ptr() + 4 * C1, width, stream())
         ctx.save_for_backward(idx, w)
         ctx.csr, ctx.dims = csr, (B, N, S, C1, C2)
         return out

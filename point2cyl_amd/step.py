@@ -55,6 +55,21 @@ def get_learning_rate(init_lr, global_step, batch_size, decay_step, decay_rate, 
 
 
 _ZEROS = {}
+_SEEDS = {}
+
+
+def backward(out):
+    """`out["total"].backward()` without its three launches: when the total is element 0 of the fused loss vector (compute_losses_fused
+    without the axis / centre terms) autograd would fill a ones tensor for the root and a zero 4-vector + an index copy for the select;
+    here the loss node receives a CONSTANT [1, 0, 0, 0] as its upstream gradient (the kernel reads element 0)."""
+    vec = out.get("_total_vec")
+    if vec is None:
+        out["total"].backward()
+        return
+    seed = _SEEDS.get(vec.device)
+    if seed is None:
+        seed = _SEEDS[vec.device] = torch.tensor([1.0, 0.0, 0.0, 0.0], device=vec.device)
+    torch.autograd.backward([vec], [seed])
 
 
 def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags, geom=None):
@@ -88,6 +103,8 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
             diff = torch.square(cen - gt_centers).sum(dim=-1)
             center_loss = losses.reduce_mean_masked_instance(diff, mask_gt).mean() * fl.weight_center
         total = total + ext_loss + center_loss
+    else:
+        res["_total_vec"] = out4              # step.backward(res): the loss node gets a constant seed instead of ones / select-backward launches
     res.update(total=total, ext=ext_loss, center=center_loss, heads=heads)
     return res
 
@@ -158,7 +175,7 @@ def train_step(model, optimizer, batch, fl: StepFlags, sync_grads=None, fused=Fa
     fused=True evaluates the losses with csrc/loss.hip when the flag set allows it."""
     out = (compute_losses_fused if (fused and fused_loss_applicable(fl)) else compute_losses)(model, *batch, fl)
     optimizer.zero_grad(set_to_none=True)
-    out["total"].backward()                                                     # :368
+    backward(out)                                                               # :368
     if sync_grads is not None:
         sync_grads()
     optimizer.step()                                                            # :369

@@ -125,7 +125,7 @@ class Runner:
         with ops.step_arena(self.dev):
             out = self.loss_fn(self.model, *self.batch, self.fl, geom=geom)
             self.sync.zero()
-            out["total"].backward()
+            step.backward(out)
             self.sync.pack()
         res = {"scalars": torch.stack([out[k].detach().float().reshape(()) for k in SCALARS])}
         del out

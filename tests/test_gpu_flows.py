@@ -657,8 +657,9 @@ def test_autograph_is_an_autograd_citizen_and_follows_moved_parameters():
     torch.manual_seed(1)
     X, W = m(pcs)
     (X.square().mean() + W.square().mean()).backward()
-    for k, p, g in zip(names, params, got):
-        assert float((p.grad - g).norm()) <= 1e-5 * float(g.norm()) + 1e-9, k      # (fp64 stat atomics: order noise only)
+    gmax = max(float(g.norm()) for g in got)
+    for k, p, g in zip(names, params, got):        # (fp atomics: order noise only; a BatchNorm shift in front of another BatchNorm has a zero gradient)
+        assert float((p.grad - g).norm()) <= 1e-4 * float(g.norm()) + 1e-6 * gmax, k
     kept = {k: p.grad for k, p in zip(names, params)}
     snap = {k: g.clone() for k, g in kept.items()}
     for p in params:

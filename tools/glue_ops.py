@@ -23,7 +23,7 @@ def one():
     with ops.step_arena(dev):
         res = stepmod.compute_losses_fused(model, pcs, nrm, inst, bbl, axes, cen, fl)
         opt.zero_grad(set_to_none=True)
-        res["total"].backward()
+        stepmod.backward(res)
     opt.step()
     ops.step_done()
 

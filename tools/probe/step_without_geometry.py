@@ -29,7 +29,7 @@ def run(mode):
         with ops.step_arena(dev):
             out = stepmod.compute_losses_fused(model, *batch, fl, geom=geom0 if mode == "static" else geom)
             sync.zero()
-            out["total"].backward()
+            stepmod.backward(out)
         return {"total": out["total"].detach()}
 
     g = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=batch[0] if mode == "prefetch" else None, stream=torch.cuda.current_stream(),

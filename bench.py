@@ -52,30 +52,37 @@ _PMC_NAME = {"p2c_linear_bwd_fused_f32": ("bwd_fused_pp_kernel", "bwd_fused3_ker
 
 
 def _pmc_traffic(entry):
-    """-> (bytes per launch, source file, source_hash of the tree the counters were collected on, stale?).  The counters need their own
-    rocprofv3 passes, so `traffic` cannot be measured by the run that prints it: the line names the file it was read from and says
-    whether the kernels have changed since (stale = the sources hash differently now)."""
+    """-> dict(per_step, kernel_launches_per_step, by_kernel, source, source_hash, stale) or None.  The counters need their own rocprofv3
+    passes, so `traffic` cannot be measured by the run that prints it: the line names the file it was read from and says whether the
+    kernels have changed since (stale = the sources hash differently now).  Everything is reported PER STEP and per CALL of the entry
+    point (one call = one layer's backward; the 256-wide layer runs as two kernel launches of one call), never per kernel launch."""
     pmc = _newest_pmc()
     if pmc is None:
-        return None, None, None, None
+        return None
     try:
         with open(pmc) as f:
             doc = json.load(f)
         ks = doc["kernels"]
+        steps = float(doc.get("steps_in_trace") or 1)
         from point2cyl_amd.build import source_hash
         shash = doc.get("source_hash")
         stale = (shash != source_hash()) if shash else None
         subs = _PMC_NAME.get(entry, ())
         # (the IMODE-2 instantiation "<.., .., .., 2, ...>" belongs to p2c_linear_bwd_fused_fold0_f32, a different entry point)
-        sel = [v for k, v in ks.items() if any(re.match(r"(void )?%s<" % sub, k) for sub in subs)
-               and not re.search(r"bwd_fused_pp_kernel<\d+, \d+, \d+, 2,", k)]
-        n = sum(v["launches"] for v in sel)
-        if not n:
-            return None, None, None, None
-        tot = sum(v["launches"] * (v.get("fetch_bytes_per_launch", 0.0) + v.get("write_bytes_per_launch", 0.0)) for v in sel)
-        return round(tot / n), "profiles/" + os.path.basename(pmc), shash, stale
-    except (OSError, KeyError, ValueError):
-        return None, None, None, None
+        sel = {k: v for k, v in ks.items() if any(re.match(r"(void )?%s<" % sub, k) for sub in subs)
+               and not re.search(r"bwd_fused_pp_kernel<\d+, \d+, \d+, 2,", k)}
+        if not sel:
+            return None
+        by = {k: dict(launches_per_step=v["launches"] / steps,
+                      bytes_per_launch=round(v.get("fetch_bytes_per_launch", 0.0) + v.get("write_bytes_per_launch", 0.0)),
+                      mfma_busy=(round(v["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * v["SQ_BUSY_CU_CYCLES"]), 3)
+                                 if v.get("SQ_BUSY_CU_CYCLES") and v.get("SQ_VALU_MFMA_BUSY_CYCLES") is not None else None))
+              for k, v in sel.items()}
+        per_step = sum(d["launches_per_step"] * d["bytes_per_launch"] for d in by.values())
+        return dict(per_step=round(per_step), kernel_launches_per_step=sum(d["launches_per_step"] for d in by.values()), by_kernel=by,
+                    source="profiles/" + os.path.basename(pmc), source_hash=shash, stale=stale)
+    except (OSError, KeyError, ValueError, TypeError):
+        return None
 
 
 def _cpu_model():
@@ -316,6 +323,20 @@ def _bench(args, rank, world, local, dev):
     ms = dt / args.steps * 1e3
     value = world * B * N * args.steps / dt
     prof = ops.PROFILE.summary()           # per kernel family: launches, total ms (HIP events on the launch stream), flops, bytes
+    # the same records split by the call's algorithmic size (bytes, flops): the members of a family at different shapes - the fused backward's
+    # 128x128 layers next to the 256-wide two-pass call - each with its own rate (event time per call, this run)
+    by_shape = {}
+    for name, e0, e1, flops, nbytes in ops.PROFILE.records:
+        if nbytes <= 0:
+            continue
+        r = by_shape.setdefault(name, {}).setdefault((round(nbytes), round(flops)), dict(calls=0, ms=0.0))
+        r["calls"] += 1
+        r["ms"] += e0.elapsed_time(e1)
+    by_shape = {name: [dict(algorithmic_bytes_per_call=k[0], algorithmic_flops_per_call=k[1], calls_per_step=v["calls"] / prof_steps,
+                            avg_call_us=round(v["ms"] * 1e3 / v["calls"], 2), hbm_gbs=round(k[0] / (v["ms"] / v["calls"] * 1e-3) / 1e9, 1),
+                            hbm_frac=round(k[0] / (v["ms"] / v["calls"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                            tflops_fp32_equivalent=round(k[1] / (v["ms"] / v["calls"] * 1e-3) / 1e12, 2))
+                       for k, v in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])] for name, shapes in by_shape.items()}
     dom = max(prof.items(), key=lambda kv: kv[1]["ms"]) if prof else (None, None)
     roofline = None
     from point2cyl_amd import _lib
@@ -324,10 +345,13 @@ def _bench(args, rank, world, local, dev):
         d = dom[1]
         if d["flops"] > 0 and not split:
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic, tsrc, thash, tstale = _pmc_traffic(dom[0])
+            tr = _pmc_traffic(dom[0])
+            cps = d["launches"] / prof_steps
             roofline = dict(bound="mfma", kernel=dom[0], achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (HBM read+write, PMC)",
-                            traffic_source=tsrc, traffic_source_hash=thash, traffic_stale=tstale, algorithmic_bytes_per_launch=round(d["bytes"] / max(1, d["launches"])),
+                            frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None if tr is None else round(tr["per_step"] / cps),
+                            traffic_unit="HBM bytes (read + write, PMC) per call of the entry point",
+                            traffic_source=None if tr is None else tr["source"], traffic_source_hash=None if tr is None else tr["source_hash"],
+                            traffic_stale=None if tr is None else tr["stale"], algorithmic_bytes_per_launch=round(d["bytes"] / max(1, d["launches"])),
                             launches_per_step=d["launches"] / prof_steps, avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
                             share_of_step=round(d["ms"] / prof_steps / ms, 3))
         elif d["flops"] > 0:
@@ -335,18 +359,33 @@ def _bench(args, rank, world, local, dev):
             # 2500 / 6 = 417 fp32-equivalent TFLOP/s; the kernel then sits nearer its HBM bound than its matrix-pipe bound, and the line
             # reports the tighter of the two as `bound` with the other beside it (and the fraction of the fp32-MFMA peak the
             # round-2 line was priced against, for continuity).
+            # UNITS: a "launch" of this object is one CALL of the entry point = one layer's backward (5 per step); the 256-wide
+            # layer is one call that runs two kernel launches (6 kernel launches per step).  `achieved` = algorithmic bytes per call /
+            # average call duration (HIP events on the launch stream, this run); `traffic` = PMC bytes per call (committed counters:
+            # sum over the family's kernels of launches x bytes, / calls); `traffic_ratio` = PMC / algorithmic, both per step.
+            calls = d["launches"]
+            calls_per_step = calls / prof_steps
             tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
             gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-            traffic, tsrc, thash, tstale = _pmc_traffic(dom[0])
+            alg_step = d["bytes"] / prof_steps
+            tr = _pmc_traffic(dom[0])
             f_hbm, f_pipe = gbs / PEAK_HBM_GBS, 6.0 * tf / PEAK_BF16_MFMA_TFLOPS
-            common = dict(traffic=traffic, traffic_unit="bytes/launch (HBM read+write, PMC)", traffic_source=tsrc, traffic_source_hash=thash,
-                          traffic_stale=tstale, algorithmic_bytes_per_launch=round(d["bytes"] / max(1, d["launches"])),
-                          algorithmic_flops_per_launch=round(d["flops"] / max(1, d["launches"])),
-                          launches_per_step=d["launches"] / prof_steps, avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
-                          share_of_step=round(d["ms"] / prof_steps / ms, 3),
+            common = dict(launch_unit="one call of the entry point (a layer's backward); kernel launches are listed in traffic_by_kernel",
+                          traffic=None if tr is None else round(tr["per_step"] / calls_per_step), traffic_unit="HBM bytes (read + write, PMC) per call",
+                          traffic_per_step=None if tr is None else tr["per_step"], algorithmic_bytes_per_step=round(alg_step),
+                          traffic_ratio=None if tr is None else round(tr["per_step"] / alg_step, 3),
+                          kernel_launches_per_step=None if tr is None else tr["kernel_launches_per_step"],
+                          traffic_by_kernel=None if tr is None else tr["by_kernel"],
+                          traffic_source=None if tr is None else tr["source"], traffic_source_hash=None if tr is None else tr["source_hash"],
+                          traffic_stale=None if tr is None else tr["stale"],
+                          algorithmic_bytes_per_launch=round(d["bytes"] / max(1, calls)),
+                          algorithmic_flops_per_launch=round(d["flops"] / max(1, calls)),
+                          launches_per_step=calls_per_step, avg_launch_us=round(d["ms"] * 1e3 / calls, 2),
+                          ms_per_step=round(d["ms"] / prof_steps, 4), share_of_step=round(d["ms"] / prof_steps / ms, 3),
                           hbm=dict(achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(f_hbm, 4)),
                           mfma=dict(achieved_fp32_equivalent=round(tf, 2), issued_bf16=round(6.0 * tf, 1), peak_bf16=PEAK_BF16_MFMA_TFLOPS, unit="TFLOP/s",
-                                    frac=round(f_pipe, 4), frac_of_fp32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4)))
+                                    frac=round(f_pipe, 4), frac_of_fp32_mfma_peak=round(tf / PEAK_F32_MFMA_TFLOPS, 4)),
+                          by_shape=by_shape.get(dom[0]))
             if f_hbm >= f_pipe:
                 roofline = dict(bound="hbm", kernel=dom[0], achieved=round(gbs, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(f_hbm, 4), **common)
             else:
@@ -430,6 +469,7 @@ def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
             pass
 
     leg("path_roofline", lambda: measure.path_roofline(B, ms, 3.0, N))
+    leg("power_cap", lambda: measure.power_cap_probe(dev))
     leg("stages", lambda: dict(sa1_forward=measure.sa1_stage(model, batch[0], steps=30)))
     leg("forward_only", lambda: measure.forward_only(model, batch[0], steps=30))
 

@@ -145,9 +145,13 @@ def _mlp(sd, prefix, n_layers, x, training, momentum, conv):
     return x
 
 
-def set_abstraction(sd, cfg, xyz, feats, start, training, momentum, geom):
+def set_abstraction(sd, cfg, xyz, feats, start, training, momentum, geom, forced_winners=None):
     """pointnet_util.py:181-207 (+ sample_and_group :110-143 / sample_and_group_all :146-163).
-    xyz (B,N,3), feats (B,N,D) or None -> new_xyz (B,S,3), new_feats (B,S,C'), aux dict."""
+    xyz (B,N,3), feats (B,N,D) or None -> new_xyz (B,S,3), new_feats (B,S,C'), aux dict.
+    forced_winners (B,S,C') int64 (test instrument, not in the reference): the max over the neighbours (:205) takes THESE rows instead of its
+    own arg-max - the device path's stored winners - so that two candidates within fp32 rounding of each other send the gradient to the same
+    row in both implementations; aux then carries this oracle's own winners and, per pooled entry, how far below its own maximum the forced
+    row's value lies (`pool_gap` >= 0; ~1e-7 relative at a near-tie, large if a winner were really wrong)."""
     B, N, _ = xyz.shape
     aux = {}
     if cfg["npoint"] is None:
@@ -162,6 +166,12 @@ def set_abstraction(sd, cfg, xyz, feats, start, training, momentum, geom):
         aux.update(fps_idx=fps_idx, group_idx=gidx)
     x = grouped.permute(0, 3, 2, 1)                      # (B, C, nsample, S)  :200
     x = _mlp(sd, cfg["name"], len(cfg["mlp"]), x, training, momentum, F.conv2d)
+    if forced_winners is not None:
+        own_val, own_idx = x.max(2)                                                   # (B,C',S)
+        fw = forced_winners.to(torch.int64).permute(0, 2, 1).unsqueeze(2)             # (B,C',1,S)
+        pooled = x.gather(2, fw).squeeze(2)
+        aux.update(own_winners=own_idx.transpose(1, 2), pool_gap=(own_val - pooled).detach().transpose(1, 2), pool_max=own_val.detach().transpose(1, 2))
+        return new_xyz, pooled.transpose(1, 2), aux
     return new_xyz, x.max(2)[0].transpose(1, 2), aux     # (B,S,C')
 
 
@@ -184,16 +194,17 @@ def feature_propagation(sd, cfg, xyz1, xyz2, feats1, feats2, training, momentum,
 
 
 def backbone_forward(sd, x, fps_start, dropout_mask=None, training=True, momentum=0.1, geom="c",
-                     return_aux=False):
+                     return_aux=False, forced_winners=None):
     """pointnet_extrusion.py:37-66.  x (B,N,3[+D]); fps_start = [start_sa1 (B,), start_sa2 (B,)]
     (the two CPU randint draws); dropout_mask (B,N,128) of {0,1} or None for
     identity.  The reference's F.dropout(p=.5) is always on (:60): out = feat*mask*2.
     Returns list of (B,N,o_i) [, aux]."""
     xyz = x[:, :, :3]
     feats0 = x[:, :, 3:] if x.shape[2] > 3 else None
-    l1_xyz, l1, a1 = set_abstraction(sd, SA_CFG[0], xyz, feats0, fps_start[0], training, momentum, geom)
-    l2_xyz, l2, a2 = set_abstraction(sd, SA_CFG[1], l1_xyz, l1, fps_start[1], training, momentum, geom)
-    l3_xyz, l3, _ = set_abstraction(sd, SA_CFG[2], l2_xyz, l2, None, training, momentum, geom)
+    fw = forced_winners or {}          # {"sa1": (B,512,128), "sa2": (B,128,256), "sa3": (B,1,1024)} (see set_abstraction)
+    l1_xyz, l1, a1 = set_abstraction(sd, SA_CFG[0], xyz, feats0, fps_start[0], training, momentum, geom, fw.get("sa1"))
+    l2_xyz, l2, a2 = set_abstraction(sd, SA_CFG[1], l1_xyz, l1, fps_start[1], training, momentum, geom, fw.get("sa2"))
+    l3_xyz, l3, a3 = set_abstraction(sd, SA_CFG[2], l2_xyz, l2, None, training, momentum, geom, fw.get("sa3"))
     l4, _ = feature_propagation(sd, FP_CFG[0], l2_xyz, l3_xyz, l2, l3, training, momentum, geom)
     l5, a5 = feature_propagation(sd, FP_CFG[1], l1_xyz, l2_xyz, l1, l4, training, momentum, geom)
     l6, a6 = feature_propagation(sd, FP_CFG[2], xyz, l1_xyz, feats0, l5, training, momentum, geom)
@@ -212,7 +223,7 @@ def backbone_forward(sd, x, fps_start, dropout_mask=None, training=True, momentu
         outs.append(F.conv1d(f, sd["fc2.%d.weight" % i], sd["fc2.%d.bias" % i]).transpose(1, 2))
         i += 1
     if return_aux:
-        aux = dict(sa1=a1, sa2=a2, fp2=a5, fp1=a6, l1_xyz=l1_xyz, l2_xyz=l2_xyz, l1=l1, l2=l2, l3=l3, l4=l4,
+        aux = dict(sa1=a1, sa2=a2, sa3=a3, fp2=a5, fp1=a6, l1_xyz=l1_xyz, l2_xyz=l2_xyz, l1=l1, l2=l2, l3=l3, l4=l4,
                    l5=l5, l6=l6, pre_dropout=pre_dropout)
         return outs, aux
     return outs

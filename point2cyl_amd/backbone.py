@@ -95,11 +95,14 @@ class PointNetSetAbstraction(nn.Module):
                            ns=ns, rows=G * ns)
                 F2 = feats.reshape(B * N, -1)
                 out = ops.mlp_stack(F2, F2.shape[1], layers, "maxpool", self.training, G=G, ns=ns, pre=pre,
-                                    staged={0: staged} if (staged is not None and "pre_wx" in staged) else None)
+                                    staged={0: staged} if (staged is not None and "pre_wx" in staged) else None, aux_out=self.last_aux)
                 return new_xyz, out.view(B, -1, out.shape[-1])
             X0 = geom["X0"] if (feats is None and "X0" in geom) else ops.group_gather(xyz, feats, new_xyz, gidx, geom.get("csr"))
         use = staged is not None and "pre_wx" not in staged and tuple(staged["W2"].shape) == (self.mlp_convs[0].weight.shape[0], (cin + 3) // 4 * 4)
-        out = ops.mlp_stack(X0, cin, layers, "maxpool", self.training, G=G, ns=ns, xyz_last=True, staged={0: staged} if use else None)
+        if self.group_all:
+            self.last_aux = {}
+        out = ops.mlp_stack(X0, cin, layers, "maxpool", self.training, G=G, ns=ns, xyz_last=True, staged={0: staged} if use else None,
+                            aux_out=self.last_aux)
         return new_xyz, out.view(B, -1, out.shape[-1])
 
     def forward(self, xyz, points):

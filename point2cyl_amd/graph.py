@@ -203,8 +203,10 @@ class GraphedForwardBackward:
         self._first = True
         _ops.step_done()
 
-    def __call__(self):
-        if self.draw_starts and (self.prefetch or not self._first):
+    def __call__(self, draw=True):
+        """draw=False: no fresh FPS start draws for this replay (PipelinedForward's last batch: the geometry it prefetches is discarded, and
+        the CPU generator must be left where the serial path leaves it)."""
+        if draw and self.draw_starts and (self.prefetch or not self._first):
             # with the prefetch the geometry of replay k+1's batch is computed DURING replay k, from the next pair of draws; without it
             # the first replay consumes the pair drawn at construction
             self.starts.stage()
@@ -226,3 +228,52 @@ class GraphedForwardBackward:
         for m in self._hooked:
             if m.fps_start is self.starts:
                 m.fps_start = None
+
+
+class PipelinedForward:
+    """Inference over a sequence of equal-shaped batches with the geometry hidden: ONE HIP graph per call runs the backbone forward of the
+    CURRENT batch on the geometry computed by the previous call, while a forked stream inside the same graph computes the parameter-free
+    geometry (FPS -> ball query -> grouped coordinates -> second FPS level -> 3-NN stencils -> inverse maps) of the NEXT batch - what
+    point2cyl_amd/train.py does for training, for the evaluation loop of the reference (eval.py:231-268 knows its next batch: it iterates a
+    DataLoader).  The serial forward spends 0.75 of its 1.84 ms in that latency-bound chain; pipelined, a batch costs max(forward, geometry).
+
+        pf = PipelinedForward(model, first_pcs)          # geometry of the first batch is computed here
+        for k in range(n):
+            heads, sizes = pf(pcs[k + 1] if k + 1 < n else None)      # forward of batch k; starts the geometry of batch k + 1
+            ... consume heads (a static buffer: overwritten by the next call) ...
+
+    The FPS start indices are drawn on the CPU generator per batch in the reference's order (SA1 then SA2), one batch ahead of their use
+    (a call without a next batch draws nothing: the generator ends where the serial path leaves it); the dropout counter advances per forward as in the serial path.  Outputs equal the serial
+    `model.forward_heads(pcs)` on the same draws bit for bit in eval mode (tests/test_gpu_parity.py)."""
+
+    def __init__(self, model, first_pcs, stream=None):
+        if first_pcs.shape[2] != 3:
+            raise ValueError("PipelinedForward: (B, N, 3) clouds only (normal_channel inputs take the serial path)")
+        self.model = model
+        self.cur = first_pcs.detach().float().contiguous().clone()
+        self.nxt = self.cur.clone()
+        dev = self.cur.device
+        self.sizes = None
+
+        def fn(geom):
+            with torch.no_grad(), _ops.step_arena(dev):
+                heads, sizes = model.forward_heads(self.cur, geom)
+            self.sizes = sizes
+            return {"heads": heads}
+
+        self.graph = GraphedForwardBackward(model, fn, prefetch_xyz=self.nxt, stream=stream)
+
+    def __call__(self, next_pcs=None):
+        """Forward of the current batch -> (heads (B*N, ld) static buffer, head sizes); next_pcs: the batch the NEXT call will return
+        (None: there is none - the prefetch runs on stale clouds and is discarded)."""
+        if next_pcs is not None:
+            if tuple(next_pcs.shape) != tuple(self.nxt.shape):
+                raise ValueError("PipelinedForward: batch of shape %s in a pipeline of %s" % (tuple(next_pcs.shape), tuple(self.nxt.shape)))
+            self.nxt.copy_(next_pcs)
+        out = self.graph(draw=next_pcs is not None)
+        _ops.step_done()
+        self.cur.copy_(self.nxt)          # stream-ordered behind the replay that read `cur`
+        return out["heads"], self.sizes
+
+    def release(self):
+        self.graph.release()

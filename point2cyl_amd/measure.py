@@ -127,6 +127,25 @@ def sa1_stage(model, xyz, steps=30):
             t_serial, t_mlp = replay_ms([gr_serial], steps), replay_ms([gr_mlp], steps)
             t_fps, t_bq = replay_ms([gr_fps], steps), replay_ms([gr_bq], steps)
             ops.step_done()
+            # pipelined: the stage's geometry for batch i + 1 (FPS -> ball query -> grouped coordinates) on a forked stream INSIDE the graph
+            # that runs batch i's grouped MLP on the geometry the previous replay produced; hand-over copies after the join
+            side = torch.cuda.Stream()
+            cur_g = {k: v.clone() for k, v in g0.items()}
+
+            def piped():
+                cap = torch.cuda.current_stream()
+                side.wait_stream(cap)
+                with torch.cuda.stream(side):
+                    nxt = geometry()
+                out = mlp(cur_g)
+                cap.wait_stream(side)
+                ks = sorted(cur_g)
+                ops.copy_flat_batch([cur_g[k] for k in ks], [nxt[k] for k in ks])
+                return out
+
+            gr_pipe, _ = capture(piped)
+            t_pipe = replay_ms([gr_pipe], steps)
+            ops.step_done()
     finally:
         sa1.fps_start = hook
     it_us = t_fps * 1e3 / sa1.npoint
@@ -137,6 +156,12 @@ def sa1_stage(model, xyz, steps=30):
     return dict(workload="SA1 forward: FPS(%d of %d) + ball query(r=%.1f, %d) + grouped MLP 3->64->64->128 + max-pool, B=%d, train-mode BatchNorm"
                          % (sa1.npoint, N, sa1.radius, sa1.nsample, B),
                 graph_serial_ms=round(t_serial, 4), points_per_s=round(B * N / (t_serial * 1e-3), 1),
+                pipelined_ms=round(t_pipe, 4), points_per_s_pipelined=round(B * N / (t_pipe * 1e-3), 1),
+                frac_of_mfma_roofline_pipelined=round(mfma_floor_ms / t_pipe, 4),
+                pipelined_frac_of_fps_latency_model=round(sa1.npoint * it_us * 1e-3 / t_pipe, 4),
+                pipelined_note="steady state per batch of: grouped MLP of batch i (on the previous replay's geometry) || FPS + ball query + grouped "
+                               "coordinates of batch i + 1 on a forked stream, one graph; bounded below by the FPS chain (512 dependent iterations on "
+                               "one CU per cloud = parts_ms.fps); pipelined_frac_of_fps_latency_model = parts_ms.fps / pipelined_ms",
                 parts_ms=dict(fps=round(t_fps, 4), ball_query=round(t_bq, 4), grouped_mlp_with_pool=round(t_mlp, 4)),
                 gflop=round(fl / 1e9, 2), module_boundary_mbytes=round(by / 1e6, 2),
                 mfma_floor_ms=round(mfma_floor_ms, 4), hbm_floor_ms=round(by / PEAK_HBM * 1e3, 5), bound="mfma",
@@ -182,10 +207,37 @@ def forward_only(model, pcs, steps=30):
     finally:
         for m, h in hooks:
             m.fps_start = h
+    # pipelined (what point2cyl_amd.eval runs): the geometry of batch i + 1 on a forked stream inside the graph of batch i's forward
+    t3 = None
+    with _KeepBuffers(model):
+        from .graph import PipelinedForward
+        cur = torch.cuda.current_stream()
+        if cur == torch.cuda.default_stream():
+            cur = torch.cuda.Stream()
+            cur.wait_stream(torch.cuda.default_stream())
+        with torch.cuda.stream(cur):
+            pf = PipelinedForward(model, pcs, stream=cur)
+            try:
+                for _ in range(3):
+                    pf(pcs)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    pf(pcs)
+                torch.cuda.synchronize()
+                t3 = (time.perf_counter() - t0) / steps * 1e3
+            finally:
+                pf.release()
+        torch.cuda.current_stream().wait_stream(cur)
+        ops.step_done()
     return dict(workload="backbone forward, B=%d x N=%d, train-mode BatchNorm + dropout, FPS / ball query / 3-NN included, one HIP graph" % (B, N),
                 ms=round(t, 4), points_per_s=round(B * N / (t * 1e-3), 1),
                 ms_geometry_precomputed=round(t2, 4), points_per_s_geometry_precomputed=round(B * N / (t2 * 1e-3), 1),
-                path_roofline=path_roofline(B, t, 1.0, N))
+                ms_pipelined=round(t3, 4), points_per_s_pipelined=round(B * N / (t3 * 1e-3), 1),
+                pipelined_note="steady state of graph.PipelinedForward (point2cyl_amd/eval.py): per batch one graph = forward of batch i on the geometry "
+                               "the previous replay produced + FPS / ball query / 3-NN / inverse maps of batch i + 1 on a forked stream + the hand-over "
+                               "copies; includes the host-side FPS start draws and the copy of the next clouds",
+                path_roofline=path_roofline(B, t, 1.0, N), path_roofline_pipelined=path_roofline(B, t3, 1.0, N))
 
 
 class FittingWorkload:
@@ -248,3 +300,65 @@ class FittingWorkload:
                    per_kernel={k: dict(ms_per_pass=round(v["ms"] / steps, 4), launches_per_pass=v["launches"] / steps)
                                for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])})
         return res, out
+
+
+def power_cap_probe(dev, M=262144, Co=128, Ci=128):
+    """How much of the dominant kernel's time is CLOCK: the fused backward of a 128 x 128 layer at M = 262,144 (the family bench.py's roofline
+    object reports) launched (a) in isolation - one launch, a synchronisation and 4 ms of idle time, so that it starts on a cool socket at the
+    boost clock - and (b) back to back for ~0.3 s, where the socket power limit sets the shader clock (2.0 GHz at ~1350 W
+    against 2.4 GHz).  -> dict(isolated_us, sustained_us, ratio, sclk / power sampled from rocm-smi during (b) when the tool is there)."""
+    import re
+    import subprocess
+    dZ = torch.randn(M, Co, device=dev)
+    Y = torch.randn(M, Co, device=dev)
+    X = torch.randn(M, Ci, device=dev)
+    W = torch.randn(Co, Ci, device=dev) * 0.1
+    coef = torch.rand(5, Co, device=dev)
+    sc, sh = torch.rand(Ci, device=dev) + 0.5, torch.randn(Ci, device=dev) * 0.1
+    dX = torch.empty(M, Ci, device=dev)
+    dW8 = torch.zeros(8, Co, Ci, device=dev)
+    pstat = torch.rand(4, Ci, device=dev) + 0.5
+    parts = torch.zeros(ops.STAT_SLOTS, 2, Ci, device=dev, dtype=torch.float64)
+
+    def run():
+        ops.call("p2c_linear_bwd_fused_f32", ops.ptr(dZ), Co, ops.ptr(Y), Co, 1, ops.ptr(coef), None, 0, ops.ptr(X), Ci, 1, ops.ptr(sc), ops.ptr(sh),
+                 ops.ptr(W), Ci, ops.ptr(dX), Ci, ops.ptr(dW8), Ci, Co * Ci, None, ops.ptr(pstat), ops.ptr(parts), M, Co, Ci, ops.stream())
+
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    iso = []
+    for _ in range(12):
+        time.sleep(0.004)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); run(); e1.record()
+        torch.cuda.synchronize()
+        iso.append(e0.elapsed_time(e1) * 1e3)
+    iso.sort()
+    for _ in range(1500):          # ~0.2 s: the socket reaches its power limit
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 600
+    for _ in range(n):
+        run()
+    e1.record()
+    sclk = power = None
+    try:                                                   # sampled while the queue above is still draining
+        for _ in range(3000):
+            run()
+        o = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        p = re.search(r"Package Power \(W\): ([\d.]+)", o)
+        c = re.search(r"sclk clock level: \d+: \((\d+)Mhz\)", o)
+        power, sclk = (float(p.group(1)) if p else None), (int(c.group(1)) if c else None)
+    except Exception:
+        pass
+    torch.cuda.synchronize()
+    sus = e0.elapsed_time(e1) * 1e3 / n
+    med = iso[len(iso) // 2]
+    nbytes = 4.0 * M * (2 * Co + 2 * Ci)
+    return dict(kernel="p2c_linear_bwd_fused_f32 (Co = Ci = 128, M = %d, the role-split bf16x3 kernel)" % M, isolated_us=round(med, 1), isolated_min_us=round(iso[0], 1),
+                sustained_us=round(sus, 1), sustained_over_isolated=round(sus / med, 3), isolated_hbm_frac=round(nbytes / (med * 1e-6) / PEAK_HBM, 4),
+                sustained_hbm_frac=round(nbytes / (sus * 1e-6) / PEAK_HBM, 4), sclk_mhz_sustained=sclk, package_power_w_sustained=power,
+                note="isolated = one launch after 4 ms of idle time (cool socket, boost clock), median of 12; sustained = 600 launches back to back after 1500 "
+                     "warm-up launches (socket at its power limit); the ratio is the share of the sustained time that is clock, not code")

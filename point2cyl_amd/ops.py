@@ -487,6 +487,8 @@ class _MLPStack(torch.autograd.Function):
                 call("p2c_pool_select_f32", ptr(pool[0]), ptr(pool[1]), ptr(pool[2]), ptr(sc), ptr(sh), G, K, ptr(out), K, ptr(arg), ptr(ywin), stream())
             else:
                 call("p2c_maxpool_bnrelu_f32", ptr(Ys[-1]), K, ptr(sc), ptr(sh), G, ns, K, ptr(out), K, ptr(arg), ptr(ywin), stream())
+            if cfg.get("aux_out") is not None:
+                cfg["aux_out"]["pool_arg"] = arg          # (G, C) int32: the row (0..ns-1) of its group that won each pooled entry
             arg = (arg, ywin)
         elif tail == "bnrelu":
             out = torch.empty(M, K, dtype=torch.float32, device=dev)
@@ -801,8 +803,9 @@ class _MLPStack(torch.autograd.Function):
 
 
 def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mask=None, drop_scale=1.0, drop_seed=None,
-              keep_padding=False, xyz_last=False, pre=None, staged=None):
-    """layers: list of dicts {W, b, gamma, beta, bn: BNState} (gamma/beta/bn None for a BN-less last layer)."""
+              keep_padding=False, xyz_last=False, pre=None, staged=None, aux_out=None):
+    """layers: list of dicts {W, b, gamma, beta, bn: BNState} (gamma/beta/bn None for a BN-less last layer).
+    aux_out: optional dict that receives `pool_arg` (the max-pool's winner rows) for inspection."""
     params, bns = [], []
     for ly in layers:
         params += [ly["W"], ly["b"]]
@@ -810,7 +813,7 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
             params += [ly["gamma"], ly["beta"]]
         bns.append(ly.get("bn"))
     cfg = dict(in_channels=in_channels, n_layers=len(layers), tail=tail, training=training, bns=bns, G=G, ns=ns,
-               drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed, xyz_last=xyz_last, pre=pre, staged=staged)
+               drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed, xyz_last=xyz_last, pre=pre, staged=staged, aux_out=aux_out)
     if pre is not None and pre["kind"] == "repeat":
         params = [pre.pop("V")] + params
     out = _MLPStack.apply(cfg, X0, *params)

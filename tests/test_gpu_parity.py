@@ -14,7 +14,7 @@ from tests.conftest import load_golden, same_up_to_sign
 pytestmark = pytest.mark.gpu
 
 if torch.cuda.is_available():
-    from point2cyl_amd import ops, losses, fitting, step
+    from point2cyl_amd import ops, losses, fitting, step, synth
     from point2cyl_amd.backbone import backbone
 
 DEV = "cuda"
@@ -738,6 +738,69 @@ def test_precomputed_geometry_gives_the_same_forward():
         h2, _ = m.forward_heads(x, geom)
     assert torch.equal(h1, h2)
     assert torch.equal(geom["sa1"]["fps_idx"].cpu().long(), m.sa1.last_aux["fps_idx"].cpu().long())
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_pipelined_forward_equals_the_serial_forward(mode):
+    """graph.PipelinedForward (point2cyl_amd/eval.py's loop: the geometry of batch i + 1 computed on a forked stream inside the graph of batch
+    i's forward; eval.py:231-268 knows its next batch) against the serial model.forward_heads on the same sequence of five different
+    batches with the same seeds: the CPU generator is consumed in the same order (FPS starts SA1 then SA2 per batch), the dropout
+    counter advances once per forward.  Eval mode (running statistics: nothing depends on the summation order) must agree BIT FOR BIT
+    with the serial path; train mode to the run-to-run spread of the fp64 statistics atomics."""
+    from point2cyl_amd.graph import PipelinedForward
+    B, N, nb = 4, 2048, 5
+    batches = [synth.make_batch(B, N, 8, seed=300 + i)[0].float().to(DEV) for i in range(nb)]
+    torch.manual_seed(12)
+    m = backbone(output_sizes=[3, 16]).to(DEV)
+    with torch.no_grad():
+        for b_ in m.buffers():
+            if b_.dtype.is_floating_point:
+                b_.add_(0.05 * torch.rand_like(b_))                # (non-trivial running statistics)
+    m.train() if mode == "train" else m.eval()
+    keep = {k: v.clone() for k, v in m.state_dict().items()}
+    from point2cyl_amd import autograph
+    old = autograph.ENABLED
+    autograph.ENABLED = False
+    try:
+        torch.manual_seed(77)
+        with torch.no_grad():
+            m.forward_heads(batches[0])                           # creates the dropout counter (its draw follows the first FPS draws)
+        seed0 = m._drop_seed.clone()
+        m.load_state_dict(keep)
+        torch.manual_seed(78)
+        serial = []
+        with torch.no_grad():
+            for x in batches:
+                serial.append(m.forward_heads(x)[0].clone())
+        bufs_serial = {k: v.clone() for k, v in m.state_dict().items()}
+        m.load_state_dict(keep)
+        m._drop_seed.copy_(seed0)
+        torch.manual_seed(78)
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        piped = []
+        with torch.cuda.stream(st):
+            pf = PipelinedForward(m, batches[0], stream=st)
+            for i in range(nb):
+                h, sizes = pf(batches[i + 1] if i + 1 < nb else None)
+                piped.append(h.clone())
+            pf.release()
+        torch.cuda.current_stream().wait_stream(st)
+        torch.cuda.synchronize()
+    finally:
+        autograph.ENABLED = old
+    assert sizes == [3, 16] and m.sa1.fps_start is None and m.sa2.fps_start is None
+    for i in range(nb):
+        if mode == "eval":
+            assert torch.equal(serial[i], piped[i]), i
+        else:
+            assert float((serial[i] - piped[i]).abs().max()) <= 2e-5 * float(serial[i].abs().max()), i
+    for k, v in m.state_dict().items():
+        if "num_batches_tracked" in k:
+            assert int(v) == int(bufs_serial[k]), k               # warm-up passes of the capture leave no trace
+        else:
+            np.testing.assert_allclose(v.cpu().numpy(), bufs_serial[k].cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+    assert int(m._drop_seed) == int(seed0) + nb * (0x9E3779B97F4A7C15 % (2 ** 62))
 
 
 def test_copy_flat_batch_equals_torch_copies():

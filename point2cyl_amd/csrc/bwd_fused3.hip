@@ -730,9 +730,8 @@ static int launch_fused3(const BwdFused3Args &a, hipStream_t s)
                                   (int)lds);                                                                                          \
         hipLaunchKernelGGL((bwd_fused3_kernel<Co, Ci, GMODE, IMODE, DX_, ST_>), dim3(grid), dim3(256), lds, s, a);                    \
     } while (0)
-    static const bool roles_on = !(getenv("P2C_BWD3_ROLES") && atoi(getenv("P2C_BWD3_ROLES")) == 0);        // A/B switch
     if constexpr (Ci == 128) {
-        if (a.dx && roles_on) {
+        if (a.dx) {        // role split (two waves per SIMD in the same phase): 163 -> 142 us against one wave per SIMD, DESIGN.md section 3
             const size_t lds = (size_t)3 * BM * LDR + 3 * Co * LDT + 3 * Ci * LDT + Ci * LDXR + (2 * Ci + Co) * 4;
             if (a.pstat) {
                 (void)hipFuncSetAttribute((const void *)bwd_fused3r_kernel<Co, Ci, GMODE, IMODE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

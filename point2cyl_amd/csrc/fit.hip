@@ -593,7 +593,12 @@ extern "C" int p2c_fit_trace_read(void *out) { return hipMemcpyFromSymbol(out, H
 
 // THREADS 1024 / PLDS: one workgroup per CU, the cloud's points parked in LDS.  THREADS 512 / !PLDS: two workgroups per CU (one streams
 // while the other is in its serial phases), the projection gathers its points from global memory (L2 / MALL: the workgroup has just read them).
-template <int KK, int THREADS, bool PLDS>
+// HARD: the memberships are IMPLIED by the labels (Wb[n,k] = [seg == k and bb == 0], Wc[n,k] = [seg == k and bb == 1]: pre-segmented clouds,
+// eval.py's --use_gt_segmentation --use_gt_bb operands, BASELINE configs[3]) and are not read: 40 B per point instead of 104 (SURVEY 8(d):
+// "16 B of labels if one-hot is implied").  With no per-(point, segment) operand left a lane takes a whole POINT (LPP = K/4 lanes per point
+// above 4 segments, 4 segments each): one wave instruction then fetches 32-64 distinct points instead of 8 (eight times fewer memory
+// instructions per byte), and the segment sums are selected by the label with 0/1 factors - the same products, another summation order.
+template <int KK, int THREADS, bool PLDS, bool HARD = false>
 __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__restrict__ X, const float *__restrict__ Wb, const float *__restrict__ Wc,
                                                                 const float *__restrict__ P, const int64_t *__restrict__ seg,
                                                                 const int64_t *__restrict__ bb, const int64_t *__restrict__ rand_idx, int normalize,
@@ -617,9 +622,44 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
     const int g = tid / KK, k = tid % KK;
     // ---------------- phase 1
     FIT_TR(0);
-    float acc[NA];
+    constexpr int LPP = HARD ? (KK > 4 ? KK / 4 : 1) : 1, SPL = HARD ? KK / LPP : 1;       // HARD: lanes per point, segments per lane
+    float acc[HARD ? 1 : NA];
+    float hacc[SPL][NA];
+    if constexpr (!HARD) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j)
+#pragma unroll
+            for (int i = 0; i < NA; ++i) hacc[j][i] = 0.f;
+    }
+    if constexpr (HARD) {
+        const float *x = X + (size_t)b * N * 3, *pp = P + (size_t)b * N * 3;
+        const int *sg = reinterpret_cast<const int *>(seg + (size_t)b * N), *bl = reinterpret_cast<const int *>(bb + (size_t)b * N);
+        const int hsel = tid % LPP, k0 = hsel * SPL;
+#pragma unroll 4
+        for (int n = tid / LPP; n < N; n += THREADS / LPP) {
+            const float x0 = x[n * 3 + 0], x1 = x[n * 3 + 1], x2 = x[n * 3 + 2];
+            const float p0 = pp[n * 3 + 0], p1 = pp[n * 3 + 1], p2 = pp[n * 3 + 2];
+            const int sv = sg[2 * n], bv = bl[2 * n];
+            const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const bool mine = sv == k0 + j;
+                const float b2 = (mine && bv == 0) ? 1.f : 0.f, c2 = (mine && bv == 1) ? 1.f : 0.f, w = mine ? 1.f : 0.f;
+                float *a_ = hacc[j];
+                a_[0] += b2 * p00; a_[1] += b2 * p01; a_[2] += b2 * p02; a_[3] += b2 * p11; a_[4] += b2 * p12; a_[5] += b2 * p22;
+                a_[6] += c2 * p00; a_[7] += c2 * p01; a_[8] += c2 * p02; a_[9] += c2 * p11; a_[10] += c2 * p12; a_[11] += c2 * p22;
+                if (normalize) { a_[12] += b2; a_[13] += c2; }
+                a_[14] += w * p0; a_[15] += w * p1; a_[16] += w * p2; a_[17] += w;
+            }
+            if (hsel == 0) {
+                if (PLDS) { Ps[n * 3 + 0] = p0; Ps[n * 3 + 1] = p1; Ps[n * 3 + 2] = p2; }
+                keyb[n] = (signed char)((bv == 0 && sv >= 0 && sv < KK) ? (int)sv : -1);
+            }
+        }
+    } else
     {
         const float *x = X + (size_t)b * N * 3, *pp = P + (size_t)b * N * 3;
         const float *wb = Wb + (size_t)b * N * KK, *wc = Wc + (size_t)b * N * KK;
@@ -665,12 +705,25 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
     // ---------------- phase 2: the 64/K slices of a wave in fp32, fp64 from there on (see axis_kernel)
     {
         double *wsum = reinterpret_cast<double *>(list);                  // [WAVES][KK][NA]
+        if constexpr (HARD) {
+            __syncthreads();                                              // (the keys / points parked above share no LDS with wsum; the lists do)
+#pragma unroll
+            for (int j = 0; j < SPL; ++j)
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    float v = hacc[j][i];
+#pragma unroll
+                    for (int o = LPP; o < 64; o <<= 1) v += __shfl_xor(v, o);      // the lanes of this segment group in the wave: lane % LPP
+                    if (lane < LPP) wsum[(wave * KK + lane * SPL + j) * NA + i] = (double)v;
+                }
+        } else {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             float v = acc[i];
 #pragma unroll
             for (int o = KK; o < 64; o <<= 1) v += __shfl_xor(v, o);      // the lanes of segment k in this wave: lane % KK == k
             if (lane < KK) wsum[(wave * KK + lane) * NA + i] = (double)v;
+        }
         }
         __syncthreads();
         if (tid < KK * NA) {
@@ -782,9 +835,11 @@ extern "C" int p2c_fit_fused_f32(const float *X, const float *Wb, const float *W
                                  const float *P, const int64_t *rand_idx, int B, int N, int K, int S, float *axis_out, float *centroids_out,
                                  float *cfound_out, float *extents_out, float *found_out, double *axis64_out, void *ws, void *stream)
 {
-    if (!X || !Wb || !Wc || !bb_gt || !inst_gt || !P || !rand_idx || !axis_out || !centroids_out || !cfound_out || !extents_out || !found_out || !ws ||
+    if (!X || !bb_gt || !inst_gt || !P || !rand_idx || !axis_out || !centroids_out || !cfound_out || !extents_out || !found_out || !ws ||
         B <= 0 || !p2c_fit_fused_supported(N, K, S))
         return P2C_EINVAL;
+    if ((Wb == nullptr) != (Wc == nullptr)) return P2C_EINVAL;
+    const bool hard = Wb == nullptr;            // memberships implied by the labels: not read (fit_fused_kernel<.., HARD>)
     float *ext_tmp = (float *)ws;
     int *counts = (int *)(ext_tmp + (size_t)B * K * 2);
     hipStream_t s = (hipStream_t)stream;
@@ -799,12 +854,20 @@ extern "C" int p2c_fit_fused_f32(const float *X, const float *Wb, const float *W
         hipLaunchKernelGGL((fit_fused_kernel<KK_, TH_, PLDS_>), dim3(B), dim3(TH_), lds, s, X, Wb, Wc, P, inst_gt, bb_gt, rand_idx, normalize, N, S,    \
                            axis_out, centroids_out, cfound_out, ext_tmp, counts, axis64_out);                                          \
     } while (0)
-#define P2C_FFK(KK_) do { if (half) P2C_FF(KK_, 512, false); else P2C_FF(KK_, 1024, true); } while (0)
+#define P2C_FFH(KK_)                                                                                                                    \
+    do {                                                                                                                                \
+        const size_t lds = fit_fused_lds(N, K, 16, true);                                                                               \
+        (void)hipFuncSetAttribute((const void *)fit_fused_kernel<KK_, 1024, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL((fit_fused_kernel<KK_, 1024, true, true>), dim3(B), dim3(1024), lds, s, X, Wb, Wc, P, inst_gt, bb_gt, rand_idx, normalize, N, \
+                           S, axis_out, centroids_out, cfound_out, ext_tmp, counts, axis64_out);                                       \
+    } while (0)
+#define P2C_FFK(KK_) do { if (hard) P2C_FFH(KK_); else if (half) P2C_FF(KK_, 512, false); else P2C_FF(KK_, 1024, true); } while (0)
     if (K == 8) P2C_FFK(8);
     else if (K == 4) P2C_FFK(4);
     else if (K == 2) P2C_FFK(2);
     else P2C_FFK(1);
 #undef P2C_FFK
+#undef P2C_FFH
 #undef P2C_FF
     hipLaunchKernelGGL(extents_finish_kernel, dim3(K), dim3(256), 0, s, ext_tmp, counts, B, K, extents_out, found_out);
     P2C_LAUNCH_CHECK();

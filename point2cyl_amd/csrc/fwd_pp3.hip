@@ -398,8 +398,7 @@ static int launch_pp3(const FwdPPArgs &a, hipStream_t s)
 int p2c_fwd_pp3_launch(const FwdPPArgs &a_in, int in_mode, hipStream_t s)
 {
     FwdPPArgs a = a_in;
-    static const int lock = getenv("P2C_FWD3_LOCKSTEP") ? atoi(getenv("P2C_FWD3_LOCKSTEP")) : 1;      // A/B switch; lockstep measured faster
-    a.lockstep = lock;
+    a.lockstep = 1;          // both halves of the workgroup in the same phase: -5...13 % per launch against the one-phase offset
     const int K = a.K;          // EX columns already split off by the caller
     if (a.pool_max) {
         if (!a.pool_min || !a.pool_idx || !p2c_linear_fwd_pool_supported(a.M, a.N, K, in_mode, 64)) return P2C_EINVAL;

@@ -419,7 +419,7 @@ extern "C" int p2c_three_interp_bias_stats_f32(const float *feats, int ldf, cons
     const long long rows = (long long)B * N;
     const int blocks = p2c_cdiv(rows, 64);
     hipStream_t s = (hipStream_t)stream;
-    static const bool xcd_on = !(getenv("P2C_XCD_GATHER") && atoi(getenv("P2C_XCD_GATHER")) == 0);         // A/B switch
+    const bool xcd_on = true;          // cloud b served by XCD b % 8 (its rows share one L2): csr_gather_bn fetch 742 -> 543 MB, DESIGN.md 3
     const int xcd_bpc = (xcd_on && B % 8 == 0 && N % 64 == 0) ? N / 64 : 0;
 #define P2C_TI(CPL_) hipLaunchKernelGGL(three_interp_stats_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, feats, ldf, idx, weight, N, S, C, rows, bias, out, ldo, stat_slots, xcd_bpc)
     if (C <= 64) P2C_TI(1);
@@ -525,8 +525,7 @@ extern "C" int p2c_csr_gather_bn_f32(const float *dz, int lddz, const float *y, 
     if (!dz || !y || !coef || !offsets || !rows || !out || B <= 0 || E <= 0 || T <= 0 || C <= 0 || C > 256) return P2C_EINVAL;
     const long long total = (long long)B * T;
     hipStream_t s = (hipStream_t)stream;
-    static const bool xcd_on = !(getenv("P2C_XCD_GATHER") && atoi(getenv("P2C_XCD_GATHER")) == 0);         // A/B switches
-    static const bool split_on = !(getenv("P2C_GATHER_SPLIT") && atoi(getenv("P2C_GATHER_SPLIT")) == 0);
+    const bool xcd_on = true, split_on = true;      // cloud -> XCD mapping; channel halves (4.2 MB working set per XCD): 118 -> 91 us, DESIGN.md 3
     const int xcd_clouds = (xcd_on && B % 8 == 0 && T % 4 == 0) ? 1 : 0;
     const int nsplit = (xcd_clouds && split_on && C == 128) ? 2 : 1;
     dim3 grid(p2c_cdiv(total, 4) * nsplit);
@@ -623,7 +622,7 @@ extern "C" int p2c_group_linear_bias_stats_f32(const float *G, int ldg, const fl
     const long long rows = (long long)B * S * nsample;
     const int blocks = p2c_cdiv(rows, 64);
     hipStream_t s = (hipStream_t)stream;
-    static const bool xcd_on = !(getenv("P2C_XCD_GATHER") && atoi(getenv("P2C_XCD_GATHER")) == 0);         // A/B switch
+    const bool xcd_on = true;          // cloud b served by XCD b % 8 (its rows share one L2): csr_gather_bn fetch 742 -> 543 MB, DESIGN.md 3
     const long long rows_b = (long long)S * nsample;
     const int xcd_bpc = (xcd_on && B % 8 == 0 && rows_b % 64 == 0) ? (int)(rows_b / 64) : 0;
 #define P2C_GL(CPL_) hipLaunchKernelGGL(group_linear_stats_kernel<CPL_>, dim3(blocks), dim3(256), 0, s, G, ldg, xyz, new_xyz, idx, Wx, bias, N, S, nsample, C, rows, out, ldo, stat_slots, xcd_bpc)

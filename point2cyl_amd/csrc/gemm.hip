@@ -638,22 +638,12 @@ __global__ void __launch_bounds__(256) gemm_dual_kernel(OpG gA, OpPlain wA, EpiB
     }
 }
 
-// The tiled kernels follow the switch of the persistent ones (p2c_set_mfma_mode / P2C_MFMA=f32); P2C_GEMM_SPLIT=0 keeps just them on the
-// fp32 matrix instructions (A/B).
-static bool gemm_split()
-{
-    static const bool own = !(getenv("P2C_GEMM_SPLIT") && atoi(getenv("P2C_GEMM_SPLIT")) == 0);
-    return own && p2c_mfma_split();
-}
+// The tiled kernels follow the switch of the persistent ones (p2c_set_mfma_mode / P2C_MFMA=f32).
+static bool gemm_split() { return p2c_mfma_split(); }
 
 // ... and the products with an operand whose k runs down the rows in memory (both backward products: their tiles are transposed on the way
-// into LDS, Tile3's permuted rows make that conflict-free): sa3.2 dX 83 -> 59 us, dW 70 -> 56 us; step -0.06 ms.  P2C_GEMM_SPLIT=1 keeps
-// them on the fp32 instructions (A/B).
-static bool gemm_split_t()
-{
-    static const bool off = getenv("P2C_GEMM_SPLIT") && atoi(getenv("P2C_GEMM_SPLIT")) == 1;
-    return !off && gemm_split();
-}
+// into LDS, Tile3's permuted rows make that conflict-free): sa3.2 dX 83 -> 59 us, dW 70 -> 56 us; step -0.06 ms.
+static bool gemm_split_t() { return gemm_split(); }
 
 static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 #define P2C_REQ_ALIGNED(ptr_, ld_)                                   \
@@ -662,23 +652,14 @@ static inline bool al16(const void *p) { return ((uintptr_t)p & 15) == 0; }
     } while (0)
 
 // Row-tile height of the forward / backward-data kernels (also the granularity of the per-tile partial sums).
-static int tile_m()
-{
-    static int v = 0;
-    if (!v) {
-        const char *e = getenv("P2C_TILE_M");
-        v = (e && atoi(e) == 128) ? 128 : 64;
-    }
-    return v;
-}
+static constexpr int tile_m() { return 64; }
 extern "C" int p2c_linear_tile_m(void) { return tile_m(); }
 // Small problems (the SA3 / FP3 / FP2 layers: 4 k - 16 k rows): with 64 x 128 tiles the grid has fewer workgroups than the chip has
 // CUs, one workgroup per CU cannot hide the operand latency behind its own MFMAs, and the kernel runs at 15-40 TFLOP/s.  64 x 64
 // tiles double the number of workgroups (twice the loads in flight per CU) at the price of one more LDS read per MFMA.
 static bool narrow_tiles(int rows, int cols)
 {
-    static const int thr = getenv("P2C_GEMM_NARROW") ? atoi(getenv("P2C_GEMM_NARROW")) : 512;
-    return (long long)p2c_cdiv(rows, 64) * p2c_cdiv(cols, 128) < thr;
+    return (long long)p2c_cdiv(rows, 64) * p2c_cdiv(cols, 128) < 512;
 }
 extern "C" int p2c_linear_stat_tiles(int M) { return (M + tile_m() - 1) / tile_m(); }
 
@@ -736,10 +717,9 @@ static int launch_fwd(const float *X, int ldx, const float *W, int ldw, const fl
     // backbone stay on the fp32 instructions - there the larger LDS / register footprint costs co-residency with the sampling kernel
     // of the forked stream and the step got 0.03 ms slower
     // ... except the one product of those levels that is large enough to pay (SA3's 512 -> 1024 layer: K * N >= 400,000; -0.02 ms)
-    static const long long fw_kn = getenv("P2C_GEMM_FWD_KN") ? atoll(getenv("P2C_GEMM_FWD_KN")) : 400000;
+    constexpr long long fw_kn = 400000;
 #define P2C_FW(TM_, TN_) do { if (gemm_split() && (M >= 65536 || (long long)K * N >= fw_kn)) P2C_FW_(TM_, TN_, true); else P2C_FW_(TM_, TN_, false); } while (0)
-    if (tile_m() == 128) { if (N > 64) P2C_FW(2, 2); else P2C_FW(2, 1); }
-    else { if (N > 64 && !narrow_tiles(M, N)) P2C_FW(1, 2); else P2C_FW(1, 1); }
+    if (N > 64 && !narrow_tiles(M, N)) P2C_FW(1, 2); else P2C_FW(1, 1);
 #undef P2C_FW
 #undef P2C_FW_
     P2C_LAUNCH_CHECK();
@@ -764,8 +744,7 @@ extern "C" int p2c_linear_fwd_f32(const float *X, int ldx, const float *W, int l
         P2C_LAUNCH_CHECK();
         return P2C_OK;
     }
-    static const bool use_pp = !(getenv("P2C_FWD_PP") && atoi(getenv("P2C_FWD_PP")) == 0);      // A/B switch for profiling
-    if (use_pp && p2c_linear_fwd_pp_supported(M, N, K, in_mode)) {
+    if (p2c_linear_fwd_pp_supported(M, N, K, in_mode)) {
         FwdPPArgs a{X, ldx, W, ldw, bias, Y, ldy, M, N, K == 132 ? 128 : K, in_scale, in_shift, (const uint32_t *)drop_mask,
                     (uint32_t)ldmask, drop_scale, K, stat_partials, nullptr, nullptr, nullptr, nullptr, nullptr};
         return p2c_fwd_pp_launch(a, in_mode, s);
@@ -838,6 +817,7 @@ static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy
                            const float *spz = nullptr, int ldspz = 0, float sp_beta = 0.f, float sp_thr = 0.f)
 {
     // layer: Y[M,N] = in[M,K] . W[N,K]^T ; here the GEMM is dX[M,K] = dY[M,N] . W[N,K]
+    if (out_mask && ldmask < 0 && !p2c_drop_scale_representable(out_mask_scale)) return P2C_EINVAL;      // hashed dropout (ldmask -1): p in steps of 1/256
     OpGrad<GMODE> a{dZ, lddz, Yfwd, ldy, coef, N, pool_arg, pool_ns};
     OpPlain b{W, ldw};
     EpiBwdData e{dX, lddx, out_mask, ldmask, out_mask_scale, p2c_drop_threshold(out_mask_scale), Yprev, ldyp, prev_stat, bwd_partials, spz, ldspz, sp_beta, sp_thr};
@@ -846,8 +826,7 @@ static int launch_bwd_data(const float *dZ, int lddz, const float *Yfwd, int ldy
     hipLaunchKernelGGL((gemm_kernel<TM_, TN_, true, false, OpGrad<GMODE>, OpPlain, EpiBwdData, SP_>),                               \
                        dim3(p2c_cdiv(M, 64 * TM_), p2c_cdiv(K, 64 * TN_), 1), dim3(256), 0, s, a, b, e, M, K, N, kps)
 #define P2C_BDL(TM_, TN_) do { if (gemm_split_t()) P2C_BDL_(TM_, TN_, true); else P2C_BDL_(TM_, TN_, false); } while (0)
-    if (tile_m() == 128) { if (K > 64) P2C_BDL(2, 2); else P2C_BDL(2, 1); }
-    else { if (K > 64 && !narrow_tiles(M, K)) P2C_BDL(1, 2); else P2C_BDL(1, 1); }
+    if (K > 64 && !narrow_tiles(M, K)) P2C_BDL(1, 2); else P2C_BDL(1, 1);
 #undef P2C_BDL
 #undef P2C_BDL_
     P2C_LAUNCH_CHECK();

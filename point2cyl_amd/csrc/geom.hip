@@ -129,8 +129,8 @@ extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start,
     const int Npad = (N + 3) & ~3;
     // Clouds whose SoA copy is larger than 24 KB read the centroid from global memory (an L1/L2 hit, measured equally
     // fast) instead: FPS runs on a side stream under the persistent GEMM kernels, whose 135 KB workgroups cannot share a
-    // CU with a 96 KB copy (N = 8192) and would queue behind the 32 FPS workgroups.  P2C_FPS_LDS_KB overrides.
-    static const size_t lds_cap = (getenv("P2C_FPS_LDS_KB") ? (size_t)atoi(getenv("P2C_FPS_LDS_KB")) : 24) * 1024;
+    // CU with a 96 KB copy (N = 8192) and would queue behind the 32 FPS workgroups.
+    constexpr size_t lds_cap = 24 * 1024;
     const bool in_lds = (size_t)(3 * Npad + 64) * sizeof(float) <= lds_cap;
     const size_t lds = in_lds ? (size_t)(3 * Npad + 64) * sizeof(float) : 64 * sizeof(float);
 #define P2C_FPS_LAUNCH(P, L)                                                                                              \
@@ -167,83 +167,12 @@ extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start,
 // =============================================================================================
 // Ball query without the sort: a wave scans the cloud in ascending index order, 64 points per step;
 // ballot + prefix popcount append the in-ball indices in order; stop at nsample; pad with the first.
-// A workgroup (4 waves) serves QPB consecutive query centres of one cloud and stages the cloud through
-// LDS in chunks (x, y, z, |p|^2 as SoA) so every chunk is read from L2 once per 16 queries.
+// (The round-1 form staged the cloud through LDS for 16 queries per workgroup, which then moved in lockstep through two barriers per 1024
+// points; it is in the history up to round 4.)
 // =============================================================================================
-#define BQ_QPW 4            // queries per wave
-#define BQ_QPB (4 * BQ_QPW) // queries per workgroup
-#define BQ_CHUNK 1024
-
-__global__ void __launch_bounds__(256) ball_query_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz, int N,
-                                                         int S, float r2, int nsample, int32_t *__restrict__ idx_out)
-{
-    __shared__ float sp[4][BQ_CHUNK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.y;
-    const int q0 = blockIdx.x * BQ_QPB + wave * BQ_QPW;
-    const float *cloud = xyz + (size_t)b * N * 3;
-    float cx[BQ_QPW], cy[BQ_QPW], cz[BQ_QPW], cn[BQ_QPW];
-    int cnt[BQ_QPW], first[BQ_QPW];
-#pragma unroll
-    for (int q = 0; q < BQ_QPW; ++q) {
-        const int s = q0 + q;
-        const float *c = new_xyz + ((size_t)b * S + (s < S ? s : 0)) * 3;
-        cx[q] = c[0]; cy[q] = c[1]; cz[q] = c[2];
-        cn[q] = p2c_norm2(cx[q], cy[q], cz[q]);
-        cnt[q] = s < S ? 0 : nsample;      // out-of-range queries are "done"
-        first[q] = N;
-    }
-    for (int base = 0; base < N; base += BQ_CHUNK) {
-        bool wave_done = true;
-#pragma unroll
-        for (int q = 0; q < BQ_QPW; ++q) wave_done = wave_done && (cnt[q] >= nsample);
-        if (__syncthreads_and(wave_done)) break;
-        const int len = min(BQ_CHUNK, N - base);
-        for (int i = tid; i < len; i += 256) {
-            const float x = cloud[(size_t)(base + i) * 3 + 0], y = cloud[(size_t)(base + i) * 3 + 1],
-                        z = cloud[(size_t)(base + i) * 3 + 2];
-            sp[0][i] = x; sp[1][i] = y; sp[2][i] = z; sp[3][i] = p2c_norm2(x, y, z);
-        }
-        __syncthreads();
-        // points outer, the wave's queries inner: a point's four LDS words are read once for all of them (every query still sees the
-        // points in ascending index order, so the output is unchanged)
-        for (int off = 0; off < len; off += 64) {
-            bool all_done = true;
-#pragma unroll
-            for (int q = 0; q < BQ_QPW; ++q) all_done = all_done && (cnt[q] >= nsample);
-            if (all_done) break;                                 // wave-uniform
-            const int i = off + lane;
-            const bool ok = i < len;
-            const float px = ok ? sp[0][i] : 0.f, py = ok ? sp[1][i] : 0.f, pz = ok ? sp[2][i] : 0.f, pn = ok ? sp[3][i] : 0.f;
-#pragma unroll
-            for (int q = 0; q < BQ_QPW; ++q) {
-                if (cnt[q] >= nsample) continue;                 // wave-uniform
-                const float d = p2c_sqdist(cx[q], cy[q], cz[q], cn[q], px, py, pz, pn);
-                const bool in = ok && !(d > r2);                 // :102 excludes only d > r^2
-                const unsigned long long m = __ballot(in);
-                if (m) {
-                    const int pos = cnt[q] + __popcll(m & ((1ull << lane) - 1ull));
-                    if (in && pos < nsample) idx_out[((size_t)b * S + q0 + q) * nsample + pos] = base + i;
-                    if (first[q] == N) first[q] = base + off + (__ffsll((long long)m) - 1);
-                    cnt[q] += __popcll(m);
-                }
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int q = 0; q < BQ_QPW; ++q) {
-        if (q0 + q >= S) continue;
-        int32_t *o = idx_out + ((size_t)b * S + q0 + q) * nsample;
-        const int c = min(cnt[q], nsample);
-        for (int k = c + lane; k < nsample; k += 64) o[k] = first[q];      // :104-106
-    }
-}
-
-// The same scan WITHOUT the shared staging: every wave walks the cloud on its own (the 96 KB of a cloud are L1 / L2 hits), next step's
-// points requested before the current ones are tested.  With the LDS chunks the 16 queries of a workgroup move in lockstep through two
-// barriers per 1024 points and all wait for the slowest of them (a centre in a sparse region scans the whole cloud while its neighbours
-// are done after a few hundred points); here a wave retires as soon as ITS queries are complete.
+// No shared staging: every wave walks the cloud on its own (the 96 KB of a cloud are L1 / L2 hits), next step's
+// points requested before the current ones are tested; a wave retires as soon as ITS queries are complete (a centre in a sparse region
+// scans the whole cloud while its neighbours are done after a few hundred points).
 template <int QPW>
 __global__ void __launch_bounds__(256) ball_query_direct_kernel(const float *__restrict__ xyz, const float *__restrict__ new_xyz, int N,
                                                                 int S, float r2, int nsample, int32_t *__restrict__ idx_out)
@@ -322,18 +251,10 @@ extern "C" int p2c_ball_query_f32(const float *xyz, const float *new_xyz, int B,
                                   int32_t *idx_out, void *stream)
 {
     if (!xyz || !new_xyz || !idx_out || B <= 0 || N <= 0 || S <= 0 || nsample <= 0) return P2C_EINVAL;
-    static const int direct = getenv("P2C_BQ_DIRECT") ? atoi(getenv("P2C_BQ_DIRECT")) : 2;                 // A/B: 0 = LDS chunks, 1 / 2 / 4 queries per wave
-    if (direct == 1 || direct == 2 || direct == 4) {
-        const int qpb = 4 * direct;
-        dim3 g(p2c_cdiv(S, qpb), B);
-        if (direct == 1) hipLaunchKernelGGL(ball_query_direct_kernel<1>, g, dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, radius2, nsample, idx_out);
-        else if (direct == 2) hipLaunchKernelGGL(ball_query_direct_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, radius2, nsample, idx_out);
-        else hipLaunchKernelGGL(ball_query_direct_kernel<4>, g, dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, radius2, nsample, idx_out);
-        P2C_LAUNCH_CHECK();
-        return P2C_OK;
-    }
-    dim3 grid(p2c_cdiv(S, BQ_QPB), B);
-    hipLaunchKernelGGL(ball_query_kernel, grid, dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, radius2, nsample, idx_out);
+    // every wave walks the cloud on its own (L1 / L2 hits), two queries per wave: 86 -> 64 us for the two levels against the LDS-chunk
+    // scan whose 16 queries per workgroup moved in lockstep (1 and 4 queries per wave measured slower)
+    dim3 g(p2c_cdiv(S, 8), B);
+    hipLaunchKernelGGL(ball_query_direct_kernel<2>, g, dim3(256), 0, (hipStream_t)stream, xyz, new_xyz, N, S, radius2, nsample, idx_out);
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }

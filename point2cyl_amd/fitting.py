@@ -64,14 +64,23 @@ def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_cen
 
 
 def fit_cylinders(X, W_barrel, W_base, gt_bb_labels, seg_label, P, num_points_to_sample=1024, rand_idx=None, normalize=False,
-                  return_float64=False, validate=True):
+                  return_float64=False, validate=True, K=None):
     """The fitting-only chain on pre-segmented clouds (BASELINE configs[3]): estimate_extrusion_axis (eval.py:397) -> hard centroids
     (eval.py:409-436) -> get_extrusion_extents on the fitted axes / centroids (data_utils.py:1650-1730), one pass per cloud where the
     shape allows (ops.fit_fused), the three ops otherwise.  -> axes (B,K,3), centroids (B,K,3), centroid found (B,K), extents (K,B,2),
     extent found (B,K) [, axes in float64 with return_float64, see estimate_extrusion_axis].  Forward only.
     validate: the kernels read the labels' low words; labels outside [-1, K) / {0, 1} raise here instead of aliasing (one device->host
-    sync; a caller that loops over the same labels passes validate=False after its first call)."""
-    B, N, K = W_barrel.shape
+    sync; a caller that loops over the same labels passes validate=False after its first call).
+    W_barrel = W_base = None (then K must be given): the memberships are the one-hot encodings IMPLIED by the labels - W_barrel[b,n,k] =
+    [seg == k and bb == 0], W_base = [seg == k and bb == 1], what pre-segmented clouds (eval.py --use_gt_segmentation --use_gt_bb, configs[3])
+    hand in - and are not read at all: 40 bytes per point instead of 104.  Same arithmetic, another summation order (1e-6)."""
+    hard = W_barrel is None and W_base is None
+    if hard:
+        if K is None:
+            raise ValueError("fit_cylinders: pass K when the memberships are implied by the labels (W_barrel = W_base = None)")
+        B, N = seg_label.shape
+    else:
+        B, N, K = W_barrel.shape
     S = num_points_to_sample if rand_idx is None else rand_idx.shape[2]
     if validate:
         ops.check_labels(seg_label, K)
@@ -80,7 +89,10 @@ def fit_cylinders(X, W_barrel, W_base, gt_bb_labels, seg_label, P, num_points_to
         rand_idx = _barrel_draws(seg_label, gt_bb_labels, K, S)
     rand_idx = rand_idx.to(P.device)
     if ops.fit_fused_supported(N, K, S):
-        return ops.fit_fused(X, W_barrel, W_base, gt_bb_labels, seg_label, P, rand_idx, normalize=normalize, axes64=return_float64)
+        return ops.fit_fused(X, W_barrel, W_base, gt_bb_labels, seg_label, P, rand_idx, normalize=normalize, axes64=return_float64, K=K)
+    if hard:
+        onehot = torch.nn.functional.one_hot(seg_label.clamp(min=0), K).float() * (seg_label >= 0).unsqueeze(-1)
+        W_barrel, W_base = onehot * (gt_bb_labels == 0).unsqueeze(-1), onehot * (gt_bb_labels == 1).unsqueeze(-1)
     with torch.no_grad():
         axes = estimate_extrusion_axis(X, W_barrel, W_base, gt_bb_labels, seg_label, normalize=normalize, return_float64=return_float64)
         axes, a64 = axes if return_float64 else (axes, None)

@@ -257,11 +257,12 @@ class FittingWorkload:
         self.path_bytes = self.points * (12 + 12 + 2 * K * 4 + 8 + 8) + n_clouds * K * S * 8
         self.survey_bytes = self.points * (12 + 2 * K * 4)        # X + W_barrel + W_base = 76 B/point at K = 8
 
-    def fit(self, fused=True, validate=False):
+    def fit(self, fused=True, validate=False, hard=False):
+        """hard: the memberships implied by the labels (the workload's W ARE the one-hot encodings of (seg, bb)): not read."""
         d = self.dev
         if fused and ops.fit_fused_supported(self.N, self.K, self.S):
-            return fitting.fit_cylinders(d["X"], d["Wb"], d["Wc"], d["bb"], d["seg"], d["pcs"], rand_idx=d["ridx"], normalize=False,
-                                         return_float64=True, validate=validate)
+            return fitting.fit_cylinders(d["X"], None if hard else d["Wb"], None if hard else d["Wc"], d["bb"], d["seg"], d["pcs"],
+                                         rand_idx=d["ridx"], normalize=False, return_float64=True, validate=validate, K=self.K)
         with torch.no_grad():
             E, E64 = fitting.estimate_extrusion_axis(d["X"], d["Wb"], d["Wc"], d["bb"], d["seg"], normalize=False, return_float64=True)
             cen, cfound = ops.segment_centroids(d["pcs"], d["seg"], self.K)
@@ -299,6 +300,29 @@ class FittingWorkload:
                    kernel_frac_hbm=round(kbytes / (kms * 1e-3) / PEAK_HBM, 4) if kms else None,
                    per_kernel={k: dict(ms_per_pass=round(v["ms"] / steps, 4), launches_per_pass=v["launches"] / steps)
                                for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])})
+        if fused:
+            # The same clouds with the memberships IMPLIED by the labels (this workload's W are exactly the one-hot encodings of (seg, bb):
+            # "pre-segmented cylinders"; SURVEY 8(d): "16 B of labels if one-hot is implied"): Wb / Wc are not read, 40 B per point.
+            oh = self.fit(True, hard=True)
+            for _ in range(2):
+                oh = self.fit(True, hard=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                oh = self.fit(True, hard=True)
+            torch.cuda.synchronize()
+            dh = (time.perf_counter() - t0) / steps
+            hbytes = self.points * (12 + 12 + 8 + 8) + self.n * self.K * self.S * 8
+            dot = (oh[5] * out[5]).sum(-1).abs().clamp(max=1.0)
+            res["labels_implied"] = dict(
+                what="p2c_fit_fused_f32 with Wb = Wc = NULL: memberships implied by (seg, bb), not read; lane-per-point streaming",
+                ms=round(dh * 1e3, 4), cylinders_per_s=round(self.n * self.K / dh, 1), path_bytes=hbytes,
+                frac_hbm_path_bytes=round(hbytes / dh / PEAK_HBM, 4), frac_hbm_76B_per_point=round(self.survey_bytes / dh / PEAK_HBM, 4),
+                frac_note="frac_hbm_76B_per_point prices the time against SURVEY 8(d)'s 76 B/point although this route reads 40 B/point (+ the "
+                          "pre-drawn samples): it is the fraction the survey's byte model would see, frac_hbm_path_bytes the one of the bytes really read",
+                vs_general_route=dict(max_axis_angle_deg=float(torch.rad2deg(torch.acos(dot)).max()),
+                                      max_centroid_diff=float((oh[1] - out[1]).abs().max()), max_extent_diff=float((oh[3] - out[3]).abs().max()),
+                                      found_masks_equal=bool(torch.equal(oh[2], out[2]) and torch.equal(oh[4], out[4]))))
         return res, out
 
 

@@ -1089,13 +1089,22 @@ def fit_fused_supported(N, K, S):
     return bool(_lib.lib().p2c_fit_fused_supported(int(N), int(K), int(S)))
 
 
-def fit_fused(X, Wb, Wc, bb, seg, P, rand_idx, normalize=False, axes64=False):
+def fit_fused(X, Wb, Wc, bb, seg, P, rand_idx, normalize=False, axes64=False, K=None):
     """csrc/fit.hip fit_fused_kernel: axis -> hard centroids -> extents of pre-segmented clouds in one pass (eval.py:397, :409-436,
     data_utils.py:1650-1730).  -> axes (B,K,3), centroids (B,K,3), centroid found (B,K), extents (K,B,2), extent found (B,K)
-    [, axes in float64 (B,K,3) with axes64=True].  No gradient."""
+    [, axes in float64 (B,K,3) with axes64=True].  No gradient.  Wb = Wc = None (K given): memberships implied by the labels, not read."""
     _lib.require_device(X, Wb, Wc, bb, seg, P, rand_idx)
-    X, Wb, Wc, P = _f32c(X.detach()), _f32c(Wb.detach()), _f32c(Wc.detach()), _f32c(P)
-    B, N, K = Wb.shape
+    hard = Wb is None and Wc is None
+    if (Wb is None) != (Wc is None):
+        raise ValueError("fit_fused: W_barrel and W_base are given together or not at all")
+    X, P = _f32c(X.detach()), _f32c(P)
+    if hard:
+        B, N = seg.shape
+        if K is None:
+            raise ValueError("fit_fused: K is required when the memberships are implied by the labels")
+    else:
+        Wb, Wc = _f32c(Wb.detach()), _f32c(Wc.detach())
+        B, N, K = Wb.shape
     S = rand_idx.shape[2]
     if not fit_fused_supported(N, K, S):
         raise ValueError("fit_fused: shape N=%d K=%d S=%d is outside the fused kernel (K in {1,2,4,8}, cloud within the LDS); call the three ops" % (N, K, S))
@@ -1110,7 +1119,7 @@ def fit_fused(X, Wb, Wc, bb, seg, P, rand_idx, normalize=False, axes64=False):
     a64 = torch.empty(B, K, 3, dtype=torch.float64, device=dev) if axes64 else None
     call("p2c_fit_fused_f32", ptr(X), ptr(Wb), ptr(Wc), ptr(bb), ptr(seg), 1 if normalize else 0, ptr(P), ptr(rand_idx), B, N, K, S,
          ptr(axes), ptr(cen), ptr(cfound), ptr(ext), ptr(found), ptr(a64), ptr(ws), stream(),
-         nbytes=float(B) * N * (12 + 12 + 2 * K * 4 + 16) + float(B) * K * S * 8)
+         nbytes=float(B) * N * (12 + 12 + (0 if hard else 2 * K * 4) + 16) + float(B) * K * S * 8)
     if axes64:
         return axes, cen, cfound, ext, found, a64
     return axes, cen, cfound, ext, found

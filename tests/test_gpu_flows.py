@@ -642,6 +642,58 @@ def test_autograph_module_forward_backward_equals_eager_launches():
     autograph.reset()
 
 
+ROUTE_FLAGS = [("USE_FUSED_BWD", "P2C_FUSED_BWD"), ("USE_FUSED256", "P2C_FUSED256"), ("USE_DUAL_BWD", "P2C_DUAL_BWD"), ("USE_NARROW_BWD", "P2C_NARROW_BWD"),
+               ("USE_POOL_ALG", "P2C_POOL_ALG"), ("USE_POOL_EPI", "P2C_POOL_EPI"), ("USE_FOLD0", "P2C_FOLD0"), ("USE_PRE_LINEAR", "P2C_PRE_LINEAR"),
+               ("USE_CSR_BWD", "P2C_CSR_BWD"), ("USE_STAGED_WEIGHTS", "P2C_STAGE_WEIGHTS")]
+
+
+@pytest.mark.parametrize("flag,env", ROUTE_FLAGS)
+def test_alternate_route_equals_default_route(flag, env):
+    """every route switch the host layer still reads from the environment (README table: `env`=0 at load time sets
+    ops.`flag` False) has a run behind it.  The switched-off form sends the layers it governs down the GENERIC route of this library (the
+    tiled GEMM pair instead of the fused backward, the pooling pass instead of the GEMM epilogue, torch-side weight copies instead of the
+    staging launch, ...) - the same routes other shapes take by themselves.  One training-step forward + backward (fused losses) at
+    B = 4 x N = 2048 on recorded FPS starts and a recorded dropout mask, default route against the switched route: matching and labels
+    identical, the four loss scalars at 1e-5, every parameter gradient at 2e-4 of its norm (+ 1e-6 of the largest: zero gradients)."""
+    B, N, K = 4, 2048, 8
+    pcs, nrm, seg, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=515)
+    batch = tuple(x.to(DEV) for x in (pcs.float(), nrm.float(), seg, bb, axes.float(), cen.float()))
+    g = torch.Generator().manual_seed(4)
+    s1, s2 = torch.randint(0, N, (B,), generator=g), torch.randint(0, 512, (B,), generator=g)
+    mask = (torch.rand(B, N, 128, generator=g) < 0.5).float()
+    fl = step.StepFlags(K=K)
+    assert getattr(ops, flag) is True, "the default route must be on (is %s set in the environment of the test run?)" % env
+
+    def run():
+        torch.manual_seed(21)
+        m = backbone(output_sizes=[3, 2 * K]).to(DEV).train()
+        m.sa1.fps_start, m.sa2.fps_start, m.dropout_mask = s1, s2, mask
+        out = step.compute_losses_fused(m, *batch, fl)
+        step.backward(out)
+        torch.cuda.synchronize()
+        return ([float(out[k]) for k in ("total", "normal", "miou", "bb")], out["match"].cpu(), None,
+                {k: p.grad.detach().clone() for k, p in m.named_parameters()},
+                {k: v.detach().clone() for k, v in m.named_buffers()})
+
+    ref = run()
+    setattr(ops, flag, False)
+    try:
+        alt = run()
+    finally:
+        setattr(ops, flag, True)
+    np.testing.assert_allclose(alt[0], ref[0], rtol=1e-5)
+    assert torch.equal(alt[1], ref[1])
+    gmax = max(float(v.norm()) for v in ref[3].values())
+    for k in ref[3]:
+        d, n_ = float((alt[3][k] - ref[3][k]).norm()), float(ref[3][k].norm())
+        assert d <= 2e-4 * n_ + 1e-6 * gmax, (flag, k, d, n_)
+    for k in ref[4]:
+        if ref[4][k].dtype.is_floating_point:
+            np.testing.assert_allclose(alt[4][k].cpu().numpy(), ref[4][k].cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+        else:
+            assert torch.equal(alt[4][k], ref[4][k]), k
+
+
 def test_autograph_is_an_autograd_citizen_and_follows_moved_parameters():
     """ADVICE r4 (autograph.py:169, ops.py:862).  (a) the parameter gradients of the graphed module are real autograd outputs:
     torch.autograd.grad(loss, params) returns them (and leaves .grad alone), a parameter hook sees them, and after loss.backward() every

@@ -473,6 +473,14 @@ int p2c_linear_fwd_big_f32(const float *X, int ldx, const float *W, int ldw, con
                            void *stream);
 int p2c_linear_bwd_data_big_f32(const float *dZ, int lddz, const float *W, int ldw, const float *Z, int ldz, float beta, float threshold,
                                 float *dX, int lddx, int M, int N, int K, void *ws, void *stream);
+/* the same two products with an addend in the epilogue (ldadd % 4 == 0, 16-byte aligned, may alias the output):
+ *   p2c_linear_fwd_big_add_f32:      Y  = X . W^T + bias + add          (the decoder's skip layer as two products, IGR/network.py:75-76)
+ *   p2c_linear_bwd_data_big_add_f32: dX = (dZ . W) * sigmoid(beta Z) + add   (the two gradients a pre-activation receives in the double
+ *   backward of train_Point2Cyl.py:608-648, summed in the product's epilogue instead of by a separate pass over 0.5 GB) */
+int p2c_linear_fwd_big_add_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, const float *add, int ldadd, float *Y,
+                               int ldy, int M, int N, int K, void *ws, void *stream);
+int p2c_linear_bwd_data_big_add_f32(const float *dZ, int lddz, const float *W, int ldw, const float *Z, int ldz, float beta, float threshold,
+                                    const float *add, int ldadd, float *dX, int lddx, int M, int N, int K, void *ws, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Hungarian matching on the device (losses.py:22-52; scipy.optimize.linear_sum_assignment restated)

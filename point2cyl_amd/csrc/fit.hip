@@ -596,8 +596,9 @@ extern "C" int p2c_fit_trace_read(void *out) { return hipMemcpyFromSymbol(out, H
 // HARD: the memberships are IMPLIED by the labels (Wb[n,k] = [seg == k and bb == 0], Wc[n,k] = [seg == k and bb == 1]: pre-segmented clouds,
 // eval.py's --use_gt_segmentation --use_gt_bb operands, BASELINE configs[3]) and are not read: 40 B per point instead of 104 (SURVEY 8(d):
 // "16 B of labels if one-hot is implied").  With no per-(point, segment) operand left a lane takes a whole POINT (LPP = K/4 lanes per point
-// above 4 segments, 4 segments each): one wave instruction then fetches 32-64 distinct points instead of 8 (eight times fewer memory
-// instructions per byte), and the segment sums are selected by the label with 0/1 factors - the same products, another summation order.
+// for K segments, 2 segments each): one wave instruction then fetches 32-64 distinct points instead of 8 (eight times fewer memory
+// instructions per byte: the (slice, segment) mapping moves 32 useful bytes per wave instruction through a CU's one 64 B/clk vector
+// memory path), and the segment sums are selected by the label with 0/1 factors - the same products, another summation order.
 template <int KK, int THREADS, bool PLDS, bool HARD = false>
 __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__restrict__ X, const float *__restrict__ Wb, const float *__restrict__ Wc,
                                                                 const float *__restrict__ P, const int64_t *__restrict__ seg,
@@ -622,7 +623,8 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
     const int g = tid / KK, k = tid % KK;
     // ---------------- phase 1
     FIT_TR(0);
-    constexpr int LPP = HARD ? (KK > 4 ? KK / 4 : 1) : 1, SPL = HARD ? KK / LPP : 1;       // HARD: lanes per point, segments per lane
+    // HARD: SPL segments per lane (2: 36 accumulators - four per lane spilled at the 128 registers a 1024-thread workgroup has), LPP lanes per point
+    constexpr int SPL = HARD ? (KK >= 2 ? 2 : 1) : 1, LPP = HARD ? KK / SPL : 1;
     float acc[HARD ? 1 : NA];
     float hacc[SPL][NA];
     if constexpr (!HARD) {

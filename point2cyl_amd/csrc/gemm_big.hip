@@ -84,6 +84,7 @@ struct BigEpi {
     float *out; int ldo;
     const float *bias;                              // EPI 0: + bias[col] (may be NULL)
     const float *spz; int ldspz; float beta, thr;   // EPI 1: * sigmoid(beta * Z) (1 where beta * Z > thr); spz NULL: plain product
+    const float *add; int ldadd;                    // both: + add[row, col] after the transform above (may alias out); NULL: nothing
 };
 
 // EPI 0: forward (bias), EPI 1: data gradient (softplus derivative)
@@ -236,6 +237,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                     }
                 }
             }
+            if (epi.add) {                  // the second product of a two-operand layer, or the other gradient this tensor receives: summed here instead
+                const f32x4 ad = *reinterpret_cast<const f32x4 *>(epi.add + (size_t)row * epi.ldadd + col);      // of by a 3-stream add pass
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v4[c] += ad[c];
+            }
             *reinterpret_cast<f32x4 *>(epi.out + (size_t)row * epi.ldo + col) = v4;
         }
     }
@@ -286,7 +292,18 @@ extern "C" int p2c_linear_fwd_big_f32(const float *X, int ldx, const float *W, i
 {
     if (!X || !W || !Y || !ws || !p2c_linear_big_supported(M, N, K)) return P2C_EINVAL;
     if ((ldx & 3) || (ldy & 3) || (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)ws) & 15)) return P2C_EALIGN;
-    BigEpi e{Y, ldy, bias, nullptr, 0, 0.f, 0.f};
+    BigEpi e{Y, ldy, bias, nullptr, 0, 0.f, 0.f, nullptr, 0};
+    return big_launch(0, X, ldx, W, ldw, N, K, 0, e, M, ws, (hipStream_t)stream);
+}
+
+// ... + add[M,N] (ldadd % 4 == 0, 16-byte aligned; may be Y itself: accumulate in place).  A layer fed by two operands (the decoder's skip
+// layer: [h | input] . W^T = h . Wa^T + input . Wb^T) runs as two products, the second adding the first's result in its epilogue.
+extern "C" int p2c_linear_fwd_big_add_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, const float *add, int ldadd, float *Y,
+                                          int ldy, int M, int N, int K, void *ws, void *stream)
+{
+    if (!X || !W || !Y || !ws || !add || !p2c_linear_big_supported(M, N, K)) return P2C_EINVAL;
+    if ((ldx & 3) || (ldy & 3) || (ldadd & 3) || (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)ws | (uintptr_t)add) & 15)) return P2C_EALIGN;
+    BigEpi e{Y, ldy, bias, nullptr, 0, 0.f, 0.f, add, ldadd};
     return big_launch(0, X, ldx, W, ldw, N, K, 0, e, M, ws, (hipStream_t)stream);
 }
 
@@ -297,6 +314,19 @@ extern "C" int p2c_linear_bwd_data_big_f32(const float *dZ, int lddz, const floa
 {
     if (!dZ || !W || !dX || !ws || !p2c_linear_big_supported(M, N, K) || (Z && beta <= 0.f)) return P2C_EINVAL;
     if ((lddz & 3) || (lddx & 3) || (Z && (ldz & 3)) || (((uintptr_t)dZ | (uintptr_t)dX | (uintptr_t)ws | (uintptr_t)Z) & 15)) return P2C_EALIGN;
-    BigEpi e{dX, lddx, nullptr, Z, ldz, beta, threshold};
+    BigEpi e{dX, lddx, nullptr, Z, ldz, beta, threshold, nullptr, 0};
+    return big_launch(1, dZ, lddz, W, ldw, N, K, 1, e, M, ws, (hipStream_t)stream);
+}
+
+// ... + add[M,K] after the (optional) softplus derivative: dX = (dZ . W) * sigmoid(beta Z) + add.  The double backward of the decoder gives
+// every pre-activation two gradients (through the forward pass and through the first backward pass); the second arrives here.
+extern "C" int p2c_linear_bwd_data_big_add_f32(const float *dZ, int lddz, const float *W, int ldw, const float *Z, int ldz, float beta, float threshold,
+                                               const float *add, int ldadd, float *dX, int lddx, int M, int N, int K, void *ws, void *stream)
+{
+    if (!dZ || !W || !dX || !ws || !add || !p2c_linear_big_supported(M, N, K) || (Z && beta <= 0.f)) return P2C_EINVAL;
+    if ((lddz & 3) || (lddx & 3) || (ldadd & 3) || (Z && (ldz & 3)) ||
+        (((uintptr_t)dZ | (uintptr_t)dX | (uintptr_t)ws | (uintptr_t)Z | (uintptr_t)add) & 15))
+        return P2C_EALIGN;
+    BigEpi e{dX, lddx, nullptr, Z, ldz, beta, threshold, add, ldadd};
     return big_launch(1, dZ, lddz, W, ldw, N, K, 1, e, M, ws, (hipStream_t)stream);
 }

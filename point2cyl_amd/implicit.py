@@ -364,3 +364,185 @@ class NormalPerPoint:
         near = pc_input + torch.randn_like(pc_input) * sigma
         far = (torch.rand(nb, ns // 8, d, device=pc_input.device) * 2.0 - 1.0) * self.global_sigma
         return torch.cat([near, far], dim=1)
+
+
+# ------------------------------------------------------------------------------------------ value + input gradient of a FROZEN decoder as one node
+def _prod_nt(X, W, bias=None, add=None):
+    """X [M,K] . W [N,K]^T (+ bias) (+ add [M,N]) -> [M,N]; the big-tile kernel takes the addend in its epilogue, other shapes add afterwards."""
+    M, K = X.shape
+    N = W.shape[0]
+    Y = torch.empty(M, N, dtype=torch.float32, device=X.device)
+    ws = _big(M, N, K, X.device)
+    if ws is not None and X.stride(0) % 4 == 0:
+        if add is not None:
+            call("p2c_linear_fwd_big_add_f32", ptr(X), X.stride(0), ptr(W), K, ptr(bias), ptr(add), add.stride(0), ptr(Y), N, M, N, K, ptr(ws), stream(),
+                 flops=2.0 * M * N * K)
+        else:
+            call("p2c_linear_fwd_big_f32", ptr(X), X.stride(0), ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, ptr(ws), stream(), flops=2.0 * M * N * K)
+        return Y
+    call("p2c_linear_fwd_f32", ptr(X), X.stride(0), ptr(W), K, ptr(bias), ptr(Y), N, M, N, K, 0, None, None, None, 0, 1.0, None, stream(),
+         flops=2.0 * M * N * K)
+    if add is not None:
+        Y.add_(add)
+    return Y
+
+
+def _prod_nn(A, W, z=None, beta=0.0, thr=20.0, add=None):
+    """(A [M,N] . W [N,K]) (* sigmoid(beta z) when z is given) (+ add) -> [M,K]."""
+    M, N = A.shape
+    K = W.shape[1]
+    O = torch.empty(M, K, dtype=torch.float32, device=A.device)
+    ws = _big(M, N, K, A.device)
+    if ws is not None:
+        if add is not None:
+            call("p2c_linear_bwd_data_big_add_f32", ptr(A), N, ptr(W), K, ptr(z), K if z is not None else 0, beta, thr, ptr(add), add.stride(0), ptr(O), K,
+                 M, N, K, ptr(ws), stream(), flops=2.0 * M * N * K)
+        else:
+            call("p2c_linear_bwd_data_big_f32", ptr(A), N, ptr(W), K, ptr(z), K if z is not None else 0, beta, thr, ptr(O), K, M, N, K, ptr(ws), stream(),
+                 flops=2.0 * M * N * K)
+        return O
+    if z is not None:
+        call("p2c_linear_bwd_data_sig_f32", ptr(A), N, ptr(W), K, ptr(z), K, beta, thr, ptr(O), K, M, N, K, stream(), flops=2.0 * M * N * K)
+    else:
+        call("p2c_linear_bwd_data_f32", ptr(A), N, None, 0, 0, None, ptr(W), K, ptr(O), K, M, N, K, None, 0, 1.0, None, 0, None, None, None, 0, stream(),
+             flops=2.0 * M * N * K)
+    if add is not None:
+        O.add_(add)
+    return O
+
+
+def _decoder_layout(net, d_in):
+    """The padded operands of `net` for inputs of width d_in: per layer (Wa [Np, Kp_prev], Wb [Np, Dp] | None, bias [Np], N, Np) with
+    Dp = pad4(d_in); Wb is the block of a skip layer's weight that multiplies the re-injected input, both blocks already divided by sqrt 2
+    (IGR/network.py:75-76).  Pad rows / columns / bias entries are zero."""
+    Dp = d_in + (-d_in) % 4
+    out, prev_n, prev_np = [], d_in, Dp
+    for layer in range(net.num_layers - 1):
+        lin = getattr(net, "lin" + str(layer))
+        w, b = lin.weight.detach(), lin.bias.detach()
+        N = w.shape[0]
+        Np = N + (-N) % 4
+        skip = layer in net.skip_in
+        if w.shape[1] != prev_n + (d_in if skip else 0):
+            raise RuntimeError("ImplicitNet: layer %d expects %d inputs, the layout gives %d" % (layer, w.shape[1], prev_n + (d_in if skip else 0)))
+        sc = 1.0 / np.sqrt(2) if skip else 1.0
+        Wa = torch.zeros(Np, prev_np, dtype=torch.float32, device=w.device)
+        Wa[:N, :prev_n] = w[:, :prev_n] * sc
+        Wb = None
+        if skip:
+            Wb = torch.zeros(Np, Dp, dtype=torch.float32, device=w.device)
+            Wb[:N, :d_in] = w[:, prev_n:] * sc
+        bp = torch.zeros(Np, dtype=torch.float32, device=w.device)
+        bp[:N] = b
+        out.append((Wa, Wb, bp, N, Np))
+        prev_n, prev_np = N, Np
+    return out
+
+
+class _DecoderVG(torch.autograd.Function):
+    """(pred, g) = (net(a), d sum(net(a)) / d a) of a FROZEN softplus decoder (IGR/network.py:8-17, :20-92) as ONE autograd node whose
+    backward is the hand-written double backward w.r.t. the input `a` (train_Point2Cyl.py:608-648 differentiates the eikonal / SALD terms
+    through `gradient(a, pred)`).  Composed from autograd Functions (the route a trainable decoder still takes) every pre-activation
+    receives two gradients that autograd sums with a 3-stream pass over 0.5 GB, and the 258 / 254-wide tensors are sliced, padded and
+    concatenated around the products; here the four sweeps are written out and those sums ride in the products' epilogues:
+      F   z_0 = a W_0^T + b_0, z_l = softplus(z_{l-1}) W_l^T + b_l (a skip layer as two products: [h | a] W^T = h Wa^T + a Wb^T)
+      R1  e_L = 1, e_{l-1} = (e_l W_l) * s_{l-1},  s = sigmoid(beta z);  da = e_0 W_0 + (e_skip Wb)          -> g = da
+      T   (given ga = dL/dg)  E_0 = ga W_0^T, (t_l, q_l) = (E_l s_l, E_l e_l beta (1 - s_l)),  E_{l+1} = t_l W_{l+1}^T (+ ga Wb^T at the skip)
+      B   Z_L = dL/dpred,  Z_{l-1} = (Z_l W_l) * s_{l-1} + q_{l-1},  dL/da = Z_0 W_0 + Z_skip Wb
+    T is the forward-mode derivative of the network in direction ga; q collects what the first backward contributes to each z."""
+
+    @staticmethod
+    def forward(ctx, a, net, d_in):
+        lay = _decoder_layout(net, d_in)
+        beta, thr = float(net.beta), 20.0
+        L = len(lay)
+        M = a.shape[0]
+        Dp = d_in + (-d_in) % 4
+        ap = a if a.shape[1] == Dp else F.pad(a, (0, Dp - a.shape[1]))
+        ap = _c(ap.detach())
+        zs, x = [], ap
+        for l, (Wa, Wb, b, N, Np) in enumerate(lay):
+            h = x
+            if l > 0:
+                h = torch.empty_like(x)
+                call("p2c_softplus_fwd_f32", ptr(x), ptr(h), x.numel(), beta, thr, stream(), nbytes=8.0 * x.numel())
+            z = _prod_nt(h, Wa, b)
+            if Wb is not None:
+                z = _prod_nt(ap, Wb, None, add=z)
+            zs.append(z)
+            x = z
+        pred = zs[-1][:, :lay[-1][3]].contiguous() if lay[-1][4] != lay[-1][3] else zs[-1]
+        # R1: e_{L-1} = ones (only the real output columns)
+        e = torch.zeros(M, lay[-1][4], dtype=torch.float32, device=a.device)
+        e[:, :lay[-1][3]] = 1.0
+        es = [None] * L
+        skip_term = None
+        for l in range(L - 1, 0, -1):
+            Wa, Wb, _, _, _ = lay[l]
+            if Wb is not None:
+                skip_term = _prod_nn(e, Wb) if skip_term is None else _prod_nn(e, Wb, add=skip_term)
+            e = _prod_nn(e, Wa, zs[l - 1], beta, thr)
+            es[l - 1] = e
+        da = _prod_nn(e, lay[0][0], add=skip_term)
+        g = da[:, :d_in]
+        ctx.lay, ctx.bt, ctx.d_in, ctx.Dp = lay, (beta, thr), d_in, Dp
+        ctx.save_for_backward(ap, *zs[:-1], *es[:-1])
+        ctx.set_materialize_grads(False)
+        return pred, g
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gpred, gg):
+        lay, (beta, thr), d_in, Dp = ctx.lay, ctx.bt, ctx.d_in, ctx.Dp
+        L = len(lay)
+        saved = ctx.saved_tensors
+        ap, zs, es = saved[0], saved[1:L], saved[L:]
+        M = ap.shape[0]
+        dev = ap.device
+        qs = [None] * (L - 1)
+        if gg is not None:
+            ga = F.pad(_c(gg), (0, Dp - d_in)) if Dp != d_in else _c(gg)
+            # T: forward-mode sweep in direction ga
+            E = _prod_nt(ga, lay[0][0])                                # adjoint of da = e_0 W_0:  E_0 = ga [M,Dp] . W_0 [N0p,Dp]^T
+            for l in range(L - 1):
+                t, q = torch.empty_like(zs[l]), torch.empty_like(zs[l])
+                call("p2c_softplus_sig_bwd_f32", ptr(E), ptr(es[l]), ptr(zs[l]), ptr(t), ptr(q), zs[l].numel(), beta, thr, stream(),
+                     nbytes=20.0 * zs[l].numel())
+                qs[l] = q
+                if l + 1 < L - 1:
+                    Wa, Wb = lay[l + 1][0], lay[l + 1][1]
+                    E = _prod_nt(t, Wa)
+                    if Wb is not None:
+                        E = _prod_nt(ga, Wb, None, add=E)
+        # B: reverse sweep of the total gradients of the pre-activations
+        Np_last, N_last = lay[-1][4], lay[-1][3]
+        if gpred is not None:
+            Z = F.pad(_c(gpred), (0, Np_last - N_last)) if Np_last != N_last else _c(gpred)
+        else:
+            Z = None
+        skip_term = None
+        for l in range(L - 1, 0, -1):
+            Wa, Wb = lay[l][0], lay[l][1]
+            q = qs[l - 1]
+            if Z is None:                        # no gradient arrives from above: this pre-activation's total is its q alone
+                Z = q
+                continue
+            if Wb is not None:
+                skip_term = _prod_nn(Z, Wb) if skip_term is None else _prod_nn(Z, Wb, add=skip_term)
+            Z = _prod_nn(Z, Wa, zs[l - 1], beta, thr, add=q)
+        if Z is None:
+            return None, None, None
+        dA = _prod_nn(Z, lay[0][0], add=skip_term)
+        return (dA[:, :d_in] if Dp != d_in else dA), None, None
+
+
+def decoder_value_and_grad_applicable(net):
+    """The one-node route needs a frozen decoder with softplus activations (the with-sketch trainer's: implicit_net.eval(), requires_grad False)."""
+    return net.beta > 0 and not any(p.requires_grad for p in net.parameters())
+
+
+def decoder_value_and_grad(net, a):
+    """-> (net(a) [M,1], d sum(net(a)) / d a [M, d_in]) with the graph kept through ONE node (see _DecoderVG); `a` [M, d_in] on the device."""
+    if not a.is_cuda:
+        raise RuntimeError("point2cyl_amd.implicit.decoder_value_and_grad runs on the HIP device only (got %s); there is no CPU path" % a.device)
+    return _DecoderVG.apply(a, net, a.shape[1])

@@ -7,16 +7,25 @@ its double backward (csrc/gemm.hip)."""
 import torch
 
 from . import fitting, losses
-from .implicit import add_latent, gradient
+from .implicit import add_latent, decoder_value_and_grad, decoder_value_and_grad_applicable, gradient
+
+USE_DECODER_NODE = True      # the frozen decoder's value + input gradient as ONE autograd node (implicit._DecoderVG); False: composed Functions
 
 
 def implicit_losses(implicit_net, sk_pnts, sk_normals, nonmnfld_pnts, latent_codes, mask_gt, batch_size, K):
     """train_Point2Cyl.py:610-648 -> (im_loss, mnfld_loss, grad_loss, normals_loss)."""
     a = add_latent(sk_pnts, latent_codes).requires_grad_()
     n = add_latent(nonmnfld_pnts, latent_codes).requires_grad_()
-    sk_pred, nonmnfld_pred = implicit_net(a), implicit_net(n)
-    mnfld_grad = gradient(a, sk_pred).reshape(batch_size, K, -1, 2)
-    nonmnfld_grad = gradient(n, nonmnfld_pred).reshape(batch_size, K, -1, 2)
+    if USE_DECODER_NODE and decoder_value_and_grad_applicable(implicit_net):
+        # frozen decoder (the trainer's: :352-365): forward, input gradient and their double backward hand-written as one node - the sums of
+        # the two gradients every pre-activation receives ride in the products' epilogues (implicit._DecoderVG)
+        sk_pred, ga = decoder_value_and_grad(implicit_net, a)
+        nonmnfld_pred, gn = decoder_value_and_grad(implicit_net, n)
+        mnfld_grad, nonmnfld_grad = ga[:, -2:].reshape(batch_size, K, -1, 2), gn[:, -2:].reshape(batch_size, K, -1, 2)
+    else:
+        sk_pred, nonmnfld_pred = implicit_net(a), implicit_net(n)
+        mnfld_grad = gradient(a, sk_pred).reshape(batch_size, K, -1, 2)
+        nonmnfld_grad = gradient(n, nonmnfld_pred).reshape(batch_size, K, -1, 2)
     sk_normals = sk_normals.reshape(batch_size, K, -1, 2)
     mnfld_loss = losses.reduce_mean_masked_instance(sk_pred.reshape(batch_size, K, -1, 1).abs().mean(dim=-1).mean(dim=-1), mask_gt).mean()
     grad_loss = losses.reduce_mean_masked_instance(((nonmnfld_grad.norm(2, dim=-1) - 1) ** 2).mean(dim=-1), mask_gt).mean()

@@ -1228,6 +1228,70 @@ def test_big_tile_products_vs_float64(M, N, K):
     assert L.p2c_linear_fwd_big_f32(ptr(X), K + 1, ptr(W), K, ptr(b), ptr(Y), N, M, N, K, ptr(ws), None) == -2
 
 
+@pytest.mark.parametrize("M,dims,skip,d_lat", [(300, [64, 64, 64, 64], (2,), 30), (20000, [256, 256, 256, 256, 256], (3,), 254), (777, [32, 32], (), 6)])
+def test_decoder_value_and_grad_node_equals_composed_functions(M, dims, skip, d_lat):
+    """implicit._DecoderVG (forward + input gradient + their double backward of a FROZEN decoder as ONE autograd node,
+    the gradient sums in the GEMM epilogues) against the composition of autograd Functions it replaces (ImplicitNet.forward + gradient(),
+    what a trainable decoder still takes) and against float64 torch: pred, the input gradient g, and d(loss)/d(input) of a loss that uses
+    pred, g (eikonal- and normal-type terms, train_Point2Cyl.py:610-648) - with and without a skip layer, odd widths (d_in = d_lat + 2 not a
+    multiple of 4, the layer in front of the skip d_in short of the width), rows that exercise the big-tile kernels' addend epilogues
+    (M = 20000 >= 16384, widths >= 128) and the tiled ones."""
+    from point2cyl_amd import implicit
+    torch.manual_seed(M)
+    d_in = d_lat + 2
+    net = implicit.ImplicitNet(d_in=d_in, dims=list(dims), skip_in=list(skip), geometric_init=True, radius_init=1, beta=100).to(DEV)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            p_.add_(0.02 * torch.randn_like(p_))
+    lat = (torch.randn(M, d_lat, device=DEV) * 0.3)
+    pts = torch.rand(M, 2, device=DEV) * 2 - 1
+    nrm = F.normalize(torch.randn(M, 2, device=DEV), dim=-1)
+
+    def loss_of(pred, g):
+        g2 = g[:, -2:]
+        return pred.abs().mean() + 0.1 * ((g2.norm(2, dim=-1) - 1) ** 2).mean() + torch.minimum((g2 - nrm).norm(2, dim=-1), (g2 + nrm).norm(2, dim=-1)).mean()
+
+    def run(node):
+        a = torch.cat([lat, pts], 1).requires_grad_()
+        if node:
+            for p_ in net.parameters():
+                p_.requires_grad_(False)
+            assert implicit.decoder_value_and_grad_applicable(net)
+            pred, g = implicit.decoder_value_and_grad(net, a)
+        else:
+            for p_ in net.parameters():
+                p_.requires_grad_(True)                     # (a trainable decoder: the composed route; its parameter gradients are not compared)
+            pred = net(a)
+            (g,) = torch.autograd.grad(pred, a, grad_outputs=torch.ones_like(pred), create_graph=True, retain_graph=True)
+        ls = loss_of(pred, g)
+        (da,) = torch.autograd.grad(ls, a)
+        return pred.detach(), g.detach(), da.detach(), float(ls)
+
+    p1, g1, d1, l1 = run(True)
+    p0, g0, d0, l0 = run(False)
+    # float64 torch reference of the same network
+    Ws = [(getattr(net, "lin%d" % i).weight.detach().double().cpu(), getattr(net, "lin%d" % i).bias.detach().double().cpu()) for i in range(net.num_layers - 1)]
+    a64 = torch.cat([lat, pts], 1).double().cpu().requires_grad_()
+    x = a64
+    for i, (w, b) in enumerate(Ws):
+        if i in skip:
+            x = torch.cat([x, a64], 1) / np.sqrt(2)
+        x = F.linear(x, w, b)
+        if i < len(Ws) - 1:
+            x = F.softplus(x, beta=100)
+    (g64,) = torch.autograd.grad(x, a64, grad_outputs=torch.ones_like(x), create_graph=True)
+    nrm64 = nrm.double().cpu()
+    g2 = g64[:, -2:]
+    l64 = x.abs().mean() + 0.1 * ((g2.norm(2, dim=-1) - 1) ** 2).mean() + torch.minimum((g2 - nrm64).norm(2, dim=-1), (g2 + nrm64).norm(2, dim=-1)).mean()
+    (d64,) = torch.autograd.grad(l64, a64)
+    for mine, comp, ref in ((p1, p0, x.detach()), (g1, g0, g64.detach()), (d1, d0, d64)):
+        ref = ref.float()
+        e1 = float((mine.cpu() - ref).norm() / ref.norm())
+        e0 = float((comp.cpu() - ref).norm() / ref.norm())
+        assert e1 <= max(2e-5, 2.0 * e0), (e1, e0)          # as accurate as the composed route (fp32 products either way)
+    assert abs(l1 - float(l64)) <= 1e-5 * abs(float(l64)) and abs(l1 - l0) <= 1e-5 * abs(l0)
+
+
 def test_implicit_decoder_big_tiles_vs_oracle_trainer_shapes():
     """As test_implicit_decoder_vs_oracle_trainer_shapes, with enough rows (4 x 2 sketches of 2048 points: 16 384 and 18 432 rows) that every
     512-wide product of the three passes takes the big-tile route; and the same losses / gradients with the route switched off."""

@@ -42,6 +42,32 @@ __device__ __forceinline__ int p2c_wave_max_i32(int v)
     return max(max(a, b), max(c, d));
 }
 
+// Sum over the lanes of a wave that share lane % STRIDE (STRIDE a power of two <= 16), every lane ending with the sum of ITS class:
+// rotations inside the 16-lane row on the DPP path (row_ror: a VALU operand modifier), the two cross-row steps with gfx950's
+// v_permlane16_swap / v_permlane32_swap (VALU) - no ds_bpermute round trip (~100 cycles each; __shfl_xor always takes that route).
+// With both operands the same register a swap leaves {rows 0,0,2,2 | rows 1,1,3,3} (16) resp. {lanes 0-31 twice | lanes 32-63 twice} (32)
+// in the two results: their sum is the xor-16 / xor-32 exchange sum.
+template <int STRIDE>
+__device__ __forceinline__ float p2c_wave_class_sum_f32(float v)
+{
+    static_assert(STRIDE == 1 || STRIDE == 2 || STRIDE == 4 || STRIDE == 8 || STRIDE == 16, "");
+    if (STRIDE <= 1) v += __int_as_float(p2c_dpp<0x121>(__float_as_int(v)));      // row_ror:1
+    if (STRIDE <= 2) v += __int_as_float(p2c_dpp<0x122>(__float_as_int(v)));      // row_ror:2
+    if (STRIDE <= 4) v += __int_as_float(p2c_dpp<0x124>(__float_as_int(v)));      // row_ror:4
+    if (STRIDE <= 8) v += __int_as_float(p2c_dpp<0x128>(__float_as_int(v)));      // row_ror:8
+    {
+        const unsigned u = (unsigned)__float_as_int(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+    }
+    {
+        const unsigned u = (unsigned)__float_as_int(v);
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        v = __int_as_float((int)r[0]) + __int_as_float((int)r[1]);
+    }
+    return v;
+}
+
 __device__ __forceinline__ float p2c_wave_sum_f32(float v)
 {
 #pragma unroll

@@ -713,9 +713,7 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
             for (int j = 0; j < SPL; ++j)
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    float v = hacc[j][i];
-#pragma unroll
-                    for (int o = LPP; o < 64; o <<= 1) v += __shfl_xor(v, o);      // the lanes of this segment group in the wave: lane % LPP
+                    const float v = p2c_wave_class_sum_f32<LPP>(hacc[j][i]);      // the lanes of this segment group in the wave: lane % LPP
                     if (lane < LPP) wsum[(wave * KK + lane * SPL + j) * NA + i] = (double)v;
                 }
         } else {

@@ -446,7 +446,8 @@ class _DecoderVG(torch.autograd.Function):
     receives two gradients that autograd sums with a 3-stream pass over 0.5 GB, and the 258 / 254-wide tensors are sliced, padded and
     concatenated around the products; here the four sweeps are written out and those sums ride in the products' epilogues:
       F   z_0 = a W_0^T + b_0, z_l = softplus(z_{l-1}) W_l^T + b_l (a skip layer as two products: [h | a] W^T = h Wa^T + a Wb^T)
-      R1  e_L = 1, e_{l-1} = (e_l W_l) * s_{l-1},  s = sigmoid(beta z);  da = e_0 W_0 + (e_skip Wb)          -> g = da
+      R1  e_L = 1, e_{l-1} = (e_l W_l) * s_{l-1},  s = sigmoid(beta z);  da = e_0 W_0 + (e_skip Wb)          -> g = da[:, -2:] (only those
+          columns are formed: the reference's gradient() keeps nothing else, IGR/network.py:17)
       T   (given ga = dL/dg)  E_0 = ga W_0^T, (t_l, q_l) = (E_l s_l, E_l e_l beta (1 - s_l)),  E_{l+1} = t_l W_{l+1}^T (+ ga Wb^T at the skip)
       B   Z_L = dL/dpred,  Z_{l-1} = (Z_l W_l) * s_{l-1} + q_{l-1},  dL/da = Z_0 W_0 + Z_skip Wb
     T is the forward-mode derivative of the network in direction ga; q collects what the first backward contributes to each z."""
@@ -477,15 +478,18 @@ class _DecoderVG(torch.autograd.Function):
         e[:, :lay[-1][3]] = 1.0
         es = [None] * L
         skip_term = None
+        g0 = (d_in - 2) // 4 * 4                                    # the 4-aligned column block that holds the two point columns of the input
+        w0g = lay[0][0][:, g0:].contiguous()
         for l in range(L - 1, 0, -1):
             Wa, Wb, _, _, _ = lay[l]
             if Wb is not None:
-                skip_term = _prod_nn(e, Wb) if skip_term is None else _prod_nn(e, Wb, add=skip_term)
+                wbg = Wb[:, g0:].contiguous()
+                skip_term = _prod_nn(e, wbg) if skip_term is None else _prod_nn(e, wbg, add=skip_term)
             e = _prod_nn(e, Wa, zs[l - 1], beta, thr)
             es[l - 1] = e
-        da = _prod_nn(e, lay[0][0], add=skip_term)
-        g = da[:, :d_in]
-        ctx.lay, ctx.bt, ctx.d_in, ctx.Dp = lay, (beta, thr), d_in, Dp
+        da = _prod_nn(e, w0g, add=skip_term)                      # only the g0..g1 columns of da = e_0 W_0 + e_skip Wb are ever used
+        g = da[:, d_in - 2 - g0:d_in - g0]
+        ctx.lay, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0 = lay, (beta, thr), d_in, Dp, g0
         ctx.save_for_backward(ap, *zs[:-1], *es[:-1])
         ctx.set_materialize_grads(False)
         return pred, g
@@ -493,7 +497,7 @@ class _DecoderVG(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gpred, gg):
-        lay, (beta, thr), d_in, Dp = ctx.lay, ctx.bt, ctx.d_in, ctx.Dp
+        lay, (beta, thr), d_in, Dp, g0 = ctx.lay, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0
         L = len(lay)
         saved = ctx.saved_tensors
         ap, zs, es = saved[0], saved[1:L], saved[L:]
@@ -501,9 +505,11 @@ class _DecoderVG(torch.autograd.Function):
         dev = ap.device
         qs = [None] * (L - 1)
         if gg is not None:
-            ga = F.pad(_c(gg), (0, Dp - d_in)) if Dp != d_in else _c(gg)
+            # the adjoint of g lives in the block's two point columns only: the products with W_0 / Wb shrink to that 4-aligned column block
+            ga = torch.zeros(M, Dp - g0, dtype=torch.float32, device=dev)
+            ga[:, d_in - 2 - g0:d_in - g0] = gg
             # T: forward-mode sweep in direction ga
-            E = _prod_nt(ga, lay[0][0])                                # adjoint of da = e_0 W_0:  E_0 = ga [M,Dp] . W_0 [N0p,Dp]^T
+            E = _prod_nt(ga, lay[0][0][:, g0:].contiguous())           # adjoint of da = e_0 W_0:  E_0 = ga . W_0[:, block]^T
             for l in range(L - 1):
                 t, q = torch.empty_like(zs[l]), torch.empty_like(zs[l])
                 call("p2c_softplus_sig_bwd_f32", ptr(E), ptr(es[l]), ptr(zs[l]), ptr(t), ptr(q), zs[l].numel(), beta, thr, stream(),
@@ -513,7 +519,7 @@ class _DecoderVG(torch.autograd.Function):
                     Wa, Wb = lay[l + 1][0], lay[l + 1][1]
                     E = _prod_nt(t, Wa)
                     if Wb is not None:
-                        E = _prod_nt(ga, Wb, None, add=E)
+                        E = _prod_nt(ga, Wb[:, g0:].contiguous(), None, add=E)
         # B: reverse sweep of the total gradients of the pre-activations
         Np_last, N_last = lay[-1][4], lay[-1][3]
         if gpred is not None:
@@ -542,7 +548,8 @@ def decoder_value_and_grad_applicable(net):
 
 
 def decoder_value_and_grad(net, a):
-    """-> (net(a) [M,1], d sum(net(a)) / d a [M, d_in]) with the graph kept through ONE node (see _DecoderVG); `a` [M, d_in] on the device."""
+    """-> (net(a) [M,1], gradient(a, net(a)) = d sum(net(a)) / d a [:, -2:] [M,2]) with the graph kept through ONE node (see _DecoderVG);
+    `a` [M, d_in] on the device."""
     if not a.is_cuda:
         raise RuntimeError("point2cyl_amd.implicit.decoder_value_and_grad runs on the HIP device only (got %s); there is no CPU path" % a.device)
     return _DecoderVG.apply(a, net, a.shape[1])

@@ -314,6 +314,11 @@ class FittingWorkload:
             dh = (time.perf_counter() - t0) / steps
             hbytes = self.points * (12 + 12 + 8 + 8) + self.n * self.K * self.S * 8
             dot = (oh[5] * out[5]).sum(-1).abs().clamp(max=1.0)
+            res["soft_membership_route"] = {k: res[k] for k in ("ms", "cylinders_per_s", "points_per_s", "kernel_us", "path_bytes", "frac_hbm_path_bytes",
+                                                                "frac_hbm_76B_per_point", "kernel_frac_hbm")}
+            res["soft_membership_route"]["what"] = ("the same kernel family READING Wb / Wc (B,N,K) fp32 - what soft (predicted) memberships need: 104 B/point; "
+                                                    "the top-level numbers of this object are the labels-implied route below, the one configs[3]'s pre-segmented "
+                                                    "clouds call for")
             res["labels_implied"] = dict(
                 what="p2c_fit_fused_f32 with Wb = Wc = NULL: memberships implied by (seg, bb), not read; lane-per-point streaming",
                 ms=round(dh * 1e3, 4), cylinders_per_s=round(self.n * self.K / dh, 1), path_bytes=hbytes,
@@ -323,6 +328,12 @@ class FittingWorkload:
                 vs_general_route=dict(max_axis_angle_deg=float(torch.rad2deg(torch.acos(dot)).max()),
                                       max_centroid_diff=float((oh[1] - out[1]).abs().max()), max_extent_diff=float((oh[3] - out[3]).abs().max()),
                                       found_masks_equal=bool(torch.equal(oh[2], out[2]) and torch.equal(oh[4], out[4]))))
+            li = res["labels_implied"]
+            res.update(ms=li["ms"], cylinders_per_s=li["cylinders_per_s"], points_per_s=round(self.points / dh, 1), path_bytes=hbytes,
+                       frac_hbm_path_bytes=li["frac_hbm_path_bytes"], frac_hbm_76B_per_point=li["frac_hbm_76B_per_point"],
+                       kernels="one pass per cloud (fit_fused, memberships implied by the labels: Wb = Wc = NULL)", kernel_us=None, kernel_frac_hbm=None,
+                       route="labels-implied memberships (pre-segmented clouds); soft_membership_route = the same with Wb / Wc read")
+            out = oh
         return res, out
 
 

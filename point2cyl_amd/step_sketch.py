@@ -21,7 +21,7 @@ def implicit_losses(implicit_net, sk_pnts, sk_normals, nonmnfld_pnts, latent_cod
         # the two gradients every pre-activation receives ride in the products' epilogues (implicit._DecoderVG)
         sk_pred, ga = decoder_value_and_grad(implicit_net, a)
         nonmnfld_pred, gn = decoder_value_and_grad(implicit_net, n)
-        mnfld_grad, nonmnfld_grad = ga[:, -2:].reshape(batch_size, K, -1, 2), gn[:, -2:].reshape(batch_size, K, -1, 2)
+        mnfld_grad, nonmnfld_grad = ga.reshape(batch_size, K, -1, 2), gn.reshape(batch_size, K, -1, 2)
     else:
         sk_pred, nonmnfld_pred = implicit_net(a), implicit_net(n)
         mnfld_grad = gradient(a, sk_pred).reshape(batch_size, K, -1, 2)

@@ -112,11 +112,12 @@ def main():
                 value=res["cylinders_per_s"], unit="cylinders/s", n_gpus=1, steps=a.steps, ms_per_step=res["ms"],
                 points_per_s=res["points_per_s"], dtype="f32 (scatter sums, eigen-solve and the axis output in f64)", data="synthetic",
                 config=dict(workload=res["workload"], kernels=res["kernels"]),
-                roofline=dict(bound="hbm", kernel=res["kernel"], achieved=round((res["kernel_frac_hbm"] or 0) * 8000.0, 1), peak=8000.0, unit="GB/s",
-                              frac=res["kernel_frac_hbm"], avg_launch_us=res["kernel_us"], traffic=None,
+                roofline=dict(bound="hbm", kernel=res["kernel"], achieved=round((res["kernel_frac_hbm"] or res["frac_hbm_path_bytes"] or 0) * 8000.0, 1), peak=8000.0,
+                              unit="GB/s", frac=res["kernel_frac_hbm"] or res["frac_hbm_path_bytes"], avg_launch_us=res["kernel_us"], traffic=None,
                               path=dict(ms=res["ms"], algorithmic_bytes=res["path_bytes"], frac=res["frac_hbm_path_bytes"],
                                         survey_76B_per_point_bytes=res["survey_bytes_76_per_point"], frac_76B_per_point=res["frac_hbm_76B_per_point"])),
-                cpu_baseline=cpu, parity=parity, kernels=res["per_kernel"])
+                cpu_baseline=cpu, parity=parity, kernels=res["per_kernel"], route=res.get("route"), labels_implied=res.get("labels_implied"),
+                soft_membership_route=res.get("soft_membership_route"))
     print(json.dumps(line))
 
 

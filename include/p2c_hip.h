@@ -460,6 +460,16 @@ int p2c_linear_bwd_data_sig_f32(const float *dZ, int lddz, const float *W, int l
                                 float *dX, int lddx, int M, int N, int K, void *stream);
 int p2c_softplus_sig_bwd_f32(const float *g, const float *a, const float *z, float *t, float *dz, long long n, float beta, float threshold,
                              void *stream);
+/* Row-structured variants for the two ends of the decoder (one output unit; an input gradient used in two columns): z, q, e, Ein and the
+ * matrix outputs are [M, K] contiguous, K % 4 == 0, w / wa / wb are [K] rows of the layer's weight.
+ *   p2c_softplus_dot_f32:           out[m] = softplus(z[m,:]) . w + bias[0]                     (IGR/network.py:84-86, last layer forward)
+ *   p2c_softplus_row_bwd_f32:       o[m,c] = (g ? g[m*ldg] : 1) * w[c] * sigmoid(beta z[m,c]) + (q ? q[m,c] : 0)
+ *   p2c_softplus_sig_bwd_rank2_f32: E = (Ein ? Ein : 0) + ga[m*ldg] wa[c] + ga[m*ldg+1] wb[c];  t = E s(z),  dz = E e beta (1 - s(z)) */
+int p2c_softplus_dot_f32(const float *z, const float *w, const float *bias, float *out, long long M, int K, float beta, float threshold, void *stream);
+int p2c_softplus_row_bwd_f32(const float *g, int ldg, const float *w, const float *z, const float *q, float *o, long long M, int K, float beta,
+                             float threshold, void *stream);
+int p2c_softplus_sig_bwd_rank2_f32(const float *ga, int ldg, const float *wa, const float *wb, const float *Ein, const float *e, const float *z,
+                                   float *t, float *dz, long long M, int K, float beta, float threshold, void *stream);
 
 /* The same two products for the decoder's LARGE shapes (p2c_linear_big_supported: M >= 16384 rows, N, K >= 128, multiples of 4) on 128 x 256
  * tiles with W split into its three bf16 planes ONCE per call (csrc/gemm_big.hip) instead of once per workgroup: same operands, same results

@@ -99,3 +99,112 @@ extern "C" int p2c_softplus_sig_bwd_f32(const float *g, const float *a, const fl
 {
     return softplus_launch(3, z, a, g, t, dz, n, beta, threshold, stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Row-structured variants for the ends of the decoder (its last layer has ONE output, its input gradient is used in TWO columns): the
+// products there are outer products / dot products with a single weight row, so they ride on the activation passes instead of being
+// [M x 4]-padded GEMMs over 0.5 GB operands.  z, q, e, outputs: [M, K] contiguous, K % 4 == 0; one wave per row, 16 bytes per lane.
+//   ROWMODE 0  out[m]   = softplus(z[m,:]) . w + bias                          (forward of the last layer; the activation is never stored)
+//   ROWMODE 1  o[m,c]   = gs(m) * w[c] * s(z[m,c]) (+ q[m,c])                  (gradient of the last layer's input: gs = 1 or g[m])
+//   ROWMODE 2  E[m,c]   = (Ein[m,c]) + ga[m,0] wa[c] + ga[m,1] wb[c];  t = E s(z),  dz = E e beta (1 - s)      (sig_bwd with a rank-2 term)
+// ------------------------------------------------------------------------------------------------
+struct RowArgs {
+    const float *z; const float *w; const float *wb; const float *g; int ldg; const float *q; const float *e;
+    float *o0; float *o1; long long M; int K; float beta, thr; const float *bias;
+};
+
+template <int ROWMODE>
+__global__ void __launch_bounds__(256) softplus_row_kernel(RowArgs a)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (long long)gridDim.x * 4;
+    const int K4 = a.K / 4;
+    const float inv_beta = 1.f / a.beta;
+    for (long long m = wave0; m < a.M; m += nw) {
+        const v4f *zr = reinterpret_cast<const v4f *>(a.z + (size_t)m * a.K);
+        float dot = 0.f;
+        float g0 = 1.f, g1 = 0.f;
+        if (ROWMODE == 1 && a.g) g0 = a.g[(size_t)m * a.ldg];
+        if (ROWMODE == 2) { g0 = a.g[(size_t)m * a.ldg]; g1 = a.g[(size_t)m * a.ldg + 1]; }
+        for (int c4 = lane; c4 < K4; c4 += 64) {
+            const v4f zz = zr[c4];
+            const v4f ww = reinterpret_cast<const v4f *>(a.w)[c4];
+            if (ROWMODE == 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float h, unused;
+                    softplus_elem<0>(zz[c], 0.f, 0.f, a.beta, inv_beta, a.thr, h, unused);
+                    dot += h * ww[c];
+                }
+            } else if (ROWMODE == 1) {
+                v4f o;
+                v4f qq = {0.f, 0.f, 0.f, 0.f};
+                if (a.q) qq = reinterpret_cast<const v4f *>(a.q + (size_t)m * a.K)[c4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float bz = zz[c] * a.beta;
+                    const float s = bz > a.thr ? 1.f : sp_sigmoid(bz);
+                    o[c] = g0 * ww[c] * s + qq[c];
+                }
+                reinterpret_cast<v4f *>(a.o0 + (size_t)m * a.K)[c4] = o;
+            } else {
+                const v4f wb = reinterpret_cast<const v4f *>(a.wb)[c4];
+                const v4f ee = reinterpret_cast<const v4f *>(a.e + (size_t)m * a.K)[c4];
+                v4f Ein = {0.f, 0.f, 0.f, 0.f};
+                if (a.q) Ein = reinterpret_cast<const v4f *>(a.q + (size_t)m * a.K)[c4];
+                v4f t, dz;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float E = Ein[c] + (g0 * ww[c] + g1 * wb[c]);
+                    float tv, dv;
+                    softplus_elem<3>(zz[c], ee[c], E, a.beta, inv_beta, a.thr, tv, dv);
+                    t[c] = tv; dz[c] = dv;
+                }
+                reinterpret_cast<v4f *>(a.o0 + (size_t)m * a.K)[c4] = t;
+                reinterpret_cast<v4f *>(a.o1 + (size_t)m * a.K)[c4] = dz;
+            }
+        }
+        if (ROWMODE == 0) {
+            dot = p2c_wave_sum_f32(dot);
+            if (lane == 0) a.o0[m] = dot + (a.bias ? a.bias[0] : 0.f);
+        }
+    }
+}
+
+static int softplus_row_launch(int mode, const RowArgs &a, void *stream)
+{
+    if (!a.z || !a.w || !a.o0 || a.M <= 0 || a.K <= 0 || (a.K & 3) || a.beta <= 0.f) return P2C_EINVAL;
+    if (((uintptr_t)a.z | (uintptr_t)a.w | (uintptr_t)a.wb | (uintptr_t)a.q | (uintptr_t)a.e | (uintptr_t)a.o1) & 15) return P2C_EALIGN;
+    if (mode != 0 && ((uintptr_t)a.o0 & 15)) return P2C_EALIGN;
+    const long long blocks = (a.M + 3) / 4;
+    const int grid = (int)(blocks < 8192 ? blocks : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(softplus_row_kernel<0>, dim3(grid), dim3(256), 0, s, a);
+    else if (mode == 1) hipLaunchKernelGGL(softplus_row_kernel<1>, dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(softplus_row_kernel<2>, dim3(grid), dim3(256), 0, s, a);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// out[m] = softplus(z[m,:K]) . w[:K] + bias[0] (bias: device scalar or NULL)
+extern "C" int p2c_softplus_dot_f32(const float *z, const float *w, const float *bias, float *out, long long M, int K, float beta, float threshold,
+                                    void *stream)
+{
+    RowArgs a{z, w, nullptr, nullptr, 0, nullptr, nullptr, out, nullptr, M, K, beta, threshold, bias};
+    return softplus_row_launch(0, a, stream);
+}
+// o[m,c] = (g ? g[m*ldg] : 1) * w[c] * sigmoid(beta z[m,c]) + (q ? q[m,c] : 0)
+extern "C" int p2c_softplus_row_bwd_f32(const float *g, int ldg, const float *w, const float *z, const float *q, float *o, long long M, int K, float beta,
+                                        float threshold, void *stream)
+{
+    RowArgs a{z, w, nullptr, g, ldg, q, nullptr, o, nullptr, M, K, beta, threshold, nullptr};
+    return softplus_row_launch(1, a, stream);
+}
+// E = (Ein ? Ein : 0) + ga[m*ldg] wa[c] + ga[m*ldg+1] wb[c];  t = E * s(z),  dz = E * e * beta * (1 - s(z))   (p2c_softplus_sig_bwd_f32 with a rank-2 term)
+extern "C" int p2c_softplus_sig_bwd_rank2_f32(const float *ga, int ldg, const float *wa, const float *wb, const float *Ein, const float *e, const float *z,
+                                              float *t, float *dz, long long M, int K, float beta, float threshold, void *stream)
+{
+    if (!ga || !wb || !e || !t || !dz) return P2C_EINVAL;
+    RowArgs a{z, wa, wb, ga, ldg, Ein, e, t, dz, M, K, beta, threshold, nullptr};
+    return softplus_row_launch(2, a, stream);
+}

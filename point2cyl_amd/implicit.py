@@ -458,11 +458,21 @@ class _DecoderVG(torch.autograd.Function):
         beta, thr = float(net.beta), 20.0
         L = len(lay)
         M = a.shape[0]
+        dev = a.device
         Dp = d_in + (-d_in) % 4
         ap = a if a.shape[1] == Dp else F.pad(a, (0, Dp - a.shape[1]))
         ap = _c(ap.detach())
+        # the last layer has ONE output unit (IGR/network.py:38: dims + [1]): its products are a dot product / outer products with one weight
+        # row and ride on the activation passes (csrc/softplus.hip, row-structured kernels) instead of [M x 4]-padded GEMMs over 0.5 GB operands
+        one_out = L >= 2 and lay[-1][3] == 1 and lay[-1][1] is None
+        w_last = lay[-1][0][0].contiguous() if one_out else None
         zs, x = [], ap
         for l, (Wa, Wb, b, N, Np) in enumerate(lay):
+            if one_out and l == L - 1:
+                pred = torch.empty(M, 1, dtype=torch.float32, device=dev)
+                call("p2c_softplus_dot_f32", ptr(x), ptr(w_last), ptr(b), ptr(pred), M, x.shape[1], beta, thr, stream(), nbytes=4.0 * x.numel())
+                zs.append(None)
+                break
             h = x
             if l > 0:
                 h = torch.empty_like(x)
@@ -472,15 +482,23 @@ class _DecoderVG(torch.autograd.Function):
                 z = _prod_nt(ap, Wb, None, add=z)
             zs.append(z)
             x = z
-        pred = zs[-1][:, :lay[-1][3]].contiguous() if lay[-1][4] != lay[-1][3] else zs[-1]
+        if not one_out:
+            pred = zs[-1][:, :lay[-1][3]].contiguous() if lay[-1][4] != lay[-1][3] else zs[-1]
         # R1: e_{L-1} = ones (only the real output columns)
-        e = torch.zeros(M, lay[-1][4], dtype=torch.float32, device=a.device)
-        e[:, :lay[-1][3]] = 1.0
         es = [None] * L
         skip_term = None
         g0 = (d_in - 2) // 4 * 4                                    # the 4-aligned column block that holds the two point columns of the input
         w0g = lay[0][0][:, g0:].contiguous()
-        for l in range(L - 1, 0, -1):
+        if one_out:
+            e = torch.empty_like(zs[L - 2])
+            call("p2c_softplus_row_bwd_f32", None, 0, ptr(w_last), ptr(zs[L - 2]), None, ptr(e), M, e.shape[1], beta, thr, stream(), nbytes=8.0 * e.numel())
+            es[L - 2] = e
+            top = L - 2
+        else:
+            e = torch.zeros(M, lay[-1][4], dtype=torch.float32, device=dev)
+            e[:, :lay[-1][3]] = 1.0
+            top = L - 1
+        for l in range(top, 0, -1):
             Wa, Wb, _, _, _ = lay[l]
             if Wb is not None:
                 wbg = Wb[:, g0:].contiguous()
@@ -489,15 +507,15 @@ class _DecoderVG(torch.autograd.Function):
             es[l - 1] = e
         da = _prod_nn(e, w0g, add=skip_term)                      # only the g0..g1 columns of da = e_0 W_0 + e_skip Wb are ever used
         g = da[:, d_in - 2 - g0:d_in - g0]
-        ctx.lay, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0 = lay, (beta, thr), d_in, Dp, g0
-        ctx.save_for_backward(ap, *zs[:-1], *es[:-1])
+        ctx.lay, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0, ctx.one_out = lay, (beta, thr), d_in, Dp, g0, one_out
+        ctx.save_for_backward(ap, *zs[:L - 1], *es[:L - 1])
         ctx.set_materialize_grads(False)
         return pred, g
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gpred, gg):
-        lay, (beta, thr), d_in, Dp, g0 = ctx.lay, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0
+        lay, (beta, thr), d_in, Dp, g0, one_out = ctx.lay, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0, ctx.one_out
         L = len(lay)
         saved = ctx.saved_tensors
         ap, zs, es = saved[0], saved[1:L], saved[L:]
@@ -505,29 +523,40 @@ class _DecoderVG(torch.autograd.Function):
         dev = ap.device
         qs = [None] * (L - 1)
         if gg is not None:
-            # the adjoint of g lives in the block's two point columns only: the products with W_0 / Wb shrink to that 4-aligned column block
-            ga = torch.zeros(M, Dp - g0, dtype=torch.float32, device=dev)
-            ga[:, d_in - 2 - g0:d_in - g0] = gg
-            # T: forward-mode sweep in direction ga
-            E = _prod_nt(ga, lay[0][0][:, g0:].contiguous())           # adjoint of da = e_0 W_0:  E_0 = ga . W_0[:, block]^T
+            # T: forward-mode sweep in direction ga = dL/dg, which lives in the input's two point columns only: the products with W_0 (and with
+            # a skip layer's Wb) are rank-2 updates with those two weight columns, applied inside the activation pass of the layer
+            gg = _c(gg)
+            t = None
             for l in range(L - 1):
+                Wa, Wb = lay[l][0], lay[l][1]
+                Ein = None if l == 0 else _prod_nt(t, Wa)
+                wsrc = Wa if l == 0 else Wb
                 t, q = torch.empty_like(zs[l]), torch.empty_like(zs[l])
-                call("p2c_softplus_sig_bwd_f32", ptr(E), ptr(es[l]), ptr(zs[l]), ptr(t), ptr(q), zs[l].numel(), beta, thr, stream(),
-                     nbytes=20.0 * zs[l].numel())
+                if wsrc is not None:
+                    wa_, wb_ = wsrc[:, d_in - 2].contiguous(), wsrc[:, d_in - 1].contiguous()
+                    call("p2c_softplus_sig_bwd_rank2_f32", ptr(gg), gg.stride(0), ptr(wa_), ptr(wb_), ptr(Ein), ptr(es[l]), ptr(zs[l]), ptr(t), ptr(q), M,
+                         zs[l].shape[1], beta, thr, stream(), nbytes=(20.0 if Ein is not None else 16.0) * zs[l].numel())
+                else:
+                    call("p2c_softplus_sig_bwd_f32", ptr(Ein), ptr(es[l]), ptr(zs[l]), ptr(t), ptr(q), zs[l].numel(), beta, thr, stream(),
+                         nbytes=20.0 * zs[l].numel())
                 qs[l] = q
-                if l + 1 < L - 1:
-                    Wa, Wb = lay[l + 1][0], lay[l + 1][1]
-                    E = _prod_nt(t, Wa)
-                    if Wb is not None:
-                        E = _prod_nt(ga, Wb[:, g0:].contiguous(), None, add=E)
         # B: reverse sweep of the total gradients of the pre-activations
-        Np_last, N_last = lay[-1][4], lay[-1][3]
-        if gpred is not None:
+        Z = None
+        top = L - 1
+        if one_out:
+            top = L - 2
+            if gpred is not None:
+                gp = _c(gpred)
+                Z = torch.empty_like(zs[L - 2])
+                call("p2c_softplus_row_bwd_f32", ptr(gp), gp.stride(0), ptr(lay[-1][0][0].contiguous()), ptr(zs[L - 2]), ptr(qs[L - 2]), ptr(Z), M,
+                     Z.shape[1], beta, thr, stream(), nbytes=(12.0 if qs[L - 2] is not None else 8.0) * Z.numel())
+            else:
+                Z = qs[L - 2]
+        elif gpred is not None:
+            Np_last, N_last = lay[-1][4], lay[-1][3]
             Z = F.pad(_c(gpred), (0, Np_last - N_last)) if Np_last != N_last else _c(gpred)
-        else:
-            Z = None
         skip_term = None
-        for l in range(L - 1, 0, -1):
+        for l in range(top, 0, -1):
             Wa, Wb = lay[l][0], lay[l][1]
             q = qs[l - 1]
             if Z is None:                        # no gradient arrives from above: this pre-activation's total is its q alone

@@ -692,9 +692,11 @@ def test_alternate_route_equals_default_route(flag, env):
         # run is 0.7 % from its float64 twin there (test_train_step_golden).  Backward-only switches keep the forward bit-identical: 2e-4.
         tol = 2e-2 if flag in ("USE_FOLD0", "USE_PRE_LINEAR", "USE_POOL_EPI") else 2e-4
         assert d <= tol * n_ + 1e-6 * gmax, (flag, k, d, n_)
+    fwd_switch = flag in ("USE_FOLD0", "USE_PRE_LINEAR", "USE_POOL_EPI")
     for k in ref[4]:
         if ref[4][k].dtype.is_floating_point:
-            np.testing.assert_allclose(alt[4][k].cpu().numpy(), ref[4][k].cpu().numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+            np.testing.assert_allclose(alt[4][k].cpu().numpy(), ref[4][k].cpu().numpy(), rtol=2e-4 if fwd_switch else 2e-5,
+                                       atol=2e-6 if fwd_switch else 1e-7, err_msg=k)
         else:
             assert torch.equal(alt[4][k], ref[4][k]), k
 

@@ -411,6 +411,38 @@ def _prod_nn(A, W, z=None, beta=0.0, thr=20.0, add=None):
     return O
 
 
+_LAYOUTS = None
+
+
+def _decoder_layout_cached(net, d_in):
+    """_decoder_layout(net, d_in) + the small derived operands (the g-block / point-column slices), rebuilt only when a parameter of the
+    (frozen) decoder changed: ~150 pad / slice launches per step otherwise.  Built outside stream capture (the capture's eager warm-up
+    passes come first), so a graph never owns the cached tensors."""
+    global _LAYOUTS
+    import weakref
+    if _LAYOUTS is None:
+        _LAYOUTS = weakref.WeakKeyDictionary()
+    key = (d_in,) + tuple((p.data_ptr(), p._version) for p in net.parameters())
+    hit = _LAYOUTS.get(net)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    if torch.cuda.is_current_stream_capturing():
+        return _decoder_layout_full(net, d_in)          # (not cached: tensors created under capture belong to the graph's pool)
+    out = _decoder_layout_full(net, d_in)
+    _LAYOUTS[net] = (key, out)
+    return out
+
+
+def _decoder_layout_full(net, d_in):
+    lay = _decoder_layout(net, d_in)
+    g0 = (d_in - 2) // 4 * 4
+    extra = dict(g0=g0, w0g=lay[0][0][:, g0:].contiguous(), w_last=lay[-1][0][0].contiguous(),
+                 wbg=[None if l[1] is None else l[1][:, g0:].contiguous() for l in lay],
+                 cols=[None if (i > 0 and l[1] is None) else ((l[0] if i == 0 else l[1])[:, d_in - 2].contiguous(), (l[0] if i == 0 else l[1])[:, d_in - 1].contiguous())
+                       for i, l in enumerate(lay)])
+    return lay, extra
+
+
 def _decoder_layout(net, d_in):
     """The padded operands of `net` for inputs of width d_in: per layer (Wa [Np, Kp_prev], Wb [Np, Dp] | None, bias [Np], N, Np) with
     Dp = pad4(d_in); Wb is the block of a skip layer's weight that multiplies the re-injected input, both blocks already divided by sqrt 2
@@ -454,7 +486,7 @@ class _DecoderVG(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, net, d_in):
-        lay = _decoder_layout(net, d_in)
+        lay, ex = _decoder_layout_cached(net, d_in)
         beta, thr = float(net.beta), 20.0
         L = len(lay)
         M = a.shape[0]
@@ -465,7 +497,7 @@ class _DecoderVG(torch.autograd.Function):
         # the last layer has ONE output unit (IGR/network.py:38: dims + [1]): its products are a dot product / outer products with one weight
         # row and ride on the activation passes (csrc/softplus.hip, row-structured kernels) instead of [M x 4]-padded GEMMs over 0.5 GB operands
         one_out = L >= 2 and lay[-1][3] == 1 and lay[-1][1] is None
-        w_last = lay[-1][0][0].contiguous() if one_out else None
+        w_last = ex["w_last"] if one_out else None
         zs, x = [], ap
         for l, (Wa, Wb, b, N, Np) in enumerate(lay):
             if one_out and l == L - 1:
@@ -487,8 +519,7 @@ class _DecoderVG(torch.autograd.Function):
         # R1: e_{L-1} = ones (only the real output columns)
         es = [None] * L
         skip_term = None
-        g0 = (d_in - 2) // 4 * 4                                    # the 4-aligned column block that holds the two point columns of the input
-        w0g = lay[0][0][:, g0:].contiguous()
+        g0, w0g = ex["g0"], ex["w0g"]                               # the 4-aligned column block that holds the two point columns of the input
         if one_out:
             e = torch.empty_like(zs[L - 2])
             call("p2c_softplus_row_bwd_f32", None, 0, ptr(w_last), ptr(zs[L - 2]), None, ptr(e), M, e.shape[1], beta, thr, stream(), nbytes=8.0 * e.numel())
@@ -501,13 +532,13 @@ class _DecoderVG(torch.autograd.Function):
         for l in range(top, 0, -1):
             Wa, Wb, _, _, _ = lay[l]
             if Wb is not None:
-                wbg = Wb[:, g0:].contiguous()
+                wbg = ex["wbg"][l]
                 skip_term = _prod_nn(e, wbg) if skip_term is None else _prod_nn(e, wbg, add=skip_term)
             e = _prod_nn(e, Wa, zs[l - 1], beta, thr)
             es[l - 1] = e
         da = _prod_nn(e, w0g, add=skip_term)                      # only the g0..g1 columns of da = e_0 W_0 + e_skip Wb are ever used
         g = da[:, d_in - 2 - g0:d_in - g0]
-        ctx.lay, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0, ctx.one_out = lay, (beta, thr), d_in, Dp, g0, one_out
+        ctx.lay, ctx.ex, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0, ctx.one_out = lay, ex, (beta, thr), d_in, Dp, g0, one_out
         ctx.save_for_backward(ap, *zs[:L - 1], *es[:L - 1])
         ctx.set_materialize_grads(False)
         return pred, g
@@ -515,7 +546,7 @@ class _DecoderVG(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gpred, gg):
-        lay, (beta, thr), d_in, Dp, g0, one_out = ctx.lay, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0, ctx.one_out
+        lay, ex, (beta, thr), d_in, Dp, g0, one_out = ctx.lay, ctx.ex, ctx.bt, ctx.d_in, ctx.Dp, ctx.g0, ctx.one_out
         L = len(lay)
         saved = ctx.saved_tensors
         ap, zs, es = saved[0], saved[1:L], saved[L:]
@@ -530,10 +561,9 @@ class _DecoderVG(torch.autograd.Function):
             for l in range(L - 1):
                 Wa, Wb = lay[l][0], lay[l][1]
                 Ein = None if l == 0 else _prod_nt(t, Wa)
-                wsrc = Wa if l == 0 else Wb
                 t, q = torch.empty_like(zs[l]), torch.empty_like(zs[l])
-                if wsrc is not None:
-                    wa_, wb_ = wsrc[:, d_in - 2].contiguous(), wsrc[:, d_in - 1].contiguous()
+                if ex["cols"][l] is not None:
+                    wa_, wb_ = ex["cols"][l]
                     call("p2c_softplus_sig_bwd_rank2_f32", ptr(gg), gg.stride(0), ptr(wa_), ptr(wb_), ptr(Ein), ptr(es[l]), ptr(zs[l]), ptr(t), ptr(q), M,
                          zs[l].shape[1], beta, thr, stream(), nbytes=(20.0 if Ein is not None else 16.0) * zs[l].numel())
                 else:
@@ -548,7 +578,7 @@ class _DecoderVG(torch.autograd.Function):
             if gpred is not None:
                 gp = _c(gpred)
                 Z = torch.empty_like(zs[L - 2])
-                call("p2c_softplus_row_bwd_f32", ptr(gp), gp.stride(0), ptr(lay[-1][0][0].contiguous()), ptr(zs[L - 2]), ptr(qs[L - 2]), ptr(Z), M,
+                call("p2c_softplus_row_bwd_f32", ptr(gp), gp.stride(0), ptr(ex["w_last"]), ptr(zs[L - 2]), ptr(qs[L - 2]), ptr(Z), M,
                      Z.shape[1], beta, thr, stream(), nbytes=(12.0 if qs[L - 2] is not None else 8.0) * Z.numel())
             else:
                 Z = qs[L - 2]

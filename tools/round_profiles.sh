@@ -11,6 +11,7 @@ mkdir -p "$OUT"
 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o r --output-format csv -- python bench.py --steps 10 --warmup 3 --no_cpu_baseline --no_extras > "$OUT/${TAG}_bench_under_rocprof.json.log" 2> "$OUT/trace.err"
 cp "$OUT/trace/r_kernel_stats.csv" "$OUT/${TAG}_rocprofv3_kernel_stats.csv"
 python tools/timeline.py "$OUT/trace/r_kernel_trace.csv" 7 > "$OUT/${TAG}_step_timeline.md" 2>> "$OUT/trace.err"
+python tools/timeline.py "$OUT/trace/r_kernel_trace.csv" 7 --all > "$OUT/${TAG}_step_timeline_every_launch.md" 2>> "$OUT/trace.err"
 python - "$OUT" "$TAG" <<'EOF'
 import csv, json, re, sys
 out, tag = sys.argv[1:3]
@@ -53,7 +54,11 @@ python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 102
     --report "$OUT/${TAG}_trainer_report.json" > "$OUT/${TAG}_train_convergence_synthetic.log" 2> "$OUT/train.err"
 python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 256 --batch_size 32 --num_epochs 2 --logdir /tmp/${TAG}_tr2 \
     --report "$OUT/${TAG}_trainer_report_per_step_log.json" > /dev/null 2>> "$OUT/train.err"
-python -m point2cyl_amd.eval --synthetic 256 --batch_size 32 --logdir /tmp/${TAG}_tr --ckpt model.pth --dump_dir /tmp/${TAG}_ev > "$OUT/${TAG}_eval_synthetic.log" 2> "$OUT/eval.err"
+python -m point2cyl_amd.eval --synthetic 256 --batch_size 32 --logdir /tmp/${TAG}_tr --ckpt model.pth --dump_dir /tmp/${TAG}_ev --report "$OUT/${TAG}_eval_report_pipelined.json" > "$OUT/${TAG}_eval_synthetic.log" 2> "$OUT/eval.err"
+python -m point2cyl_amd.eval --synthetic 256 --batch_size 32 --logdir /tmp/${TAG}_tr --ckpt model.pth --dump_dir /tmp/${TAG}_ev --no_prefetch --report "$OUT/${TAG}_eval_report_serial.json" > "$OUT/${TAG}_eval_synthetic_no_prefetch.log" 2>> "$OUT/eval.err"
+if [ -d .ab_base ]; then bash tools/ab_commits.sh 3 > "$OUT/${TAG}_ab_vs_round4_tree.log" 2>&1; fi
+python tools/fit_trace.py > "$OUT/${TAG}_fit_fused_phase_trace.log" 2>&1; python tools/fit_trace.py --hard >> "$OUT/${TAG}_fit_fused_phase_trace.log" 2>&1
+python tools/bench_config5.py --steps 3 --glue > /dev/null 2> "$OUT/${TAG}_config5_torch_side_ops.log"
 python -m point2cyl_amd.train_sketch --pred_seg --pred_normal --pred_bb --is_pc_train --is_im_train --with_im_loss --synthetic 64 --batch_size 16 \
     --num_epochs 2 --logdir /tmp/${TAG}_sk --im_logdir /tmp/none --report "$OUT/${TAG}_sketch_trainer_report.json" > "$OUT/${TAG}_train_sketch_synthetic.log" 2> "$OUT/sk.err"
 tail -c 300 "$OUT"/*.err | tail -40

@@ -48,9 +48,10 @@ class PointNetSetAbstraction(nn.Module):
         self.fps_start = None      # hook: (B,) tensor of FPS start indices, or a callable (N, B) -> device tensor, instead of drawing
         self.last_aux = {}
 
-    def geometry(self, xyz):
+    def geometry(self, xyz, with_csr=True):
         """Parameter-free part of sample_and_group (pointnet_util.py:122-128): FPS indices, sampled centres, ball-query
-        groups.  Depends only on the coordinates, so it can be computed ahead of the step that consumes it."""
+        groups.  Depends only on the coordinates, so it can be computed ahead of the step that consumes it.
+        with_csr=False (inference): no inverse map of the grouping - only the backward pass reads it."""
         B, N, _ = xyz.shape
         if callable(self.fps_start):
             start = self.fps_start(N, B)
@@ -59,7 +60,7 @@ class PointNetSetAbstraction(nn.Module):
         fps_idx, new_xyz = ops.fps(xyz, self.npoint, start)
         gidx = ops.ball_query(self.radius, self.nsample, xyz, new_xyz)
         g = dict(fps_idx=fps_idx, new_xyz=new_xyz, group_idx=gidx)
-        if self.mlp_convs[0].weight.shape[1] > 3:          # grouped FEATURES exist -> their backward wants the inverse map
+        if with_csr and self.mlp_convs[0].weight.shape[1] > 3:          # grouped FEATURES exist -> their backward wants the inverse map
             g["csr"] = ops.build_csr(gidx, N)
         return g
 
@@ -83,14 +84,16 @@ class PointNetSetAbstraction(nn.Module):
             G, ns = B, N
         else:
             if geom is None:
-                geom = self.geometry(xyz)
+                geom = self.geometry(xyz, with_csr=torch.is_grad_enabled())
             fps_idx, new_xyz, gidx = geom["fps_idx"], geom["new_xyz"], geom["group_idx"]
             G, ns = B * self.npoint, self.nsample
             self.last_aux = dict(fps_idx=fps_idx, group_idx=gidx)
             if feats is not None and ops.USE_PRE_LINEAR and feats.shape[-1] % 4 == 0 and self.mlp_convs[0].weight.shape[0] <= 256:
                 # the first conv commutes with the grouping gather: it runs on the N points, the gather adds the coordinate part,
                 # the bias and the BatchNorm sums (ops.mlp_stack(pre=...), csrc/gather.hip); the grouped input is never built
-                csr = geom.get("csr") or ops.build_csr(gidx, N)
+                csr = geom.get("csr")
+                if csr is None and torch.is_grad_enabled():
+                    csr = ops.build_csr(gidx, N)          # (no gradient, no inverse map: the forward never reads it)
                 pre = dict(kind="group", xyz=xyz.contiguous(), new_xyz=new_xyz.contiguous(), idx=gidx, csr=csr, B=B, N=N, S=self.npoint,
                            ns=ns, rows=G * ns)
                 F2 = feats.reshape(B * N, -1)
@@ -133,7 +136,7 @@ class PointNetFeaturePropagation(nn.Module):
         else:
             if nn_ is None:
                 idx, w = ops.three_nn(xyz1, xyz2)
-                nn_ = (idx, w, ops.build_csr(idx, S, w, 3))
+                nn_ = (idx, w, ops.build_csr(idx, S, w, 3) if torch.is_grad_enabled() else None)      # (the inverse map serves the backward only)
             idx, w, csr = nn_
             self.last_aux = dict(nn_idx=idx, nn_w=w)
             if feats1 is not None:
@@ -159,7 +162,7 @@ class PointNetFeaturePropagation(nn.Module):
             # interpolation produces its dense pre-BN output (ops.mlp_stack(pre=...), csrc/gather.hip)
             if nn_ is None:
                 idx, w = ops.three_nn(xyz1, xyz2)
-                nn_ = (idx, w, ops.build_csr(idx, S, w, 3))
+                nn_ = (idx, w, ops.build_csr(idx, S, w, 3) if torch.is_grad_enabled() else None)
             idx, w, csr = nn_
             self.last_aux = dict(nn_idx=idx, nn_w=w)
             pre = dict(kind="interp", idx=idx, w=w, csr=csr, B=B, N=N, S=S, rows=B * N)
@@ -266,20 +269,21 @@ class backbone(nn.Module):
         d.pop("_wstage", None)
         return d
 
-    def compute_geometry(self, x):
+    def compute_geometry(self, x, with_csr=True):
         """Everything in the forward pass that depends on the point coordinates only (no parameters): both FPS +
         ball-query levels, SA1's grouped relative coordinates and the two 3-NN interpolation stencils.  The result can be
         passed to forward_heads(x, geom=...); computing it for batch k+1 on a side stream hides the latency-bound FPS
-        loop behind step k (point2cyl_amd/graph.py)."""
+        loop behind step k (point2cyl_amd/graph.py).  with_csr=False (inference, graph.PipelinedForward): without the three inverse
+        maps of the gathers, which only the backward pass reads."""
         x = x.float()
         xyz = x[:, :, :3].contiguous()
-        g1 = self.sa1.geometry(xyz)
+        g1 = self.sa1.geometry(xyz, with_csr)
         if x.shape[2] == 3:
             g1["X0"] = ops.group_gather(xyz, None, g1["new_xyz"], g1["group_idx"])
-        g2 = self.sa2.geometry(g1["new_xyz"])
+        g2 = self.sa2.geometry(g1["new_xyz"], with_csr)
         def nn_with_csr(dense, sparse):
             idx, w = ops.three_nn(dense, sparse)
-            return idx, w, ops.build_csr(idx, sparse.shape[1], w, 3)
+            return idx, w, (ops.build_csr(idx, sparse.shape[1], w, 3) if with_csr else None)
 
         return dict(sa1=g1, sa2=g2, fp2=nn_with_csr(g1["new_xyz"], g2["new_xyz"]), fp1=nn_with_csr(xyz, g1["new_xyz"]))
 

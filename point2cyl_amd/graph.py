@@ -94,9 +94,11 @@ class GraphedForwardBackward:
     split_tail=True (data-parallel jobs): what follows the last gradient - the copies of the prefetched geometry into the 'current' buffers -
     is captured as a SECOND graph, replayed by `tail()`.  Between `__call__` and `tail()` the caller records an event and starts the
     gradient exchange on a side stream (ddp.FlatGradSync.allreduce_async): the exchange then overlaps the tail instead of waiting for it.
-    (An external event-record node inside one graph would do the same; torch refuses external events on ROCm.)"""
+    (An external event-record node inside one graph would do the same; torch refuses external events on ROCm.)
 
-    def __init__(self, model, fn, warmup=2, prefetch_xyz=None, draw_starts=True, stream=None, split_tail=False):
+    inference=True: fn runs without gradients; the prefetched geometry omits the inverse maps of the gathers (only a backward reads them)."""
+
+    def __init__(self, model, fn, warmup=2, prefetch_xyz=None, draw_starts=True, stream=None, split_tail=False, inference=False):
         import gc
         gc.collect()       # autograd graphs of earlier eager steps that only reference cycles keep alive: their AccumulateGrad nodes are
         # bound to the stream they were created on, and autograd would order the capture stream against that stream (work the capture
@@ -132,7 +134,7 @@ class GraphedForwardBackward:
             side = self._side
             side.wait_stream(cap)                                   # fork
             with torch.cuda.stream(side):
-                nxt = model.compute_geometry(prefetch_xyz)
+                nxt = model.compute_geometry(prefetch_xyz, with_csr=not inference)
             out = fn(self.cur)
             cap.wait_stream(side)                                   # join
             self._nxt = nxt
@@ -160,7 +162,7 @@ class GraphedForwardBackward:
         try:
             if self.prefetch:
                 with torch.no_grad():
-                    self.cur = model.compute_geometry(prefetch_xyz)     # geometry for the first replay
+                    self.cur = model.compute_geometry(prefetch_xyz, with_csr=not inference)     # geometry for the first replay
                 self.starts.cursor = 0
             # warm-up passes and the capture run on ONE stream (`stream`, e.g. the stream the caller's whole loop lives on, or a private one):
             # the autograd accumulator nodes created by the warm-up are then bound to the stream that is captured
@@ -261,7 +263,7 @@ class PipelinedForward:
             self.sizes = sizes
             return {"heads": heads}
 
-        self.graph = GraphedForwardBackward(model, fn, prefetch_xyz=self.nxt, stream=stream)
+        self.graph = GraphedForwardBackward(model, fn, prefetch_xyz=self.nxt, stream=stream, inference=True)      # no inverse maps: forward only
 
     def __call__(self, next_pcs=None):
         """Forward of the current batch -> (heads (B*N, ld) static buffer, head sizes); next_pcs: the batch the NEXT call will return

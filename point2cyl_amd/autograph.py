@@ -130,6 +130,11 @@ class _Captured:
                         have = [(g, p) for g, p in zip(grads, self.params) if g is not None]
                         self.flat = torch.cat([g.reshape(-1) for g, _ in have]) if have else None
                     self.has_grad = [g is not None for g in grads]
+                    # how _Replay.backward cuts a copy of `flat` into per-parameter gradients with the fewest Python-level tensor operations
+                    # (123 slice + view pairs cost 0.6 ms of host time per step): ONE split_with_sizes, a view only where the parameter is not 1-D
+                    self.grad_pos = [i for i, h in enumerate(self.has_grad) if h]
+                    self.grad_sizes = [self.params[i].numel() for i in self.grad_pos]
+                    self.grad_views = [(j, tuple(self.params[i].shape)) for j, i in enumerate(self.grad_pos) if self.params[i].dim() != 1]
                     del grads, have
             main.wait_stream(cap)
             torch.cuda.synchronize()
@@ -184,14 +189,14 @@ class _Replay(torch.autograd.Function):
         if cap.flat is None:
             return (None, None) + (None,) * n
         fresh = cap.flat.clone()            # the static buffer is overwritten by the next replay; autograd gets tensors of its own (ONE launch)
-        outs, o = [], 0
-        for p, has in zip(cap.params, cap.has_grad):
-            if not has:
-                outs.append(None)
-                continue
-            k = p.numel()
-            outs.append(fresh[o:o + k].view(p.shape))
-            o += k
+        pieces = list(fresh.split_with_sizes(cap.grad_sizes))
+        for j, shape in cap.grad_views:
+            pieces[j] = pieces[j].view(shape)
+        if len(pieces) == n:
+            return (None, None) + tuple(pieces)
+        outs = [None] * n
+        for j, i in enumerate(cap.grad_pos):
+            outs[i] = pieces[j]
         return (None, None) + tuple(outs)
 
 

@@ -341,7 +341,7 @@ def power_cap_probe(dev, M=262144, Co=128, Ci=128):
     """How much of the dominant kernel's time is CLOCK: the fused backward of a 128 x 128 layer at M = 262,144 (the family bench.py's roofline
     object reports) launched (a) in isolation - one launch, a synchronisation and 4 ms of idle time, so that it starts on a cool socket at the
     boost clock - and (b) back to back for ~0.3 s, where the socket power limit sets the shader clock (2.0 GHz at ~1350 W
-    against 2.4 GHz).  -> dict(isolated_us, sustained_us, ratio, sclk / power sampled from rocm-smi during (b) when the tool is there)."""
+    against 2.4 GHz).  -> dict(sustained_us, the shader clock / package power rocm-smi reports during (b), after_idle_us for (a))."""
     import re
     import subprocess
     dZ = torch.randn(M, Co, device=dev)
@@ -392,8 +392,11 @@ def power_cap_probe(dev, M=262144, Co=128, Ci=128):
     sus = e0.elapsed_time(e1) * 1e3 / n
     med = iso[len(iso) // 2]
     nbytes = 4.0 * M * (2 * Co + 2 * Ci)
-    return dict(kernel="p2c_linear_bwd_fused_f32 (Co = Ci = 128, M = %d, the role-split bf16x3 kernel)" % M, isolated_us=round(med, 1), isolated_min_us=round(iso[0], 1),
-                sustained_us=round(sus, 1), sustained_over_isolated=round(sus / med, 3), isolated_hbm_frac=round(nbytes / (med * 1e-6) / PEAK_HBM, 4),
-                sustained_hbm_frac=round(nbytes / (sus * 1e-6) / PEAK_HBM, 4), sclk_mhz_sustained=sclk, package_power_w_sustained=power,
-                note="isolated = one launch after 4 ms of idle time (cool socket, boost clock), median of 12; sustained = 600 launches back to back after 1500 "
-                     "warm-up launches (socket at its power limit); the ratio is the share of the sustained time that is clock, not code")
+    return dict(kernel="p2c_linear_bwd_fused_f32 (Co = Ci = 128, M = %d, the role-split bf16x3 kernel)" % M,
+                sustained_us=round(sus, 1), sustained_hbm_frac=round(nbytes / (sus * 1e-6) / PEAK_HBM, 4), sclk_mhz_sustained=sclk,
+                package_power_w_sustained=power, boost_mhz=2400, clock_frac_of_boost=None if not sclk else round(sclk / 2400.0, 3),
+                after_idle_us=round(med, 1), after_idle_min_us=round(iso[0], 1),
+                note="sustained = 600 launches back to back after 1500 warm-up launches: the socket sits at its power limit and rocm-smi reports the shader "
+                     "clock it then holds - clock_frac_of_boost of the 2.4 GHz the part can run at is the share of this kernel's rate that is power, not "
+                     "code (its phases are issue-bound: time scales with 1 / clock).  after_idle = one launch after 4 ms of idle time, median of 12: "
+                     "NOT a boost-clock figure (the clock has dropped and ramps inside the launch); kept to show that an isolated launch is no faster")

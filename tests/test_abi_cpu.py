@@ -74,6 +74,20 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_linear_fwd_big_f32(one, 512, one, 512, None, one, 512, 1024, 512, 512, one, None) == -1                            # too few rows for this route
     assert L.p2c_linear_fwd_big_f32(one, 514, one, 512, None, one, 512, 262144, 512, 512, one, None) == -2                          # row stride not 16-byte aligned
     assert L.p2c_linear_bwd_data_big_f32(one, 512, one, 512, one, 512, 0.0, 20.0, one, 512, 262144, 512, 512, one, None) == -1      # softplus derivative needs beta > 0
+    # round 5 entries
+    assert L.p2c_fit_fused_f32(one, one, None, one, one, 0, one, one, 1, 8192, 8, 2048, one, one, one, one, one, None, one, None) == -1   # Wb without Wc (both NULL = labels-implied)
+    assert L.p2c_linear_fwd_big_add_f32(one, 512, one, 512, None, None, 512, one, 512, 262144, 512, 512, one, None) == -1               # addend missing
+    assert L.p2c_linear_fwd_big_add_f32(one, 512, one, 512, None, one, 514, one, 512, 262144, 512, 512, one, None) == -2               # addend stride not 16-byte aligned
+    assert L.p2c_linear_bwd_data_big_add_f32(one, 512, one, 512, None, 0, 0.0, 20.0, None, 512, one, 512, 262144, 512, 512, one, None) == -1
+    assert L.p2c_softplus_dot_f32(None, None, None, None, 8, 512, 100.0, 20.0, None) == -1
+    assert L.p2c_softplus_dot_f32(one, one, None, one, 8, 510, 100.0, 20.0, None) == -1                                             # K not a multiple of 4
+    assert L.p2c_softplus_row_bwd_f32(None, 1, one, one, None, None, 8, 512, 100.0, 20.0, None) == -1
+    assert L.p2c_softplus_sig_bwd_rank2_f32(None, 2, one, one, None, one, one, one, one, 8, 512, 100.0, 20.0, None) == -1
+    assert L.p2c_copy2d_batch_inc_f32(None, 0, None, 0, None) == -1 and L.p2c_copy2d_batch_inc_f32(None, 2, one, 1, None) == -1
+    assert L.p2c_three_interp_skip_f32(one, 128, one, one, 1, 64, 16, 128, None, 128, 128, one, 256, 256, None) == -1               # skip block missing
+    assert L.p2c_three_interp_skip_f32(one, 128, one, one, 1, 64, 16, 128, one, 128, 128, one, 256, 200, None) == -1                # width smaller than skip + interpolated
+    assert L.p2c_fold0_bwd_finalize_sum_f32(one, one, 10, one, None, one, one, 64, one, one, one, 5, one, 16, 8, one, 16, None) == -1    # dW0 leading dimension outside 1..4
+    assert L.p2c_group_weight_grad_f32(None, 128, None, 128, 128, 128, None, None) == -1
 
 
 def test_shape_queries_describe_the_kernel_coverage():

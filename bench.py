@@ -373,7 +373,7 @@ def _bench(args, rank, world, local, dev):
             common = dict(launch_unit="one call of the entry point (a layer's backward); kernel launches are listed in traffic_by_kernel",
                           traffic=None if tr is None else round(tr["per_step"] / calls_per_step), traffic_unit="HBM bytes (read + write, PMC) per call",
                           traffic_per_step=None if tr is None else tr["per_step"], algorithmic_bytes_per_step=round(alg_step),
-                          traffic_ratio=None if tr is None else round(tr["per_step"] / alg_step, 3),
+                          traffic_ratio=None if (tr is None or alg_step <= 0) else round(tr["per_step"] / alg_step, 3),
                           kernel_launches_per_step=None if tr is None else tr["kernel_launches_per_step"],
                           traffic_by_kernel=None if tr is None else tr["by_kernel"],
                           traffic_source=None if tr is None else tr["source"], traffic_source_hash=None if tr is None else tr["source_hash"],
@@ -423,6 +423,10 @@ def _bench(args, rank, world, local, dev):
         cpu = dict(value=round(best[0], 1), unit="points/s", cores=best[1], kind="port", cpu_model=_cpu_model(), host_cores=host, sched_affinity=affinity,
                    by_threads={str(thr): round(pps, 1), str(thra): None if ppsa is None else round(ppsa, 1), "1": round(pps1, 1)},
                    single_thread_value=round(pps1, 1), all_threads_value=None if ppsa is None else round(ppsa, 1), all_threads_note=all_note,
+                   all_threads_unbounded_reference=dict(value=178.0, unit="points/s", threads=256, seconds_for_one_step=183.6,
+                                                        source="profiles/r04_bench_all_threads_unbounded.json.log",
+                                                        note="the one time the os.cpu_count()-thread leg was allowed to finish (round 4, same CPU model): "
+                                                             "not re-measured by this run, whose leg is limited to 12 s so that the default bench stays within minutes"),
                    sample="%d full training steps (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
                           "points (same generator as the GPU batch) on %d threads, %.1f s of CPU work; all_threads_value: 1 step of the same on "
                           "os.cpu_count() = %d threads in a child process limited to 20 s; single_thread_value: %d step(s) on B=1 cloud with 1 "

@@ -48,8 +48,10 @@ def main():
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True)
         f = os.path.join(d, "r_counter_collection.csv")
         if r.returncode != 0 or not os.path.exists(f):
-            sys.stderr.write("pass %s failed (rc %d): %s\n" % (name, r.returncode, r.stderr[-600:]))
-            continue
+            err = "\n".join(l for l in r.stderr.splitlines() if "Opened result file" not in l and "simple_timer" not in l)
+            sys.stderr.write("pass %s failed (rc %d): %s\n" % (name, r.returncode, err[-1500:]))
+            if not os.path.exists(f):
+                continue
         per = collections.defaultdict(lambda: collections.defaultdict(float))     # (kernel, dispatch) -> counter -> value
         for row in csv.DictReader(open(f)):
             per[(short(row["Kernel_Name"]), row["Dispatch_Id"])][row["Counter_Name"]] += float(row["Counter_Value"])

@@ -267,11 +267,17 @@ def gradient(inputs, outputs):
     return g[:, -2:]
 
 
-def add_latent(points, latent_codes):
-    """IGR/network.py:200-206: points (B', S, d), latent_codes (B', L) -> rows [code of the sketch | point], (B'*S, L + d)."""
+def add_latent(points, latent_codes, pad=False):
+    """IGR/network.py:200-206: points (B', S, d), latent_codes (B', L) -> rows [code of the sketch | point], (B'*S, L + d).
+    pad=True: zero columns up to the next multiple of 4 are appended by the same concatenation (what the GEMM kernels want: no padding copy)."""
     nb, ns, d = points.shape
-    codes = latent_codes[:, None, :].expand(nb, ns, latent_codes.shape[-1])
-    return torch.cat([codes.reshape(nb * ns, -1), points.reshape(nb * ns, d)], dim=1)
+    L = latent_codes.shape[-1]
+    codes = latent_codes[:, None, :].expand(nb, ns, L)
+    cols = [codes.reshape(nb * ns, -1), points.reshape(nb * ns, d)]
+    extra = (-(L + d)) % 4 if pad else 0
+    if extra:
+        cols.append(torch.zeros(1, extra, dtype=points.dtype, device=points.device).expand(nb * ns, extra))
+    return torch.cat(cols, dim=1)
 
 
 class ImplicitNet(nn.Module):
@@ -494,6 +500,7 @@ class _DecoderVG(torch.autograd.Function):
         Dp = d_in + (-d_in) % 4
         ap = a if a.shape[1] == Dp else F.pad(a, (0, Dp - a.shape[1]))
         ap = _c(ap.detach())
+        ctx.padded_in = a.shape[1] == Dp
         # the last layer has ONE output unit (IGR/network.py:38: dims + [1]): its products are a dot product / outer products with one weight
         # row and ride on the activation passes (csrc/softplus.hip, row-structured kernels) instead of [M x 4]-padded GEMMs over 0.5 GB operands
         one_out = L >= 2 and lay[-1][3] == 1 and lay[-1][1] is None
@@ -598,7 +605,7 @@ class _DecoderVG(torch.autograd.Function):
         if Z is None:
             return None, None, None
         dA = _prod_nn(Z, lay[0][0], add=skip_term)
-        return (dA[:, :d_in] if Dp != d_in else dA), None, None
+        return (dA[:, :d_in] if (Dp != d_in and not ctx.padded_in) else dA), None, None
 
 
 def decoder_value_and_grad_applicable(net):
@@ -606,9 +613,12 @@ def decoder_value_and_grad_applicable(net):
     return net.beta > 0 and not any(p.requires_grad for p in net.parameters())
 
 
-def decoder_value_and_grad(net, a):
+def decoder_value_and_grad(net, a, d_in=None):
     """-> (net(a) [M,1], gradient(a, net(a)) = d sum(net(a)) / d a [:, -2:] [M,2]) with the graph kept through ONE node (see _DecoderVG);
-    `a` [M, d_in] on the device."""
+    `a` [M, d_in] on the device - or, with d_in given, [M, pad4(d_in)] with zero pad columns (add_latent(..., pad=True)): no padding copy."""
     if not a.is_cuda:
         raise RuntimeError("point2cyl_amd.implicit.decoder_value_and_grad runs on the HIP device only (got %s); there is no CPU path" % a.device)
-    return _DecoderVG.apply(a, net, a.shape[1])
+    d_in = a.shape[1] if d_in is None else int(d_in)
+    if a.shape[1] not in (d_in, d_in + (-d_in) % 4):
+        raise ValueError("decoder_value_and_grad: input of width %d for d_in = %d" % (a.shape[1], d_in))
+    return _DecoderVG.apply(a, net, d_in)

@@ -14,15 +14,22 @@ USE_DECODER_NODE = True      # the frozen decoder's value + input gradient as ON
 
 def implicit_losses(implicit_net, sk_pnts, sk_normals, nonmnfld_pnts, latent_codes, mask_gt, batch_size, K):
     """train_Point2Cyl.py:610-648 -> (im_loss, mnfld_loss, grad_loss, normals_loss)."""
-    a = add_latent(sk_pnts, latent_codes).requires_grad_()
-    n = add_latent(nonmnfld_pnts, latent_codes).requires_grad_()
     if USE_DECODER_NODE and decoder_value_and_grad_applicable(implicit_net):
         # frozen decoder (the trainer's: :352-365): forward, input gradient and their double backward hand-written as one node - the sums of
-        # the two gradients every pre-activation receives ride in the products' epilogues (implicit._DecoderVG)
-        sk_pred, ga = decoder_value_and_grad(implicit_net, a)
-        nonmnfld_pred, gn = decoder_value_and_grad(implicit_net, n)
-        mnfld_grad, nonmnfld_grad = ga.reshape(batch_size, K, -1, 2), gn.reshape(batch_size, K, -1, 2)
+        # the two gradients every pre-activation receives ride in the products' epilogues (implicit._DecoderVG).  The surface samples and
+        # the off-surface samples of a sketch go through it TOGETHER (one evaluation over S + S' points per sketch instead of two: the
+        # decoder is the same, half the launches and weight pre-passes), the rows [code | point | pad] written 4-padded by ONE concatenation.
+        nb, S1 = sk_pnts.shape[0], sk_pnts.shape[1]
+        both = torch.cat([sk_pnts, nonmnfld_pnts], dim=1)                         # (B', S + S', 2)
+        d_in = latent_codes.shape[-1] + both.shape[-1]
+        a = add_latent(both, latent_codes, pad=True).requires_grad_()
+        pred, g = decoder_value_and_grad(implicit_net, a, d_in=d_in)
+        pred, g = pred.view(nb, -1, 1), g.view(nb, -1, 2)
+        sk_pred, nonmnfld_pred = pred[:, :S1].reshape(-1, 1), pred[:, S1:].reshape(-1, 1)
+        mnfld_grad, nonmnfld_grad = g[:, :S1].reshape(batch_size, K, -1, 2), g[:, S1:].reshape(batch_size, K, -1, 2)
     else:
+        a = add_latent(sk_pnts, latent_codes).requires_grad_()
+        n = add_latent(nonmnfld_pnts, latent_codes).requires_grad_()
         sk_pred, nonmnfld_pred = implicit_net(a), implicit_net(n)
         mnfld_grad = gradient(a, sk_pred).reshape(batch_size, K, -1, 2)
         nonmnfld_grad = gradient(n, nonmnfld_pred).reshape(batch_size, K, -1, 2)

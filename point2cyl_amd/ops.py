@@ -22,7 +22,6 @@ USE_CSR_BWD = os.environ.get("P2C_CSR_BWD", "1") != "0"      # gather-formulated
 USE_NARROW_BWD = os.environ.get("P2C_NARROW_BWD", "1") != "0"  # the per-point heads' backward in one pass (csrc/heads.hip)
 STRICT_LABELS = os.environ.get("P2C_STRICT_LABELS", "0") == "1"   # validate labels with a device->host sync in every loss call instead of deferred
 USE_POOL_ALG = os.environ.get("P2C_POOL_ALG", "1") != "0"    # pooled last layer's backward without its pre-BN output (csrc/bwd_pool.hip)
-USE_SIDE_DW = os.environ.get("P2C_SIDE_DW", "0") == "1"      # EXPERIMENT (measured in DESIGN 5.0): the weight-gradient GEMMs of the 4 k - 16 k-row layers on a forked stream beside the dX chain
 USE_POOL_EPI = os.environ.get("P2C_POOL_EPI", "1") != "0"    # max over 64 neighbours from extremes emitted by the last layer's GEMM epilogue
 
 
@@ -298,42 +297,6 @@ def _zero_padded(t, *shape):
     return buf
 
 
-class _SideBranch:
-    """A forked stream for work nothing on the critical path waits for (weight-gradient GEMMs): `with side:` runs the enclosed launches on it,
-    gated on everything enqueued so far; join() makes the current stream wait for it.  Under stream capture both become edges of the graph.
-    Tensors the side launches read are kept alive until the join (the allocator hands a freed block to the NEXT allocation of the stream
-    that owns it, which may run before the side kernel has read it)."""
-
-    def __init__(self):
-        self.stream, self.used, self.keep, self._ctx = None, False, [], None
-
-    def __enter__(self):
-        cur = torch.cuda.current_stream()
-        if self.stream is None or self.stream.device != cur.device:
-            self.stream = torch.cuda.Stream(cur.device)
-        self.stream.wait_stream(cur)
-        self._ctx = torch.cuda.stream(self.stream)
-        self._ctx.__enter__()
-        self.used = True
-        return self
-
-    def __exit__(self, *exc):
-        self._ctx.__exit__(*exc)
-        return False
-
-    def hold(self, *tensors):
-        self.keep.extend(t for t in tensors if t is not None)
-
-    def join(self):
-        if self.used:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self.used = False
-        del self.keep[:]
-
-
-_SIDE = _SideBranch()
-
-
 class _MLPStack(torch.autograd.Function):
     """A chain of 1x1-conv layers  Y_i = act_{i-1}(Y_{i-1}) W_i^T + b_i  with BatchNorm+ReLU folded into the
     NEXT layer's operand load.  tail: 'maxpool' (max over ns of relu(bn(Y_last))), 'bnrelu' (materialise
@@ -591,7 +554,6 @@ class _MLPStack(torch.autograd.Function):
                 coef[3:].zero_()
             return coef
 
-        deferred = []         # (parameter slot, thunk producing the weight gradient in the parameter's layout): run after every kernel is enqueued
         pool_ns = 0
         if tail == "maxpool":
             # dZ of the pooled layer is never materialised (grad_mode 2): winners + pooled gradient are enough
@@ -627,25 +589,16 @@ class _MLPStack(torch.autograd.Function):
                 dGb = torch.empty(G_, Co, dtype=torch.float32, device=dev)
                 call("p2c_group_colsum_bn_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(coef), G_, pre["rpg"], Co, ptr(dGb), Co, stream())
                 dWb = arena.f32(Co, D2)
-                dWa = arena.f32(Co, Ci)
-
-                def rep_dw():
-                    call("p2c_linear_bwd_weight_f32", ptr(dGb), Co, None, 0, 0, None, ptr(V), V.stride(0), 0, None, None, None, 0, 1.0, ptr(dWb), D2, 0,
-                         None, G_, Co, D2, None, 0, stream(), flops=2.0 * G_ * Co * D2)
-                    call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, 1, ptr(coef), ptr(X0), X0.stride(0), 0, None, None, None, 0, 1.0,
-                         ptr(dWa), Ci, 0, None, M, Co, Ci, None, 0, stream(), flops=2.0 * M * Co * Ci)
-
-                if USE_SIDE_DW:
-                    with _SIDE:
-                        rep_dw()
-                    _SIDE.hold(dGb, V, dZ, Y, coef, X0)
-                else:
-                    rep_dw()
+                call("p2c_linear_bwd_weight_f32", ptr(dGb), Co, None, 0, 0, None, ptr(V), V.stride(0), 0, None, None, None, 0, 1.0, ptr(dWb), D2, 0,
+                     None, G_, Co, D2, None, 0, stream(), flops=2.0 * G_ * Co * D2)
                 dV = torch.empty(G_, D2, dtype=torch.float32, device=dev)
                 call("p2c_linear_bwd_data_f32", ptr(dGb), Co, None, 0, 0, None, ptr(Wb), D2, ptr(dV), D2, G_, Co, D2, None, 0, 1.0, None, 0,
                      None, None, None, 0, stream(), flops=2.0 * G_ * Co * D2)
+                dWa = arena.f32(Co, Ci)
+                call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, 1, ptr(coef), ptr(X0), X0.stride(0), 0, None, None, None, 0, 1.0,
+                     ptr(dWa), Ci, 0, None, M, Co, Ci, None, 0, stream(), flops=2.0 * M * Co * Ci)
                 Wp = params[p0]
-                deferred.append((p0, lambda dWa=dWa, dWb=dWb, Ci=Ci, Wp=Wp: torch.cat([dWa[:, :Ci], dWb], 1).reshape(Wp.shape)))
+                grads[p0] = torch.cat([dWa[:, :Ci], dWb], 1).reshape(Wp.shape)
                 grads[p0 + 1] = arena.f32(Co)
                 rep_grad = dV
                 dX = None
@@ -669,26 +622,16 @@ class _MLPStack(torch.autograd.Function):
                     call("p2c_group_linear_bwd_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, ptr(coef), ptr(offsets), ptr(rows_), ptr(pre["xyz"]),
                          ptr(pre["new_xyz"]), pre["B"], pre["N"], pre["S"], pre["ns"], Co, ptr(dG), Co, ptr(dwx), stream())
                 dW = arena.f32(Co, Ci)
+                call("p2c_linear_bwd_weight_f32", ptr(dG), Co, None, 0, 0, None, ptr(X0), X0.stride(0), 0, None, None, None, 0, 1.0, ptr(dW), Ci, 0,
+                     None, Ms, Co, Ci, None, 0, stream(), flops=2.0 * Ms * Co * Ci)
                 Wp = params[p0]
-                gW = torch.empty(Wp.shape, dtype=torch.float32, device=dev) if dwx is not None else None
-
-                def pre_dw():
-                    call("p2c_linear_bwd_weight_f32", ptr(dG), Co, None, 0, 0, None, ptr(X0), X0.stride(0), 0, None, None, None, 0, 1.0, ptr(dW), Ci, 0,
-                         None, Ms, Co, Ci, None, 0, stream(), flops=2.0 * Ms * Co * Ci)
-                    if dwx is not None:
-                        # [coordinate part (slot sums) | feature part] in the parameter's own layout by one launch (was: reduction, transpose+cast, cat)
-                        call("p2c_group_weight_grad_f32", ptr(dwx), Co, ptr(dW), Ci, Wp.shape[0], Wp.numel() // Wp.shape[0] - 3, ptr(gW), stream())
-
-                if USE_SIDE_DW:
-                    with _SIDE:
-                        pre_dw()
-                    _SIDE.hold(dG, X0, dwx)
-                else:
-                    pre_dw()
                 if dwx is not None:
+                    # [coordinate part (slot sums) | feature part] in the parameter's own layout by one launch (was: reduction, transpose+cast, cat)
+                    gW = torch.empty(Wp.shape, dtype=torch.float32, device=dev)
+                    call("p2c_group_weight_grad_f32", ptr(dwx), Co, ptr(dW), Ci, Wp.shape[0], Wp.numel() // Wp.shape[0] - 3, ptr(gW), stream())
                     grads[p0] = gW
                 else:
-                    deferred.append((p0, lambda dW=dW, Wp=Wp: dW[:Wp.shape[0], :Wp.numel() // Wp.shape[0]].reshape(Wp.shape)))
+                    grads[p0] = dW[:Wp.shape[0], :Wp.numel() // Wp.shape[0]].reshape(Wp.shape)
                 grads[p0 + 1] = arena.f32(Co)[:Wp.shape[0]]          # bias in front of a train-mode BatchNorm: exactly zero
                 dZ = None
                 if ctx.needs_input_grad[1]:
@@ -739,9 +682,9 @@ class _MLPStack(torch.autograd.Function):
             db = arena.f32(Co)
             Wp = params[p0]
             co_t, ci_t = Wp.shape[0], Wp.numel() // Wp.shape[0]
-            def _to_param_layout(g, co_t=co_t, ci_t=ci_t, first=(i == 0), Wp=Wp):      # (bound now: the call is deferred past the loop)
+            def _to_param_layout(g):
                 g = g[:co_t, :ci_t]
-                if first and cfg.get("xyz_last") and ci_t > 3:
+                if i == 0 and cfg.get("xyz_last") and ci_t > 3:
                     g = torch.cat([g[:, ci_t - 3:], g[:, :ci_t - 3]], 1)     # back to the reference's [xyz | feats] input order
                 return g.reshape(Wp.shape)
 
@@ -804,19 +747,10 @@ class _MLPStack(torch.autograd.Function):
             else:
                 use_slots = M >= 65536       # many split-k workgroups: spread the atomics over 8 copies of dW
                 dWs = arena.f32(8, Co, Ci) if use_slots else dW
-
-                def gen_dw(dZ=dZ, Y=Y, coef=coef, Xin=Xin, sc=sc, sh=sh, grad_mode=grad_mode, dWs=dWs, use_slots=use_slots):
-                    call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
-                         ptr(sh), mptr, mld, float(dscale), ptr(dWs), Ci, Co * Ci if use_slots else 0,
-                         ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
-                         flops=2.0 * M * Co * Ci)
-
-                if USE_SIDE_DW and not use_slots and need_dx:
-                    with _SIDE:
-                        gen_dw()
-                    _SIDE.hold(dZ, Y, coef, Xin, sc, sh)
-                else:
-                    gen_dw()
+                call("p2c_linear_bwd_weight_f32", ptr(dZ), dZ.stride(0), ptr(Y), Co, grad_mode, ptr(coef), ptr(Xin), ldxin, mode, ptr(sc),
+                     ptr(sh), mptr, mld, float(dscale), ptr(dWs), Ci, Co * Ci if use_slots else 0,
+                     ptr(db) if grad_mode == 0 else None, M, Co, Ci, ptr(arg) if grad_mode == 2 else None, pool_ns, stream(),
+                     flops=2.0 * M * Co * Ci)
                 if use_slots:
                     dW_copies = dWs
                 dX = part = None
@@ -848,10 +782,7 @@ class _MLPStack(torch.autograd.Function):
                         coef[3:].zero_()
             if dW_copies is not None:
                 call("p2c_sum_copies_f32", ptr(dW_copies), Co * Ci, dW_copies.shape[0], ptr(dW_final), Co * Ci, stream())
-            deferred.append((p0, lambda f=_to_param_layout, g=dW_final: f(g)))       # after the kernels are enqueued (the permuted layout is a copy)
-        _SIDE.join()          # (no-op unless P2C_SIDE_DW forked something: the side stream's dW launches are complete before anything reads them)
-        for p0_, fn_ in deferred:
-            grads[p0_] = fn_()
+            grads[p0] = _to_param_layout(dW_final)       # after the kernels are enqueued (the permuted layout is a copy)
         if evalm:
             for i in range(L):
                 p0, has_bn = slots[i]

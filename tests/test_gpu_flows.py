@@ -644,7 +644,7 @@ def test_autograph_module_forward_backward_equals_eager_launches():
 
 ROUTE_FLAGS = [("USE_FUSED_BWD", "P2C_FUSED_BWD"), ("USE_FUSED256", "P2C_FUSED256"), ("USE_DUAL_BWD", "P2C_DUAL_BWD"), ("USE_NARROW_BWD", "P2C_NARROW_BWD"),
                ("USE_POOL_ALG", "P2C_POOL_ALG"), ("USE_POOL_EPI", "P2C_POOL_EPI"), ("USE_FOLD0", "P2C_FOLD0"), ("USE_PRE_LINEAR", "P2C_PRE_LINEAR"),
-               ("USE_CSR_BWD", "P2C_CSR_BWD"), ("USE_STAGED_WEIGHTS", "P2C_STAGE_WEIGHTS"), ("USE_SIDE_DW", "P2C_SIDE_DW")]
+               ("USE_CSR_BWD", "P2C_CSR_BWD"), ("USE_STAGED_WEIGHTS", "P2C_STAGE_WEIGHTS")]
 
 
 @pytest.mark.parametrize("flag,env", ROUTE_FLAGS)
@@ -662,8 +662,7 @@ def test_alternate_route_equals_default_route(flag, env):
     s1, s2 = torch.randint(0, N, (B,), generator=g), torch.randint(0, 512, (B,), generator=g)
     mask = (torch.rand(B, N, 128, generator=g) < 0.5).float()
     fl = step.StepFlags(K=K)
-    default = flag != "USE_SIDE_DW"           # (an opt-in experiment: default off, the test runs it switched ON against the default)
-    assert getattr(ops, flag) is default, "the default route must be in force (is %s set in the environment of the test run?)" % env
+    assert getattr(ops, flag) is True, "the default route must be on (is %s set in the environment of the test run?)" % env
 
     def run():
         torch.manual_seed(21)
@@ -677,11 +676,11 @@ def test_alternate_route_equals_default_route(flag, env):
                 {k: v.detach().clone() for k, v in m.named_buffers()})
 
     ref = run()
-    setattr(ops, flag, not default)
+    setattr(ops, flag, False)
     try:
         alt = run()
     finally:
-        setattr(ops, flag, default)
+        setattr(ops, flag, True)
     np.testing.assert_allclose(alt[0], ref[0], rtol=1e-5)
     assert torch.equal(alt[1], ref[1])
     gmax = max(float(v.norm()) for v in ref[3].values())

@@ -239,7 +239,8 @@ def main(argv=None):
                    norm_eig=a.norm_eig, use_gt_normals=a.use_gt_normals, use_gt_segmentation=a.use_gt_segmentation, use_gt_bb=a.use_gt_bb,
                    num_sk_point=a.num_sk_point)
     if a.synthetic > 0:
-        ds = synth.SyntheticExtrusionDataset(a.synthetic, a.num_point, a.K, seed=99991)
+        gen = synth.SyntheticExtrusionDataset(a.synthetic, a.num_point, a.K, seed=99991)
+        ds = [gen[i] for i in range(len(gen))]        # generated up front (2 - 4 ms of host time per cloud): the loop below times the evaluation, not the generator
     else:
         from .h5data import AutodeskH5, dataset_path
         ds = AutodeskH5(dataset_path(a.data_dir, a.data_split), a.num_point, a.K, center=True)

@@ -854,13 +854,14 @@ extern "C" int p2c_fit_fused_f32(const float *X, const float *Wb, const float *W
         hipLaunchKernelGGL((fit_fused_kernel<KK_, TH_, PLDS_>), dim3(B), dim3(TH_), lds, s, X, Wb, Wc, P, inst_gt, bb_gt, rand_idx, normalize, N, S,    \
                            axis_out, centroids_out, cfound_out, ext_tmp, counts, axis64_out);                                          \
     } while (0)
-#define P2C_FFH(KK_)                                                                                                                    \
+#define P2C_FFH_(KK_, TH_, PLDS_)                                                                                                       \
     do {                                                                                                                                \
-        const size_t lds = fit_fused_lds(N, K, 16, true);                                                                               \
-        (void)hipFuncSetAttribute((const void *)fit_fused_kernel<KK_, 1024, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-        hipLaunchKernelGGL((fit_fused_kernel<KK_, 1024, true, true>), dim3(B), dim3(1024), lds, s, X, Wb, Wc, P, inst_gt, bb_gt, rand_idx, normalize, N, \
+        const size_t lds = fit_fused_lds(N, K, TH_ / 64, PLDS_);                                                                        \
+        (void)hipFuncSetAttribute((const void *)fit_fused_kernel<KK_, TH_, PLDS_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL((fit_fused_kernel<KK_, TH_, PLDS_, true>), dim3(B), dim3(TH_), lds, s, X, Wb, Wc, P, inst_gt, bb_gt, rand_idx, normalize, N, \
                            S, axis_out, centroids_out, cfound_out, ext_tmp, counts, axis64_out);                                       \
     } while (0)
+#define P2C_FFH(KK_) do { if (half) P2C_FFH_(KK_, 512, false); else P2C_FFH_(KK_, 1024, true); } while (0)
 #define P2C_FFK(KK_) do { if (hard) P2C_FFH(KK_); else if (half) P2C_FF(KK_, 512, false); else P2C_FF(KK_, 1024, true); } while (0)
     if (K == 8) P2C_FFK(8);
     else if (K == 4) P2C_FFK(4);
@@ -868,6 +869,7 @@ extern "C" int p2c_fit_fused_f32(const float *X, const float *Wb, const float *W
     else P2C_FFK(1);
 #undef P2C_FFK
 #undef P2C_FFH
+#undef P2C_FFH_
 #undef P2C_FF
     hipLaunchKernelGGL(extents_finish_kernel, dim3(K), dim3(256), 0, s, ext_tmp, counts, B, K, extents_out, found_out);
     P2C_LAUNCH_CHECK();

@@ -220,6 +220,8 @@ def build_parser():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no_prefetch", action="store_true", help="run FPS / ball query / 3-NN of every batch on the critical path instead of one batch "
                    "ahead on a forked stream (graph.PipelinedForward)")
+    p.add_argument("--prefetch_group", type=int, default=4, help="batches whose geometry is computed TOGETHER, one group ahead (FPS is 512 dependent "
+                   "steps per cloud whether 32 or 128 clouds are sampled: its latency is shared by the group; 1 = one batch ahead)")
     p.add_argument("--report", type=str, default="", help="write a JSON throughput report here")
     return p
 
@@ -284,47 +286,72 @@ def main(argv=None):
     # i + 1 are drawn (CPU generator, SA1 then SA2, like the reference) BEFORE batch i's extent samples (data_utils.py:1696, same generator),
     # in the serial loop after them: another equally valid random sampling of the same clouds, not the same one (--no_prefetch keeps the
     # reference's order).
+    import collections
     it = iter(loader)
-    cur = next(it, None)
-    cur = to_device(cur) if cur is not None else None
+    pending = collections.deque()
+    G = max(1, int(a.prefetch_group))
+
+    def fill(k):
+        while len(pending) < k:
+            b = next(it, None)
+            if b is None:
+                return
+            pending.append(to_device(b))
+
+    def same(bs):
+        return all(tuple(b[0].shape) == tuple(bs[0][0].shape) for b in bs) and bs[0][0].shape[2] == 3
+
+    def evaluate(b, heads=None):
+        m = evaluate_batch(model, *b, fl, heads=heads)
+        if a.with_sketch_fit:
+            m["pred_fit_cyl_loss"], m["pred_fit_glob_loss"] = sketch_fit_losses(m, b[0], b[1], b[2], b[3], implicit_net, pn_encoder, fl)
+        acc.add(m)
+
     pipe, pipe_shape, i, n_piped = None, None, 0, 0
     t_first = None
     stream = torch.cuda.Stream(dev)
     stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
-        while cur is not None:
-            nxt = next(it, None)
-            nxt = to_device(nxt) if nxt is not None else None
-            heads = None
-            if pipe is not None and tuple(cur[0].shape) != pipe_shape:
-                pipe.release()            # (its FPS-start hook must not meet a batch of another size)
-                pipe = None
-            if not a.no_prefetch and cur[0].shape[2] == 3:
-                if pipe is None and nxt is not None and nxt[0].shape == cur[0].shape:
+        fill(2 * G)
+        while pending:
+            group = None
+            if not a.no_prefetch and len(pending) >= G and same(list(pending)[:G]) and (pipe is None or tuple(pending[0][0].shape) == pipe_shape):
+                group = [pending.popleft() for _ in range(G)]
+                fill(2 * G)
+                nxt = list(pending)[:G] if (len(pending) >= G and same(list(pending)[:G]) and tuple(pending[0][0].shape) == tuple(group[0][0].shape)) else None
+                if pipe is None:
                     from .graph import PipelinedForward
-                    pipe, pipe_shape = PipelinedForward(model, cur[0], stream=stream), tuple(cur[0].shape)
-                if pipe is not None and tuple(cur[0].shape) == pipe_shape:
-                    heads = pipe(nxt[0] if (nxt is not None and tuple(nxt[0].shape) == pipe_shape) else None)
-                    n_piped += 1
-            m = evaluate_batch(model, *cur, fl, heads=heads)
-            if a.with_sketch_fit:
-                m["pred_fit_cyl_loss"], m["pred_fit_glob_loss"] = sketch_fit_losses(m, cur[0], cur[1], cur[2], cur[3], implicit_net, pn_encoder, fl)
-            acc.add(m)
-            if i % 20 == 0 and rank == 0:
-                print("Time elapsed: %s sec for batch %d/%d." % (time.time() - t0, i, len(loader)))
-            if i == 0:
+                    pipe, pipe_shape = PipelinedForward(model, [b[0] for b in group], stream=stream, group=G), tuple(group[0][0].shape)
+                outs = pipe([b[0] for b in nxt] if nxt is not None else None)
+                for b, h in zip(group, outs):
+                    evaluate(b, heads=h)
+                n_piped += G
+                done = G
+                if nxt is None:
+                    pipe.release()        # no further full group: what is left (a short last group, another shape) takes the serial forward
+                    pipe = None
+            else:
+                if pipe is not None:
+                    pipe.release()
+                    pipe = None
+                evaluate(pending.popleft())
+                fill(2 * G)
+                done = 1
+            if (i // 20) != ((i + done) // 20) or i == 0:
+                if rank == 0:
+                    print("Time elapsed: %s sec for batch %d/%d." % (time.time() - t0, i, len(loader)))
+            if t_first is None:
                 torch.cuda.synchronize()
-                t_first = time.time()
-            cur = nxt
-            i += 1
+                t_first, i_first = time.time(), i + done
+            i += done
     if pipe is not None:
         pipe.release()
     torch.cuda.current_stream().wait_stream(stream)
     torch.cuda.synchronize()
-    if rank == 0 and i > 1:
-        dt = (time.time() - t_first) / (i - 1)
+    if rank == 0 and t_first is not None and i > i_first:
+        dt = (time.time() - t_first) / (i - i_first)
         rep = dict(batches=i, batches_pipelined=n_piped, batch_size=a.batch_size, num_point=a.num_point, prefetch=not a.no_prefetch,
-                   ms_per_batch_after_first=dt * 1e3, points_per_s=a.batch_size * a.num_point / dt)
+                   prefetch_group=G, ms_per_batch_after_first=dt * 1e3, points_per_s=a.batch_size * a.num_point / dt)
         print("evaluation throughput: %.3f ms/batch (forward + metrics + one host transfer per batch), %.1f points/s, %d of %d batches pipelined"
               % (rep["ms_per_batch_after_first"], rep["points_per_s"], n_piped, i))
         if a.report:

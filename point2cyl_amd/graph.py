@@ -98,13 +98,13 @@ class GraphedForwardBackward:
 
     inference=True: fn runs without gradients; the prefetched geometry omits the inverse maps of the gathers (only a backward reads them)."""
 
-    def __init__(self, model, fn, warmup=2, prefetch_xyz=None, draw_starts=True, stream=None, split_tail=False, inference=False):
+    def __init__(self, model, fn, warmup=2, prefetch_xyz=None, draw_starts=True, stream=None, split_tail=False, inference=False, starts=None):
         import gc
         gc.collect()       # autograd graphs of earlier eager steps that only reference cycles keep alive: their AccumulateGrad nodes are
         # bound to the stream they were created on, and autograd would order the capture stream against that stream (work the capture
         # never joins -> hipErrorStreamCaptureUnjoined)
         dev = next(model.parameters()).device
-        self.starts = _PinnedStarts(dev)
+        self.starts = starts if starts is not None else _PinnedStarts(dev)      # (PipelinedForward injects its per-batch-ordered group draws)
         self.draw_starts = draw_starts
         self._hooked = []
         for m in model.modules():
@@ -232,50 +232,122 @@ class GraphedForwardBackward:
                 m.fps_start = None
 
 
+class _GroupStarts(_PinnedStarts):
+    """FPS start indices for G batches of B clouds computed as ONE geometry call: the draws are made batch by batch in the reference's
+    order (SA1 then SA2 of batch 0, then of batch 1, ...: pointnet_util.py:75 once per level and forward) and laid side by side into the
+    (G x B,) device tensors the grouped call reads, so every batch sees the draws the serial loop would have given it."""
+
+    def __init__(self, device, levels, B, G):
+        super().__init__(device)
+        self.B, self.G = B, G
+        for N in levels:
+            hs = [torch.empty(G * B, dtype=torch.long).pin_memory() for _ in range(_RING)]
+            self.slots.append((N, hs, torch.empty(G * B, dtype=torch.long, device=device)))
+        self.stage(G)
+        torch.cuda.current_stream().synchronize()
+
+    def stage(self, n_batches=None):
+        n = self.G if n_batches is None else n_batches
+        assert n == self.G
+        r = self.ring = (self.ring + 1) % _RING
+        if self.events[r] is not None:
+            self.events[r].synchronize()
+        B = self.B
+        for j in range(n):
+            for N, hs, d in self.slots:
+                hs[r][j * B:(j + 1) * B].copy_(_bb.draw_fps_start(N, B))
+        for N, hs, d in self.slots:
+            d.copy_(hs[r], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[r] = ev
+        self.cursor = 0
+
+
+def _slice_geometry(g, j, G):
+    """Batch j's part of a geometry computed for G batches at once (every tensor's leading dimension is a multiple of G)."""
+    if isinstance(g, dict):
+        return {k: _slice_geometry(v, j, G) for k, v in g.items()}
+    if isinstance(g, (tuple, list)):
+        return tuple(_slice_geometry(v, j, G) for v in g)
+    if g is None:
+        return None
+    per = g.shape[0] // G
+    return g[j * per:(j + 1) * per]
+
+
 class PipelinedForward:
     """Inference over a sequence of equal-shaped batches with the geometry hidden: ONE HIP graph per call runs the backbone forward of the
-    CURRENT batch on the geometry computed by the previous call, while a forked stream inside the same graph computes the parameter-free
-    geometry (FPS -> ball query -> grouped coordinates -> second FPS level -> 3-NN stencils -> inverse maps) of the NEXT batch - what
-    point2cyl_amd/train.py does for training, for the evaluation loop of the reference (eval.py:231-268 knows its next batch: it iterates a
-    DataLoader).  The serial forward spends 0.75 of its 1.84 ms in that latency-bound chain; pipelined, a batch costs max(forward, geometry).
+    CURRENT group of G batches (batch by batch: BatchNorm statistics and the dropout counter per batch, as the serial loop) on the geometry
+    computed by the previous call, while a forked stream inside the same graph computes the parameter-free geometry (FPS -> ball query ->
+    grouped coordinates -> second FPS level -> 3-NN stencils; no inverse maps: only a backward reads them) of the NEXT group - what
+    point2cyl_amd/train.py does for training, for the evaluation loop of the reference (eval.py:231-268 knows its next batches: it iterates a
+    DataLoader).  group = G > 1 computes the geometry of G batches TOGETHER: farthest point sampling is 512 dependent steps on one CU per
+    cloud (0.52 ms whether 32 or 128 clouds are sampled), so its latency is shared by G batches - the stage FPS + ball query + grouped MLP
+    goes from 0.83 ms per batch (G = 1: the FPS chain is the period) to 0.40 ms (G = 3) and 0.35 ms (G = 4), DESIGN.md 5.0.
 
-        pf = PipelinedForward(model, first_pcs)          # geometry of the first batch is computed here
-        for k in range(n):
-            heads, sizes = pf(pcs[k + 1] if k + 1 < n else None)      # forward of batch k; starts the geometry of batch k + 1
-            ... consume heads (a static buffer: overwritten by the next call) ...
+        pf = PipelinedForward(model, first_group, group=G)          # first_group: list of G (B, N, 3) tensors; their geometry is computed here
+        while groups remain:
+            outs = pf(next_group or None)                            # [(heads, sizes)] * G for the CURRENT group; starts the geometry of next_group
+            ... consume (the heads are static buffers: overwritten by the next call) ...
 
-    The FPS start indices are drawn on the CPU generator per batch in the reference's order (SA1 then SA2), one batch ahead of their use
-    (a call without a next batch draws nothing: the generator ends where the serial path leaves it); the dropout counter advances per forward as in the serial path.  Outputs equal the serial
-    `model.forward_heads(pcs)` on the same draws bit for bit in eval mode (tests/test_gpu_parity.py)."""
+    The FPS start indices are drawn on the CPU generator per batch in the reference's order (SA1 then SA2), one group ahead of their use (a
+    call without a next group draws nothing: the generator ends where the serial path leaves it); the dropout counter advances per forward as in
+    the serial path.  Outputs equal the serial `model.forward_heads(pcs)` on the same draws bit for bit in eval mode (tests/test_gpu_parity.py)."""
 
-    def __init__(self, model, first_pcs, stream=None):
-        if first_pcs.shape[2] != 3:
-            raise ValueError("PipelinedForward: (B, N, 3) clouds only (normal_channel inputs take the serial path)")
-        self.model = model
-        self.cur = first_pcs.detach().float().contiguous().clone()
+    def __init__(self, model, first, stream=None, group=1):
+        single = torch.is_tensor(first)
+        first = [first] if single else list(first)
+        G = int(group)
+        if len(first) != G:
+            raise ValueError("PipelinedForward: group = %d but %d first batches were given" % (G, len(first)))
+        if any(f.shape != first[0].shape for f in first) or first[0].shape[2] != 3:
+            raise ValueError("PipelinedForward: G equal-shaped (B, N, 3) batches (normal_channel inputs take the serial path)")
+        self.model, self.G, self.single = model, G, single
+        B, N, _ = first[0].shape
+        self.B = B
+        self.cur = torch.cat([f.detach().float() for f in first], 0).contiguous()
         self.nxt = self.cur.clone()
         dev = self.cur.device
         self.sizes = None
 
         def fn(geom):
-            with torch.no_grad(), _ops.step_arena(dev):
-                heads, sizes = model.forward_heads(self.cur, geom)
-            self.sizes = sizes
-            return {"heads": heads}
+            outs = []
+            for j in range(G):
+                _ops.step_done()
+                with torch.no_grad(), _ops.step_arena(dev):
+                    heads, sizes = model.forward_heads(self.cur[j * B:(j + 1) * B], _slice_geometry(geom, j, G))
+                outs.append(heads)
+                self.sizes = sizes
+            return {"heads%d" % j: h for j, h in enumerate(outs)}
 
-        self.graph = GraphedForwardBackward(model, fn, prefetch_xyz=self.nxt, stream=stream, inference=True)      # no inverse maps: forward only
+        starts = _GroupStarts(dev, [N, model.sa1.npoint], B, G) if G > 1 else None
+        self.graph = GraphedForwardBackward(model, fn, prefetch_xyz=self.nxt, stream=stream, inference=True, starts=starts)      # no inverse maps: forward only
 
     def __call__(self, next_pcs=None):
-        """Forward of the current batch -> (heads (B*N, ld) static buffer, head sizes); next_pcs: the batch the NEXT call will return
-        (None: there is none - the prefetch runs on stale clouds and is discarded)."""
+        """Forward of the current group -> [(heads (B*N, ld) static buffer, head sizes)] * G (a single pair when constructed from one tensor);
+        next_pcs: the batch(es) the NEXT call will return - a tensor (G = 1), a list of exactly G tensors, or None (there is no further full
+        group: the prefetch runs on stale clouds and is discarded; leftover batches take the serial forward after release())."""
+        n_next = 0
         if next_pcs is not None:
-            if tuple(next_pcs.shape) != tuple(self.nxt.shape):
-                raise ValueError("PipelinedForward: batch of shape %s in a pipeline of %s" % (tuple(next_pcs.shape), tuple(self.nxt.shape)))
-            self.nxt.copy_(next_pcs)
-        out = self.graph(draw=next_pcs is not None)
+            nxt = [next_pcs] if torch.is_tensor(next_pcs) else list(next_pcs)
+            if len(nxt) != self.G or any(tuple(t.shape) != (self.B,) + tuple(self.nxt.shape[1:]) for t in nxt):
+                raise ValueError("PipelinedForward: next group of %d batches / shapes %s in a pipeline of %d x %s (a short last group takes the "
+                                 "serial forward: its empty slots would run real forwards - BatchNorm / dropout side effects - on stale clouds)"
+                                 % (len(nxt), [tuple(t.shape) for t in nxt], self.G, (self.B,) + tuple(self.nxt.shape[1:])))
+            for j, t in enumerate(nxt):
+                self.nxt[j * self.B:(j + 1) * self.B].copy_(t)
+            n_next = len(nxt)
+        if self.G > 1:
+            if n_next:
+                self.graph.starts.stage(n_next)       # per-batch draws in the serial order, only for the batches that exist
+            out = self.graph(draw=False)
+        else:
+            out = self.graph(draw=n_next > 0)
         _ops.step_done()
         self.cur.copy_(self.nxt)          # stream-ordered behind the replay that read `cur`
-        return out["heads"], self.sizes
+        res = [(out["heads%d" % j], self.sizes) for j in range(self.G)]
+        return res[0] if self.single else res
 
     def release(self):
         self.graph.release()

@@ -146,6 +146,42 @@ def sa1_stage(model, xyz, steps=30):
             gr_pipe, _ = capture(piped)
             t_pipe = replay_ms([gr_pipe], steps)
             ops.step_done()
+            # throughput pipeline: the geometry of the next G batches computed TOGETHER (one FPS launch over G x B clouds: G x B workgroups, the same
+            # 512 dependent steps) on the forked stream while the grouped MLP of the current G batches runs batch by batch (BatchNorm per batch)
+            groups = {}
+            for G in (2, 3, 4):
+                xg = xyz.repeat(G, 1, 1)
+                sa1.fps_start = start.repeat(G)
+
+                def geometry_g():
+                    g = sa1.geometry(xg, with_csr=False)
+                    g["X0"] = ops.group_gather(xg, None, g["new_xyz"], g["group_idx"], None)
+                    return g
+
+                def mlp_g(g, j):
+                    ops.step_done()
+                    sl = {k: v[j * (v.shape[0] // G):(j + 1) * (v.shape[0] // G)] for k, v in g.items()}
+                    with torch.no_grad(), ops.step_arena(dev):
+                        return sa1.forward_pm(xg[j * B:(j + 1) * B], None, sl)
+
+                cg = {k: v.clone() for k, v in geometry_g().items()}
+
+                def piped_g():
+                    cap = torch.cuda.current_stream()
+                    side.wait_stream(cap)
+                    with torch.cuda.stream(side):
+                        nxt = geometry_g()
+                    outs = [mlp_g(cg, j) for j in range(G)]
+                    cap.wait_stream(side)
+                    ks = sorted(cg)
+                    ops.copy_flat_batch([cg[k] for k in ks], [nxt[k] for k in ks])
+                    return outs
+
+                gr_g, _ = capture(piped_g)
+                tg = replay_ms([gr_g], max(6, steps // G)) / G
+                groups[str(G)] = dict(ms_per_batch=round(tg, 4), points_per_s=round(B * N / (tg * 1e-3), 1), frac_of_mfma_roofline=round(fl / PEAK_F32_MFMA * 1e3 / tg, 4))
+                ops.step_done()
+            sa1.fps_start = start
     finally:
         sa1.fps_start = hook
     it_us = t_fps * 1e3 / sa1.npoint
@@ -159,6 +195,12 @@ def sa1_stage(model, xyz, steps=30):
                 pipelined_ms=round(t_pipe, 4), points_per_s_pipelined=round(B * N / (t_pipe * 1e-3), 1),
                 frac_of_mfma_roofline_pipelined=round(mfma_floor_ms / t_pipe, 4),
                 pipelined_frac_of_fps_latency_model=round(sa1.npoint * it_us * 1e-3 / t_pipe, 4),
+                pipelined_groups=groups,
+                pipelined_groups_note="steady-state THROUGHPUT per batch of %d clouds when the stage's geometry (FPS -> ball query -> grouped coordinates) of the "
+                                      "next G batches is computed as ONE launch chain over G x %d clouds on the forked stream, under the grouped MLPs of the "
+                                      "current G batches (BatchNorm statistics per batch): FPS is 512 dependent steps on one CU per cloud - 0.52 ms for 32 clouds "
+                                      "and 0.6 - 0.7 ms for 128 - so its latency is shared by the group; graph.PipelinedForward(group=G) runs the whole backbone "
+                                      "this way" % (B, B),
                 pipelined_note="steady state per batch of: grouped MLP of batch i (on the previous replay's geometry) || FPS + ball query + grouped "
                                "coordinates of batch i + 1 on a forked stream, one graph; bounded below by the FPS chain (512 dependent iterations on "
                                "one CU per cloud = parts_ms.fps); pipelined_frac_of_fps_latency_model = parts_ms.fps / pipelined_ms",
@@ -230,10 +272,38 @@ def forward_only(model, pcs, steps=30):
                 pf.release()
         torch.cuda.current_stream().wait_stream(cur)
         ops.step_done()
+    # ... and with the geometry of FOUR batches computed together, one group ahead (the eval CLI's default): FPS's 512 dependent steps per
+    # cloud cost the same for 128 clouds as for 32, so the chain's latency is shared by four batches
+    t4, G = None, 4
+    try:
+        with _KeepBuffers(model):
+            from .graph import PipelinedForward
+            cur = torch.cuda.current_stream()
+            grp = [pcs] * G
+            pf = PipelinedForward(model, grp, stream=cur, group=G)
+            try:
+                for _ in range(2):
+                    pf(grp)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n4 = max(4, steps // G)
+                for _ in range(n4):
+                    pf(grp)
+                torch.cuda.synchronize()
+                t4 = (time.perf_counter() - t0) / (n4 * G) * 1e3
+            finally:
+                pf.release()
+            ops.step_done()
+    except Exception as e:          # (reported, not fatal: the other figures of this leg stand)
+        t4 = None
+        grp_err = "%s: %s" % (type(e).__name__, e)
     return dict(workload="backbone forward, B=%d x N=%d, train-mode BatchNorm + dropout, FPS / ball query / 3-NN included, one HIP graph" % (B, N),
                 ms=round(t, 4), points_per_s=round(B * N / (t * 1e-3), 1),
                 ms_geometry_precomputed=round(t2, 4), points_per_s_geometry_precomputed=round(B * N / (t2 * 1e-3), 1),
                 ms_pipelined=round(t3, 4), points_per_s_pipelined=round(B * N / (t3 * 1e-3), 1),
+                ms_pipelined_group4=None if t4 is None else round(t4, 4), points_per_s_pipelined_group4=None if t4 is None else round(B * N / (t4 * 1e-3), 1),
+                pipelined_group4_note=("per batch of %d clouds, geometry of 4 batches per forked-stream launch, one group ahead (graph.PipelinedForward(group=4), "
+                                       "the eval CLI's default --prefetch_group 4)" % B) if t4 is not None else grp_err,
                 pipelined_note="steady state of graph.PipelinedForward (point2cyl_amd/eval.py): per batch one graph = forward of batch i on the geometry "
                                "the previous replay produced + FPS / ball query / 3-NN / inverse maps of batch i + 1 on a forked stream + the hand-over "
                                "copies; includes the host-side FPS start draws and the copy of the next clouds",

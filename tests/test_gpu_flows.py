@@ -864,7 +864,7 @@ def test_reference_made_checkpoint_loads_and_evaluates(mode, tmp_path):
     # 10 clouds in batches of 4: two full batches through graph.PipelinedForward (the geometry of the second computed under the forward of
     # the first), the last, shorter one through the serial forward; --no_prefetch evaluates the same clouds serially: same report
     reps = []
-    for extra in ([], ["--no_prefetch"]):
+    for extra in (["--prefetch_group", "1"], ["--no_prefetch"], ["--prefetch_group", "2"]):
         rep = str(tmp_path / ("rep%d.json" % len(reps)))
         out = subprocess.run([sys.executable, "-m", "point2cyl_amd.eval", "--logdir", str(tmp_path), "--ckpt", "model.pth", "--synthetic", "10",
                               "--batch_size", "4", "--num_point", "1024", "--dump_dir", str(tmp_path / "dump"), "--report", rep] + extra, cwd=ROOT,
@@ -873,6 +873,8 @@ def test_reference_made_checkpoint_loads_and_evaluates(mode, tmp_path):
         assert "Num evaluated= 10" in out.stdout and "Mean mIOU= " in out.stdout, out.stdout[-1500:]
         reps.append((json.load(open(rep)), [float(l.split("=")[-1]) for l in out.stdout.splitlines() if l.startswith("Mean ")]))
     assert reps[0][0]["batches"] == 3 and reps[0][0]["batches_pipelined"] == 2 and reps[1][0]["batches_pipelined"] == 0
+    assert reps[2][0]["batches"] == 3 and reps[2][0]["batches_pipelined"] == 2 and reps[2][0]["prefetch_group"] == 2      # one group of two, the short batch serial
+    np.testing.assert_allclose(reps[2][1], reps[1][1], rtol=0.15, atol=1e-3)
     # The two runs are NOT draw-for-draw identical: the pipelined loop draws batch i + 1's FPS starts before batch i's extent samples
     # (data_utils.py:1696 draws those on the same CPU generator), the serial loop after them - another random sampling of the same clouds, as
     # two runs of the reference with different seeds are.  (Bit-equality of the two forwards on the SAME draws is

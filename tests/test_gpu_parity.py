@@ -833,15 +833,17 @@ def test_precomputed_geometry_gives_the_same_forward():
     assert torch.equal(geom["sa1"]["fps_idx"].cpu().long(), m.sa1.last_aux["fps_idx"].cpu().long())
 
 
-@pytest.mark.parametrize("mode", ["eval", "train"])
-def test_pipelined_forward_equals_the_serial_forward(mode):
-    """graph.PipelinedForward (point2cyl_amd/eval.py's loop: the geometry of batch i + 1 computed on a forked stream inside the graph of batch
-    i's forward; eval.py:231-268 knows its next batch) against the serial model.forward_heads on the same sequence of five different
-    batches with the same seeds: the CPU generator is consumed in the same order (FPS starts SA1 then SA2 per batch), the dropout
-    counter advances once per forward.  Eval mode (running statistics: nothing depends on the summation order) must agree BIT FOR BIT
-    with the serial path; train mode to the run-to-run spread of the fp64 statistics atomics."""
+@pytest.mark.parametrize("mode,group", [("eval", 1), ("train", 1), ("eval", 2), ("eval", 3), ("train", 2)])
+def test_pipelined_forward_equals_the_serial_forward(mode, group):
+    """graph.PipelinedForward (point2cyl_amd/eval.py's loop: the geometry of the NEXT group of `group` batches computed on a forked stream inside
+    the graph of the current group's forwards; eval.py:231-268 knows its next batches) against the serial model.forward_heads on the same
+    sequence of five different batches with the same seeds: the CPU generator is consumed in the same order (FPS starts SA1 then SA2 PER
+    BATCH, also when a group's geometry is one call over group x B clouds), the dropout counter advances once per forward, BatchNorm
+    statistics are per batch.  Eval mode (running statistics: nothing depends on the summation order) must agree BIT FOR BIT with the
+    serial path; train mode to the run-to-run spread of the fp64 statistics atomics.  Five batches in groups of 2 / 3 leave a SHORT last
+    group: it takes the serial forward after the pipeline (its empty slots would otherwise run real forwards on stale clouds)."""
     from point2cyl_amd.graph import PipelinedForward
-    B, N, nb = 4, 2048, 5
+    B, N, nb, G = 4, 2048, 5, group
     batches = [synth.make_batch(B, N, 8, seed=300 + i)[0].float().to(DEV) for i in range(nb)]
     torch.manual_seed(12)
     m = backbone(output_sizes=[3, 16]).to(DEV)
@@ -866,28 +868,39 @@ def test_pipelined_forward_equals_the_serial_forward(mode):
             for x in batches:
                 serial.append(m.forward_heads(x)[0].clone())
         bufs_serial = {k: v.clone() for k, v in m.state_dict().items()}
+        cpu_rng_serial = torch.get_rng_state().clone()
         m.load_state_dict(keep)
         m._drop_seed.copy_(seed0)
         torch.manual_seed(78)
         st = torch.cuda.Stream()
         st.wait_stream(torch.cuda.current_stream())
         piped = []
+        groups = [batches[i:i + G] for i in range(0, nb, G)]
+        full = [g_ for g_ in groups if len(g_) == G]
         with torch.cuda.stream(st):
-            pf = PipelinedForward(m, batches[0], stream=st)
-            for i in range(nb):
-                h, sizes = pf(batches[i + 1] if i + 1 < nb else None)
-                piped.append(h.clone())
+            pf = PipelinedForward(m, full[0] if G > 1 else full[0][0], stream=st, group=G)
+            for gi, grp in enumerate(full):
+                nxt = full[gi + 1] if gi + 1 < len(full) else None
+                out = pf((nxt if G > 1 else nxt[0]) if nxt is not None else None)
+                out = out if G > 1 else [out]
+                for j in range(G):
+                    h, sizes = out[j]
+                    piped.append(h.clone())
             pf.release()
+            with torch.no_grad():
+                for x in batches[len(full) * G:]:                 # the short last group: serial
+                    piped.append(m.forward_heads(x)[0].clone())
         torch.cuda.current_stream().wait_stream(st)
         torch.cuda.synchronize()
     finally:
         autograph.ENABLED = old
-    assert sizes == [3, 16] and m.sa1.fps_start is None and m.sa2.fps_start is None
+    assert sizes == [3, 16] and m.sa1.fps_start is None and m.sa2.fps_start is None and len(piped) == nb
     for i in range(nb):
         if mode == "eval":
             assert torch.equal(serial[i], piped[i]), i
         else:
             assert float((serial[i] - piped[i]).abs().max()) <= 2e-5 * float(serial[i].abs().max()), i
+    assert torch.equal(torch.get_rng_state(), cpu_rng_serial), "the pipelined loop must leave the CPU generator where the serial loop leaves it"
     for k, v in m.state_dict().items():
         if "num_batches_tracked" in k:
             assert int(v) == int(bufs_serial[k]), k               # warm-up passes of the capture leave no trace

@@ -315,10 +315,14 @@ def main(argv=None):
         fill(2 * G)
         while pending:
             group = None
-            if not a.no_prefetch and len(pending) >= G and same(list(pending)[:G]) and (pipe is None or tuple(pending[0][0].shape) == pipe_shape):
+            fill(2 * G)
+            head = list(pending)[:G]
+            can = not a.no_prefetch and len(head) == G and same(head) and (pipe is None or tuple(head[0][0].shape) == pipe_shape)
+            nxt = list(pending)[G:2 * G]
+            if not (len(nxt) == G and same(nxt) and can and tuple(nxt[0][0].shape) == tuple(head[0][0].shape)):
+                nxt = None
+            if can and (pipe is not None or nxt is not None):          # (a pipeline is only STARTED when there is a next full group to prefetch for)
                 group = [pending.popleft() for _ in range(G)]
-                fill(2 * G)
-                nxt = list(pending)[:G] if (len(pending) >= G and same(list(pending)[:G]) and tuple(pending[0][0].shape) == tuple(group[0][0].shape)) else None
                 if pipe is None:
                     from .graph import PipelinedForward
                     pipe, pipe_shape = PipelinedForward(model, [b[0] for b in group], stream=stream, group=G), tuple(group[0][0].shape)
@@ -335,7 +339,6 @@ def main(argv=None):
                     pipe.release()
                     pipe = None
                 evaluate(pending.popleft())
-                fill(2 * G)
                 done = 1
             if (i // 20) != ((i + done) // 20) or i == 0:
                 if rank == 0:

@@ -861,24 +861,24 @@ def test_reference_made_checkpoint_loads_and_evaluates(mode, tmp_path):
     # the evaluation script on the upstream-made file
     import shutil
     shutil.copy(os.path.join(ROOT, "tests", "golden", "ref_ckpt_3steps.pth"), str(tmp_path / "model.pth"))
-    # 10 clouds in batches of 4: two full batches through graph.PipelinedForward (the geometry of the second computed under the forward of
-    # the first), the last, shorter one through the serial forward; --no_prefetch evaluates the same clouds serially: same report
+    # 18 clouds in batches of 4: four full batches through graph.PipelinedForward (one batch ahead, or in groups of two whose geometry is
+    # computed together), the last, shorter one through the serial forward; --no_prefetch evaluates the same clouds serially: same report
     reps = []
     for extra in (["--prefetch_group", "1"], ["--no_prefetch"], ["--prefetch_group", "2"]):
         rep = str(tmp_path / ("rep%d.json" % len(reps)))
-        out = subprocess.run([sys.executable, "-m", "point2cyl_amd.eval", "--logdir", str(tmp_path), "--ckpt", "model.pth", "--synthetic", "10",
+        out = subprocess.run([sys.executable, "-m", "point2cyl_amd.eval", "--logdir", str(tmp_path), "--ckpt", "model.pth", "--synthetic", "18",
                               "--batch_size", "4", "--num_point", "1024", "--dump_dir", str(tmp_path / "dump"), "--report", rep] + extra, cwd=ROOT,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
-        assert "Num evaluated= 10" in out.stdout and "Mean mIOU= " in out.stdout, out.stdout[-1500:]
+        assert "Num evaluated= 18" in out.stdout and "Mean mIOU= " in out.stdout, out.stdout[-1500:]
         reps.append((json.load(open(rep)), [float(l.split("=")[-1]) for l in out.stdout.splitlines() if l.startswith("Mean ")]))
-    assert reps[0][0]["batches"] == 3 and reps[0][0]["batches_pipelined"] == 2 and reps[1][0]["batches_pipelined"] == 0
-    assert reps[2][0]["batches"] == 3 and reps[2][0]["batches_pipelined"] == 2 and reps[2][0]["prefetch_group"] == 2      # one group of two, the short batch serial
+    assert reps[0][0]["batches"] == 5 and reps[0][0]["batches_pipelined"] == 4 and reps[1][0]["batches_pipelined"] == 0
+    assert reps[2][0]["batches"] == 5 and reps[2][0]["batches_pipelined"] == 4 and reps[2][0]["prefetch_group"] == 2      # two groups of two, the short batch serial
     np.testing.assert_allclose(reps[2][1], reps[1][1], rtol=0.15, atol=1e-3)
-    # The two runs are NOT draw-for-draw identical: the pipelined loop draws batch i + 1's FPS starts before batch i's extent samples
+    # The runs are NOT draw-for-draw identical: the pipelined loop draws batch i + 1's FPS starts before batch i's extent samples
     # (data_utils.py:1696 draws those on the same CPU generator), the serial loop after them - another random sampling of the same clouds, as
     # two runs of the reference with different seeds are.  (Bit-equality of the two forwards on the SAME draws is
-    # test_pipelined_forward_equals_the_serial_forward's job.)  The report lines agree to the sampling noise of 10 clouds:
+    # test_pipelined_forward_equals_the_serial_forward's job.)  The report lines agree to the sampling noise of 18 clouds:
     np.testing.assert_allclose(reps[0][1], reps[1][1], rtol=0.15, atol=1e-3)
 
 

@@ -172,6 +172,8 @@ def main():
                          % (args.gpus, world))
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    from point2cyl_amd import hostmem
+    hostmem.setup_cli()          # host allocator + torch's CPU pool fitted to the cgroup's CPU quota (the CPU legs set their own thread counts)
     # everything - warm-up, capture, replays, exchange, Adam, the event-timed eager leg - on ONE non-default stream (a HIP graph cannot be
     # captured on the default stream; autograd binds its accumulator nodes to the stream they first ran on)
     with torch.cuda.stream(torch.cuda.Stream(dev)):
@@ -404,25 +406,27 @@ def _bench(args, rank, world, local, dev):
         cb = args.cpu_batch
         sample = tuple(x[:cb].contiguous() for x in (pcs, normals, seg, bb))
         host = os.cpu_count() or 1
-        pps, sec, thr, nst = ref_step.time_cpu_baseline(sample, threads=min(32, host), budget_s=10.0)
+        from point2cyl_amd.hostmem import cpu_quota
+        quota = cpu_quota()       # what the cgroup lets this process use (16 of the 256 hardware threads on this pool's boxes): the leg's thread count
+        pps, sec, thr, nst = ref_step.time_cpu_baseline(sample, threads=min(32, host, quota), budget_s=10.0)
         one = tuple(x[:1].contiguous() for x in (pcs, normals, seg, bb))
         pps1, sec1, _, nst1 = ref_step.time_cpu_baseline(one, threads=1, budget_s=8.0)
-        # torch.set_num_threads(os.cpu_count()) as well - in a child process with a time limit: with every hardware thread in
-        # each of the step's thousands of small ops the run is slower, not faster (measured once without a limit on this pool's boxes:
-        # 183.6 s for ONE step at 256 threads = 178 points/s, profiles/r04_bench_all_threads_unbounded.json.log), and the default bench must
-        # finish within minutes
+        # torch.set_num_threads(os.cpu_count()) as well - in a child process with a time limit: with one thread per hardware
+        # thread under a CPU quota of a sixteenth of them, in each of the step's thousands of small ops, the run is slower, not faster
+        # (measured once without a limit on this pool's boxes: 183.6 s for ONE step at 256 threads = 178 points/s,
+        # profiles/r04_bench_all_threads_unbounded.json.log), and the default bench must finish within minutes
         ppsa, seca, thra, all_note = None, None, host, None
         if host > 32:
             ppsa, seca, all_note = _cpu_all_threads_leg(cb, N, K, host, limit_s=12.0)
         else:
             ppsa, seca = pps, sec
-        torch.set_num_threads(min(32, host))
+        torch.set_num_threads(min(32, host, quota))
         best = max(((pps, thr), (ppsa or 0.0, thra), (pps1, 1)), key=lambda t: t[0])
         try:
             affinity = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             affinity = None
-        cpu = dict(value=round(best[0], 1), unit="points/s", cores=best[1], kind="port", cpu_model=_cpu_model(), host_cores=host, sched_affinity=affinity,
+        cpu = dict(value=round(best[0], 1), unit="points/s", cores=best[1], kind="port", cpu_model=_cpu_model(), host_cores=host, sched_affinity=affinity, cpu_quota=quota,
                    by_threads={str(thr): round(pps, 1), str(thra): None if ppsa is None else round(ppsa, 1), "1": round(pps1, 1)},
                    single_thread_value=round(pps1, 1), all_threads_value=None if ppsa is None else round(ppsa, 1), all_threads_note=all_note,
                    all_threads_unbounded_reference=dict(value=178.0, unit="points/s", threads=256, seconds_for_one_step=183.6,
@@ -432,8 +436,8 @@ def _bench(args, rank, world, local, dev):
                    sample="%d full training steps (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
                           "points (same generator as the GPU batch) on %d threads, %.1f s of CPU work; all_threads_value: 1 step of the same on "
                           "os.cpu_count() = %d threads in a child process limited to 20 s; single_thread_value: %d step(s) on B=1 cloud with 1 "
-                          "thread, %.1f s; `value` is the fastest (the step is thousands of small ops - a Python FPS loop, sorts, gathers: more "
-                          "threads than ~32 only add fork/join cost)" % (nst, cb, N, thr, sec * nst, host, nst1, sec1 * nst1))
+                          "thread, %.1f s; `value` is the fastest (the step is thousands of small ops - a Python FPS loop, sorts, gathers; the cgroup's "
+                          "CPU quota is %d: threads beyond it are throttled, not run)" % (nst, cb, N, thr, sec * nst, host, nst1, sec1 * nst1, quota))
     line = dict(metric="training-step points/sec (BxN) at N=8192", value=round(value, 1), unit="points/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                 vs_baseline=None, dtype="f32", data="synthetic",
@@ -524,9 +528,10 @@ def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
     def config3():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_config4
+        from point2cyl_amd.hostmem import cpu_quota
         w = measure.FittingWorkload(1250, 8192, 8, 2048, device=dev)
         res, (E, cen, cfound, ext, found, E64) = w.time(20)
-        cpu, parity = bench_config4.cpu_fitting_legs(w, E, cen, ext, E64, thread_counts=(min(32, os.cpu_count() or 1), 1))
+        cpu, parity = bench_config4.cpu_fitting_legs(w, E, cen, ext, E64, thread_counts=(min(32, os.cpu_count() or 1, cpu_quota()), 1))
         res.update(cpu_baseline=cpu, parity=parity)
         del w
         return res

@@ -25,6 +25,7 @@ import torch
 import torch.nn.functional as F
 
 from . import fitting, losses
+from . import hostmem
 
 
 @dataclass
@@ -228,6 +229,7 @@ def build_parser():
 
 def main(argv=None):
     a = build_parser().parse_args(argv)
+    hostmem.setup_cli()        # large host blocks stay mapped after free; torch's CPU pool sized to the cgroup's CPU quota (hostmem.py)
     if not torch.cuda.is_available():
         raise SystemExit("point2cyl_amd.eval needs an MI355X (HIP) device; there is no CPU path")
     from . import ddp, synth
@@ -247,8 +249,10 @@ def main(argv=None):
         from .h5data import AutodeskH5, dataset_path
         ds = AutodeskH5(dataset_path(a.data_dir, a.data_split), a.num_point, a.K, center=True)
     lo, hi = ddp.shard_range(len(ds), rank, world)                               # clouds are independent: shard, no data-path collective
-    loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=a.batch_size, num_workers=0, pin_memory=True,
-                                         shuffle=a.data_split != "test")
+    # (no pin_memory: the loader pins in the calling thread, 9 ms per tensor here - 80 ms a batch, twenty times the evaluation itself)
+    shuffle = a.data_split != "test"
+    loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=a.batch_size, num_workers=0, shuffle=shuffle,
+                                         generator=torch.Generator().manual_seed(a.seed) if shuffle else None)
     model = backbone(output_sizes=fl.pred_sizes())
     if not a.random_init:
         sd = torch.load(os.path.join(a.logdir, a.ckpt), map_location="cpu")["model"]            # eval.py:206-207
@@ -286,17 +290,45 @@ def main(argv=None):
     # i + 1 are drawn (CPU generator, SA1 then SA2, like the reference) BEFORE batch i's extent samples (data_utils.py:1696, same generator),
     # in the serial loop after them: another equally valid random sampling of the same clouds, not the same one (--no_prefetch keeps the
     # reference's order).
+    # Host side: the loader's collate, --add_noise and the host->device copies run in a producer thread a few batches ahead (they release the
+    # GIL).  Random streams stay the serial loop's: NumPy's generator is drawn from by that thread only (h5 subsampling, the noise), torch's
+    # CPU generator by this one only (the loader's base seed here below, the FPS starts, the extent samples).
     import collections
+    import queue
+    import threading
     it = iter(loader)
     pending = collections.deque()
     G = max(1, int(a.prefetch_group))
+    ready, drained = queue.Queue(maxsize=2 * G + 2), [False]
+
+    def produce():
+        try:
+            torch.cuda.set_device(dev)
+            for b in it:
+                t = to_device(b)
+                torch.cuda.current_stream().synchronize()        # (the float64 -> float32 casts of to_device run on this thread's stream)
+                ready.put(t)
+            ready.put(None)
+        except BaseException as e:          # surfaces in the consuming loop
+            ready.put(e)
+
+    threading.Thread(target=produce, daemon=True).start()
+
+    waited = [0.0]
 
     def fill(k):
-        while len(pending) < k:
-            b = next(it, None)
+        while len(pending) < k and not drained[0]:
+            t_w = time.perf_counter()
+            b = ready.get()
+            waited[0] += time.perf_counter() - t_w
             if b is None:
-                return
-            pending.append(to_device(b))
+                drained[0] = True
+            elif isinstance(b, BaseException):
+                raise b
+            else:
+                for t in b:
+                    t.record_stream(stream)       # allocated on the producer's stream, read on the loop's
+                pending.append(b)
 
     def same(bs):
         return all(tuple(b[0].shape) == tuple(bs[0][0].shape) for b in bs) and bs[0][0].shape[2] == 3
@@ -345,7 +377,7 @@ def main(argv=None):
                     print("Time elapsed: %s sec for batch %d/%d." % (time.time() - t0, i, len(loader)))
             if t_first is None:
                 torch.cuda.synchronize()
-                t_first, i_first = time.time(), i + done
+                t_first, i_first, waited[0] = time.time(), i + done, 0.0
             i += done
     if pipe is not None:
         pipe.release()
@@ -354,9 +386,10 @@ def main(argv=None):
     if rank == 0 and t_first is not None and i > i_first:
         dt = (time.time() - t_first) / (i - i_first)
         rep = dict(batches=i, batches_pipelined=n_piped, batch_size=a.batch_size, num_point=a.num_point, prefetch=not a.no_prefetch,
-                   prefetch_group=G, ms_per_batch_after_first=dt * 1e3, points_per_s=a.batch_size * a.num_point / dt)
-        print("evaluation throughput: %.3f ms/batch (forward + metrics + one host transfer per batch), %.1f points/s, %d of %d batches pipelined"
-              % (rep["ms_per_batch_after_first"], rep["points_per_s"], n_piped, i))
+                   prefetch_group=G, ms_per_batch_after_first=dt * 1e3, points_per_s=a.batch_size * a.num_point / dt,
+                   ms_per_batch_waiting_for_loader=waited[0] / (i - i_first) * 1e3)
+        print("evaluation throughput: %.3f ms/batch (forward + metrics + one host transfer per batch; %.3f of it waiting for the loader thread), "
+              "%.1f points/s, %d of %d batches pipelined" % (rep["ms_per_batch_after_first"], rep["ms_per_batch_waiting_for_loader"], rep["points_per_s"], n_piped, i))
         if a.report:
             import json
             with open(a.report, "w") as f:

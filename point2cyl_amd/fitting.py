@@ -59,7 +59,7 @@ def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_cen
     B, K, _ = extrusion_axes.shape
     S = num_points_to_sample
     if rand_idx is None:
-        rand_idx = _barrel_draws(seg_label, bb_labels, K, S)
+        rand_idx = _barrel_draws(seg_label, bb_labels, K, S, device=P.device)
     return ops.extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, rand_idx.to(P.device))
 
 
@@ -86,7 +86,7 @@ def fit_cylinders(X, W_barrel, W_base, gt_bb_labels, seg_label, P, num_points_to
         ops.check_labels(seg_label, K)
         ops.check_labels(gt_bb_labels, 2)
     if rand_idx is None:
-        rand_idx = _barrel_draws(seg_label, gt_bb_labels, K, S)
+        rand_idx = _barrel_draws(seg_label, gt_bb_labels, K, S, device=P.device)
     rand_idx = rand_idx.to(P.device)
     if ops.fit_fused_supported(N, K, S):
         return ops.fit_fused(X, W_barrel, W_base, gt_bb_labels, seg_label, P, rand_idx, normalize=normalize, axes64=return_float64, K=K)
@@ -112,21 +112,55 @@ def barrel_draws_on_device(seg_label, bb_labels, K, S):
     return torch.minimum((u * counts.unsqueeze(-1)).long(), (counts - 1).clamp_min(0).unsqueeze(-1))
 
 
-def _barrel_draws(seg_label, bb_labels, K, S):
+class _DrawRing:
+    """Two pinned (B,K,S) int64 host buffers per shape, written by the CPU generator and copied to the device without blocking: a fresh
+    4 MB host tensor per batch costs 6 - 20 ms of page faults on the virtualised hosts this runs on, more than the draws themselves."""
+    rings = {}
+
+    def __init__(self, shape):
+        self.bufs = [torch.zeros(shape, dtype=torch.int64).pin_memory() for _ in range(2)]
+        self.rows = [[r.unbind(0) for r in b.unbind(0)] for b in self.bufs]
+        self.copied, self.i = [None, None], 0
+
+    @classmethod
+    def take(cls, shape):
+        ring = cls.rings.get(shape)
+        if ring is None:
+            ring = cls.rings[shape] = cls(shape)
+        i = ring.i
+        ring.i ^= 1
+        if ring.copied[i] is not None:
+            ring.copied[i].synchronize()                 # the copy that last read this buffer (two batches ago) is done
+        return ring, i
+
+
+def _barrel_draws(seg_label, bb_labels, K, S, device=None):
     """The reference's torch.randint draws for its K x B sampling loops (data_utils.py:1064, :1696): k outer, b inner, only
-    where the segment has > 1 barrel point in the batch and in the cloud, on the CPU generator."""
+    where the segment has > 1 barrel point in the batch and in the cloud, on the CPU generator.  -> (B,K,S) int64 on the host, or, with
+    `device`, on that device (drawn into a recycled pinned buffer, copied on the current stream)."""
     B = seg_label.shape[0]
     barrel = (seg_label.unsqueeze(-1) == torch.arange(K, device=seg_label.device)) & (bb_labels == 0).unsqueeze(-1)
-    counts = barrel.sum(dim=1).cpu()                     # (B,K): ONE sync; the reference syncs K*B times here
-    rand_idx = torch.zeros(B, K, S, dtype=torch.int64)
+    counts = barrel.sum(dim=1).t().tolist()              # [K][B]: ONE sync; the reference syncs K*B times here
+    if device is None or torch.device(device).type != "cuda":
+        rand_idx = torch.zeros(B, K, S, dtype=torch.int64)
+        rows, ring = [r.unbind(0) for r in rand_idx.unbind(0)], None
+    else:
+        ring, i = _DrawRing.take((B, K, S))
+        rand_idx, rows = ring.bufs[i], ring.rows[i]
     for k in range(K):
-        if int(counts[:, k].sum()) <= 1:
-            continue
+        ck = counts[k]
+        none = sum(ck) <= 1
         for b in range(B):
-            if int(counts[b, k]) <= 1:
-                continue
-            rand_idx[b, k] = torch.randint(0, int(counts[b, k]), (S,))
-    return rand_idx
+            if ck[b] > 1 and not none:
+                torch.randint(0, ck[b], (S,), out=rows[b][k])          # (the draw itself: same generator, same order, same values)
+            elif ring is not None:
+                rows[b][k].zero_()
+    if ring is None:
+        return rand_idx if device is None else rand_idx.to(device)
+    out = rand_idx.to(device, non_blocking=True)
+    ring.copied[i] = torch.cuda.Event()
+    ring.copied[i].record()
+    return out
 
 
 def sketch_implicit_projection(P, X, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample=1024, rand_idx=None):
@@ -139,7 +173,7 @@ def sketch_implicit_projection2(P, X, seg_label, bb_labels, extrusion_axes, extr
     """data_utils.py:1149-1282: the same + found_centers_mask (B,K)."""
     K, S = extrusion_axes.shape[1], num_points_to_sample
     if rand_idx is None:
-        rand_idx = _barrel_draws(seg_label, bb_labels, K, S)
+        rand_idx = _barrel_draws(seg_label, bb_labels, K, S, device=P.device)
     return ops.sketch_projection(P, X, seg_label, bb_labels, extrusion_axes, extrusion_centers, rand_idx.to(P.device), S)
 
 

@@ -31,6 +31,7 @@ import numpy as np
 import torch
 
 from . import ops, ddp, optim, step, synth
+from . import hostmem
 from .backbone import backbone
 
 SCALARS = ("total", "normal", "miou", "bb", "ext", "center")
@@ -176,6 +177,7 @@ class Runner:
 
 def main(argv=None):
     a = build_parser().parse_args(argv)
+    hostmem.setup_cli()        # large host blocks stay mapped after free; torch's CPU pool sized to the cgroup's CPU quota (hostmem.py)
     rank, world, local = ddp.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("point2cyl_amd.train needs an MI355X (HIP) device; there is no CPU path")

@@ -35,6 +35,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ddp, fitting, ops, optim, step, step_sketch, synth
+from . import hostmem
 from .backbone import backbone
 from .implicit import ImplicitNet, NormalPerPoint
 from .sketch import PointNetEncoder
@@ -99,6 +100,7 @@ def synthetic_sketches(data, K, S, dev, chunk=16):
 
 def main(argv=None):
     a = build_parser().parse_args(argv)
+    hostmem.setup_cli()        # large host blocks stay mapped after free; torch's CPU pool sized to the cgroup's CPU quota (hostmem.py)
     if a.use_extrusion_axis_feat and not a.use_whole_pc:
         raise SystemExit("--use_extrusion_axis_feat only changes the --use_whole_pc encoder input (train_Point2Cyl.py:271-276, :528, :577)")
     if a.use_extrusion_axis_feat and not (a.use_gt_im or a.pred_extrusion):

@@ -51,8 +51,11 @@ def _reorder_gather(W, matching_indices):
     return losses._reorder(W, matching_indices)
 
 
-def eval_metrics(X_head, W_raw, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: EvalFlags, extent_rand_idx=None):
+def eval_metrics(X_head, W_raw, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: EvalFlags, extent_rand_idx=None, barrel_counts=None,
+                 labels_validated=False):
     """eval.py:270-457 from the two head outputs.  gt_bb may be float (the reference casts it, :257) or integer.
+    barrel_counts / labels_validated (not in the reference): fitting.barrel_counts(gt_inst, gt_bb, K) and "gt_inst is in [-1, K)" when the
+    caller established them on the host copy of the labels - the call then has no device->host synchronisation in it.
     Returns a dict: per-cloud `mIoU`, `normal_difference`, `pred_bb_acc`, `extrusion_difference`, `centroid_difference` (B,);
     `extrusion_difference_uncollapsed`, `centroid_difference_uncollapsed` (B,K); `matching_indices`, `mask`, `label`,
     `pred_bb_label`, `E_AX` (B,K,3), `predicted_centroids` (B,K,3), `found_centers_mask` (B,K), `extents` (B,K,2), `mask_gt`."""
@@ -75,7 +78,7 @@ def eval_metrics(X_head, W_raw, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
     matching_indices = mask = W_reordered = W_ = None
     if fl.pred_seg:
         W_ = losses.hard_W_encoding(W, to_null_mask=True)                             # :316
-        matching_indices, mask = losses.hungarian_matching(W_, gt_inst, with_mask=True)   # :318
+        matching_indices, mask = losses.hungarian_matching(W_, gt_inst, with_mask=True, validate=not labels_validated)   # :318
         mask = mask.float()
         out["mIoU"] = losses.compute_segmentation_iou(W_, gt_inst, matching_indices, mask)   # :320
         W_re_un = _reorder_gather(W_, matching_indices)
@@ -126,14 +129,15 @@ def eval_metrics(X_head, W_raw, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
         out.update(extrusion_difference=z, centroid_difference=z, extrusion_difference_uncollapsed=torch.zeros(B, K, device=dev),
                    centroid_difference_uncollapsed=torch.zeros(B, K, device=dev))
     extents, _ = fitting.get_extrusion_extents(pcs, gt_inst, gt_bb_i, gt_axes, gt_centers, num_points_to_sample=fl.num_sk_point,
-                                               rand_idx=extent_rand_idx)                                           # :456
+                                               rand_idx=extent_rand_idx, counts=barrel_counts)                     # :456
     out["extents"] = extents.permute(1, 0, 2)                                                                      # :457
     out.update(matching_indices=matching_indices, mask=mask, X=X, W=W)
     return out
 
 
 @torch.no_grad()
-def evaluate_batch(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: EvalFlags, extent_rand_idx=None, heads=None):
+def evaluate_batch(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: EvalFlags, extent_rand_idx=None, heads=None,
+                   barrel_counts=None, labels_validated=False):
     """eval.py:268 + eval_metrics.  heads = (heads (B*N, ld), sizes) from graph.PipelinedForward instead of running the forward here."""
     if heads is not None:
         h, sizes = heads
@@ -142,7 +146,7 @@ def evaluate_batch(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, 
         X_head, W_raw = h[:, :, 0:sizes[0]], h[:, :, sizes[0]:sizes[0] + sizes[1]]
     else:
         X_head, W_raw = model(pcs)
-    return eval_metrics(X_head, W_raw, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl, extent_rand_idx)
+    return eval_metrics(X_head, W_raw, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl, extent_rand_idx, barrel_counts, labels_validated)
 
 
 @torch.no_grad()
@@ -182,19 +186,45 @@ REPORT = (("mIoU", "Mean mIOU= "), ("normal_difference", "Mean normal angle erro
 
 
 class Accumulator:
-    """eval.py:638-676, :690-715: per-shape sums in float64 on the host, ONE device->host transfer per batch."""
+    """eval.py:638-676, :690-715: per-shape sums in float64 on the host, ONE device->host transfer per batch - asynchronous: the
+    (n_metrics, B) block of a batch lands in one of `depth` pinned buffers and is summed when its copy has completed (at the latest
+    `depth` batches later, or in means()), so the loop that calls add() never waits for the device."""
 
-    def __init__(self, extra=()):
+    def __init__(self, extra=(), depth=4):
         self.keys = [k for k, _ in REPORT] + list(extra)
         self.n, self.tot = 0, np.zeros(len(self.keys), dtype=np.float64)
+        self.depth, self.ring, self.inflight = depth, {}, []
+
+    def _drain(self, keep):
+        while len(self.inflight) > keep:
+            buf, ev = self.inflight.pop(0)
+            ev.synchronize()
+            v = buf.numpy()
+            self.tot += v.sum(1)
+            self.n += v.shape[1]
+            self.ring[tuple(buf.shape)].append(buf)
 
     def add(self, m):
-        v = torch.stack([m[k].float() for k in self.keys], 0).double().cpu().numpy()          # (n_metrics, B)
-        self.tot += v.sum(1)
-        self.n += v.shape[1]
+        v = torch.stack([m[k].float() for k in self.keys], 0).double()          # (n_metrics, B)
+        if not v.is_cuda:
+            self.tot += v.numpy().sum(1)
+            self.n += v.shape[1]
+            return
+        self._drain(self.depth - 1)
+        free = self.ring.setdefault(tuple(v.shape), [])
+        buf = free.pop() if free else torch.empty(v.shape, dtype=torch.float64).pin_memory()
+        buf.copy_(v, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.inflight.append((buf, ev))
+
+    def sums(self):
+        self._drain(0)
+        return self.tot, self.n
 
     def means(self):
-        return dict(zip(self.keys, self.tot / max(1, self.n)))
+        tot, n = self.sums()
+        return dict(zip(self.keys, tot / max(1, n)))
 
 
 def build_parser():
@@ -281,8 +311,14 @@ def main(argv=None):
         pcs, nrm, inst, bb, _, _, axes, _, cen = b[:9]
         if a.add_noise:
             pcs = fitting.add_noise(pcs, nrm, sigma=a.noise_sigma)                               # eval.py:241
+        # on the host copy of the labels, before the upload: the range check losses.py:36-46 makes per cloud, and the barrel counts that
+        # decide the extent draws (data_utils.py:1674-1697) - the evaluation of the batch then never waits for the device
+        lo, hi = int(inst.min()), int(inst.max())
+        if hi >= a.K or lo < -1:
+            raise ValueError("instance labels must be in [-1, %d); got [%d, %d]" % (a.K, lo, hi))
+        extras = dict(barrel_counts=fitting.barrel_counts(inst.long(), bb.long(), a.K), labels_validated=True)
         pcs, nrm, axes, cen = [t.to(dev, torch.float) for t in (pcs, nrm, axes, cen)]
-        return pcs, nrm, inst.to(dev, torch.long), bb.to(dev, torch.float), axes, cen             # eval.py:254-257
+        return pcs, nrm, inst.to(dev, torch.long), bb.to(dev, torch.float), axes, cen, extras     # eval.py:254-257
 
     # The reference's loop (eval.py:231-268) knows its next batch; the geometry of batch i + 1 (FPS / ball query / 3-NN: 0.75 of the
     # 1.84 ms serial forward at B = 32 x 8192) is computed inside the graph that runs batch i's forward (graph.PipelinedForward).
@@ -326,7 +362,7 @@ def main(argv=None):
             elif isinstance(b, BaseException):
                 raise b
             else:
-                for t in b:
+                for t in b[:6]:
                     t.record_stream(stream)       # allocated on the producer's stream, read on the loop's
                 pending.append(b)
 
@@ -334,7 +370,7 @@ def main(argv=None):
         return all(tuple(b[0].shape) == tuple(bs[0][0].shape) for b in bs) and bs[0][0].shape[2] == 3
 
     def evaluate(b, heads=None):
-        m = evaluate_batch(model, *b, fl, heads=heads)
+        m = evaluate_batch(model, *b[:6], fl, heads=heads, **b[6])
         if a.with_sketch_fit:
             m["pred_fit_cyl_loss"], m["pred_fit_glob_loss"] = sketch_fit_losses(m, b[0], b[1], b[2], b[3], implicit_net, pn_encoder, fl)
         acc.add(m)
@@ -394,7 +430,8 @@ def main(argv=None):
             import json
             with open(a.report, "w") as f:
                 json.dump(rep, f)
-    tot, n = torch.tensor(acc.tot), torch.tensor([acc.n], dtype=torch.float64)
+    tot, n = acc.sums()
+    tot, n = torch.tensor(tot), torch.tensor([n], dtype=torch.float64)
     if world > 1:                                      # the only exchange of an evaluation run: the metric sums
         import torch.distributed as dist
         tot, n = tot.to(dev), n.to(dev)

@@ -51,15 +51,24 @@ def segment_centroids(EA_W, pcs):
     return cen * found.unsqueeze(-1), found
 
 
-def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample=1024, rand_idx=None):
+def barrel_counts(seg_label, bb_labels, K):
+    """-> [K][B] nested list: the number of barrel points (bb == 0) of every segment of every cloud - what decides which draws the
+    reference makes.  On host tensors this costs no device sync (the evaluation loop calls it before the upload)."""
+    idx = seg_label.clamp(min=0).to(torch.int64)
+    sel = ((seg_label >= 0) & (seg_label < K) & (bb_labels == 0)).to(torch.int64)
+    return torch.zeros(seg_label.shape[0], K, dtype=torch.int64, device=seg_label.device).scatter_add_(1, idx.clamp(max=K - 1), sel).t().tolist()
+
+
+def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample=1024, rand_idx=None, counts=None):
     """data_utils.py:1650-1730 -> extents (K,B,2), found_centers_mask (B,K).
     The reference samples barrel points with torch.randint on the CPU generator inside a K x B loop (:1696);
     the same draws are made here in the same order (k outer, b inner, only where > 1 barrel point exists),
-    or taken from `rand_idx` (B,K,S) when given."""
+    or taken from `rand_idx` (B,K,S) when given.  counts (not in the reference): barrel_counts(seg_label, bb_labels, K) when the caller
+    has it already - the draws then need no device->host sync."""
     B, K, _ = extrusion_axes.shape
     S = num_points_to_sample
     if rand_idx is None:
-        rand_idx = _barrel_draws(seg_label, bb_labels, K, S, device=P.device)
+        rand_idx = _barrel_draws(seg_label, bb_labels, K, S, device=P.device, counts=counts)
     return ops.extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, rand_idx.to(P.device))
 
 
@@ -134,13 +143,14 @@ class _DrawRing:
         return ring, i
 
 
-def _barrel_draws(seg_label, bb_labels, K, S, device=None):
+def _barrel_draws(seg_label, bb_labels, K, S, device=None, counts=None):
     """The reference's torch.randint draws for its K x B sampling loops (data_utils.py:1064, :1696): k outer, b inner, only
     where the segment has > 1 barrel point in the batch and in the cloud, on the CPU generator.  -> (B,K,S) int64 on the host, or, with
     `device`, on that device (drawn into a recycled pinned buffer, copied on the current stream)."""
     B = seg_label.shape[0]
-    barrel = (seg_label.unsqueeze(-1) == torch.arange(K, device=seg_label.device)) & (bb_labels == 0).unsqueeze(-1)
-    counts = barrel.sum(dim=1).t().tolist()              # [K][B]: ONE sync; the reference syncs K*B times here
+    if counts is None:
+        barrel = (seg_label.unsqueeze(-1) == torch.arange(K, device=seg_label.device)) & (bb_labels == 0).unsqueeze(-1)
+        counts = barrel.sum(dim=1).t().tolist()          # [K][B]: ONE sync; the reference syncs K*B times here
     if device is None or torch.device(device).type != "cuda":
         rand_idx = torch.zeros(B, K, S, dtype=torch.int64)
         rows, ring = [r.unbind(0) for r in rand_idx.unbind(0)], None

@@ -14,10 +14,10 @@ g_zero_tol = 1.0e-6                                  # global_variables.py:15
 TORCH_PI = torch.acos(torch.zeros(1)).item() * 2     # losses.py:17
 
 
-def hungarian_matching(W_pred, I_gt, with_mask=False):
+def hungarian_matching(W_pred, I_gt, with_mask=False, validate=True):
     """losses.py:22-52.  W_pred (B,N,K), I_gt (B,N) with -1 = background -> matching_indices (B,K) int64
-    [, mask (B,K) bool].  No gradient (by design, :23)."""
-    match, mask = ops.hungarian(W_pred, I_gt)
+    [, mask (B,K) bool].  No gradient (by design, :23).  validate (not in the reference): see ops.hungarian."""
+    match, mask = ops.hungarian(W_pred, I_gt, validate=validate)
     return (match, mask) if with_mask else match
 
 

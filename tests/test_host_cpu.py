@@ -344,3 +344,52 @@ def test_dropin_falls_through_to_the_shadowed_reference_module(tmp_path):
                                     "assert callable(estimate_extrusion_axis)\nprint('degraded ok')\n")
     out = subprocess.run([sys.executable, "-m", "point2cyl_amd.dropin.run", str(ref / "script2.py")], cwd=ROOT, capture_output=True, text=True, timeout=180)
     assert out.returncode == 0 and "degraded ok" in out.stdout, out.stderr + out.stdout
+
+
+def test_barrel_counts_from_the_host_labels_give_the_same_draws():
+    """The evaluation loop counts the barrel points per (cloud, segment) on the host copy of the labels (fitting.barrel_counts) so that the
+    extent draws (data_utils.py:1674-1697) need no device sync: the counts equal the ones the draws derive themselves, and the draws - same
+    generator, same order - are the same numbers."""
+    from point2cyl_amd import fitting
+    g = torch.Generator().manual_seed(3)
+    B, N, K, S = 5, 700, 8, 32
+    seg = torch.randint(-1, K, (B, N), generator=g)
+    bb = torch.randint(0, 2, (B, N), generator=g)
+    seg[1][seg[1] == 3] = 0                       # a segment absent from one cloud
+    seg[2] = -1                                   # a cloud without any segment
+    one = ((seg[3] == 5) & (bb[3] == 0)).nonzero().flatten()
+    bb[3, one[1:]] = 1                            # exactly one barrel point: "not found" in the reference, no draw
+    barrel = (seg.unsqueeze(-1) == torch.arange(K)) & (bb == 0).unsqueeze(-1)
+    counts = fitting.barrel_counts(seg, bb, K)
+    assert counts == barrel.sum(dim=1).t().tolist() and counts[5][3] == 1
+    torch.manual_seed(11)
+    a = fitting._barrel_draws(seg, bb, K, S)
+    torch.manual_seed(11)
+    b = fitting._barrel_draws(seg, bb, K, S, counts=counts)
+    assert torch.equal(a, b) and int(a[3, 5].abs().sum()) == 0 and int(a[2].abs().sum()) == 0
+
+
+def test_eval_accumulator_on_host_tensors():
+    from point2cyl_amd import eval as ev
+    acc = ev.Accumulator(extra=("x",))
+    keys = acc.keys
+    m1 = {k: torch.full((3,), float(i)) for i, k in enumerate(keys)}
+    m2 = {k: torch.full((2,), float(10 * i)) for i, k in enumerate(keys)}
+    acc.add(m1)
+    acc.add(m2)
+    means = acc.means()
+    for i, k in enumerate(keys):
+        assert abs(means[k] - (3 * i + 2 * 10 * i) / 5.0) < 1e-12
+
+
+def test_cpu_quota_and_thread_fit():
+    """hostmem: the CPU count a process may use is the cgroup's quota, not os.cpu_count(); the torch pool follows it."""
+    from point2cyl_amd import hostmem
+    q = hostmem.cpu_quota()
+    assert 1 <= q <= (os.cpu_count() or 1)
+    before = torch.get_num_threads()
+    try:
+        n = hostmem.fit_threads_to_quota(reserve=0)
+        assert 1 <= n <= q and torch.get_num_threads() == n
+    finally:
+        torch.set_num_threads(before)

@@ -13,6 +13,10 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the CPU oracle legs run on torch's CPU pool: one thread per visible core under a cgroup CPU quota of a sixteenth of them is throttled
+    # in every op (point2cyl_amd/hostmem.py) - size the pool to the quota for the whole session
+    from point2cyl_amd import hostmem
+    hostmem.fit_threads_to_quota(reserve=0)
 
 
 def load_golden(name):

@@ -24,7 +24,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import fitting, losses
+from . import fitting, losses, ops
 from . import hostmem
 
 
@@ -204,8 +204,13 @@ class Accumulator:
             self.n += v.shape[1]
             self.ring[tuple(buf.shape)].append(buf)
 
+    def block(self, m):
+        return torch.stack([m[k].float() for k in self.keys], 0).double()          # (n_metrics, B)
+
     def add(self, m):
-        v = torch.stack([m[k].float() for k in self.keys], 0).double()          # (n_metrics, B)
+        self.add_block(self.block(m))
+
+    def add_block(self, v):
         if not v.is_cuda:
             self.tot += v.numpy().sum(1)
             self.n += v.shape[1]
@@ -225,6 +230,68 @@ class Accumulator:
     def means(self):
         tot, n = self.sums()
         return dict(zip(self.keys, tot / max(1, n)))
+
+
+class _PinnedCollate:
+    """collate_fn of the evaluation loader: the fields the loop reads (clouds, normals, labels, axes, centres) stacked into one of two
+    sets of recycled pinned buffers, the others left out; -> the reference's 9-tuple with None in the unused places.  The host->device
+    copies that follow run at the pinned rate, and nothing is first-touched per batch (hostmem.py)."""
+    USED = (0, 1, 2, 3, 6, 8)
+
+    def __init__(self):
+        self.slots, self.i = [{}, {}], 0
+
+    def __call__(self, items):
+        slot = self.slots[self.i]
+        self.i ^= 1
+        n, out = len(items), [None] * len(items[0])
+        for j in self.USED:
+            first = np.asarray(items[0][j])
+            buf = slot.get(j)
+            if buf is None or buf.shape[0] < n or buf.shape[1:] != first.shape or buf.numpy().dtype != first.dtype:
+                buf = slot[j] = torch.from_numpy(np.empty((n,) + first.shape, first.dtype)).pin_memory()
+            np.stack([np.asarray(it[j]) for it in items], out=buf.numpy()[:n])
+            out[j] = buf[:n]
+        return out
+
+
+class GraphedMetrics:
+    """eval_metrics + the accumulator's (n_metrics, B) block of one batch as ONE HIP-graph replay (the evaluation loop's default for the batches
+    of its pipeline: ~120 small launches, 2 ms of host time, become one).  What makes the chain capturable: the barrel counts and the label
+    check come from the host copy of the labels, the extent draws (CPU generator, data_utils.py:1696) are made BEFORE the replay into a
+    fixed device buffer.  Same kernels on the same values as the eager call; the dict of per-point outputs is not returned (the loop only
+    accumulates the report's metrics - --with_sketch_fit, which needs them, takes the eager call)."""
+
+    def __init__(self, fl, keys, batch, heads):
+        from . import measure
+        h, self.sizes = heads
+        self.fl, self.keys = fl, list(keys)
+        self.h = torch.empty_like(h)
+        self.inp = [torch.empty_like(t) for t in batch[:6]]
+        B, N = batch[0].shape[0], batch[0].shape[1]
+        self.rand = torch.zeros(B, fl.K, fl.num_sk_point, dtype=torch.int64, device=h.device)
+        self.load(batch, heads)
+
+        def body():
+            hv = self.h.view(B, N, self.h.shape[-1])
+            m = eval_metrics(hv[:, :, 0:self.sizes[0]], hv[:, :, self.sizes[0]:self.sizes[0] + self.sizes[1]], *self.inp, fl,
+                             extent_rand_idx=self.rand, labels_validated=True)
+            return torch.stack([m[k].float() for k in self.keys], 0).double()
+
+        self.graph, self.out = measure.capture(body)
+
+    def load(self, batch, heads):
+        ops.copy_flat_batch(self.inp + [self.h], [t.contiguous() for t in batch[:6]] + [heads[0]])
+        fitting._barrel_draws(batch[2], batch[3], self.fl.K, self.fl.num_sk_point, device=self.h.device, counts=batch[6]["barrel_counts"],
+                              out=self.rand)
+
+    def __call__(self, batch=None, heads=None):
+        """-> the (n_metrics, B) float64 block of this batch (a static buffer: consume it - Accumulator.add_block - before the next call).
+        Without arguments: of the batch the constructor was given (its draws are made once)."""
+        if batch is not None:
+            self.load(batch, heads)
+        self.graph.replay()
+        return self.out
 
 
 def build_parser():
@@ -254,6 +321,7 @@ def build_parser():
     p.add_argument("--prefetch_group", type=int, default=4, help="batches whose geometry is computed TOGETHER, one group ahead (FPS is 512 dependent "
                    "steps per cloud whether 32 or 128 clouds are sampled: its latency is shared by the group; 1 = one batch ahead)")
     p.add_argument("--report", type=str, default="", help="write a JSON throughput report here")
+    p.add_argument("--no_graph_metrics", action="store_true", help="launch the metric kernels of a pipelined batch one by one instead of replaying a HIP graph")
     return p
 
 
@@ -279,10 +347,11 @@ def main(argv=None):
         from .h5data import AutodeskH5, dataset_path
         ds = AutodeskH5(dataset_path(a.data_dir, a.data_split), a.num_point, a.K, center=True)
     lo, hi = ddp.shard_range(len(ds), rank, world)                               # clouds are independent: shard, no data-path collective
-    # (no pin_memory: the loader pins in the calling thread, 9 ms per tensor here - 80 ms a batch, twenty times the evaluation itself)
+    # (no pin_memory: the loader pins fresh buffers in the calling thread, 9 ms per tensor here - 80 ms a batch; _PinnedCollate recycles two)
     shuffle = a.data_split != "test"
+    collate = _PinnedCollate() if not a.no_prefetch else None
     loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=a.batch_size, num_workers=0, shuffle=shuffle,
-                                         generator=torch.Generator().manual_seed(a.seed) if shuffle else None)
+                                         generator=torch.Generator().manual_seed(a.seed) if shuffle else None, collate_fn=collate)
     model = backbone(output_sizes=fl.pred_sizes())
     if not a.random_init:
         sd = torch.load(os.path.join(a.logdir, a.ckpt), map_location="cpu")["model"]            # eval.py:206-207
@@ -308,7 +377,7 @@ def main(argv=None):
     t0 = time.time()
 
     def to_device(b):
-        pcs, nrm, inst, bb, _, _, axes, _, cen = b[:9]
+        pcs, nrm, inst, bb, axes, cen = b[0], b[1], b[2], b[3], b[6], b[8]
         if a.add_noise:
             pcs = fitting.add_noise(pcs, nrm, sigma=a.noise_sigma)                               # eval.py:241
         # on the host copy of the labels, before the upload: the range check losses.py:36-46 makes per cloud, and the barrel counts that
@@ -317,8 +386,8 @@ def main(argv=None):
         if hi >= a.K or lo < -1:
             raise ValueError("instance labels must be in [-1, %d); got [%d, %d]" % (a.K, lo, hi))
         extras = dict(barrel_counts=fitting.barrel_counts(inst.long(), bb.long(), a.K), labels_validated=True)
-        pcs, nrm, axes, cen = [t.to(dev, torch.float) for t in (pcs, nrm, axes, cen)]
-        return pcs, nrm, inst.to(dev, torch.long), bb.to(dev, torch.float), axes, cen, extras     # eval.py:254-257
+        pcs, nrm, axes, cen = [t.to(dev, torch.float, non_blocking=True) for t in (pcs, nrm, axes, cen)]
+        return pcs, nrm, inst.to(dev, torch.long, non_blocking=True), bb.to(dev, torch.float, non_blocking=True), axes, cen, extras     # eval.py:254-257
 
     # The reference's loop (eval.py:231-268) knows its next batch; the geometry of batch i + 1 (FPS / ball query / 3-NN: 0.75 of the
     # 1.84 ms serial forward at B = 32 x 8192) is computed inside the graph that runs batch i's forward (graph.PipelinedForward).
@@ -327,11 +396,15 @@ def main(argv=None):
     # in the serial loop after them: another equally valid random sampling of the same clouds, not the same one (--no_prefetch keeps the
     # reference's order).
     # Host side: the loader's collate, --add_noise and the host->device copies run in a producer thread a few batches ahead (they release the
-    # GIL).  Random streams stay the serial loop's: NumPy's generator is drawn from by that thread only (h5 subsampling, the noise), torch's
-    # CPU generator by this one only (the loader's base seed here below, the FPS starts, the extent samples).
+    # GIL).  Random streams: NumPy's generator is drawn from by that thread only (the noise); torch's CPU generator by this one only (the
+    # loader's base seed here below, the FPS starts, the extent samples) - the per-item subsampling permutations of the h5 dataset
+    # (dataloader.py:69-85, the same generator in the reference) come from a private generator seeded from it HERE, so that a seeded run is
+    # reproducible whatever the two threads' timing.  --no_prefetch: no thread, every draw in the reference's order.
     import collections
     import queue
     import threading
+    if not a.no_prefetch and hasattr(ds, "generator"):
+        ds.generator = torch.Generator().manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
     it = iter(loader)
     pending = collections.deque()
     G = max(1, int(a.prefetch_group))
@@ -342,20 +415,25 @@ def main(argv=None):
             torch.cuda.set_device(dev)
             for b in it:
                 t = to_device(b)
-                torch.cuda.current_stream().synchronize()        # (the float64 -> float32 casts of to_device run on this thread's stream)
-                ready.put(t)
+                torch.cuda.current_stream().synchronize()        # the copies (and --add_noise's float64 -> float32 cast) of this thread's stream:
+                ready.put(t)                                     # done before the pinned buffers are written again, and before the loop reads
             ready.put(None)
         except BaseException as e:          # surfaces in the consuming loop
             ready.put(e)
 
-    threading.Thread(target=produce, daemon=True).start()
+    if not a.no_prefetch:
+        threading.Thread(target=produce, daemon=True).start()
 
     waited = [0.0]
 
     def fill(k):
         while len(pending) < k and not drained[0]:
             t_w = time.perf_counter()
-            b = ready.get()
+            if a.no_prefetch:
+                b = next(it, None)
+                b = b if b is None else to_device(b)
+            else:
+                b = ready.get()
             waited[0] += time.perf_counter() - t_w
             if b is None:
                 drained[0] = True
@@ -375,15 +453,16 @@ def main(argv=None):
             m["pred_fit_cyl_loss"], m["pred_fit_glob_loss"] = sketch_fit_losses(m, b[0], b[1], b[2], b[3], implicit_net, pn_encoder, fl)
         acc.add(m)
 
-    pipe, pipe_shape, i, n_piped = None, None, 0, 0
+    pipe, pipe_shape, i, n_piped, metrics_graph = None, None, 0, 0, None
     t_first = None
     stream = torch.cuda.Stream(dev)
     stream.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(stream):
-        fill(2 * G)
-        while pending:
+        while True:
             group = None
-            fill(2 * G)
+            fill(1 if a.no_prefetch else 2 * G)          # (--no_prefetch: nothing is read ahead, every draw in the reference's order)
+            if not pending:
+                break
             head = list(pending)[:G]
             can = not a.no_prefetch and len(head) == G and same(head) and (pipe is None or tuple(head[0][0].shape) == pipe_shape)
             nxt = list(pending)[G:2 * G]
@@ -396,7 +475,13 @@ def main(argv=None):
                     pipe, pipe_shape = PipelinedForward(model, [b[0] for b in group], stream=stream, group=G), tuple(group[0][0].shape)
                 outs = pipe([b[0] for b in nxt] if nxt is not None else None)
                 for b, h in zip(group, outs):
-                    evaluate(b, heads=h)
+                    if a.with_sketch_fit or a.no_graph_metrics:
+                        evaluate(b, heads=h)
+                    elif metrics_graph is None or metrics_graph.inp[0].shape != b[0].shape:
+                        metrics_graph = GraphedMetrics(fl, acc.keys, b, h)
+                        acc.add_block(metrics_graph())
+                    else:
+                        acc.add_block(metrics_graph(b, h))
                 n_piped += G
                 done = G
                 if nxt is None:
@@ -422,7 +507,7 @@ def main(argv=None):
     if rank == 0 and t_first is not None and i > i_first:
         dt = (time.time() - t_first) / (i - i_first)
         rep = dict(batches=i, batches_pipelined=n_piped, batch_size=a.batch_size, num_point=a.num_point, prefetch=not a.no_prefetch,
-                   prefetch_group=G, ms_per_batch_after_first=dt * 1e3, points_per_s=a.batch_size * a.num_point / dt,
+                   prefetch_group=G, graph_metrics=metrics_graph is not None, ms_per_batch_after_first=dt * 1e3, points_per_s=a.batch_size * a.num_point / dt,
                    ms_per_batch_waiting_for_loader=waited[0] / (i - i_first) * 1e3)
         print("evaluation throughput: %.3f ms/batch (forward + metrics + one host transfer per batch; %.3f of it waiting for the loader thread), "
               "%.1f points/s, %d of %d batches pipelined" % (rep["ms_per_batch_after_first"], rep["ms_per_batch_waiting_for_loader"], rep["points_per_s"], n_piped, i))

@@ -143,10 +143,11 @@ class _DrawRing:
         return ring, i
 
 
-def _barrel_draws(seg_label, bb_labels, K, S, device=None, counts=None):
+def _barrel_draws(seg_label, bb_labels, K, S, device=None, counts=None, out=None):
     """The reference's torch.randint draws for its K x B sampling loops (data_utils.py:1064, :1696): k outer, b inner, only
     where the segment has > 1 barrel point in the batch and in the cloud, on the CPU generator.  -> (B,K,S) int64 on the host, or, with
-    `device`, on that device (drawn into a recycled pinned buffer, copied on the current stream)."""
+    `device`, on that device (drawn into a recycled pinned buffer, copied on the current stream - into `out`, a (B,K,S) int64 device tensor,
+    when given: a captured graph reads its draws from a fixed address)."""
     B = seg_label.shape[0]
     if counts is None:
         barrel = (seg_label.unsqueeze(-1) == torch.arange(K, device=seg_label.device)) & (bb_labels == 0).unsqueeze(-1)
@@ -166,8 +167,9 @@ def _barrel_draws(seg_label, bb_labels, K, S, device=None, counts=None):
             elif ring is not None:
                 rows[b][k].zero_()
     if ring is None:
-        return rand_idx if device is None else rand_idx.to(device)
-    out = rand_idx.to(device, non_blocking=True)
+        res = rand_idx if device is None else rand_idx.to(device)
+        return res if out is None else out.copy_(res)
+    out = rand_idx.to(device, non_blocking=True) if out is None else out.copy_(rand_idx, non_blocking=True)
     ring.copied[i] = torch.cuda.Event()
     ring.copied[i].record()
     return out

@@ -79,6 +79,7 @@ class _Base(torch.utils.data.Dataset):
         self.n_instances = d["n_instances"]
         self.npoints, self.K = num_points, max_instances
         self.op, self.center, self.extent = op, center, extent
+        self.generator = None      # None: torch's global CPU generator, as the reference; a loader that runs in its own thread sets a private one
         if op:
             self.operations = d["operations"]
         if center:
@@ -99,7 +100,7 @@ class _Base(torch.utils.data.Dataset):
         else:
             if P < self.npoints:
                 print("ERROR. Sampling more points than point cloud resolution.")       # dataloader.py:72-73 prints and goes on: the item is short
-            sel = torch.randperm(P)[: self.npoints]
+            sel = torch.randperm(P, generator=self.generator)[: self.npoints]
         lab = self.extrusion_labels[index][sel]
         head = (self.pcs[index][sel, :], self.normals[index][sel, :], lab, self.bb_labels[index][sel],
                 self.extrusion_axes[index][lab], self.extrusion_distances[index][lab],
@@ -141,7 +142,7 @@ class AutodeskH5Sketches(_Base):
 
     def __getitem__(self, index):
         _, item = self._sample_cloud(index)
-        sk_sel = torch.randperm(self.sketches.shape[2])[: self.num_sk_points]                  # dataloader.py:211-214
+        sk_sel = torch.randperm(self.sketches.shape[2], generator=self.generator)[: self.num_sk_points]                  # dataloader.py:211-214
         sampled_sketch = self.sketches[index][:, sk_sel, :]
         if self.op:
             item += (self.operations[index][sk_sel],)

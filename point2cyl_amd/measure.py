@@ -196,6 +196,11 @@ def sa1_stage(model, xyz, steps=30):
                 frac_of_mfma_roofline_pipelined=round(mfma_floor_ms / t_pipe, 4),
                 pipelined_frac_of_fps_latency_model=round(sa1.npoint * it_us * 1e-3 / t_pipe, 4),
                 pipelined_groups=groups,
+                best=(lambda g: dict(mode="pipelined, geometry groups of %s batches" % g, ms_per_batch=groups[g]["ms_per_batch"],
+                                     points_per_s=groups[g]["points_per_s"], frac_of_mfma_roofline=groups[g]["frac_of_mfma_roofline"],
+                                     note="the stage's throughput figure (north_star: >= 0.40 of its fp32-MFMA roofline); graph_serial_ms / "
+                                          "frac_of_mfma_roofline are its single-batch LATENCY, which the 512-step FPS chain bounds"))(
+                    max(groups, key=lambda g: groups[g]["frac_of_mfma_roofline"])) if groups else None,
                 pipelined_groups_note="steady-state THROUGHPUT per batch of %d clouds when the stage's geometry (FPS -> ball query -> grouped coordinates) of the "
                                       "next G batches is computed as ONE launch chain over G x %d clouds on the forked stream, under the grouped MLPs of the "
                                       "current G batches (BatchNorm statistics per batch): FPS is 512 dependent steps on one CU per cloud - 0.52 ms for 32 clouds "

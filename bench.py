@@ -153,7 +153,7 @@ def main():
     ap.add_argument("--sync_exchange", action="store_true", help="N > 1, conservative form of the exchange: ONE graph per step (no split tail) and the "
                     "all-reduce issued on the step's own stream right behind the replay (no side stream, no overlap); still all-HIP / RCCL")
     ap.add_argument("--extras", type=str, default="all", help="comma-separated subset of the extra legs (path_roofline,power_cap,stages,forward_only,ab,"
-                    "config3_fitting,dropin) to run after the timed region; default all")
+                    "config3_fitting,dropin,eval_loop) to run after the timed region; default all")
     ap.add_argument("--no_extras", action="store_true", help="only the training-step line: skip stages / forward_only / config3_fitting / ab / dropin")
     ap.add_argument("--dropin", action="store_true", help="make the DROP-IN step the timed one: the step composed as train_Point2Cyl_without_sketch.py:244-369 "
                     "composes it through the reference's import names (model(pcs), compute_all_losses, inline BB block, torch.optim.Adam, six .item())")
@@ -543,6 +543,29 @@ def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
         return _dropin_leg(args, batch, fl, dev, B, N, K, ms)
 
     leg("dropin", dropin)
+
+    def eval_loop():
+        # The evaluation script (point2cyl_amd/eval.py = eval.py:231-457, :690-715) on 1024 synthetic clouds in batches of B, randomly
+        # initialised backbone, in a child process (it owns a loader thread and process-wide host settings): forward + every metric + report.
+        import subprocess, tempfile
+        res = {}
+        with tempfile.TemporaryDirectory() as d:
+            for key, extra in (("pipelined", []), ("serial_reference_order", ["--no_prefetch"])):
+                rep = os.path.join(d, key + ".json")
+                cmd = [sys.executable, "-m", "point2cyl_amd.eval", "--random_init", "--synthetic", str(32 * B), "--batch_size", str(B), "--num_point", str(N),
+                       "--K", str(K), "--dump_dir", d, "--report", rep] + extra
+                r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+                if r.returncode != 0 or not os.path.exists(rep):
+                    res[key] = dict(error=r.stderr[-400:])
+                    continue
+                j = json.load(open(rep))
+                res[key] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in j.items()}
+        res["what"] = ("python -m point2cyl_amd.eval --random_init --synthetic %d --batch_size %d: per batch the forward (geometry of --prefetch_group batches "
+                       "computed together one group ahead), every metric of eval.py:270-457 as one HIP-graph replay, the report's sums; "
+                       "serial_reference_order = --no_prefetch (no loader thread, nothing read ahead, every random draw in the reference's order)" % (32 * B, B))
+        return res
+
+    leg("eval_loop", eval_loop)
     return out
 
 

@@ -981,3 +981,34 @@ def test_trainer_and_eval_cli_on_a_dataset_file(tmp_path):
     a, b = val(reports[0]), val(reports[2])
     assert np.isfinite(a).all() and np.isfinite(b).all() and np.isfinite(val(reports[3])).all()
     np.testing.assert_allclose(a[[0, 2]], b[[0, 2]], atol=0.08)            # mIoU, base / barrel accuracy: other subsamples of the same clouds
+
+
+@pytest.mark.gpu
+def test_with_sketch_trainer_cli_on_a_dataset_file(tmp_path):
+    """train_Point2Cyl.py's counterpart on a dataset FILE with ground-truth sketches (schema of utils.py:1251-1268: `sketches` (n,K,S_all,4) =
+    [2-D point | 2-D normal], `sketches_norms`): clouds of 1536 points and sketches of 384 subsampled per step to --num_point 1024 /
+    --num_sk_point 256 (dataloader.py:69-85, :211-214)."""
+    n, P, K, SA = 6, 1536, 8, 384
+    pcs, nrm, seg, bb, _, _, axes, dist_, cen = synth.make_batch(n, P, K, seed=91)
+    g = np.random.default_rng(5)
+    ang = g.uniform(0, 2 * np.pi, (n, K, SA))
+    rad = g.uniform(0.2, 0.9, (n, K, 1))
+    circ = np.stack([np.cos(ang), np.sin(ang)], -1)
+    sketches = np.concatenate([rad[..., None] * circ, circ], -1).astype(np.float32)            # circles: points and outward normals
+    data = tmp_path / "data"
+    data.mkdir()
+    np.savez(str(data / "train.npz"), point_cloud=pcs.numpy().astype(np.float32), normals=nrm.numpy().astype(np.float32),
+             extrusion_labels=seg.numpy(), base_barrel_labels=bb.numpy(), n_instances=(seg.max(dim=1)[0] + 1).numpy(),
+             extrusion_axes=axes.numpy().astype(np.float32), extrusion_distances=dist_.numpy().astype(np.float32),
+             extrusion_centers=cen.numpy().astype(np.float32), sketches=sketches, sketches_norms=rad[..., 0].astype(np.float32))
+    logdir = str(tmp_path / "sk")
+    out = _run(["-m", "point2cyl_amd.train_sketch", "--pred_seg", "--pred_normal", "--pred_bb", "--pred_extrusion", "--is_pc_train", "--is_im_train",
+                "--with_im_loss", "--data_dir", str(data), "--batch_size", "2", "--num_point", "1024", "--num_sk_point", "256", "--num_epochs", "1",
+                "--save_every", "1", "--logdir", logdir, "--im_logdir", str(tmp_path / "none")])
+    assert out.returncode == 0, out.stderr[-3000:]
+    im = [l for l in out.stdout.splitlines() if "latent loss" in l]
+    assert len(im) == 3, out.stdout[-2000:]
+    vals = np.array([float(x.split(":")[1]) for l in im for x in l.split("|")[2:]])
+    assert np.isfinite(vals).all()
+    ck = torch.load(os.path.join(logdir, "model.pth"), map_location="cpu")
+    assert set(ck.keys()) == {"model", "implicit_net", "pn_encoder"}

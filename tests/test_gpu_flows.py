@@ -981,6 +981,12 @@ def test_trainer_and_eval_cli_on_a_dataset_file(tmp_path):
     a, b = val(reports[0]), val(reports[2])
     assert np.isfinite(a).all() and np.isfinite(b).all() and np.isfinite(val(reports[3])).all()
     np.testing.assert_allclose(a[[0, 2]], b[[0, 2]], atol=0.08)            # mIoU, base / barrel accuracy: other subsamples of the same clouds
+    # --with_sketch_fit (eval.py:459-590; no pre-trained decoder on disk: randomly initialised, the path and the two extra report lines are the test)
+    o = _run(["-m", "point2cyl_amd.eval", "--logdir", logdir, "--ckpt", "model.pth", "--data_dir", str(data), "--data_split", "test", "--batch_size", "4",
+              "--num_point", "1024", "--num_sk_point", "256", "--dump_dir", str(tmp_path / "dump"), "--with_sketch_fit", "--im_logdir", str(tmp_path / "none")])
+    assert o.returncode == 0, o.stderr[-3000:]
+    extra = [l for l in o.stdout.splitlines() if "fitting loss=" in l]
+    assert len(extra) == 2 and all(np.isfinite(float(l.split("=")[1])) for l in extra), o.stdout[-1500:]
 
 
 @pytest.mark.gpu

@@ -1018,3 +1018,31 @@ def test_with_sketch_trainer_cli_on_a_dataset_file(tmp_path):
     assert np.isfinite(vals).all()
     ck = torch.load(os.path.join(logdir, "model.pth"), map_location="cpu")
     assert set(ck.keys()) == {"model", "implicit_net", "pn_encoder"}
+
+
+@pytest.mark.gpu
+def test_eval_cli_two_ranks_on_one_gpu_over_gloo(tmp_path):
+    """point2cyl_amd.eval as a job of two ranks (clouds are independent: ddp.shard_range, no data-path collective; ONE exchange at the end,
+    the metric sums): 18 clouds sharded 9 + 9, rank 0 prints the report over all 18; per-rank logs exist; the numbers are those of a
+    one-process run up to the random draws (FPS starts, extent samples) each rank makes for its own shard."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(P2C_ONE_GPU_RANKS="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    shutil = __import__("shutil")
+    shutil.copy(os.path.join(ROOT, "tests", "golden", "ref_ckpt_3steps.pth"), str(tmp_path / "model.pth"))
+    common = ["-m", "point2cyl_amd.eval", "--logdir", str(tmp_path), "--ckpt", "model.pth", "--synthetic", "18", "--batch_size", "4", "--num_point", "1024"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)] + \
+        common + ["--dump_dir", str(tmp_path / "d2")]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert "Num evaluated= 18" in out.stdout, out.stdout[-1500:]
+    assert os.path.exists(str(tmp_path / "d2" / "log_evaluate.0.txt")) and os.path.exists(str(tmp_path / "d2" / "log_evaluate.1.txt"))
+    one = _run(common + ["--dump_dir", str(tmp_path / "d1")])
+    assert one.returncode == 0 and "Num evaluated= 18" in one.stdout
+    val = lambda txt: np.array([float(l.split("=")[1]) for l in txt.splitlines() if l.startswith("Mean ")])
+    a, b = val(out.stdout), val(one.stdout)
+    assert a.shape == b.shape == (5,) and np.isfinite(a).all()
+    np.testing.assert_allclose(a[[0, 2]], b[[0, 2]], atol=0.08)

@@ -80,6 +80,8 @@ def build_parser():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--save_every", type=int, default=10)
     p.add_argument("--max_steps", type=int, default=0)
+    p.add_argument("--no_graph", action="store_true", help="launch every kernel of the step from Python (and draw the projections' barrel samples on the "
+                   "CPU generator, as the reference does) instead of replaying a HIP graph")
     p.add_argument("--report", type=str, default="")
     return p
 
@@ -236,83 +238,160 @@ def _main(a, rank, world, dev):
     mom_fwd = 0.1
     scal = defaultdict(list)
     t0, steps_timed = None, 0
-    for epoch in range(1, a.num_epochs + 1):
-        perm = torch.randperm(len(data)).to(dev)
-        hist = []
-        for i in range(nb):
-            idx = perm[i * B:(i + 1) * B]
-            it = data.gather(idx)
-            pcs, nrm, inst, bb, axes, cen = it[0], it[1], it[2], it[3], it[6], it[8]
-            gt_sk = sketches.index_select(0, idx)
-            if gt_sk.shape[2] != S:          # dataset sketches: a fresh num_sk_point subset per item and step (dataloader.py:211-214), drawn on the device
-                sel = torch.rand(B, gt_sk.shape[2], device=dev).argsort(dim=1)[:, :S]
-                gt_sk = torch.gather(gt_sk, 2, sel.view(B, 1, S, 1).expand(B, K, S, 4))
-            if a.add_noise:
-                pcs = pcs + torch.randn(B, N, 1, device=dev) * a.noise_sigma * nrm
-            step.update_momentum(model, mom_fwd)
-            ops.step_done()
-            with ops.step_arena(dev):
-                if a.use_gt_im:                                                # :405, :566-600: no backbone pass, ground-truth labels feed the encoder
-                    zero = torch.zeros((), device=dev)
-                    out = dict(total=zero, normal=zero, miou=zero, ext=zero, bb=zero, center=zero)
-                    sk = step_sketch.sketch_branch_losses(pcs, None, None, None, None, None, nrm, inst, bb, axes, cen, gt_sk, pn_encoder,
-                                                          loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2,
-                                                          use_whole_pc=a.use_whole_pc, use_gt_im=True,
-                                                          axis_feat=axes if a.use_extrusion_axis_feat else None)
-                else:
-                    out = (step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses)(model, pcs, nrm, inst, bb, axes, cen, fl)
-                    h = out["heads"].view(B, N, -1) if "heads" in out else None
+
+    # ---- one step on STATIC tensors: launched from Python, or - backbone trained, default - replayed as ONE HIP graph (forward, losses, the
+    # decoder's double backward, gradient packing) with the next batch's FPS / ball query / 3-NN on a forked stream inside it, as
+    # point2cyl_amd.train does (graph.GraphedForwardBackward).  The replayed step draws the projections' barrel samples from the device
+    # generator (fitting.barrel_draws_on_device: the reference's CPU draws need the barrel counts on the host); --no_graph keeps the
+    # reference's draws.  BatchNorm momentum is a captured constant: the graph is rebuilt when the staircase moves.
+    f32, i64 = torch.float32, torch.int64
+    st_batch = [torch.zeros(B, N, 3, device=dev), torch.zeros(B, N, 3, device=dev), torch.zeros(B, N, dtype=i64, device=dev),
+                torch.zeros(B, N, dtype=i64, device=dev), torch.zeros(B, K, 3, device=dev), torch.zeros(B, K, 3, device=dev),
+                torch.zeros(B, K, S, 4, device=dev)]
+    st_next_xyz = torch.zeros(B, N, 3, dtype=f32, device=dev)
+    use_graph = [not a.no_graph and a.is_pc_train and not a.use_gt_im]
+    graph_state = dict(graph=None, momentum=None, captures=0)
+
+    def fwd_bwd(geom=None, device_draws=False):
+        pcs, nrm, inst, bb, axes, cen, gt_sk = st_batch
+        ops.step_done()
+        with ops.step_arena(dev):
+            if a.use_gt_im:                                                # :405, :566-600: no backbone pass, ground-truth labels feed the encoder
+                zero = torch.zeros((), device=dev)
+                out = dict(total=zero, normal=zero, miou=zero, ext=zero, bb=zero, center=zero)
+                sk = step_sketch.sketch_branch_losses(pcs, None, None, None, None, None, nrm, inst, bb, axes, cen, gt_sk, pn_encoder,
+                                                      loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2,
+                                                      use_whole_pc=a.use_whole_pc, use_gt_im=True,
+                                                      axis_feat=axes if a.use_extrusion_axis_feat else None)
+            else:
+                out = (step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses)(model, pcs, nrm, inst, bb, axes, cen, fl,
+                                                                                                             geom=geom)
+                h = out["heads"].view(B, N, -1) if "heads" in out else None
+                with torch.no_grad():
+                    if h is not None:
+                        X = F.normalize(h[:, :, 0:3], p=2, dim=2, eps=1e-12)
+                        W2K = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2)
+                    else:
+                        X, W2K = out["X"].detach(), torch.softmax(out["W_raw"].detach(), dim=2)
+                    W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
+                W_enc = None
+                if a.use_whole_pc and a.is_pc_train:     # the membership channel keeps its history: the sketch losses reach the backbone (:519-536)
+                    Wg = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2) if h is not None else torch.softmax(out["W_raw"], dim=2)
+                    W_enc = Wg[:, :, 0::2] + Wg[:, :, 1::2]
+                ax_feat = None
+                if a.use_extrusion_axis_feat:            # :528: the fitted axes, with their history when the backbone trains
+                    ax_feat = out["E_AX"] if a.is_pc_train else out["E_AX"].detach()
+                sk = step_sketch.sketch_branch_losses(pcs, X, W, W2K, out["match"], out["mask"], nrm, inst, bb, axes, cen, gt_sk, pn_encoder,
+                                                      loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2,
+                                                      use_whole_pc=a.use_whole_pc, W_encoder=W_enc, axis_feat=ax_feat, device_draws=device_draws)
+            total = (out["total"] + sk["im_loss"]) if a.is_pc_train else sk["im_loss"]                    # :690-693
+            sync.zero()
+            total.backward()
+            sync.pack()
+        row = torch.stack([total.detach()] + [sk[k].detach().float().reshape(()) for k in IM_SCALARS] +
+                          [out[k].detach().float().reshape(()) for k in PC_SCALARS])
+        return dict(row=row)
+
+    def run_step(momentum, eager=False):
+        """One optimizer step on the static batch; momentum = the BatchNorm momentum of this step's forward."""
+        step.update_momentum(model, momentum)
+        if eager or not use_graph[0]:
+            out = fwd_bwd()
+        else:
+            gs = graph_state
+            if gs["graph"] is None or gs["momentum"] != momentum:
+                from .graph import GraphedForwardBackward
+                if gs["graph"] is not None:
+                    gs["graph"].release()
+                    gs["graph"] = None
+                # warm-up passes and the capture run the step three times: the sketch encoder's BatchNorm statistics are put back afterwards
+                # (GraphedForwardBackward restores the backbone's itself); its first replay trains on the geometry of what the prefetch
+                # buffer holds at construction, which must be the current batch
+                keep = [(b_, b_.detach().clone()) for b_ in pn_encoder.buffers()]
+                nxt = st_next_xyz.clone()
+                st_next_xyz.copy_(st_batch[0])
+                try:
+                    gs["graph"] = GraphedForwardBackward(model, lambda geom=None: fwd_bwd(geom, device_draws=True), prefetch_xyz=st_next_xyz,
+                                                         stream=torch.cuda.current_stream())
+                except Exception as e:      # something in this configuration cannot be captured: train on, launched from Python
+                    sys.stderr.write("point2cyl_amd.train_sketch: HIP graph capture failed (%s: %s); continuing without the graph\n" % (type(e).__name__, e))
+                    fresh = torch.cuda.Stream(dev)                          # the capture stream may be left in capture mode
+                    fresh.wait_stream(torch.cuda.current_stream())
+                    torch.cuda.set_stream(fresh)
+                    for m_ in model.modules():
+                        if hasattr(m_, "fps_start"):
+                            m_.fps_start = None
+                    use_graph[0], gs["graph"] = False, None
                     with torch.no_grad():
-                        if h is not None:
-                            X = F.normalize(h[:, :, 0:3], p=2, dim=2, eps=1e-12)
-                            W2K = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2)
-                        else:
-                            X, W2K = out["X"].detach(), torch.softmax(out["W_raw"].detach(), dim=2)
-                        W = W2K[:, :, 0::2] + W2K[:, :, 1::2]
-                    W_enc = None
-                    if a.use_whole_pc and a.is_pc_train:     # the membership channel keeps its history: the sketch losses reach the backbone (:519-536)
-                        Wg = torch.softmax(h[:, :, 3:3 + 2 * K], dim=2) if h is not None else torch.softmax(out["W_raw"], dim=2)
-                        W_enc = Wg[:, :, 0::2] + Wg[:, :, 1::2]
-                    ax_feat = None
-                    if a.use_extrusion_axis_feat:            # :528: the fitted axes, with their history when the backbone trains
-                        ax_feat = out["E_AX"] if a.is_pc_train else out["E_AX"].detach()
-                    sk = step_sketch.sketch_branch_losses(pcs, X, W, W2K, out["match"], out["mask"], nrm, inst, bb, axes, cen, gt_sk, pn_encoder,
-                                                          loaded_pn_encoder, implicit_net, sampler, K, S, with_im_loss=a.with_im_loss, is_l2=a.is_L2,
-                                                          use_whole_pc=a.use_whole_pc, W_encoder=W_enc, axis_feat=ax_feat)
-                total = (out["total"] + sk["im_loss"]) if a.is_pc_train else sk["im_loss"]                    # :690-693
-                sync.zero()
-                # the staircases count SAMPLES: under data parallelism a step consumes world * B of them (as point2cyl_amd.train does)
-                mom_fwd = step.get_batch_norm_decay(gstep, B * world, a.bn_decay_step)                        # :698-701 (reaches the next forward)
-                lr = step.get_learning_rate(a.learning_rate, gstep, B * world, a.decay_step, a.decay_rate)     # :703-706: group 0 only
-                if old_lr != lr:
-                    opt.param_groups[0]["lr"] = lr
-                    old_lr = lr
-                total.backward()
-                sync.pack()
-            sync.allreduce()
-            opt.step()
-            ops.step_done()
-            gstep += 1
-            row = torch.stack([total.detach()] + [sk[k].detach().float().reshape(()) for k in IM_SCALARS] +
-                              [out[k].detach().float().reshape(()) for k in PC_SCALARS])
-            hist.append(row)
-            v = row.tolist()                                                                                   # one sync per step (the reference: ~12)
-            say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | latent loss: %.4f | manifold loss: %.4f | eikonal loss: %.4f | normal loss: %.4f"
-                % (epoch, a.num_epochs, i, nb, v[1], v[2], v[3], v[4], v[5]))
-            if a.is_pc_train:
-                say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | normal loss: %.4f | mIOU loss: %.4f | ext loss: %.4f | bb loss: %.4f | center loss: %.4f"
-                    % (epoch, a.num_epochs, i, nb, v[0], v[6], v[7], v[8], v[9], v[10]))
-            if gstep == 2:
-                torch.cuda.synchronize()
-                t0, steps_timed = time.perf_counter(), 0
-            elif gstep > 2:
-                steps_timed += 1
-            if a.max_steps and gstep >= a.max_steps:
-                break
+                        for b_, v_ in keep:
+                            b_.copy_(v_)
+                    st_next_xyz.copy_(nxt)
+                    return run_step(momentum, eager=True)
+                with torch.no_grad():
+                    for b_, v_ in keep:
+                        b_.copy_(v_)
+                st_next_xyz.copy_(nxt)
+                gs["momentum"] = momentum
+                gs["captures"] += 1
+            out = gs["graph"]()
+        sync.allreduce()
+        opt.step()
+        ops.step_done()
+        return out["row"]
+
+    def batches():
+        for epoch_ in range(1, a.num_epochs + 1):
+            perm = torch.randperm(len(data)).to(dev)
+            for i_ in range(nb):
+                idx = perm[i_ * B:(i_ + 1) * B]
+                it_ = data.gather(idx)
+                pcs, nrm, inst, bb, axes, cen = it_[0], it_[1], it_[2], it_[3], it_[6], it_[8]
+                gt_sk = sketches.index_select(0, idx)
+                if gt_sk.shape[2] != S:      # dataset sketches: a fresh num_sk_point subset per item and step (dataloader.py:211-214), drawn on the device
+                    sel = torch.rand(B, gt_sk.shape[2], device=dev).argsort(dim=1)[:, :S]
+                    gt_sk = torch.gather(gt_sk, 2, sel.view(B, 1, S, 1).expand(B, K, S, 4))
+                if a.add_noise:
+                    pcs = pcs + torch.randn(B, N, 1, device=dev) * a.noise_sigma * nrm
+                yield epoch_, i_, [pcs.float(), nrm.float(), inst.long(), bb.long(), axes.float(), cen.float(), gt_sk.float()]
+
+    stream_it = batches()
+    cur = next(stream_it, None)
+    hist = []
+    while cur is not None:
+        nxt = next(stream_it, None)          # one batch ahead: its clouds are the ones whose geometry the replayed step prefetches
+        epoch, i, tensors = cur
+        ops.copy_flat_batch(st_batch, [t.contiguous() for t in tensors])
+        st_next_xyz.copy_(nxt[2][0] if nxt is not None else tensors[0])
+        # the staircases count SAMPLES: under data parallelism a step consumes world * B of them (as point2cyl_amd.train does)
+        lr = step.get_learning_rate(a.learning_rate, gstep, B * world, a.decay_step, a.decay_rate)     # :703-706: group 0 only
+        if old_lr != lr:
+            opt.param_groups[0]["lr"] = lr
+            old_lr = lr
+        row = run_step(mom_fwd, eager=gstep == 0)          # (the first step's momentum differs from every later one: not worth a capture)
+        mom_fwd = step.get_batch_norm_decay(gstep, B * world, a.bn_decay_step)                        # :698-701 (reaches the next forward)
+        gstep += 1
+        v = row.tolist()                                                                               # one sync per step (the reference: ~12)
+        hist.append(torch.tensor(v))                       # (a copy: in graph mode every replay returns the same static tensor)
+        say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | latent loss: %.4f | manifold loss: %.4f | eikonal loss: %.4f | normal loss: %.4f"
+            % (epoch, a.num_epochs, i, nb, v[1], v[2], v[3], v[4], v[5]))
+        if a.is_pc_train:
+            say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | normal loss: %.4f | mIOU loss: %.4f | ext loss: %.4f | bb loss: %.4f | center loss: %.4f"
+                % (epoch, a.num_epochs, i, nb, v[0], v[6], v[7], v[8], v[9], v[10]))
+        if gstep == 3:                                     # steady state: steps 0 and 1 are the eager one and the capture
+            torch.cuda.synchronize()
+            t0, steps_timed = time.perf_counter(), 0
+        elif gstep > 3:
+            steps_timed += 1
+        stopping = bool(a.max_steps) and gstep >= a.max_steps
+        end_of_epoch = nxt is None or nxt[0] != epoch or stopping
+        cur = nxt
+        if not end_of_epoch:
+            continue
         ep = torch.stack(hist).mean(0).tolist()
         for k, val in zip(("total_loss",) + tuple("IM_" + s for s in IM_SCALARS) + PC_SCALARS, ep):
             scal[k].append(val)
-        last = epoch == a.num_epochs or (a.max_steps and gstep >= a.max_steps)
+        hist = []
+        last = nxt is None or stopping
         if epoch % a.save_every == 0 or last:
             save("checkpoint_%04d.pth" % epoch)
             save("model.pth")
@@ -340,12 +419,15 @@ def _main(a, rank, world, dev):
                      allreduce_bytes=int(sync.flat.numel() * 4) if sync.flat is not None else 0, trainable_parameters=sum(p.numel() for p in trainable))
     if t0 is not None and steps_timed > 0 and rank == 0:
         dt = (time.perf_counter() - t0) / steps_timed
-        rep = dict(steps=gstep, ms_per_step=dt * 1e3, points_per_s=world * B * N / dt, batch_per_gpu=B, num_point=N, num_sk_point=S, world=world,
+        rep = dict(steps=gstep, steady_steps=steps_timed, ms_per_step=dt * 1e3, points_per_s=world * B * N / dt, batch_per_gpu=B, num_point=N, num_sk_point=S,
+                   world=world, graph=graph_state["graph"] is not None, graph_captures=graph_state["captures"],
                    epoch_means={k: v for k, v in scal.items()}, multi_gpu=multi)
         print("with-sketch trainer throughput: %.2f ms/step, %.1f points/s" % (rep["ms_per_step"], rep["points_per_s"]))
         if a.report:
             with open(a.report, "w") as f:
                 json.dump(rep, f)
+    if graph_state["graph"] is not None:
+        graph_state["graph"].release()
     if log is not None:
         log.close()
     if world > 1:

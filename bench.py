@@ -554,7 +554,8 @@ def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
                 rep = os.path.join(d, key + ".json")
                 cmd = [sys.executable, "-m", "point2cyl_amd.eval", "--random_init", "--synthetic", str(32 * B), "--batch_size", str(B), "--num_point", str(N),
                        "--K", str(K), "--dump_dir", d, "--report", rep] + extra
-                r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240)
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+                r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=240, env=env)      # (a one-process job of its own)
                 if r.returncode != 0 or not os.path.exists(rep):
                     res[key] = dict(error=r.stderr[-400:])
                     continue

@@ -1046,3 +1046,45 @@ def test_eval_cli_two_ranks_on_one_gpu_over_gloo(tmp_path):
     a, b = val(out.stdout), val(one.stdout)
     assert a.shape == b.shape == (5,) and np.isfinite(a).all()
     np.testing.assert_allclose(a[[0, 2]], b[[0, 2]], atol=0.08)
+
+
+@pytest.mark.gpu
+def test_graphed_metrics_equal_the_eager_metrics():
+    """eval.GraphedMetrics (the evaluation loop's default for pipelined batches: every metric kernel of a batch as one HIP-graph replay,
+    the extent draws made before the replay into a fixed buffer) returns the accumulator block of the eager eval_metrics call, bit for
+    bit, for the batch it was captured on and for later batches of other clouds - same generator state, same draws."""
+    from point2cyl_amd import fitting
+    B, N, K = 4, 2048, 8
+    fl = p2c_eval.EvalFlags(K=K, num_sk_point=512)
+    torch.manual_seed(3)
+    model = backbone(output_sizes=fl.pred_sizes()).to(DEV).eval()
+    acc = p2c_eval.Accumulator()
+
+    def make(seed):
+        pcs, nrm, inst, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=seed)
+        extras = dict(barrel_counts=fitting.barrel_counts(inst.long(), bb.long(), K), labels_validated=True)
+        batch = (pcs.float().to(DEV), nrm.float().to(DEV), inst.to(DEV), bb.float().to(DEV), axes.float().to(DEV), cen.float().to(DEV), extras)
+        with torch.no_grad():
+            heads, sizes = model.forward_heads(batch[0], model.compute_geometry(batch[0], with_csr=False))
+        return batch, (heads.clone(), sizes)
+
+    def eager(batch, heads):
+        h, sizes = heads
+        hv = h.view(B, N, h.shape[-1])
+        with torch.no_grad():
+            m = p2c_eval.eval_metrics(hv[:, :, 0:sizes[0]], hv[:, :, sizes[0]:sizes[0] + sizes[1]], *batch[:6], fl, **batch[6])
+        return acc.block(m).clone()
+
+    b1, h1 = make(11)
+    b2, h2 = make(12)
+    torch.manual_seed(100); e1 = eager(b1, h1)
+    torch.manual_seed(101); e2 = eager(b2, h2)
+    torch.manual_seed(100)
+    gm = p2c_eval.GraphedMetrics(fl, acc.keys, b1, h1)
+    g1 = gm().clone()
+    torch.manual_seed(101)
+    g2 = gm(b2, h2).clone()
+    torch.manual_seed(100)
+    g1b = gm(b1, h1).clone()
+    assert torch.equal(g1, e1) and torch.equal(g2, e2) and torch.equal(g1b, e1)
+    assert not torch.equal(e1, e2) and torch.isfinite(e1).all()

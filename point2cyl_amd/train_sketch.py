@@ -354,6 +354,20 @@ def _main(a, rank, world, dev):
                     pcs = pcs + torch.randn(B, N, 1, device=dev) * a.noise_sigma * nrm
                 yield epoch_, i_, [pcs.float(), nrm.float(), inst.long(), bb.long(), axes.float(), cen.float(), gt_sk.float()]
 
+    log_ring = [torch.zeros(1 + len(IM_SCALARS) + len(PC_SCALARS), dtype=torch.float32).pin_memory() for _ in range(2)]
+    lagged = None
+
+    def emit(item):
+        ep_, i_, hb_, ev_ = item
+        ev_.synchronize()
+        v = hb_.tolist()
+        hist.append(torch.tensor(v))
+        say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | latent loss: %.4f | manifold loss: %.4f | eikonal loss: %.4f | normal loss: %.4f"
+            % (ep_, a.num_epochs, i_, nb, v[1], v[2], v[3], v[4], v[5]))
+        if a.is_pc_train:
+            say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | normal loss: %.4f | mIOU loss: %.4f | ext loss: %.4f | bb loss: %.4f | center loss: %.4f"
+                % (ep_, a.num_epochs, i_, nb, v[0], v[6], v[7], v[8], v[9], v[10]))
+
     stream_it = batches()
     cur = next(stream_it, None)
     hist = []
@@ -370,13 +384,16 @@ def _main(a, rank, world, dev):
         row = run_step(mom_fwd, eager=gstep == 0)          # (the first step's momentum differs from every later one: not worth a capture)
         mom_fwd = step.get_batch_norm_decay(gstep, B * world, a.bn_decay_step)                        # :698-701 (reaches the next forward)
         gstep += 1
-        v = row.tolist()                                                                               # one sync per step (the reference: ~12)
-        hist.append(torch.tensor(v))                       # (a copy: in graph mode every replay returns the same static tensor)
-        say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | latent loss: %.4f | manifold loss: %.4f | eikonal loss: %.4f | normal loss: %.4f"
-            % (epoch, a.num_epochs, i, nb, v[1], v[2], v[3], v[4], v[5]))
-        if a.is_pc_train:
-            say("Epoch: %d/%d | Batch [%04d/%04d] | total loss: %.4f | normal loss: %.4f | mIOU loss: %.4f | ext loss: %.4f | bb loss: %.4f | center loss: %.4f"
-                % (epoch, a.num_epochs, i, nb, v[0], v[6], v[7], v[8], v[9], v[10]))
+        # The reference prints every step from ~12 .item() syncs.  Here step k's scalars go to a pinned host buffer asynchronously and its two
+        # lines are printed after step k+1 has been ENQUEUED (the host waits for an event that precedes step k+1's work): the log never
+        # drains the device queue.  (The copy also un-aliases the row: in graph mode every replay returns the same static tensor.)
+        hb = log_ring[gstep % 2]
+        hb.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        if lagged is not None:
+            emit(lagged)
+        lagged = (epoch, i, hb, ev)
         if gstep == 3:                                     # steady state: steps 0 and 1 are the eager one and the capture
             torch.cuda.synchronize()
             t0, steps_timed = time.perf_counter(), 0
@@ -387,6 +404,8 @@ def _main(a, rank, world, dev):
         cur = nxt
         if not end_of_epoch:
             continue
+        emit(lagged)                                       # the epoch's last lines in front of its summary
+        lagged = None
         ep = torch.stack(hist).mean(0).tolist()
         for k, val in zip(("total_loss",) + tuple("IM_" + s for s in IM_SCALARS) + PC_SCALARS, ep):
             scal[k].append(val)

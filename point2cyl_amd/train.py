@@ -82,15 +82,19 @@ class ResidentDataset:
     def __len__(self):
         return self.n
 
-    def gather(self, idx):
-        """idx: (B,) long on the device -> the reference's 9-tuple for those clouds."""
-        out = [t.index_select(0, idx) for t in self.t]
+    USED = (0, 1, 2, 3, 6, 8)       # clouds, normals, instance labels, base / barrel labels, axes (K), centres (K): what the trainers read
+
+    def gather(self, idx, fields=None):
+        """idx: (B,) long on the device -> the reference's 9-tuple for those clouds; `fields`: only these positions (None elsewhere - the
+        per-point axes / distances of positions 4, 5 are a third of the bytes and no trainer reads them)."""
+        out = [t.index_select(0, idx) if fields is None or j in fields else None for j, t in enumerate(self.t)]
         if self.subsample:                     # dataloader.py:71-77: a fresh random num_point-subset per access
             B, Nfull = out[0].shape[0], out[0].shape[1]
             sel = torch.rand(B, Nfull, device=self.dev).argsort(dim=1)[:, : self.num_point]
             for j in (0, 1, 2, 3, 4, 5):       # the per-point tensors
                 t = out[j]
-                out[j] = torch.gather(t, 1, sel.unsqueeze(-1).expand(-1, -1, t.shape[2])) if t.dim() == 3 else torch.gather(t, 1, sel)
+                if t is not None:
+                    out[j] = torch.gather(t, 1, sel.unsqueeze(-1).expand(-1, -1, t.shape[2])) if t.dim() == 3 else torch.gather(t, 1, sel)
         return out
 
 
@@ -232,7 +236,7 @@ def _main(a, rank, world, local, dev, stream):
         for epoch in range(1, a.num_epochs + 1):
             perm = torch.randperm(len(data)).to(dev)
             for i in range(nb):
-                it = data.gather(perm[i * B:(i + 1) * B])
+                it = data.gather(perm[i * B:(i + 1) * B], fields=ResidentDataset.USED)
                 pcs = it[0]
                 if a.add_noise:                               # data_utils.py:84-96 on the device: p + N(0, sigma) * normal
                     pcs = pcs + torch.randn(pcs.shape[0], pcs.shape[1], 1, device=dev) * a.noise_sigma * it[1]

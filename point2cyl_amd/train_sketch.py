@@ -344,7 +344,7 @@ def _main(a, rank, world, dev):
             perm = torch.randperm(len(data)).to(dev)
             for i_ in range(nb):
                 idx = perm[i_ * B:(i_ + 1) * B]
-                it_ = data.gather(idx)
+                it_ = data.gather(idx, fields=ResidentDataset.USED)
                 pcs, nrm, inst, bb, axes, cen = it_[0], it_[1], it_[2], it_[3], it_[6], it_[8]
                 gt_sk = sketches.index_select(0, idx)
                 if gt_sk.shape[2] != S:      # dataset sketches: a fresh num_sk_point subset per item and step (dataloader.py:211-214), drawn on the device

@@ -149,7 +149,7 @@ def sa1_stage(model, xyz, steps=30):
             # throughput pipeline: the geometry of the next G batches computed TOGETHER (one FPS launch over G x B clouds: G x B workgroups, the same
             # 512 dependent steps) on the forked stream while the grouped MLP of the current G batches runs batch by batch (BatchNorm per batch)
             groups = {}
-            for G in (2, 3, 4):
+            for G in (2, 3, 4, 8):
                 xg = xyz.repeat(G, 1, 1)
                 sa1.fps_start = start.repeat(G)
 

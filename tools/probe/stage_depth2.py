@@ -11,7 +11,7 @@ B, N = 32, 8192
 torch.manual_seed(0)
 model = backbone(output_sizes=[3, 16]).to(dev).train()
 sa1 = model.sa1
-for G in (1, 2, 3, 4):
+for G in (1, 2, 3, 4, 6, 8):
     xyz = torch.cat([synth.make_batch(B, N, 8, seed=10 + j)[0].float() for j in range(G)]).to(dev)          # (G*B, N, 3)
     start = torch.randint(0, N, (G * B,)).to(dev)
     sa1.fps_start = start

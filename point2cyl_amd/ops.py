@@ -23,6 +23,7 @@ USE_NARROW_BWD = os.environ.get("P2C_NARROW_BWD", "1") != "0"  # the per-point h
 STRICT_LABELS = os.environ.get("P2C_STRICT_LABELS", "0") == "1"   # validate labels with a device->host sync in every loss call instead of deferred
 USE_POOL_ALG = os.environ.get("P2C_POOL_ALG", "1") != "0"    # pooled last layer's backward without its pre-BN output (csrc/bwd_pool.hip)
 USE_POOL_EPI = os.environ.get("P2C_POOL_EPI", "1") != "0"    # max over 64 neighbours from extremes emitted by the last layer's GEMM epilogue
+USE_INFER_PATHS = True     # eval mode without gradients takes the folded first layer / the pooled last layer without its Y too (a test switches it off)
 
 
 def _f32c(t):
@@ -319,6 +320,9 @@ class _MLPStack(torch.autograd.Function):
         K = _pad4(cfg["in_channels"])
         assert X0.shape[1] >= K and ldx0 % 4 == 0, (X0.shape, K)
         training = cfg["training"]
+        # INFERENCE: eval-mode BatchNorm and no gradient wanted by anyone - nothing of this call is read again, so the forms that keep an
+        # activation out of HBM (folded first layer, pooled last layer without its Y) apply as they do in training, minus the statistics
+        infer = (not training) and USE_INFER_PATHS and not cfg.get("wants_grad", True)
         bns = cfg["bns"]
         L = cfg["n_layers"]
         tail = cfg["tail"]
@@ -336,7 +340,7 @@ class _MLPStack(torch.autograd.Function):
             arena = _ZeroArena(sum(STAT_SLOTS * 2 * c for c in widths) + 16, dev)
         # Folded first layer (csrc/bn.hip): 3 input channels (+pad), 64 outputs, train mode, no gradient wanted for the input,
         # a BatchNorm'ed middle layer of 64/128 channels next: Y_0 is never written; layer 1 rebuilds it from the input rows.
-        fold0 = (USE_FOLD0 and pre is None and training and K == 4 and cfg["in_channels"] <= 3 and ldx0 == 4 and M >= 8192 and not X0.requires_grad and mask is None and seed is None
+        fold0 = (USE_FOLD0 and pre is None and (training or infer) and K == 4 and cfg["in_channels"] <= 3 and ldx0 == 4 and M >= 8192 and not X0.requires_grad and mask is None and seed is None
                  and (L >= 3 or (L == 2 and tail == "bnrelu")) and params[0].shape[0] == 64 and params[4].shape[0] in (64, 128)
                  and bns[0] is not None and bns[1] is not None)
         mom = None
@@ -385,13 +389,17 @@ class _MLPStack(torch.autograd.Function):
                 gamma, beta = params[pi], params[pi + 1]
                 pi += 2
                 bn = bns[0]
-                mom = arena.f64(16)
-                call("p2c_input_moments_f32", ptr(X0), ldx0, M, ptr(mom), stream())
                 st = torch.empty(4, Co, dtype=torch.float32, device=dev)
-                call("p2c_bn_finalize_affine_f32", ptr(mom), M, ptr(W2), ptr(b), ptr(gamma), ptr(beta), float(bn.eps), float(bn.momentum),
-                     ptr(bn.running_mean), ptr(bn.running_var), Co, ptr(st), stream())
-                if bn.nbt is not None and not _NBT_BUMPED[0]:
-                    PENDING_NBT.append(bn.nbt)
+                if training:
+                    mom = arena.f64(16)
+                    call("p2c_input_moments_f32", ptr(X0), ldx0, M, ptr(mom), stream())
+                    call("p2c_bn_finalize_affine_f32", ptr(mom), M, ptr(W2), ptr(b), ptr(gamma), ptr(beta), float(bn.eps), float(bn.momentum),
+                         ptr(bn.running_mean), ptr(bn.running_var), Co, ptr(st), stream())
+                    if bn.nbt is not None and not _NBT_BUMPED[0]:
+                        PENDING_NBT.append(bn.nbt)
+                else:           # running statistics: the layer's affine without its output
+                    call("p2c_bn_finalize_f32", None, Co, M, ptr(b), ptr(gamma), ptr(beta), float(bn.eps), float(bn.momentum), 0,
+                         ptr(bn.running_mean), ptr(bn.running_var), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
                 Ys.append(None)
                 Ws.append(W2)
                 aff.append(st)
@@ -400,12 +408,12 @@ class _MLPStack(torch.autograd.Function):
                 K = Co
                 continue
             # the pooled last layer of SA1: when its backward takes the Y-free route (csrc/bwd_pool.hip) the forward does not store Y either
-            no_y = (USE_POOL_ALG and USE_POOL_EPI and tail == "maxpool" and i == L - 1 and in_mode == 1 and mptr_free and training and ldx == K
+            no_y = (USE_POOL_EPI and tail == "maxpool" and i == L - 1 and in_mode == 1 and mptr_free and ldx == K
                     and L > 1 and _lib.lib().p2c_linear_fwd_pool_supported(M, Co, K, 1, cfg["ns"])
-                    and _lib.lib().p2c_linear_bwd_pool_alg_supported(M, Co, K, cfg["ns"]))
+                    and (infer or (USE_POOL_ALG and training and _lib.lib().p2c_linear_bwd_pool_alg_supported(M, Co, K, cfg["ns"]))))
             Y = torch.empty(0 if no_y else M, Co, dtype=torch.float32, device=dev)
             if fold0 and i == 1:
-                partials = arena.f64(STAT_SLOTS, 2, Co)
+                partials = arena.f64(STAT_SLOTS, 2, Co) if training else None
                 call("p2c_linear_fwd_fold0_f32", ptr(X0), ldx0, ptr(Ws[0]), ptr(fold_b0), ptr(sc), ptr(sh), K, ptr(W2), K, ptr(b), ptr(Y), Co, M, Co,
                      ptr(partials), stream(), flops=2.0 * M * Co * K)
                 Ys.append(Y)
@@ -415,9 +423,9 @@ class _MLPStack(torch.autograd.Function):
                 bn = bns[1]
                 st = torch.empty(4, Co, dtype=torch.float32, device=dev)
                 call("p2c_bn_finalize_f32", ptr(partials), Co, M, ptr(b), ptr(gamma),
-                     ptr(beta), float(bn.eps), float(bn.momentum), 1, ptr(bn.running_mean), ptr(bn.running_var),
+                     ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
                      ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
-                if bn.nbt is not None and not _NBT_BUMPED[0]:
+                if training and bn.nbt is not None and not _NBT_BUMPED[0]:
                     PENDING_NBT.append(bn.nbt)
                 aff.append(st)
                 sc, sh, in_mode = st[0], st[1], 1
@@ -449,7 +457,7 @@ class _MLPStack(torch.autograd.Function):
                 else:
                     call("p2c_group_linear_bias_stats_f32", ptr(Gs), Co, ptr(pre["xyz"]), ptr(pre["new_xyz"]), ptr(pre["idx"]), ptr(pre_wx),
                          ptr(b), pre["B"], pre["N"], pre["S"], pre["ns"], Co, ptr(Y), Co, ptr(partials), stream())
-            elif (USE_POOL_EPI and tail == "maxpool" and i == L - 1 and mode == 1 and mptr is None and training and ldx == K
+            elif (USE_POOL_EPI and tail == "maxpool" and i == L - 1 and mode == 1 and mptr is None and (training or infer) and ldx == K
                   and _lib.lib().p2c_linear_fwd_pool_supported(M, Co, K, 1, cfg["ns"])):
                 # last layer of a set-abstraction stack: the GEMM epilogue also emits the extremes the max over the 64 neighbours needs
                 pool = (torch.empty(2 * cfg["G"], Co, dtype=torch.float32, device=dev), torch.empty(2 * cfg["G"], Co, dtype=torch.float32, device=dev),
@@ -816,6 +824,8 @@ def mlp_stack(X0, in_channels, layers, tail, training, G=None, ns=None, drop_mas
                drop_mask=drop_mask, drop_scale=drop_scale, drop_seed=drop_seed, xyz_last=xyz_last, pre=pre, staged=staged, aux_out=aux_out)
     if pre is not None and pre["kind"] == "repeat":
         params = [pre.pop("V")] + params
+    # (decided HERE: inside Function.forward grad mode is off and ctx.needs_input_grad is True for every Parameter even under no_grad)
+    cfg["wants_grad"] = torch.is_grad_enabled() and (X0.requires_grad or any(torch.is_tensor(p_) and p_.requires_grad for p_ in params))
     out = _MLPStack.apply(cfg, X0, *params)
     if not _DEFER_NBT[0]:
         flush_nbt()

@@ -1907,3 +1907,63 @@ def test_compute_all_losses_fused_equals_torch_expressions(K):
     ro = R.compute_all_losses(a[5].cpu(), I.cpu(), a[6].cpu(), Xg.cpu(), 0.7, 1.3)
     np.testing.assert_allclose(a[0], [float(ro[0]), float(ro[1]), float(ro[2])], rtol=1e-5, atol=1e-7)
     assert torch.equal(a[1], ro[3]) and torch.equal(a[2].bool(), ro[4].bool())
+
+
+@pytest.mark.gpu
+def test_inference_forward_paths_equal_the_plain_eval_forward():
+    """Eval mode without gradients (what eval.py runs) takes the forms that keep an activation out of HBM - SA1's folded first layer, the
+    pooled last layers from the extremes of the GEMM epilogue without storing their pre-BatchNorm output - as the training forward does,
+    minus the statistics.  Against the plain eval forward (every layer's output materialised, ops.USE_INFER_PATHS off) on the same
+    geometry: the same heads to fp32 rounding (the folded layer's 3 -> 64 product is rebuilt in another summation order; the pooled
+    maximum itself is bit-identical), no BatchNorm buffer touched; with gradients enabled eval mode still takes the plain path."""
+    from point2cyl_amd import ops
+    from point2cyl_amd.backbone import backbone
+    B, N, K = 4, 8192, 8
+    torch.manual_seed(0)
+    model = backbone(output_sizes=[3, 2 * K]).to(DEV)
+    pcs = synth.make_batch(B, N, K, seed=21)[0].to(DEV, torch.float)
+    model.train()
+    with torch.no_grad():
+        for _ in range(2):
+            model(pcs)                                    # running statistics that mean something
+    model.eval()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    calls = []
+    real = ops.call
+
+    def spy(name, *a, **kw):
+        calls.append(name)
+        return real(name, *a, **kw)
+
+    with torch.no_grad():
+        geom = model.compute_geometry(pcs, with_csr=False)
+        model.forward_heads(pcs, geom)
+        seed0 = model._drop_seed.clone()                  # F.dropout(training=True) also in eval mode (pointnet_extrusion.py:60): same counter for both forwards
+        ops.call = spy
+        try:
+            fast = model.forward_heads(pcs, geom)[0].clone()
+            n_fast = list(calls)
+            del calls[:]
+            ops.USE_INFER_PATHS = False
+            model._drop_seed.copy_(seed0)
+            plain = model.forward_heads(pcs, geom)[0].clone()
+            n_plain = list(calls)
+        finally:
+            ops.USE_INFER_PATHS = True
+            ops.call = real
+    assert "p2c_linear_fwd_fold0_f32" in n_fast and n_fast.count("p2c_linear_fwd_pool_f32") >= 2
+    assert n_fast.count("p2c_maxpool_bnrelu_f32") < n_plain.count("p2c_maxpool_bnrelu_f32")
+    assert "p2c_linear_fwd_fold0_f32" not in n_plain and "p2c_linear_fwd_pool_f32" not in n_plain
+    scale = float(plain.abs().max())
+    assert float((fast - plain).abs().max()) <= 2e-6 * scale, (float((fast - plain).abs().max()), scale)
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    del calls[:]
+    ops.call = spy
+    try:
+        x = pcs.clone()
+        out = model(x)                                    # gradients enabled: the plain path (its backward reads the stored outputs)
+        (out[0].sum() + out[1].sum()).backward()
+    finally:
+        ops.call = real
+    assert "p2c_linear_fwd_fold0_f32" not in calls and "p2c_linear_fwd_pool_f32" not in calls

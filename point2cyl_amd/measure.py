@@ -302,7 +302,41 @@ def forward_only(model, pcs, steps=30):
     except Exception as e:          # (reported, not fatal: the other figures of this leg stand)
         t4 = None
         grp_err = "%s: %s" % (type(e).__name__, e)
+    # ... and the INFERENCE forward (eval-mode BatchNorm: what point2cyl_amd.eval runs - running statistics, no statistics passes, the folded /
+    # pooled layer forms without their activations in HBM): geometry precomputed, and pipelined in groups of four
+    inf = {}
+    was_training = model.training
+    try:
+        model.eval()
+        with torch.no_grad():
+            g0 = model.compute_geometry(pcs, with_csr=False)
+        gr3, _ = capture(lambda: fwd_geom(g0))
+        inf["ms_geometry_precomputed"] = round(replay_ms([gr3], steps), 4)
+        ops.step_done()
+        from .graph import PipelinedForward
+        cur = torch.cuda.current_stream()
+        grp = [pcs] * 4
+        pf = PipelinedForward(model, grp, stream=cur, group=4)
+        try:
+            for _ in range(2):
+                pf(grp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n4 = max(4, steps // 4)
+            for _ in range(n4):
+                pf(grp)
+            torch.cuda.synchronize()
+            inf["ms_pipelined_group4"] = round((time.perf_counter() - t0) / (n4 * 4) * 1e3, 4)
+            inf["points_per_s_pipelined_group4"] = round(B * N / (inf["ms_pipelined_group4"] * 1e-3), 1)
+        finally:
+            pf.release()
+        ops.step_done()
+    except Exception as e:
+        inf["error"] = "%s: %s" % (type(e).__name__, e)
+    finally:
+        model.train(was_training)
     return dict(workload="backbone forward, B=%d x N=%d, train-mode BatchNorm + dropout, FPS / ball query / 3-NN included, one HIP graph" % (B, N),
+                inference_eval_mode=inf,
                 ms=round(t, 4), points_per_s=round(B * N / (t * 1e-3), 1),
                 ms_geometry_precomputed=round(t2, 4), points_per_s_geometry_precomputed=round(B * N / (t2 * 1e-3), 1),
                 ms_pipelined=round(t3, 4), points_per_s_pipelined=round(B * N / (t3 * 1e-3), 1),

@@ -57,9 +57,10 @@ python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 256
 python -m point2cyl_amd.eval --synthetic 4096 --batch_size 32 --logdir /tmp/${TAG}_tr --ckpt model.pth --dump_dir /tmp/${TAG}_ev --report "$OUT/${TAG}_eval_report_pipelined.json" > "$OUT/${TAG}_eval_synthetic.log" 2> "$OUT/eval.err"
 python -m point2cyl_amd.eval --synthetic 4096 --batch_size 32 --logdir /tmp/${TAG}_tr --ckpt model.pth --dump_dir /tmp/${TAG}_ev --no_prefetch --report "$OUT/${TAG}_eval_report_serial.json" > "$OUT/${TAG}_eval_synthetic_no_prefetch.log" 2>> "$OUT/eval.err"
 EV="python -m point2cyl_amd.eval --synthetic 4096 --batch_size 32 --logdir /tmp/${TAG}_tr --ckpt model.pth --dump_dir /tmp/${TAG}_ev"
-for f in "--prefetch_group 1" "--prefetch_group 1 --no_graph_metrics" "--prefetch_group 4 --add_noise"; do echo "$f: $($EV $f 2>> "$OUT/eval.err" | grep throughput)"; done > "$OUT/${TAG}_eval_variants.log"
+for f in "--prefetch_group 1" "--prefetch_group 1 --no_graph_metrics" "--prefetch_group 8" "--prefetch_group 4 --add_noise"; do echo "$f: $($EV $f 2>> "$OUT/eval.err" | grep throughput)"; done > "$OUT/${TAG}_eval_variants.log"
 python tools/probe/eval_metrics_time.py > "$OUT/${TAG}_eval_metrics_probe.log" 2>> "$OUT/eval.err"
 python tools/probe/stage_depth2.py > "$OUT/${TAG}_stage_depth.log" 2>> "$OUT/eval.err"
+python tools/probe/forward_modes.py 2>> "$OUT/eval.err" | grep "mode:" > "$OUT/${TAG}_forward_modes.log"
 if [ -d .ab_base ]; then bash tools/ab_commits.sh 3 > "$OUT/${TAG}_ab_vs_round4_tree.log" 2>&1; fi
 python tools/fit_trace.py > "$OUT/${TAG}_fit_fused_phase_trace.log" 2>&1; python tools/fit_trace.py --hard >> "$OUT/${TAG}_fit_fused_phase_trace.log" 2>&1
 python tools/bench_config5.py --steps 3 --glue > /dev/null 2> "$OUT/${TAG}_config5_torch_side_ops.log"

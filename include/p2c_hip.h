@@ -521,6 +521,14 @@ int p2c_seg_losses_grad_f32(const float *heads, int ld, int xoff, int woff, cons
                             const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
                             float w_normal, float w_bb, const float *gscale, float *dheads, void *ws, void *stream);
 
+/* The two fitting terms of the full loss set on their [B,K,3] operands, forward and gradient in one launch (one workgroup):
+ * out2[0] = w_ext * mean_b masked-mean_k (1 - |E_AX . gt_axes|)   (losses.py:127-143 angle_diff=False, :83-88; train_Point2Cyl_without_sketch.py:326-332),
+ * out2[1] = w_center * mean_b masked-mean_k |centers - gt_centers|^2   (:342-353).  mask [B,K] bytes = k < instances of cloud b (p2c_hungarian_f32's
+ * mask; a cloud without instances contributes 0).  dE / dC [B,K,3] = d out2[0] / d E_AX, d out2[1] / d centers (NULL: not wanted).  E_AX or centers
+ * NULL: that term is off (0).  K must divide 256. */
+int p2c_fit_terms_f32(const float *E_AX, const float *gt_axes, const float *centers, const float *gt_centers, const uint8_t *mask,
+                      int B, int K, float w_ext, float w_center, float *out2, float *dE, float *dC, void *stream);
+
 /* compute_all_losses on its own inputs (losses.py:317-351, collapse=True): W [B,N,K] softmaxed membership and X [B,N,3] unit normals as the
  * reference's trainer forms them in torch (train_Point2Cyl_without_sketch.py:246-271) - what the drop-in of that function is handed.
  * match / mask [B,K] from p2c_hungarian_f32.  out2 = {mean normal loss, mean mIoU loss}; dW [B,N,K] = d out2[1] / d W and

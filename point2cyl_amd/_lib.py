@@ -100,6 +100,7 @@ _SIGS = {
     "p2c_hungarian_logits_f32": [c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p],
     "p2c_all_losses_f32": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p],
     "p2c_seg_losses_grad_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
+    "p2c_fit_terms_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p],
     "p2c_seg_losses_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
 }
 

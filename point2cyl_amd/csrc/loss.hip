@@ -494,3 +494,77 @@ extern "C" int p2c_all_losses_f32(const float *W, const float *X, const float *n
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
+
+// =============================================================================================
+// The two fitting terms of the full loss set on their (B, K) operands - extrusion-axis loss  mean_b masked-mean_k (1 - |E . A_gt|)
+// (losses.py:127-143 with angle_diff = False, :83-88; train...:326-332) and centre loss  mean_b masked-mean_k |c - c_gt|^2 (:342-353) -
+// forward AND gradient in one launch of one workgroup: as torch expressions they are ~36 launches on 256-element tensors forward and as
+// many backward, a dependent chain of 4-5 us nodes in the replayed step.  mask [B,K] = k < number of ground-truth instances of cloud b
+// (what the matching returns); a cloud without instances contributes 0.  dE / dC = the gradients of the WEIGHTED terms w.r.t. the
+// fitted axes / centres (the caller scales them by the upstream gradient of the total).  E or C may be NULL (term switched off: 0).
+// =============================================================================================
+__global__ void __launch_bounds__(256) fit_terms_kernel(const float *__restrict__ E, const float *__restrict__ A, const float *__restrict__ C,
+                                                        const float *__restrict__ Cg, const uint8_t *__restrict__ mask, int B, int K,
+                                                        float w_ext, float w_cen, float *__restrict__ out2, float *__restrict__ dE,
+                                                        float *__restrict__ dC)
+{
+    __shared__ float s_ext[256], s_cen[256], s_n[256];
+    __shared__ double acc[2];
+    const int tid = threadIdx.x;
+    if (tid < 2) acc[tid] = 0.0;
+    __syncthreads();
+    const int BK = B * K;
+    for (int base = 0; base < BK; base += 256) {          // K divides 256 (K in {1, 2, 4, 8, ...}): a cloud's K entries lie in one pass
+        const int e = base + tid;
+        const bool ok = e < BK;
+        const bool m = ok && mask[e] != 0;
+        float ext = 0.f, cen = 0.f, sgn = 0.f;
+        float dx = 0.f, dy = 0.f, dz = 0.f;
+        if (ok && E) {
+            const float d = E[e * 3] * A[e * 3] + E[e * 3 + 1] * A[e * 3 + 1] + E[e * 3 + 2] * A[e * 3 + 2];
+            ext = 1.f - fabsf(d);
+            sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        }
+        if (ok && C) {
+            dx = C[e * 3] - Cg[e * 3]; dy = C[e * 3 + 1] - Cg[e * 3 + 1]; dz = C[e * 3 + 2] - Cg[e * 3 + 2];
+            cen = dx * dx + dy * dy + dz * dz;
+        }
+        s_ext[tid] = m ? ext : 0.f;
+        s_cen[tid] = m ? cen : 0.f;
+        s_n[tid] = m ? 1.f : 0.f;
+        __syncthreads();
+        const int k0 = tid - (tid % K);
+        float n = 0.f, se = 0.f, sc = 0.f;
+        for (int k = 0; k < K; ++k) { n += s_n[k0 + k]; se += s_ext[k0 + k]; sc += s_cen[k0 + k]; }
+        const float inv = n > 0.f ? 1.f / n : 0.f;          // reduce_mean_masked_instance: 0 for a cloud without instances
+        if (ok && (tid % K) == 0) {
+            atomicAdd(&acc[0], (double)(se * inv));
+            atomicAdd(&acc[1], (double)(sc * inv));
+        }
+        const float g = m ? inv / (float)B : 0.f;
+        if (ok && E && dE) {
+            const float c = -sgn * g * w_ext;
+            dE[e * 3] = c * A[e * 3]; dE[e * 3 + 1] = c * A[e * 3 + 1]; dE[e * 3 + 2] = c * A[e * 3 + 2];
+        }
+        if (ok && C && dC) {
+            const float c = 2.f * g * w_cen;
+            dC[e * 3] = c * dx; dC[e * 3 + 1] = c * dy; dC[e * 3 + 2] = c * dz;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        out2[0] = E ? (float)(acc[0] / (double)B) * w_ext : 0.f;
+        out2[1] = C ? (float)(acc[1] / (double)B) * w_cen : 0.f;
+    }
+}
+
+extern "C" int p2c_fit_terms_f32(const float *E_AX, const float *gt_axes, const float *centers, const float *gt_centers, const uint8_t *mask,
+                                 int B, int K, float w_ext, float w_center, float *out2, float *dE, float *dC, void *stream)
+{
+    if (!mask || !out2 || B <= 0 || K <= 0 || K > 256 || (256 % K) != 0) return P2C_EINVAL;
+    if ((E_AX && !gt_axes) || (centers && !gt_centers)) return P2C_EINVAL;
+    hipLaunchKernelGGL(fit_terms_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, E_AX, gt_axes, centers, gt_centers, mask, B, K, w_ext,
+                       w_center, out2, dE, dC);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}

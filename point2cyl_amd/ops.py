@@ -1356,6 +1356,43 @@ class _HeadPost(torch.autograd.Function):
         return dh, None, None, None, None, None, None
 
 
+class _FitTerms(torch.autograd.Function):
+    """(w_ext * extrusion-axis loss, w_center * centre loss) from the fitted axes / centres (B,K,3), forward + gradient in ONE launch
+    (csrc/loss.hip fit_terms_kernel) instead of ~36 torch launches on 256-element tensors forward and as many backward."""
+
+    @staticmethod
+    def forward(ctx, E_AX, gt_axes, centers, gt_centers, mask, w_ext, w_center):
+        ref = E_AX if E_AX is not None else centers
+        B, K = ref.shape[0], ref.shape[1]
+        dev = ref.device
+        out2 = torch.empty(2, dtype=torch.float32, device=dev)
+        E = _f32c(E_AX.detach()) if E_AX is not None else None
+        C = _f32c(centers.detach()) if centers is not None else None
+        dE = torch.empty_like(E) if E is not None else None
+        dC = torch.empty_like(C) if C is not None else None
+        m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+        call("p2c_fit_terms_f32", ptr(E), ptr(_f32c(gt_axes)) if E is not None else None, ptr(C), ptr(_f32c(gt_centers)) if C is not None else None,
+             ptr(m8.contiguous()), B, K, float(w_ext), float(w_center), ptr(out2), ptr(dE), ptr(dC), stream())
+        ctx.grads = (dE, dC)
+        ctx.set_materialize_grads(False)
+        return out2
+
+    @staticmethod
+    def backward(ctx, gout):
+        dE, dC = ctx.grads
+        if gout is None:
+            return (None,) * 7
+        return (None if dE is None else dE * gout[0], None, None if dC is None else dC * gout[1], None, None, None, None)
+
+
+def fit_terms(E_AX, gt_axes, centers, gt_centers, mask, w_ext=1.0, w_center=1.0):
+    """-> (2,) = [w_ext * mean_b masked-mean_k (1 - |E_AX . gt_axes|), w_center * mean_b masked-mean_k |centers - gt_centers|^2]
+    (train_Point2Cyl_without_sketch.py:326-332, :342-353; losses.py:83-88).  E_AX / centers (B,K,3) or None (term off: 0);
+    mask (B,K) bool / bytes = k < number of ground-truth instances (hungarian's mask = losses.get_mask_gt)."""
+    _lib.require_device(mask)
+    return _FitTerms.apply(E_AX, gt_axes, centers, gt_centers, mask, w_ext, w_center)
+
+
 def head_post(heads, match, B, N, K, xoff=0, woff=3):
     return _HeadPost.apply(heads, match, B, N, K, xoff, woff)
 

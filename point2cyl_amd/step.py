@@ -72,6 +72,9 @@ def backward(out):
     torch.autograd.backward([vec], [seed])
 
 
+FUSED_FIT_TERMS = True      # the extrusion-axis / centre terms of the full loss set as one launch (ops.fit_terms); a test switches it off
+
+
 def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags, geom=None):
     """Same result as compute_losses for --pred_seg --pred_normal --pred_bb (K=8), with the head post-processing, the
     Hungarian matching and the three losses (forward + gradient) in csrc/loss.hip instead of ~60 torch launches.
@@ -92,17 +95,26 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
         # normalised normals, softmax, barrel / base split and the reorder by the matching (train...:247-265, :319-325, :342-344) in
         # one kernel forward and one backward (ops.head_post) instead of ~25 torch launches over (B,N,2K) tensors
         X, Wb_re, Wc_re = ops.head_post(heads, match, B, N, K, 0, 3)
-        mask_gt = losses.get_mask_gt(gt_inst, K)
+        E_AX = cen = None
         if fl.pred_extrusion:
             E_AX = fitting.estimate_extrusion_axis(X, Wb_re, Wc_re, gt_bb, gt_inst, normalize=fl.norm_eig)
             res["E_AX"] = E_AX                                   # (with its history: train_Point2Cyl.py:528 feeds it to the sketch encoder)
-            ext = losses.compute_normal_loss(E_AX, gt_axes, angle_diff=False, collapse=False)
-            ext_loss = losses.reduce_mean_masked_instance(ext, mask_gt).mean() * fl.weight_extrusion
         if fl.pred_center:
             cen = fitting.estimate_extrusion_centers(Wb_re + Wc_re, pcs)
-            diff = torch.square(cen - gt_centers).sum(dim=-1)
-            center_loss = losses.reduce_mean_masked_instance(diff, mask_gt).mean() * fl.weight_center
-        total = total + ext_loss + center_loss
+        if FUSED_FIT_TERMS and 256 % K == 0:
+            # both terms, forward and gradient, in one launch; the matching's mask IS losses.get_mask_gt(gt_inst, K) (k < instances of the cloud)
+            terms = ops.fit_terms(E_AX, gt_axes, cen, gt_centers, mask, fl.weight_extrusion, fl.weight_center)
+            ext_loss, center_loss = (terms[0] if fl.pred_extrusion else zero), (terms[1] if fl.pred_center else zero)
+            total = total + terms.sum()
+        else:
+            mask_gt = losses.get_mask_gt(gt_inst, K)
+            if fl.pred_extrusion:
+                ext = losses.compute_normal_loss(E_AX, gt_axes, angle_diff=False, collapse=False)
+                ext_loss = losses.reduce_mean_masked_instance(ext, mask_gt).mean() * fl.weight_extrusion
+            if fl.pred_center:
+                diff = torch.square(cen - gt_centers).sum(dim=-1)
+                center_loss = losses.reduce_mean_masked_instance(diff, mask_gt).mean() * fl.weight_center
+            total = total + ext_loss + center_loss
     else:
         res["_total_vec"] = out4              # step.backward(res): the loss node gets a constant seed instead of ones / select-backward launches
     res.update(total=total, ext=ext_loss, center=center_loss, heads=heads)

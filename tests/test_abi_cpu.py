@@ -84,6 +84,9 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_softplus_row_bwd_f32(None, 1, one, one, None, None, 8, 512, 100.0, 20.0, None) == -1
     assert L.p2c_softplus_sig_bwd_rank2_f32(None, 2, one, one, None, one, one, one, one, 8, 512, 100.0, 20.0, None) == -1
     assert L.p2c_copy2d_batch_inc_f32(None, 0, None, 0, None) == -1 and L.p2c_copy2d_batch_inc_f32(None, 2, one, 1, None) == -1
+    assert L.p2c_fit_terms_f32(one, one, one, one, None, 4, 8, 1.0, 1.0, one, one, one, None) == -1                                   # no mask
+    assert L.p2c_fit_terms_f32(one, one, one, one, one, 4, 3, 1.0, 1.0, one, one, one, None) == -1                                    # K must divide 256
+    assert L.p2c_fit_terms_f32(one, None, one, one, one, 4, 8, 1.0, 1.0, one, one, one, None) == -1                                   # axes without their ground truth
     assert L.p2c_three_interp_skip_f32(one, 128, one, one, 1, 64, 16, 128, None, 128, 128, one, 256, 256, None) == -1               # skip block missing
     assert L.p2c_three_interp_skip_f32(one, 128, one, one, 1, 64, 16, 128, one, 128, 128, one, 256, 200, None) == -1                # width smaller than skip + interpolated
     assert L.p2c_fold0_bwd_finalize_sum_f32(one, one, 10, one, None, one, one, 64, one, one, one, 5, one, 16, 8, one, 16, None) == -1    # dW0 leading dimension outside 1..4

@@ -1967,3 +1967,49 @@ def test_inference_forward_paths_equal_the_plain_eval_forward():
     finally:
         ops.call = real
     assert "p2c_linear_fwd_fold0_f32" not in calls and "p2c_linear_fwd_pool_f32" not in calls
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [8, 4])
+def test_fit_terms_one_launch_equal_the_torch_expressions(K):
+    """ops.fit_terms (the extrusion-axis and centre terms of the full loss set, forward + gradient in one launch) against the reference's
+    expressions (train_Point2Cyl_without_sketch.py:326-332, :342-353; losses.py:83-88, :127-143): values and both gradients, clouds
+    with fewer than K instances, a cloud without any, axes exactly orthogonal to the ground truth (sign 0), one term switched off;
+    and the matching's mask is losses.get_mask_gt of the same labels."""
+    from point2cyl_amd import losses, ops
+    B = 7
+    g = torch.Generator().manual_seed(K)
+    E = F.normalize(torch.randn(B, K, 3, generator=g), dim=-1).to(DEV).requires_grad_(True)
+    A = F.normalize(torch.randn(B, K, 3, generator=g), dim=-1).to(DEV)
+    C = torch.randn(B, K, 3, generator=g).to(DEV).requires_grad_(True)
+    Cg = torch.randn(B, K, 3, generator=g).to(DEV)
+    with torch.no_grad():
+        E[1, 0] = torch.tensor([1.0, 0.0, 0.0]); A[1, 0] = torch.tensor([0.0, 1.0, 0.0])          # dot == 0: subgradient 0
+    n_inst = torch.tensor([K, 1, 0, 3 % (K + 1), K - 1, 2, K])
+    I_gt = torch.stack([torch.randint(0, int(n), (64,), generator=g) if n > 0 else torch.full((64,), -1) for n in n_inst])
+    for b, n in enumerate(n_inst):
+        if n > 0:
+            I_gt[b, 0] = int(n) - 1                       # the largest label is present
+    I_gt = I_gt.to(DEV)
+    mask_gt = losses.get_mask_gt(I_gt, K)
+    W = torch.softmax(torch.randn(B, 64, K, generator=g), dim=-1).to(DEV)
+    _, mask = ops.hungarian(W, I_gt)
+    assert torch.equal(mask, mask_gt)
+    w_e, w_c = 0.7, 1.3
+    ext = losses.compute_normal_loss(E, A, angle_diff=False, collapse=False)
+    ref_e = losses.reduce_mean_masked_instance(ext, mask_gt).mean() * w_e
+    ref_c = losses.reduce_mean_masked_instance(torch.square(C - Cg).sum(dim=-1), mask_gt).mean() * w_c
+    gE, gC = torch.autograd.grad(3.0 * ref_e + 0.5 * ref_c, [E, C])
+    out = ops.fit_terms(E, A, C, Cg, mask, w_e, w_c)
+    hE, hC = torch.autograd.grad(3.0 * out[0] + 0.5 * out[1], [E, C])
+    torch.testing.assert_close(out[0], ref_e, rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(out[1], ref_c, rtol=2e-6, atol=1e-7)
+    torch.testing.assert_close(hE, gE, rtol=2e-6, atol=1e-8)
+    torch.testing.assert_close(hC, gC, rtol=2e-6, atol=1e-8)
+    assert float(hE[2].abs().max()) == 0.0 and float(hC[2].abs().max()) == 0.0 and float(hE[1, 0].abs().max()) == 0.0
+    only_c = ops.fit_terms(None, None, C, Cg, mask, w_e, w_c)
+    assert float(only_c[0]) == 0.0
+    torch.testing.assert_close(only_c[1], ref_c, rtol=2e-6, atol=1e-7)
+    only_e = ops.fit_terms(E, A, None, None, mask, w_e, w_c)
+    assert float(only_e[1]) == 0.0
+    torch.testing.assert_close(only_e[0], ref_e, rtol=2e-6, atol=1e-7)

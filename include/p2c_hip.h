@@ -489,6 +489,10 @@ int p2c_linear_bwd_data_big_f32(const float *dZ, int lddz, const float *W, int l
  *   backward of train_Point2Cyl.py:608-648, summed in the product's epilogue instead of by a separate pass over 0.5 GB) */
 int p2c_linear_fwd_big_add_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, const float *add, int ldadd, float *Y,
                                int ldy, int M, int N, int K, void *ws, void *stream);
+/* Y = softplus(X . W^T + bias [+ add], beta, threshold) (IGR/network.py:58-59, :83-84): the layer's activation in the product's epilogue, for
+ * inference - the pre-activation a backward would need is not kept.  add may be NULL. */
+int p2c_linear_fwd_big_sp_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, const float *add, int ldadd, float beta,
+                              float threshold, float *Y, int ldy, int M, int N, int K, void *ws, void *stream);
 int p2c_linear_bwd_data_big_add_f32(const float *dZ, int lddz, const float *W, int ldw, const float *Z, int ldz, float beta, float threshold,
                                     const float *add, int ldadd, float *dX, int lddx, int M, int N, int K, void *ws, void *stream);
 

@@ -91,6 +91,7 @@ _SIGS = {
     "p2c_softplus_row_bwd_f32": [c_p, c_i, c_p, c_p, c_p, c_p, c_ll, c_i, c_f, c_f, c_p],
     "p2c_softplus_sig_bwd_rank2_f32": [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_ll, c_i, c_f, c_f, c_p],
     "p2c_linear_fwd_big_add_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
+    "p2c_linear_fwd_big_sp_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_f, c_f, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "p2c_linear_bwd_data_big_add_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p],
     "p2c_linear_sum_assignment_f64": [c_p, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_linear_bwd_both_f32": [c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p],

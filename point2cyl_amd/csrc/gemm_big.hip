@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(256) big_split_kernel(const float *__restrict_
 struct BigEpi {
     float *out; int ldo;
     const float *bias;                              // EPI 0: + bias[col] (may be NULL)
-    const float *spz; int ldspz; float beta, thr;   // EPI 1: * sigmoid(beta * Z) (1 where beta * Z > thr); spz NULL: plain product
+    const float *spz; int ldspz; float beta, thr;   // EPI 1: * sigmoid(beta * Z) (1 where beta * Z > thr); spz NULL: plain product.  EPI 0 with beta > 0: softplus(. , beta, thr) of the result
     const float *add; int ldadd;                    // both: + add[row, col] after the transform above (may alias out); NULL: nothing
 };
 
@@ -242,6 +242,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int c = 0; c < 4; ++c) v4[c] += ad[c];
             }
+            if (EPI == 0 && epi.beta > 0.f) {       // inference: the layer's activation instead of its pre-activation (softplus.hip's MODE 0, term for term)
+                const float inv_beta = 1.f / epi.beta;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float z = v4[c], bz = z * epi.beta;
+                    const float e = __expf(-fabsf(bz));
+                    const float l1p = e < 0.0078125f ? e * (1.f - e * (0.5f - e * 0.33333334f)) : __logf(1.f + e);
+                    v4[c] = bz > epi.thr ? z : (fmaxf(bz, 0.f) + l1p) * inv_beta;
+                }
+            }
             *reinterpret_cast<f32x4 *>(epi.out + (size_t)row * epi.ldo + col) = v4;
         }
     }
@@ -293,6 +303,17 @@ extern "C" int p2c_linear_fwd_big_f32(const float *X, int ldx, const float *W, i
     if (!X || !W || !Y || !ws || !p2c_linear_big_supported(M, N, K)) return P2C_EINVAL;
     if ((ldx & 3) || (ldy & 3) || (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)ws) & 15)) return P2C_EALIGN;
     BigEpi e{Y, ldy, bias, nullptr, 0, 0.f, 0.f, nullptr, 0};
+    return big_launch(0, X, ldx, W, ldw, N, K, 0, e, M, ws, (hipStream_t)stream);
+}
+
+// Y = softplus(X . W^T + bias [+ add], beta, threshold): the layer's ACTIVATION, for inference (nobody differentiates: the pre-activation is not kept)
+extern "C" int p2c_linear_fwd_big_sp_f32(const float *X, int ldx, const float *W, int ldw, const float *bias, const float *add, int ldadd, float beta,
+                                         float threshold, float *Y, int ldy, int M, int N, int K, void *ws, void *stream)
+{
+    if (!X || !W || !Y || !ws || !(beta > 0.f) || !p2c_linear_big_supported(M, N, K)) return P2C_EINVAL;
+    if ((ldx & 3) || (ldy & 3) || (((uintptr_t)X | (uintptr_t)Y | (uintptr_t)ws) & 15)) return P2C_EALIGN;
+    if (add && ((ldadd & 3) || ((uintptr_t)add & 15))) return P2C_EALIGN;
+    BigEpi e{Y, ldy, bias, nullptr, 0, beta, threshold, add, add ? ldadd : 0};
     return big_launch(0, X, ldx, W, ldw, N, K, 0, e, M, ws, (hipStream_t)stream);
 }
 

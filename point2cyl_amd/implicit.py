@@ -50,6 +50,7 @@ def _tn(A, X):
 
 
 USE_BIG = os.environ.get("P2C_GEMM_BIG", "1") != "0"      # A/B switch: the decoder's large products on csrc/gemm_big.hip
+INFER_EPILOGUE = True     # ImplicitNet.forward without gradients: softplus in the big-tile product's epilogue, no pre-activations kept (a test switches it off)
 
 
 def _big(M, N, K, dev):
@@ -316,6 +317,7 @@ class ImplicitNet(nn.Module):
         d_in = input.shape[1]
         inp = F.pad(input, (0, (-d_in) % 4)) if d_in % 4 else input
         x, pending = inp, False                         # pending: x still needs its softplus
+        infer = INFER_EPILOGUE and not (torch.is_grad_enabled() and (input.requires_grad or any(p_.requires_grad for p_ in self.parameters())))
         segs = [(d_in, inp.shape[1])]
         N = Np = d_in
         for layer in range(0, self.num_layers - 1):
@@ -345,8 +347,14 @@ class ImplicitNet(nn.Module):
             if Np != N:
                 w = F.pad(w, (0, 0, 0, Np - N))
                 b = F.pad(b, (0, Np - N)) if b is not None else None
-            x = sp_linear(x, w, b, self.beta) if fused else _nt(x, w, b)
             segs = [(N, Np)]
+            if infer:
+                # inference: x carries ACTIVATIONS; the layer's softplus rides in the product's epilogue, no pre-activation is kept
+                x = _prod_nt(_c(x), _c(w), b, sp=(self.beta, 20.0) if (layer < self.num_layers - 2 and self.beta > 0) else None)
+                if layer < self.num_layers - 2 and not self.beta > 0:
+                    x = F.relu(x)
+                continue
+            x = sp_linear(x, w, b, self.beta) if fused else _nt(x, w, b)
             if layer < self.num_layers - 2:
                 if self.beta > 0:
                     pending = True
@@ -373,14 +381,18 @@ class NormalPerPoint:
 
 
 # ------------------------------------------------------------------------------------------ value + input gradient of a FROZEN decoder as one node
-def _prod_nt(X, W, bias=None, add=None):
-    """X [M,K] . W [N,K]^T (+ bias) (+ add [M,N]) -> [M,N]; the big-tile kernel takes the addend in its epilogue, other shapes add afterwards."""
+def _prod_nt(X, W, bias=None, add=None, sp=None):
+    """X [M,K] . W [N,K]^T (+ bias) (+ add [M,N]) -> [M,N]; the big-tile kernel takes the addend in its epilogue, other shapes add afterwards.
+    sp = (beta, threshold): softplus of the result (inference: in the big-tile product's epilogue, a separate pass for other shapes)."""
     M, K = X.shape
     N = W.shape[0]
     Y = torch.empty(M, N, dtype=torch.float32, device=X.device)
     ws = _big(M, N, K, X.device)
     if ws is not None and X.stride(0) % 4 == 0:
-        if add is not None:
+        if sp is not None:
+            call("p2c_linear_fwd_big_sp_f32", ptr(X), X.stride(0), ptr(W), K, ptr(bias), ptr(add), add.stride(0) if add is not None else 0,
+                 float(sp[0]), float(sp[1]), ptr(Y), N, M, N, K, ptr(ws), stream(), flops=2.0 * M * N * K)
+        elif add is not None:
             call("p2c_linear_fwd_big_add_f32", ptr(X), X.stride(0), ptr(W), K, ptr(bias), ptr(add), add.stride(0), ptr(Y), N, M, N, K, ptr(ws), stream(),
                  flops=2.0 * M * N * K)
         else:
@@ -390,6 +402,8 @@ def _prod_nt(X, W, bias=None, add=None):
          flops=2.0 * M * N * K)
     if add is not None:
         Y.add_(add)
+    if sp is not None:
+        call("p2c_softplus_fwd_f32", ptr(Y), ptr(Y), Y.numel(), float(sp[0]), float(sp[1]), stream())
     return Y
 
 

@@ -84,6 +84,8 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_softplus_row_bwd_f32(None, 1, one, one, None, None, 8, 512, 100.0, 20.0, None) == -1
     assert L.p2c_softplus_sig_bwd_rank2_f32(None, 2, one, one, None, one, one, one, one, 8, 512, 100.0, 20.0, None) == -1
     assert L.p2c_copy2d_batch_inc_f32(None, 0, None, 0, None) == -1 and L.p2c_copy2d_batch_inc_f32(None, 2, one, 1, None) == -1
+    assert L.p2c_linear_fwd_big_sp_f32(one, 512, one, 512, None, None, 0, 0.0, 20.0, one, 512, 262144, 512, 512, one, None) == -1      # beta must be positive
+    assert L.p2c_linear_fwd_big_sp_f32(one, 512, one, 512, None, one, 514, 100.0, 20.0, one, 512, 262144, 512, 512, one, None) == -2   # addend stride not 16-byte aligned
     assert L.p2c_fit_terms_f32(one, one, one, one, None, 4, 8, 1.0, 1.0, one, one, one, None) == -1                                   # no mask
     assert L.p2c_fit_terms_f32(one, one, one, one, one, 4, 3, 1.0, 1.0, one, one, one, None) == -1                                    # K must divide 256
     assert L.p2c_fit_terms_f32(one, None, one, one, one, 4, 8, 1.0, 1.0, one, one, one, None) == -1                                   # axes without their ground truth

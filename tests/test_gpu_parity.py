@@ -2013,3 +2013,45 @@ def test_fit_terms_one_launch_equal_the_torch_expressions(K):
     only_e = ops.fit_terms(E, A, None, None, mask, w_e, w_c)
     assert float(only_e[1]) == 0.0
     torch.testing.assert_close(only_e[0], ref_e, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.gpu
+def test_decoder_inference_forward_equals_the_differentiable_forward():
+    """ImplicitNet.forward without gradients (eval.py:561-563, :577-590: the decoder evaluated on millions of projected points) puts every
+    layer's softplus into the big-tile product's epilogue and keeps no pre-activation (p2c_linear_fwd_big_sp_f32); with gradients enabled
+    the pre-activations are kept for the backward.  Same values: the epilogue is softplus.hip's forward term for term."""
+    from point2cyl_amd import implicit
+    from point2cyl_amd.implicit import ImplicitNet
+    torch.manual_seed(2)
+    net = ImplicitNet(d_in=2 + 256, dims=[512] * 8, skip_in=[4], geometric_init=True, radius_init=1, beta=100).to(DEV)
+    x = torch.randn(262144 + 77, 258, device=DEV) * 0.5
+    calls = []
+    real = implicit.call
+
+    def spy(name, *a, **kw):
+        calls.append(name)
+        return real(name, *a, **kw)
+
+    implicit.call = spy
+    try:
+        with torch.no_grad():
+            fast = net(x)
+        n_fast = list(calls)
+        del calls[:]
+        ref = net(x).detach()
+        n_ref = list(calls)
+        del calls[:]
+        implicit.INFER_EPILOGUE = False
+        with torch.no_grad():
+            plain = net(x)
+    finally:
+        implicit.INFER_EPILOGUE = True
+        implicit.call = real
+    assert n_fast.count("p2c_linear_fwd_big_sp_f32") >= 6 and "p2c_softplus_fwd_f32" not in n_fast
+    assert "p2c_linear_fwd_big_sp_f32" not in n_ref
+    scale = float(ref.abs().max())
+    assert float((fast - ref).abs().max()) <= 1e-6 * scale and float((plain - ref).abs().max()) <= 1e-6 * scale, (float((fast - ref).abs().max()), scale)
+    small = torch.randn(1000, 258, device=DEV) * 0.5              # below the big-tile route's sizes: the separate softplus pass
+    with torch.no_grad():
+        a = net(small)
+    torch.testing.assert_close(a, net(small).detach(), rtol=1e-5, atol=1e-6)

@@ -7,7 +7,9 @@ driver's form), or - when no WORLD_SIZE is in the environment - bench.py starts 
 torch.distributed.run on 127.0.0.1.  Either way the run fails loudly unless exactly N ranks on N distinct GPUs take part.
 
 A step = backbone forward + (seg, normal, base/barrel) losses + backward + Adam on one synthetic batch of
-B=32 clouds x 8192 points per GPU, already resident in HBM.  Prints ONE JSON line on rank 0.
+B=32 clouds x 8192 points per GPU, already resident in HBM.  Rank 0 prints ONE compact JSON line (< 4 KB: compact_line) on stdout, last;
+the detailed objects (per-kernel table, stage / forward / fitting / drop-in / evaluation legs) go to stderr as "extra" lines before it and to
+gpurun_out/bench_extras.json.  Default legs finish in about a minute; --extras all runs every leg.
 """
 import argparse
 import json
@@ -28,6 +30,9 @@ PEAK_HBM_GBS = 8000.0
 
 # HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE and
 # WRITE_SIZE need separate passes, so they cannot be read inside the timed run); launch-weighted over the family's kernels.
+DEFAULT_EXTRAS = "ab,stages,config3_fitting,eval_loop"
+ALL_EXTRAS = "path_roofline,power_cap,stages,forward_only,ab,config3_fitting,config3_cpu,dropin,eval_loop,eval_serial,cpu_threads"
+LINE_LIMIT = 4096            # bytes of the last stdout line (round 5's 20 KB line could not be parsed from the driver's capture)
 _PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 
 
@@ -152,8 +157,9 @@ def main():
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     ap.add_argument("--sync_exchange", action="store_true", help="N > 1, conservative form of the exchange: ONE graph per step (no split tail) and the "
                     "all-reduce issued on the step's own stream right behind the replay (no side stream, no overlap); still all-HIP / RCCL")
-    ap.add_argument("--extras", type=str, default="all", help="comma-separated subset of the extra legs (path_roofline,power_cap,stages,forward_only,ab,"
-                    "config3_fitting,dropin,eval_loop) to run after the timed region; default all")
+    ap.add_argument("--extras", type=str, default=DEFAULT_EXTRAS, help="comma-separated subset of the extra legs (%s) to run after the timed "
+                    "region, or 'all'; default: %s" % (ALL_EXTRAS, DEFAULT_EXTRAS))
+    ap.add_argument("--extras_file", type=str, default=None, help="where the detailed objects go (default gpurun_out/bench_extras.json)")
     ap.add_argument("--no_extras", action="store_true", help="only the training-step line: skip stages / forward_only / config3_fitting / ab / dropin")
     ap.add_argument("--dropin", action="store_true", help="make the DROP-IN step the timed one: the step composed as train_Point2Cyl_without_sketch.py:244-369 "
                     "composes it through the reference's import names (model(pcs), compute_all_losses, inline BB block, torch.optim.Adam, six .item())")
@@ -181,6 +187,7 @@ def main():
 
 
 def _bench(args, rank, world, local, dev):
+    t_bench = time.perf_counter()
     from point2cyl_amd import ddp, ops, optim, step, synth
     from point2cyl_amd.backbone import backbone
     import torch.distributed as dist
@@ -194,6 +201,7 @@ def _bench(args, rank, world, local, dev):
         if len(set(devices)) != world and not os.environ.get("P2C_ONE_GPU_RANKS"):
             raise SystemExit("bench: %d ranks share GPUs %s; one process per GPU is required" % (world, devices))
 
+    xchg = world > 1 or (ddp.force_exchange() and dist.is_initialized())      # P2C_FORCE_EXCHANGE=1: the real exchange on a one-rank nccl group
     B, N, K = args.batch_size, args.num_point, args.K
     fl = step.StepFlags(K=K, pred_extrusion=args.full_losses, pred_center=args.full_losses)
     pcs, normals, seg, bb, _, _, axes, _, centers = synth.make_batch(B, N, K, seed=1234 + 1000 * rank)
@@ -206,11 +214,11 @@ def _bench(args, rank, world, local, dev):
         t0 = time.perf_counter()
         res = _dropin_leg(args, batch, fl, dev, B, N, K, native_ms=float("nan"), steps=args.steps)
         res.pop("ratio_to_native_step", None)
-        print(json.dumps(dict(metric="training-step points/sec (BxN) at N=8192", value=res["points_per_s"], unit="points/s", n_gpus=1, steps=args.steps,
-                              warmup=3, ms_per_step=res["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32",
-                              data="synthetic", config=dict(workload="configs[%d] through the DROP-IN boundary: B=%d x N=%d, K=%d" % (2 if args.full_losses else 1, B, N, K),
-                                                            mfma="bf16x3-split" if _lib.lib().p2c_get_mfma_mode() else "f32", launch="reference trainer composition on the drop-in import names"),
-                              roofline=None, cpu_baseline=None, dropin=res)))
+        emit(dict(metric="training-step points/sec (BxN) at N=8192", value=res["points_per_s"], unit="points/s", n_gpus=1, steps=args.steps,
+                  warmup=3, ms_per_step=res["ms_per_step"], higher_is_better=True, scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+                  config=dict(workload="configs[%d] through the DROP-IN boundary: B=%d x N=%d, K=%d" % (2 if args.full_losses else 1, B, N, K),
+                              mfma="bf16x3-split" if _lib.lib().p2c_get_mfma_mode() else "f32", launch="reference trainer composition on the drop-in import names"),
+                  roofline=None, cpu_baseline=None, dropin=res), args.extras_file)
         return
 
     torch.manual_seed(0)
@@ -241,7 +249,7 @@ def _bench(args, rank, world, local, dev):
         from point2cyl_amd.graph import GraphedForwardBackward
         try:
             graphed = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=None if args.no_prefetch else batch[0], stream=torch.cuda.current_stream(),
-                                             split_tail=world > 1 and not args.sync_exchange)
+                                             split_tail=xchg and not args.sync_exchange)
         except Exception as e:      # keep the bench alive: fall back to eager launches
             sys.stderr.write("bench: HIP graph capture failed (%s: %s); running eager\n" % (type(e).__name__, e))
             torch.cuda.set_stream(torch.cuda.Stream(dev))      # a failed capture can leave its stream in capture mode: continue on a fresh one
@@ -254,7 +262,7 @@ def _bench(args, rank, world, local, dev):
 
     def one_step(timed=False):
         out = graphed() if graphed is not None else fwd_bwd()
-        if world > 1 and timed:         # events on the step's stream: from "gradients ready" to "exchange joined" (the graph's tail runs inside)
+        if xchg and timed:         # events on the step's stream: from "gradients ready" to "exchange joined" (the graph's tail runs inside)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         if args.sync_exchange:
@@ -264,7 +272,7 @@ def _bench(args, rank, world, local, dev):
             if graphed is not None:
                 graphed.tail()          # N > 1: the prefetched geometry's copies, a second graph, under the exchange
             sync.wait()
-        if world > 1 and timed:
+        if xchg and timed:
             e1.record()
             ar_events.append((e0, e1))
         opt.step()
@@ -272,7 +280,7 @@ def _bench(args, rank, world, local, dev):
         return out
 
     def fence():
-        if world > 1:
+        if xchg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -298,7 +306,7 @@ def _bench(args, rank, world, local, dev):
         torch.cuda.synchronize()
         ops.PROFILE.enabled = False
     multi = None
-    if world > 1:
+    if xchg:
         # what a scaling line needs to be diagnosable: every rank's own time, the event-timed exchange, and proof that the replicas
         # hold the same parameters after the timed steps (sum of squares in float64, gathered)
         ar_ms = sum(a.elapsed_time(b) for a, b in ar_events) / max(1, len(ar_events))
@@ -311,7 +319,7 @@ def _bench(args, rank, world, local, dev):
         multi = dict(rank_ms_per_step=[round(float(v), 4) for v in allr[:, 0]], allreduce_ms=[round(float(v), 4) for v in allr[:, 1]],
                      allreduce_bytes=int(sync.flat.numel() * 4) if sync.flat is not None else 0,
                      param_checksum=[float(v) for v in allr[:, 2]], params_identical=bool((allr[:, 2] == allr[0, 2]).all()),
-                     recapture_count=1 if graphed is not None else 0, preflight=pre,
+                     recapture_count=1 if graphed is not None else 0, preflight=pre, exchanges=sync.exchanges, avg_op=bool(sync._avg_ok),
                      exchange="sync (step's stream, one graph)" if args.sync_exchange else "async (side stream under the split tail)",
                      allreduce_note="allreduce_ms: from 'gradients ready' to 'exchange joined' on the step's stream; the exchange runs on a side stream and the "
                                     "step's tail (the copies of the next batch's prefetched geometry, a second graph, ~0.04 ms) runs under it")
@@ -320,7 +328,7 @@ def _bench(args, rank, world, local, dev):
         dt = float(tmax.item())
     loss = float(out["total"].detach())
     if rank != 0:
-        if world > 1:
+        if xchg:
             dist.destroy_process_group()
         return
 
@@ -401,6 +409,9 @@ def _bench(args, rank, world, local, dev):
                             launches_per_step=d["launches"] / prof_steps, avg_launch_us=round(d["ms"] * 1e3 / d["launches"], 2),
                             share_of_step=round(d["ms"] / prof_steps / ms, 3))
     cpu = None
+    want = set(ALL_EXTRAS.split(",")) if args.extras == "all" else set(x for x in args.extras.split(",") if x)
+    if args.no_extras:
+        want = set()
     if world == 1 and not args.no_cpu_baseline:
         from oracle import ref_step
         cb = args.cpu_batch
@@ -409,39 +420,36 @@ def _bench(args, rank, world, local, dev):
         from point2cyl_amd.hostmem import cpu_quota
         quota = cpu_quota()       # what the cgroup lets this process use (16 of the 256 hardware threads on this pool's boxes): the leg's thread count
         pps, sec, thr, nst = ref_step.time_cpu_baseline(sample, threads=min(32, host, quota), budget_s=10.0)
-        one = tuple(x[:1].contiguous() for x in (pcs, normals, seg, bb))
-        pps1, sec1, _, nst1 = ref_step.time_cpu_baseline(one, threads=1, budget_s=8.0)
-        # torch.set_num_threads(os.cpu_count()) as well - in a child process with a time limit: with one thread per hardware
-        # thread under a CPU quota of a sixteenth of them, in each of the step's thousands of small ops, the run is slower, not faster
-        # (measured once without a limit on this pool's boxes: 183.6 s for ONE step at 256 threads = 178 points/s,
-        # profiles/r04_bench_all_threads_unbounded.json.log), and the default bench must finish within minutes
-        ppsa, seca, thra, all_note = None, None, host, None
-        if host > 32:
-            ppsa, seca, all_note = _cpu_all_threads_leg(cb, N, K, host, limit_s=12.0)
-        else:
-            ppsa, seca = pps, sec
-        torch.set_num_threads(min(32, host, quota))
-        best = max(((pps, thr), (ppsa or 0.0, thra), (pps1, 1)), key=lambda t: t[0])
+        by_threads = {str(thr): round(pps, 1)}
+        best = (pps, thr)
+        pps1 = ppsa = all_note = None
+        if "cpu_threads" in want:
+            # SURVEY 8(d)'s other two thread counts, behind --extras cpu_threads (20 s more): 1 thread on one cloud, and os.cpu_count() threads
+            # in a child process with a time limit (one thread per hardware thread under a CPU quota of a sixteenth of them never finishes
+            # in seconds: measured once without a limit, 183.6 s for ONE step = 178 points/s, profiles/r04_bench_all_threads_unbounded.json.log)
+            one = tuple(x[:1].contiguous() for x in (pcs, normals, seg, bb))
+            pps1, sec1, _, nst1 = ref_step.time_cpu_baseline(one, threads=1, budget_s=8.0)
+            by_threads["1"] = round(pps1, 1)
+            if host > 32:
+                ppsa, seca, all_note = _cpu_all_threads_leg(cb, N, K, host, limit_s=12.0)
+            else:
+                ppsa = pps
+            by_threads[str(host)] = None if ppsa is None else round(ppsa, 1)
+            torch.set_num_threads(min(32, host, quota))
+            best = max(((pps, thr), (ppsa or 0.0, host), (pps1, 1)), key=lambda t: t[0])
         try:
             affinity = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):
             affinity = None
-        cpu = dict(value=round(best[0], 1), unit="points/s", cores=best[1], kind="port", cpu_model=_cpu_model(), host_cores=host, sched_affinity=affinity, cpu_quota=quota,
-                   by_threads={str(thr): round(pps, 1), str(thra): None if ppsa is None else round(ppsa, 1), "1": round(pps1, 1)},
-                   single_thread_value=round(pps1, 1), all_threads_value=None if ppsa is None else round(ppsa, 1), all_threads_note=all_note,
-                   all_threads_unbounded_reference=dict(value=178.0, unit="points/s", threads=256, seconds_for_one_step=183.6,
-                                                        source="profiles/r04_bench_all_threads_unbounded.json.log",
-                                                        note="the one time the os.cpu_count()-thread leg was allowed to finish (round 4, same CPU model): "
-                                                             "not re-measured by this run, whose leg is limited to 12 s so that the default bench stays within minutes"),
-                   sample="%d full training steps (fwd+losses+bwd+Adam) of the oracle's literal torch op sequence on B=%d clouds x %d "
-                          "points (same generator as the GPU batch) on %d threads, %.1f s of CPU work; all_threads_value: 1 step of the same on "
-                          "os.cpu_count() = %d threads in a child process limited to 20 s; single_thread_value: %d step(s) on B=1 cloud with 1 "
-                          "thread, %.1f s; `value` is the fastest (the step is thousands of small ops - a Python FPS loop, sorts, gathers; the cgroup's "
-                          "CPU quota is %d: threads beyond it are throttled, not run)" % (nst, cb, N, thr, sec * nst, host, nst1, sec1 * nst1, quota))
-    line = dict(metric="training-step points/sec (BxN) at N=8192", value=round(value, 1), unit="points/s", n_gpus=world,
+        cpu = dict(value=round(best[0], 1), unit="points/s", cores=best[1], kind="port", cpu_model=_cpu_model(), host_cores=host, sched_affinity=affinity,
+                   cpu_quota=quota, by_threads=by_threads, single_thread_value=None if pps1 is None else round(pps1, 1),
+                   all_threads_value=None if ppsa is None else round(ppsa, 1), all_threads_note=all_note,
+                   sample="%d training steps (fwd+losses+bwd+Adam) of oracle/ref_step.py on B=%d clouds x %d points, %d threads, %.1f s"
+                          % (nst, cb, N, thr, sec * nst))
+    full = dict(metric="training-step points/sec (BxN) at N=8192", value=round(value, 1), unit="points/s", n_gpus=world,
                 steps=args.steps, warmup=args.warmup, ms_per_step=round(ms, 3), higher_is_better=True, scaling="weak",
                 vs_baseline=None, dtype="f32", data="synthetic",
-                backend=backend, world_size=(dist.get_world_size() if world > 1 else 1), devices=devices,
+                backend=backend, world_size=(dist.get_world_size() if xchg else 1), devices=devices,
                 config=dict(workload="configs[%d]: B=%d clouds/GPU x N=%d points, K=%d, %s, random-init backbone, synthetic "
                                      "extrusion-cylinder clouds; step = fwd + losses + bwd + Adam" %
                                      (2 if args.full_losses else 1, B, N, K,
@@ -451,31 +459,109 @@ def _bench(args, rank, world, local, dev):
                 roofline=roofline, cpu_baseline=cpu, multi_gpu=multi,
                 kernels={k: dict(ms_per_step=round(v["ms"] / prof_steps, 3), launches_per_step=v["launches"] / prof_steps)
                          for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])})
-    if world == 1 and not args.no_extras:
+    if world == 1 and want:
         if graphed is not None:
             graphed.release()
-        line.update(_extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt))
-    print(json.dumps(line))
-    if world > 1:
+        full.update(_extras(args, want, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt))
+    full["bench_seconds"] = round(time.perf_counter() - t_bench, 1)
+    emit(full, args.extras_file)
+    if xchg:
         dist.destroy_process_group()
 
 
-def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
+_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_step", "traffic_ratio", "traffic_stale",
+              "avg_launch_us", "launches_per_step", "share_of_step")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "cpu_model")
+
+
+def _dig(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def compact_line(full):
+    """The record the driver parses: the contract's keys, roofline, cpu_baseline and a handful of scalars; numbers and short names only
+    (no prose), < LINE_LIMIT bytes.  Everything else of `full` goes to stderr / the extras file (emit)."""
+    cfg = full.get("config") or {}
+    line = {k: full.get(k) for k in _LINE_KEYS}
+    line["config"] = {k: cfg.get(k) for k in ("workload", "mfma", "batch_per_gpu", "global_batch", "num_point", "parallelism", "loss") if k in cfg}
+    if isinstance(line["config"].get("workload"), str):
+        line["config"]["workload"] = line["config"]["workload"][:160]
+    line["config"]["graph"] = str(cfg.get("launch", "")).startswith("hip_graph")
+    roof = full.get("roofline")
+    line["roofline"] = None if not roof else {k: roof.get(k) for k in _ROOF_KEYS if k in roof or k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    cpu = full.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cpu else dict({k: cpu.get(k) for k in _CPU_KEYS}, sample=str(cpu.get("sample", ""))[:140])
+    m = full.get("multi_gpu")
+    if m:
+        line["multi_gpu"] = {k: m.get(k) for k in ("rank_ms_per_step", "allreduce_ms", "allreduce_bytes", "params_identical") if k in m}
+        line["multi_gpu"]["exchange"] = str(m.get("exchange", ""))[:5].strip()
+        line["backend"] = full.get("backend")
+    scal = dict(f32_mfma_ms_per_step=_dig(full, "ab", "f32_mfma_ms_per_step"),
+                split_ms_per_step_ab=_dig(full, "ab", "bf16x3_split_ms_per_step"),
+                sa1_stage_frac_best=_dig(full, "stages", "sa1_forward", "best", "frac_of_mfma_roofline"),
+                sa1_stage_frac_serial=_dig(full, "stages", "sa1_forward", "frac_of_mfma_roofline"),
+                fps_ms=_dig(full, "stages", "sa1_forward", "parts_ms", "fps"),
+                config3_ms=_dig(full, "config3_fitting", "ms"),
+                config3_frac_hbm_path_bytes=_dig(full, "config3_fitting", "frac_hbm_path_bytes"),
+                eval_ms_per_batch=_dig(full, "eval_loop", "pipelined", "ms_per_batch_after_first"),
+                dropin_ms_per_step=_dig(full, "dropin", "ms_per_step"),
+                dropin_max_over_median=_dig(full, "dropin", "max_over_median"),
+                rccl_allreduce_us=_dig(full, "rccl_selftest", "allreduce_us"),
+                bench_seconds=full.get("bench_seconds"))
+    line.update({k: v for k, v in scal.items() if v is not None})
+    top = list((full.get("kernels") or {}).items())[:6]
+    line["top_kernels_ms"] = {k.replace("p2c_", "").replace("_f32", ""): v.get("ms_per_step") for k, v in top}
+    line["extras_file"] = full.get("extras_file")
+    while len(json.dumps(line)) >= LINE_LIMIT and line.get("top_kernels_ms"):      # (cannot happen with the keys above; belt and braces)
+        line["top_kernels_ms"].popitem()
+    return line
+
+
+def emit(full, extras_file=None):
+    """Detailed objects -> stderr (one "extra" line per key) and the extras file; then the compact line, LAST, alone on stdout."""
+    path = extras_file or os.path.join(ROOT, "gpurun_out", "bench_extras.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        full["extras_file"] = os.path.relpath(path, ROOT)
+    except OSError:
+        full["extras_file"] = None
+    basic = set(_LINE_KEYS) | {"config", "extras_file"}
+    for k, v in full.items():
+        if k not in basic and v is not None:
+            sys.stderr.write("extra " + json.dumps({k: v}) + "\n")
+    sys.stderr.flush()
+    line = compact_line(full)
+    text = json.dumps(line)
+    assert len(text) < LINE_LIMIT, len(text)
+    sys.stdout.write(text + "\n")
+    sys.stdout.flush()
+    return line
+
+
+def _extras(args, want, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
     """The measurements SURVEY 8(d) asks for beside the training-step number, in the same process after the timed region (rank 0, N = 1):
     stages.sa1_forward, forward_only, path_roofline, config3_fitting, ab (fp32-MFMA kernels), dropin (the step through the import names).
     Each leg is guarded: a failure is reported in the line instead of taking the training-step number down with it."""
     from point2cyl_amd import _lib, measure, ops, step
     out = {}
-
-    want = None if args.extras == "all" else set(args.extras.split(","))
+    leg_s = out.setdefault("leg_seconds", {})
 
     def leg(name, fn):
-        if want is not None and name not in want:
+        if name not in want:
             return
+        t0 = time.perf_counter()
         try:
             out[name] = fn()
         except Exception as e:
             out[name] = dict(error="%s: %s" % (type(e).__name__, e))
+        leg_s[name] = round(time.perf_counter() - t0, 1)
         try:
             torch.cuda.synchronize()
             ops.step_done()
@@ -531,8 +617,9 @@ def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
         from point2cyl_amd.hostmem import cpu_quota
         w = measure.FittingWorkload(1250, 8192, 8, 2048, device=dev)
         res, (E, cen, cfound, ext, found, E64) = w.time(20)
-        cpu, parity = bench_config4.cpu_fitting_legs(w, E, cen, ext, E64, thread_counts=(min(32, os.cpu_count() or 1, cpu_quota()), 1))
-        res.update(cpu_baseline=cpu, parity=parity)
+        if "config3_cpu" in want:       # the oracle's fitting on the host cores beside it + parity of all 1250 clouds (tests/test_gpu_configs.py holds the same)
+            cpu, parity = bench_config4.cpu_fitting_legs(w, E, cen, ext, E64, thread_counts=(min(32, os.cpu_count() or 1, cpu_quota()), 1))
+            res.update(cpu_baseline=cpu, parity=parity)
         del w
         return res
 
@@ -550,7 +637,7 @@ def _extras(args, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
         import subprocess, tempfile
         res = {}
         with tempfile.TemporaryDirectory() as d:
-            for key, extra in (("pipelined", []), ("serial_reference_order", ["--no_prefetch"])):
+            for key, extra in (("pipelined", []), ("serial_reference_order", ["--no_prefetch"]))[:2 if "eval_serial" in want else 1]:
                 rep = os.path.join(d, key + ".json")
                 cmd = [sys.executable, "-m", "point2cyl_amd.eval", "--random_init", "--synthetic", str(32 * B), "--batch_size", str(B), "--num_point", str(N),
                        "--K", str(K), "--dump_dir", d, "--report", rep] + extra
@@ -577,7 +664,7 @@ def _dropin_leg(args, batch, fl, dev, B, N, K, native_ms, steps=20):
     from point2cyl_amd import autograph
     from point2cyl_amd.dropin.trainer_step import TrainerStep
     res = {}
-    for label, on, n in (("ms_per_step", True, max(steps, 40)), ("eager_ms_per_step", False, max(9, steps // 4))):
+    for label, on, n in (("ms_per_step", True, max(steps, 120)), ("eager_ms_per_step", False, max(9, steps // 4))):
         old = autograph.ENABLED
         autograph.ENABLED = on
         try:
@@ -601,6 +688,8 @@ def _dropin_leg(args, batch, fl, dev, B, N, K, native_ms, steps=20):
             res[label] = round(per[len(per) // 2] * 1e3, 4)
             res[label.replace("ms_per_step", "mean_ms_per_step")] = round(mean_ms, 4)
             if on:
+                res.update(steps_timed=n, p50_ms=round(per[len(per) // 2] * 1e3, 4), p99_ms=round(per[min(n - 1, int(n * 0.99))] * 1e3, 4),
+                           max_ms=round(per[-1] * 1e3, 4), max_over_median=round(per[-1] / per[len(per) // 2], 2))
                 res["loss_after_%d_steps" % (n + 3)] = round(logs[0], 5)
             autograph.reset(st.model)
             del st

@@ -8,7 +8,10 @@ HIP graph when the step is replayed), one RCCL all-reduce over xGMI averages it 
 .grad are views of that buffer from then on - nothing is allocated or unpacked per step.  The exchange is issued from a side stream
 gated on the replay that produced the gradients (`allreduce_async` / `wait`), so the step's tail - the copies of the next batch's
 prefetched geometry, a second small graph - runs under it.  With backend "gloo"
-the same code runs on CPU tensors for the tests.  With world_size 1 nothing is packed at all.
+the same code runs on CPU tensors for the tests.  With world_size 1 nothing is packed at all - unless P2C_FORCE_EXCHANGE=1, which
+creates a one-rank process group and sends every step through the real exchange (pack, RCCL all-reduce on the side stream, wait): AVG over
+one rank is the identity, so a forced run must reproduce the plain run bit for bit (ddp_selftest.py, the one-GPU proof that librccl loads,
+supports ncclAvg on gfx950 and orders correctly between the two graph replays of a split-tail step).
 
 BatchNorm buffers: per-replica running statistics during training (no SyncBN upstream either); `average_buffers`
 makes the checkpoint hold the MEAN of the replicas' statistics instead of rank 0's alone.
@@ -19,6 +22,10 @@ import torch
 import torch.distributed as dist
 
 
+def force_exchange():
+    return os.environ.get("P2C_FORCE_EXCHANGE", "0") == "1"
+
+
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -26,7 +33,7 @@ def init_from_env(backend=None):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if os.environ.get("P2C_ONE_GPU_RANKS"):          # test hook: several ranks share GPU 0 (RCCL refuses that; use the gloo backend)
         local, backend = 0, backend or "gloo"
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force_exchange()) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -55,7 +62,9 @@ class FlatGradSync:
         self.flat = None
         self.views = None
         self._src = None          # keeps the packed-from tensors of a captured step alive
+        self.active = self.world > 1 or (force_exchange() and dist.is_initialized())     # is there an exchange at all
         self._avg_ok = True
+        self.exchanges = 0        # all-reduces issued (a forced one-rank run must count one per step)
         self._side, self._pending = None, False
 
     def zero(self):
@@ -71,7 +80,7 @@ class FlatGradSync:
             o += p.numel()
 
     def pack(self):
-        if self.world <= 1:
+        if not self.active:
             return
         if self.flat is None:
             self._alloc()
@@ -92,10 +101,11 @@ class FlatGradSync:
                 p.grad = v
 
     def allreduce(self):
-        if self.world <= 1:
+        if not self.active:
             return
         if self.flat is None or any(p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(self.params, self.views)):
             self.pack()           # eager callers that did not pack after backward
+        self.exchanges += 1
         with torch.no_grad():
             if dist.get_backend() == "nccl" and self._avg_ok:
                 try:
@@ -104,13 +114,13 @@ class FlatGradSync:
                 except (RuntimeError, ValueError):      # a collective library without ncclAvg: sum and scale from here on
                     self._avg_ok = False
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-            self.flat.div_(self.world)
-
+            if self.world > 1:
+                self.flat.div_(self.world)
 
     def allreduce_async(self):
         """The exchange on a SIDE stream, gated on everything enqueued on the current stream so far (the replay that produced the gradients):
         work the caller enqueues next on the current stream (graph.GraphedForwardBackward.tail) overlaps it.  `wait()` before the optimizer."""
-        if self.world <= 1:
+        if not self.active:
             return
         if not self.params[0].is_cuda:
             return self.allreduce()
@@ -134,7 +144,7 @@ def preflight(modules, device=None):
     on this node at all - xGMI / IPC / device visibility problems surface here, with the backend's own error text, not inside a graph
     capture) and proof that the replicas start from the same parameters (float64 sum of squares, gathered).  Raises RuntimeError with
     the backend's message; returns a dict for the bench / trainer report.  world_size 1: nothing."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_exchange()):
         return None
     world, rank = dist.get_world_size(), dist.get_rank()
     backend = dist.get_backend()

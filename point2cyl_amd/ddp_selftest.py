@@ -1,0 +1,157 @@
+"""One-GPU proof of the exchange path: `python -m point2cyl_amd.ddp_selftest [--steps 20]` -> one JSON line.
+
+SURVEY.md 8(e): the batch shards by cloud and the step has ONE exchange (RCCL all-reduce of 5.6 MB of gradients).  The 8-GPU job is the
+driver's to launch; what one GPU can prove is everything up to the wire: a one-rank `nccl` process group (librccl loads, a communicator
+forms on gfx950), `ddp.preflight`, `ReduceOp.AVG` (does `FlatGradSync._avg_ok` stay true or did it fall back to SUM + scale), the exchange
+on the SIDE stream between the two graph replays of a split-tail step (`allreduce_async` / `tail` / `wait`), and the conservative
+`--sync_exchange` form.  AVG over one rank is the identity, so the flat gradient buffer after the exchange must equal - bit for bit - a
+snapshot taken right after the replay that produced it, in every step; a wrong stream order (the exchange starting before the replay's last
+kernel, or the tail / the next replay overwriting it) shows as a mismatch.  The loss trajectory is compared with the plain run's as well:
+train-mode steps are not run-to-run deterministic (fp64 statistics atomics), so that comparison is against the distance between
+TWO plain runs, not bit for bit.  What this does NOT exercise: more than one rank, xGMI, IPC handles, ring / tree protocol choice.
+"""
+import argparse
+import json
+import os
+import socket
+import sys
+import time
+
+import torch
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def run(steps=20, B=32, N=8192, K=8, device=0):
+    import torch.distributed as dist
+    from point2cyl_amd import ddp, ops, optim, step, synth
+    from point2cyl_amd.backbone import backbone
+    from point2cyl_amd.graph import GraphedForwardBackward
+
+    os.environ["P2C_FORCE_EXCHANGE"] = "1"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("RANK", "0")
+    dev = torch.device("cuda", device)
+    torch.cuda.set_device(dev)
+    t0 = time.perf_counter()
+    rank, world, local = ddp.init_from_env(backend="nccl")
+    assert dist.is_initialized() and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    res = dict(backend=dist.get_backend(), world_size=world, steps=steps, batch=[B, N, K])
+
+    fl = step.StepFlags(K=K)
+    pcs, normals, seg, bb, _, _, axes, _, centers = synth.make_batch(B, N, K, seed=1234)
+    batch = tuple(x.to(dev) for x in (pcs, normals, seg, bb, axes, centers))
+    loss_fn = step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses
+
+    def trajectory(mode):
+        """mode: 'plain' (no exchange), 'async' (side stream under the split tail), 'sync' (the step's stream, one graph)."""
+        torch.manual_seed(0)
+        model = backbone(output_sizes=fl.pred_sizes()).to(dev).train()
+        step.update_momentum(model, step.get_batch_norm_decay(0, B, 200000))
+        pre = ddp.preflight(model, dev) if mode != "plain" else None
+        sync = ddp.FlatGradSync(model.parameters(), world)
+        if mode == "plain":
+            sync.active = False
+        opt = optim.Adam(model.parameters(), lr=1e-3)
+
+        def fwd_bwd(geom=None):
+            ops.step_done()
+            with ops.step_arena(dev):
+                out = loss_fn(model, *batch, fl, geom=geom)
+                sync.zero()
+                step.backward(out)
+                sync.pack()
+            return {"total": out["total"].detach()}
+
+        g = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=batch[0], stream=torch.cuda.current_stream(), split_tail=(mode == "async"))
+        losses, identical, ar_us = [], [], []
+        try:
+            for _ in range(steps):
+                out = g()
+                if sync.active:
+                    snap = sync.flat.clone()            # on the step's stream, right behind the replay: the gradients as backward left them
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                if mode == "sync":
+                    sync.allreduce()
+                else:
+                    sync.allreduce_async()
+                    g.tail()
+                    sync.wait()
+                if sync.active:
+                    e1.record()
+                    identical.append(torch.equal(sync.flat, snap) and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views)))
+                    ar_us.append((e0, e1))
+                opt.step()
+                ops.step_done()
+                losses.append(out["total"].clone())
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                ck = sum(float((p.detach().double() ** 2).sum()) for p in model.parameters())
+            r = dict(losses=torch.stack(losses).double().cpu(), checksum=ck, preflight=pre, exchanges=sync.exchanges, avg_op_kept=bool(sync._avg_ok),
+                     grads_identical_every_step=bool(all(identical)) if identical else None,
+                     exchange_us_on_step_stream=[round(a.elapsed_time(b) * 1e3, 1) for a, b in ar_us])
+            if sync.active:
+                # the all-reduce alone: 50 back to back on the flat buffer
+                for _ in range(5):
+                    dist.all_reduce(sync.flat, op=dist.ReduceOp.AVG if sync._avg_ok else dist.ReduceOp.SUM)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    dist.all_reduce(sync.flat, op=dist.ReduceOp.AVG if sync._avg_ok else dist.ReduceOp.SUM)
+                e1.record()
+                torch.cuda.synchronize()
+                r["allreduce_us"] = round(e0.elapsed_time(e1) * 1e3 / 50, 2)
+                r["allreduce_bytes"] = int(sync.flat.numel() * 4)
+            return r
+        finally:
+            g.release()
+            for m in model.modules():
+                if hasattr(m, "fps_start"):
+                    m.fps_start = None
+
+    with torch.cuda.stream(torch.cuda.Stream(dev)):
+        p1 = trajectory("plain")
+        p2 = trajectory("plain")
+        a = trajectory("async")
+        s = trajectory("sync")
+    noise = float((p1["losses"] - p2["losses"]).abs().max())
+
+    def summ(r):
+        ex = sorted(r["exchange_us_on_step_stream"])
+        return dict(exchanges=r["exchanges"], avg_op_kept=r["avg_op_kept"], grads_identical_every_step=r["grads_identical_every_step"],
+                    loss_first=float(r["losses"][0]), loss_last=float(r["losses"][-1]),
+                    max_loss_diff_vs_plain=float((r["losses"] - p1["losses"]).abs().max()),
+                    first_step_loss_equal_plain=bool(r["losses"][0] == p1["losses"][0]),
+                    exchange_us_median=ex[len(ex) // 2] if ex else None, preflight=r["preflight"])
+
+    res.update(seconds=round(time.perf_counter() - t0, 1), plain_vs_plain_max_loss_diff=noise, async_split_tail=summ(a), sync_one_graph=summ(s),
+               allreduce_us=a.get("allreduce_us"), allreduce_bytes=a.get("allreduce_bytes"),
+               allreduce_gbs=None if not a.get("allreduce_us") else round(a["allreduce_bytes"] / (a["allreduce_us"] * 1e-6) / 1e9, 1))
+    tol = max(10.0 * noise, 1e-4)
+    res["ok"] = bool(a["grads_identical_every_step"] and s["grads_identical_every_step"] and a["exchanges"] == steps and s["exchanges"] == steps
+                     and res["async_split_tail"]["max_loss_diff_vs_plain"] <= tol and res["sync_one_graph"]["max_loss_diff_vs_plain"] <= tol)
+    res["loss_tolerance"] = tol
+    dist.destroy_process_group()
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--batch_size", type=int, default=32)
+    ap.add_argument("--num_point", type=int, default=8192)
+    a = ap.parse_args()
+    res = run(a.steps, a.batch_size, a.num_point)
+    print(json.dumps(res))
+    sys.exit(0 if res["ok"] else 1)
+
+
+if __name__ == "__main__":
+    main()

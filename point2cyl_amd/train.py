@@ -153,7 +153,7 @@ class Runner:
                 self.next_xyz.copy_(self.batch[0])
                 try:
                     self.graph = GraphedForwardBackward(self.model, self._fwd_bwd, prefetch_xyz=self.next_xyz if self.prefetch else None,
-                                                        stream=self.stream, split_tail=self.sync.world > 1)
+                                                        stream=self.stream, split_tail=self.sync.active)
                 except Exception as e:      # something in this configuration cannot be captured: train on, launched from Python
                     import sys
                     sys.stderr.write("point2cyl_amd.train: HIP graph capture failed (%s: %s); continuing without the graph\n" % (type(e).__name__, e))

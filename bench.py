@@ -30,8 +30,8 @@ PEAK_HBM_GBS = 8000.0
 
 # HBM bytes per launch of a kernel family from the committed rocprofv3 --pmc summary of this same command (FETCH_SIZE and
 # WRITE_SIZE need separate passes, so they cannot be read inside the timed run); launch-weighted over the family's kernels.
-DEFAULT_EXTRAS = "ab,stages,config3_fitting,eval_loop"
-ALL_EXTRAS = "path_roofline,power_cap,stages,forward_only,ab,config3_fitting,config3_cpu,dropin,eval_loop,eval_serial,cpu_threads"
+DEFAULT_EXTRAS = "ab,stages,config3_fitting,eval_loop,rccl_selftest"
+ALL_EXTRAS = "path_roofline,power_cap,stages,forward_only,ab,config3_fitting,config3_cpu,dropin,eval_loop,eval_serial,cpu_threads,rccl_selftest"
 LINE_LIMIT = 4096            # bytes of the last stdout line (round 5's 20 KB line could not be parsed from the driver's capture)
 _PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
 
@@ -654,6 +654,21 @@ def _extras(args, want, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
         return res
 
     leg("eval_loop", eval_loop)
+
+    def rccl_selftest():
+        # SURVEY 8(e) on the one GPU this run has: a one-rank nccl group through the real FlatGradSync path (point2cyl_amd/ddp_selftest.py), in a
+        # child process (the process group and P2C_FORCE_EXCHANGE are process-wide)
+        import subprocess
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        r = subprocess.run([sys.executable, "-m", "point2cyl_amd.ddp_selftest", "--steps", "20", "--batch_size", str(B), "--num_point", str(N)],
+                           cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+        try:
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            return dict(error="rc %d: %s" % (r.returncode, r.stderr[-600:]))
+
+    leg("rccl_selftest", rccl_selftest)
     return out
 
 

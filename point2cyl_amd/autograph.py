@@ -203,7 +203,8 @@ class _Replay(torch.autograd.Function):
 def _key(model, x, want_grad):
     # the LIVE parameters and buffers: tensors that got new storage must not meet a graph captured on the old one
     st = _state(model)
-    return (tuple(x.shape), x.dtype, x.device.index, model.training, want_grad, tuple(b.momentum for b in st["bns"]),
+    # (every BatchNorm's own mode: model.train(); model.sa1.eval() is a different launch sequence than the all-train one)
+    return (tuple(x.shape), x.dtype, x.device.index, model.training, tuple(b.training for b in st["bns"]), want_grad, tuple(b.momentum for b in st["bns"]),
             _live_ptrs(model), tuple(d[n].requires_grad for d, n in st["slots"]) if want_grad else None)
 
 

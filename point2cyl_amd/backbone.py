@@ -259,7 +259,7 @@ class backbone(nn.Module):
         nbt = [((lambda m=m: m.num_batches_tracked), 1) for m in bn_mods]
         seed = [((lambda: self._drop_seed), DROP_STRIDE)]
         ws = self.__dict__["_wstage"] = ops.WeightStage(entries, device, counters=nbt + seed)
-        ws.nbt_counters, ws.seed_counter = nbt, seed
+        ws.nbt_counters, ws.seed_counter, ws.nbt_mods = nbt, seed, bn_mods
         ws.owner_id = id(self)
         return ws
 
@@ -326,8 +326,10 @@ class backbone(nn.Module):
             ws = self._weight_stage(x.device)
             # ONE launch: every padded / re-ordered / column-sliced weight operand of this forward, the 17 num_batches_tracked += 1 (train
             # mode) and the dropout seed's advance
-            bumped = ws.run(bump=(ws.nbt_counters if self.training else []) + (ws.seed_counter if have_seed else []))
-            ops._NBT_BUMPED[0] = bumped and self.training
+            # (only the BatchNorms whose OWN .training is set advance, as in torch: model.train(); model.sa1.eval() freezes sa1's counters too)
+            live_nbt = [c for c, m in zip(ws.nbt_counters, ws.nbt_mods) if m.training]
+            bumped = ws.run(bump=live_nbt + (ws.seed_counter if have_seed else []))
+            ops._NBT_BUMPED[0] = bumped and bool(live_nbt)
             seed_bumped = bumped and have_seed
         st = (lambda **kw: {k: ws[v] for k, v in kw.items()}) if ws is not None else (lambda **kw: None)
         l1_xyz, l1 = self.sa1.forward_pm(xyz, feats0, gm.get("sa1"), staged=st(W2="sa1_W") if (ws is not None and feats0 is None) else None)

@@ -879,7 +879,7 @@ class WeightStage:
         num_batches_tracked (+1 each) and the dropout hash seed (+ its stride) - otherwise a multi-tensor add and a scalar add launch per forward."""
         self.entries, self.device = entries, device
         self.counters = list(counters)
-        self.ctable, self.cptrs = None, None
+        self.ctables = {}         # one device table per live counter set, kept for the stage's lifetime: captured graphs hold their addresses
         self.bufs = {key: torch.zeros(*shape, dtype=torch.float32, device=device) for key, shape, _ in entries}
         for b in self.bufs.values():
             b._p2c_stage = self          # (ops._MLPStack finds the stage of a staged operand through this tag)
@@ -910,13 +910,16 @@ class WeightStage:
         live = [(get(), inc) for get, inc in which]
         live = [(t, inc) for t, inc in live if t is not None]
         key = tuple((t.data_ptr(), inc) for t, inc in live)
-        if self.cptrs != key:
+        # The live set depends on the mode (train: every num_batches_tracked + the dropout counter; eval: the dropout counter only).  A HIP
+        # graph captured in one mode has the ADDRESS of its table baked into the copy2d_batch_inc node, and graphs of both modes stay
+        # cached (autograph keeps one per model.training): a table is therefore never dropped or rewritten once built (a single
+        # cached table was freed on the mode switch and the earlier graph's replay wrote through it).
+        if key not in self.ctables:
             for t, _ in live:
                 assert t.dtype == torch.int64 and t.is_cuda and t.numel() == 1
             raw = b"".join(struct.pack("<Qq", t.data_ptr(), inc) for t, inc in live)
-            self.ctable = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device) if live else None
-            self.cptrs = key
-        return self.ctable, len(live)
+            self.ctables[key] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device) if live else None
+        return self.ctables[key], len(live)
 
     def run(self, bump=None):
         """bump: None (copies only) or the subset of self.counters to advance in the same launch."""

@@ -701,6 +701,79 @@ def test_alternate_route_equals_default_route(flag, env):
             assert torch.equal(alt[4][k], ref[4][k]), k
 
 
+def test_autograph_train_eval_train_with_cache_flush_keeps_counter_tables_alive():
+    """ADVICE r5 (ops.py WeightStage._counter_table): the staging launch advances num_batches_tracked / the dropout counter through a device
+    table of (address, increment) pairs whose ADDRESS is baked into the captured graph; the live counter set differs between train and eval
+    mode.  train forward+backward (captures graph A) -> eval forward under no_grad (another table) -> torch.cuda.empty_cache() + allocator
+    churn -> train again (replays graph A): every counter must advance exactly as a never-graphed module's does, nothing else may move,
+    and the stage must still hold one table per mode."""
+    from point2cyl_amd import autograph
+    B, N = 2, 1024
+    pcs = synth.make_batch(B, N, 8, seed=79)[0].float().to(DEV)
+
+    def run(enabled):
+        old = autograph.ENABLED
+        autograph.ENABLED = enabled
+        try:
+            m = _fresh_backbone(4)
+            torch.manual_seed(3)
+            trail = []
+            for phase in ("train", "eval", "train", "eval", "train"):
+                if phase == "train":
+                    m.train()
+                    for p in m.parameters():
+                        p.grad = None
+                    X, W = m(pcs)
+                    (X.square().mean() + W.square().mean()).backward()
+                else:
+                    m.eval()
+                    with torch.no_grad():
+                        X, W = m(pcs)
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                    junk = [torch.full((257 * (i + 1),), 7, dtype=torch.int64, device=DEV) for i in range(64)]     # reuse whatever was freed
+                    del junk
+                torch.cuda.synchronize()
+                trail.append((phase, {k: int(v) for k, v in m.named_buffers() if "num_batches_tracked" in k}, int(m._drop_seed),
+                              bool(torch.isfinite(X).all() and torch.isfinite(W).all())))
+            return m, trail
+        finally:
+            autograph.ENABLED = old
+
+    m0, t0 = run(False)
+    m1, t1 = run(True)
+    assert not autograph._state(m1)["failed"]
+    for (ph, n0, d0, ok0), (_, n1, d1, ok1) in zip(t0, t1):
+        assert ok0 and ok1, ph
+        assert n0 == n1, (ph, {k: (n0[k], n1[k]) for k in n0 if n0[k] != n1[k]})
+    assert set(t1[-1][1].values()) == {3}                    # three train-mode forwards; the eval forwards advance none of them
+    # the dropout counter advances once per forward in both modes, by the same stride graphed or not
+    assert [t[2] - t1[0][2] for t in t1] == [t[2] - t0[0][2] for t in t0]
+    stages = [s_ for s_ in vars(m1).values() if hasattr(s_, "ctables")]
+    assert stages and all(len(s_.ctables) >= 2 for s_ in stages), "one counter table per mode must stay alive"
+    # partially frozen BatchNorm (ADVICE r5, backbone.py): model.train(); model.sa1.eval() - sa1's counters and running statistics stand
+    # still, as in torch, everyone else's advance; graphed and eager alike
+    for m in (m0, m1):
+        m.train()
+        m.sa1.eval()
+        before = {k: v.clone() for k, v in m.named_buffers()}
+        old = autograph.ENABLED
+        autograph.ENABLED = m is m1
+        try:
+            X, W = m(pcs)
+            (X.square().mean() + W.square().mean()).backward()
+        finally:
+            autograph.ENABLED = old
+        torch.cuda.synchronize()
+        for k, v in m.named_buffers():
+            if k.startswith("sa1."):
+                assert torch.equal(v, before[k]), k
+            elif "num_batches_tracked" in k:
+                assert int(v) == int(before[k]) + 1, k
+            elif "running_mean" in k:
+                assert not torch.equal(v, before[k]), k
+
+
 def test_autograph_is_an_autograd_citizen_and_follows_moved_parameters():
     """ADVICE r4 (autograph.py:169, ops.py:862).  (a) the parameter gradients of the graphed module are real autograd outputs:
     torch.autograd.grad(loss, params) returns them (and leaves .grad alone), a parameter hook sees them, and after loss.backward() every

@@ -1658,7 +1658,7 @@ def test_softplus_kernels_match_torch_double_backward(n):
 
 
 @pytest.mark.parametrize("exchange", ["async", "sync"])
-def test_bench_two_ranks_on_one_gpu_over_gloo(exchange):
+def test_bench_two_ranks_on_one_gpu_over_gloo(exchange, tmp_path):
     """[exchange = sync: `--sync_exchange`, the conservative fallback for the first run on a multi-GPU node - one graph per step, the all-reduce
     on the step's own stream.]  The multi-process flow of bench.py (one HIP graph per rank, flat gradient exchange, fused Adam, max-over-ranks timing, one
     JSON line from rank 0) with two ranks that SHARE this GPU (test hook P2C_ONE_GPU_RANKS: RCCL refuses two ranks per device, so the
@@ -1669,12 +1669,17 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(exchange):
     env.update(P2C_ONE_GPU_RANKS="1", MASTER_ADDR="127.0.0.1")
     # no launcher: `python bench.py --gpus 2` starts its two ranks itself (bench._self_launch)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                          "--batch_size", "4", "--num_point", "2048", "--no_cpu_baseline"] + (["--sync_exchange"] if exchange == "sync" else []),
+                          "--batch_size", "4", "--num_point", "2048", "--no_cpu_baseline", "--extras_file", str(tmp_path / "full.json")]
+                         + (["--sync_exchange"] if exchange == "sync" else []),
                          env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout[-2000:]
-    d = json.loads(lines[0])
+    assert len(lines) == 1 and out.stdout.rstrip().endswith(lines[0]) and len(lines[0]) < 4096, out.stdout[-2000:]
+    line = json.loads(lines[0])         # the compact record the driver parses ...
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["config"]["global_batch"] == 8 and line["backend"] == "gloo"
+    assert len(line["multi_gpu"]["rank_ms_per_step"]) == 2 and line["multi_gpu"]["params_identical"] and line["multi_gpu"]["exchange"] == exchange
+    d = json.load(open(tmp_path / "full.json"))      # ... and the full one beside it
+    assert d["value"] == line["value"] and d["ms_per_step"] == line["ms_per_step"]
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
     assert d["world_size"] == 2 and d["backend"] == "gloo" and d["devices"] == [0, 0]
     assert np.isfinite(d["config"]["loss"]) and d["value"] > 0 and d["config"]["launch"].startswith("hip_graph")
@@ -1687,6 +1692,33 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(exchange):
     assert pre["eager_allreduce_ok"] and pre["params_identical"] and pre["world_size"] == 2 and pre["backend"] == "gloo"
     assert mg["params_identical"] and mg["param_checksum"][0] == mg["param_checksum"][1] and mg["param_checksum"][0] > 0
     assert abs(d["ms_per_step"] - max(mg["rank_ms_per_step"])) < 0.05 * d["ms_per_step"] + 0.5
+
+
+def test_rccl_one_rank_group_through_the_real_exchange_path():
+    """SURVEY.md 8(e) as far as one GPU reaches: python -m point2cyl_amd.ddp_selftest creates a world-size-1 `nccl`
+    process group (librccl on gfx950) and runs 20 steps of bench.py's step with P2C_FORCE_EXCHANGE=1 through FlatGradSync's real path -
+    preflight, pack, ReduceOp.AVG on the SIDE stream between the two graph replays of a split-tail step, wait; and the --sync_exchange form.
+    AVG over one rank is the identity: the flat gradient buffer after every exchange equals the snapshot taken behind the replay BIT FOR BIT,
+    and the loss trajectory stays within the run-to-run distance of two plain runs (train-mode statistics use fp64 atomics: no two runs
+    are bit-equal, so that comparison cannot be)."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "P2C_ONE_GPU_RANKS")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, "-m", "point2cyl_amd.ddp_selftest", "--steps", "20"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-2500:])
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    _rec_line = "rccl one-rank selftest: all-reduce of %d bytes %.1f us, AVG kept %s, exchange on the step's stream async %s us / sync %s us" % (
+        r["allreduce_bytes"], r["allreduce_us"], r["async_split_tail"]["avg_op_kept"], r["async_split_tail"]["exchange_us_median"],
+        r["sync_one_graph"]["exchange_us_median"])
+    print(_rec_line)
+    assert r["ok"] and r["backend"] == "nccl" and r["world_size"] == 1 and r["allreduce_bytes"] == 5616972
+    for k in ("async_split_tail", "sync_one_graph"):
+        assert r[k]["exchanges"] == 20 and r[k]["grads_identical_every_step"] is True
+        assert r[k]["preflight"]["eager_allreduce_ok"] and r[k]["preflight"]["backend"] == "nccl"
+        assert r[k]["max_loss_diff_vs_plain"] <= r["loss_tolerance"]
+        assert r[k]["loss_last"] < r[k]["loss_first"]            # the exchanged gradients train
+    assert r["async_split_tail"]["avg_op_kept"] is True, "ReduceOp.AVG fell back to SUM + scale on this RCCL"
 
 
 def test_bench_refuses_more_ranks_than_gpus():

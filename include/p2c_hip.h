@@ -541,6 +541,25 @@ size_t p2c_all_losses_ws_bytes(int B, int K);
 int p2c_all_losses_f32(const float *W, const float *X, const float *normals_gt, const int64_t *I_gt, const int64_t *match,
                        const uint8_t *mask, int B, int N, int K, float *out2, float *dW, float *dX, void *ws, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The evaluation metrics of one batch in two launches (eval.py:270-446 with its default operands: predicted normals, predicted
+ * segmentation and base/barrel split; replaces F.normalize + softmax + losses.hard_W_encoding(to_null_mask=True) + hungarian_matching +
+ * compute_segmentation_iou + compute_normal_difference + the base/barrel accuracy + estimate_extrusion_axis on the matched memberships +
+ * the hard-centroid loop, ~90 torch kernels).  heads [B*N, ld]: raw normals at columns [xoff, xoff+3), 2K logits at [woff, woff+2K);
+ * pcs / gt_normals [B,N,3]; gt_inst [B,N] int64 in [-1, K) (checked by the caller); gt_bb [B,N] FLOAT 0/1 (eval.py:257 casts it);
+ * gt_axes / gt_centers [B,K,3]; normalize = --norm_eig (data_utils.py:133-160); null_thr = float(N) * 0.005 as fp32 (losses.py:62);
+ * pi = the reference's TORCH_PI (float32 acos(0) * 2 as a double, losses.py:17).
+ * out5 [5,B] fp64 = per cloud {mIoU, normal angle error deg, base/barrel accuracy, extrusion angle error deg, centroid difference} - the
+ * rows eval.py:690-715 averages.  Optional (NULL = not wanted): match [B,K] i64, mask [B,K] u8, axis64 [B,K,3] f64 (fitted unit axes of the
+ * matched segments, zeros elsewhere), cen [B,K,3] f32 + found [B,K] f32 (hard centroids; <= 1 point = not found).
+ * ws: p2c_eval_metrics_ws_bytes(B, K) bytes, no initialisation needed.  K in {2, 4, 8} (p2c_eval_metrics_supported). */
+size_t p2c_eval_metrics_ws_bytes(int B, int K);
+int p2c_eval_metrics_supported(int K);
+int p2c_eval_metrics_f32(const float *heads, int ld, int xoff, int woff, const float *pcs, const float *gt_normals, const int64_t *gt_inst,
+                         const float *gt_bb, const float *gt_axes, const float *gt_centers, int normalize, float null_thr, double pi,
+                         int B, int N, int K, double *out5, int64_t *match_out, uint8_t *mask_out, double *axis64_out, float *cen_out,
+                         float *found_out, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

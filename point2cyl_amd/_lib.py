@@ -103,6 +103,7 @@ _SIGS = {
     "p2c_seg_losses_grad_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
     "p2c_fit_terms_f32": [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_p],
     "p2c_seg_losses_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_f, c_p, c_p, c_p, c_p],
+    "p2c_eval_metrics_f32": [c_p, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_f, ctypes.c_double, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
 }
 
 
@@ -147,6 +148,10 @@ def lib():
     L.p2c_linear_bwd_fused_parts.argtypes = [c_i, c_i]
     L.p2c_linear_bwd_fused_parts.restype = c_i
     L.p2c_linear_tile_m.restype = c_i
+    L.p2c_eval_metrics_ws_bytes.argtypes = [c_i, c_i]
+    L.p2c_eval_metrics_ws_bytes.restype = ctypes.c_size_t
+    L.p2c_eval_metrics_supported.argtypes = [c_i]
+    L.p2c_eval_metrics_supported.restype = c_i
     L.p2c_hungarian_ws_bytes.argtypes = [c_i]
     L.p2c_hungarian_ws_bytes.restype = ctypes.c_size_t
     L.p2c_linear_bwd_narrow_supported.argtypes = [c_i, c_i, c_i, c_i]

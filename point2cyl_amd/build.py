@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libp2c_hip.so")
-SOURCES = ["geom.hip", "gather.hip", "gemm.hip", "gemm_big.hip", "fwd_pp.hip", "fwd_pp3.hip", "bwd_fused.hip", "bwd_fused3.hip", "bwd_pool.hip", "heads.hip", "bn.hip", "fit.hip", "assign.hip", "loss.hip", "softplus.hip"]
+SOURCES = ["metrics.hip", "geom.hip", "gather.hip", "gemm.hip", "gemm_big.hip", "fwd_pp.hip", "fwd_pp3.hip", "bwd_fused.hip", "bwd_fused3.hip", "bwd_pool.hip", "heads.hip", "bn.hip", "fit.hip", "assign.hip", "loss.hip", "softplus.hip"]
 # -ffp-contract=off: geom.hip reproduces the reference's rounding order (explicit fmaf only)
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
 
@@ -44,7 +44,7 @@ def _newer(a, b):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fwd_pp.h"), os.path.join(HERE, "..", "include", "p2c_hip.h")]
+    deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fwd_pp.h"), os.path.join(CSRC, "lsa.h"), os.path.join(CSRC, "eigh3.h"), os.path.join(HERE, "..", "include", "p2c_hip.h")]
     objs, dirty = [], False
     procs = []
     for src in SOURCES:

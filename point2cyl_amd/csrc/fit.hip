@@ -13,50 +13,7 @@
 #define FIT_THREADS 1024
 #define FIT_MAXK 16
 
-// cyclic Jacobi for a symmetric 3x3 (fp64).  a = {a00,a01,a02,a11,a12,a22}; out: lam[3] ascending, v[3][3]
-// (v[j] = j-th eigenvector).  Zero matrix -> identity eigenvectors (LAPACK's answer too).
-__device__ void p2c_eigh3(const double a_in[6], double lam[3], double v[3][3])
-{
-    double A[3][3] = {{a_in[0], a_in[1], a_in[2]}, {a_in[1], a_in[3], a_in[4]}, {a_in[2], a_in[4], a_in[5]}};
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 12; ++sweep) {
-        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-        const double diag = fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]);
-        if (off <= 1e-18 * diag || off == 0.0) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (A[p][q] == 0.0) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                for (int r = 0; r < 3; ++r) {   // A <- A J
-                    const double arp = A[r][p], arq = A[r][q];
-                    A[r][p] = c * arp - s * arq;
-                    A[r][q] = s * arp + c * arq;
-                }
-                for (int r = 0; r < 3; ++r) {   // A <- J^T A
-                    const double apr = A[p][r], aqr = A[q][r];
-                    A[p][r] = c * apr - s * aqr;
-                    A[q][r] = s * apr + c * aqr;
-                }
-                for (int r = 0; r < 3; ++r) {
-                    const double vrp = V[r][p], vrq = V[r][q];
-                    V[r][p] = c * vrp - s * vrq;
-                    V[r][q] = s * vrp + c * vrq;
-                }
-            }
-    }
-    int o[3] = {0, 1, 2};
-    double d[3] = {A[0][0], A[1][1], A[2][2]};
-    // stable ascending sort of 3
-    if (d[o[1]] < d[o[0]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
-    if (d[o[2]] < d[o[1]]) { int t = o[1]; o[1] = o[2]; o[2] = t; }
-    if (d[o[1]] < d[o[0]]) { int t = o[0]; o[0] = o[1]; o[1] = t; }
-    for (int j = 0; j < 3; ++j) {
-        lam[j] = d[o[j]];
-        for (int r = 0; r < 3; ++r) v[j][r] = V[r][o[j]];
-    }
-}
+#include "eigh3.h"
 
 template <int THREADS>      // 1024: one workgroup per CU (few clouds: each gets a whole CU); 512: two per CU, one streams while the other is in its
                             // serial tail (LDS reduction, fp64 eigen-solve on K threads) - the fitting-only path runs 1250 clouds

@@ -115,6 +115,156 @@ __global__ void __launch_bounds__(1024) fps_kernel(const float *__restrict__ xyz
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same selection for clouds whose points live in registers (PPT 2..16, coordinates NOT mirrored in LDS): the iteration is a chain of
+// VALU work (4 waves per SIMD, each issuing its points' updates) -> wave reduction -> LDS exchange + barrier -> centroid fetch.
+// Against fps_kernel this variant
+//   * does the update of two points per instruction (v_pk_add_f32 / v_pk_mul_f32 on float2 lanes: same IEEE operations, same order
+//     ((dx*dx + dy*dy) + dz*dz), nothing fused), the running minimum as v_min_f32 and the lane's best as a v_max3 tree - the index of the
+//     best point is NOT tracked per point (two selects each): after the wave maximum is known, one compare per register slot yields the 64-bit
+//     mask of lanes holding it, and the first (lane, slot) - lowest point index, torch.max's tie rule (:83) - is picked on the scalar unit;
+//   * carries the winner's COORDINATES through the exchange (read from the winning lane's registers), so the next iteration starts from an
+//     LDS slot instead of a dependent global load of xyz[far].
+// Bit-identical indices by construction (tests/test_gpu_parity.py: G1, the oracle shapes, the duplicate-point tie test).
+// ---------------------------------------------------------------------------------------------------------------------------------
+typedef float p2c_f2 __attribute__((ext_vector_type(2)));
+
+// max over a row of 16 lanes / the wave with the DPP operand folded into v_max_i32 (old = INT_MIN, the operation's identity: the DPP
+// combiner then emits ONE instruction per step instead of mov + mov_dpp + max)
+template <int CTRL>
+__device__ __forceinline__ int p2c_dpp_maxid(int v)
+{
+    return max(v, __builtin_amdgcn_update_dpp((int)0x80000000, v, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ int p2c_row16_max_i32_folded(int v)
+{
+    v = p2c_dpp_maxid<0xB1>(v);
+    v = p2c_dpp_maxid<0x4E>(v);
+    v = p2c_dpp_maxid<0x141>(v);
+    v = p2c_dpp_maxid<0x140>(v);
+    return v;
+}
+
+#ifdef P2C_FPS_TRACE       // tools/fps_trace.py: shader-clock stamps of workgroup 0 (first and last wave) inside a few iterations
+__device__ unsigned long long p2c_fps_stamps[2][4][8];
+extern "C" int p2c_fps_trace_read(void *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_fps_stamps), sizeof(p2c_fps_stamps)) == hipSuccess ? 0 : 1; }
+#define FPS_TR(i) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == nwaves - 1) && it >= 100 && it < 104) \
+        p2c_fps_stamps[wave ? 1 : 0][it - 100][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FPS_TR(i) do { } while (0)
+#endif
+
+template <int PPT>
+__global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ xyz, int N, const int64_t *__restrict__ start,
+                                                      int npoint, int32_t *__restrict__ idx_out, float *__restrict__ new_xyz_out)
+{
+    static_assert(PPT == 2 || PPT == 4 || PPT == 8, "");
+    constexpr int H = PPT / 2;
+    // The coordinates live in one 32-slot register vector [x | y | z]: reading "slot bj of the winner" is then a register-relative
+    // move with a wave-uniform index (s_set_gpr_idx) - for vectors of <= 16 elements the compiler expands a dynamic index into a
+    // compare + select per element instead.
+    typedef float vec32 __attribute__((ext_vector_type(32)));
+    // The exchange between the waves: ONE 64-bit LDS maximum per iteration.  key = (distance bits with the sign flipped: unsigned order,
+    // padding's -1 below every real distance) << 32 | ~index - the largest key is the largest distance and, among equal distances, the
+    // LOWEST index (torch.max's rule, :83).  Three keys rotate (the one for the next iteration is cleared before this iteration's
+    // barrier); the candidates' coordinates travel in per-wave slots (double buffered) so that the next centroid is an LDS read, not a
+    // global load that depends on the reduced index.
+    __shared__ unsigned long long keys[3];
+    __shared__ __attribute__((aligned(16))) float cslot[2][16][4];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6, nwaves = nthreads >> 6;
+    const int b = blockIdx.x;
+    const float *p = xyz + (size_t)b * N * 3;
+    if (tid < 3) keys[tid] = 0ull;
+    __syncthreads();
+    vec32 q;                                                 // q[j] = x_j, q[PPT + j] = y_j, q[2 PPT + j] = z_j  (24 of 32 used at PPT = 8)
+    int dist[PPT];                                           // the running minimum distances, as their bit patterns
+#pragma unroll
+    for (int j = 0; j < 32; ++j) q[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+        const int n = tid * PPT + j;
+        const bool ok = n < N;
+        q[j] = ok ? p[n * 3 + 0] : 0.f;
+        q[PPT + j] = ok ? p[n * 3 + 1] : 0.f;
+        q[2 * PPT + j] = ok ? p[n * 3 + 2] : 0.f;
+        dist[j] = __float_as_int(ok ? 1e10f : -1.0f);        // :74; padded slots can never win the argmax
+    }
+    int far = (int)start[b];
+    float cx = p[far * 3 + 0], cy = p[far * 3 + 1], cz = p[far * 3 + 2];
+    int32_t *out = idx_out + (size_t)b * npoint;
+    float *oxyz = new_xyz_out ? new_xyz_out + (size_t)b * npoint * 3 : nullptr;
+    int kb = 0;                                              // it % 3
+    for (int it = 0; it < npoint; ++it) {
+        if (tid == 0) {
+            out[it] = far;
+            if (oxyz) { oxyz[it * 3 + 0] = cx; oxyz[it * 3 + 1] = cy; oxyz[it * 3 + 2] = cz; }
+        }
+        FPS_TR(0);
+        const p2c_f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const p2c_f2 x2 = {q[2 * h], q[2 * h + 1]}, y2 = {q[PPT + 2 * h], q[PPT + 2 * h + 1]}, z2 = {q[2 * PPT + 2 * h], q[2 * PPT + 2 * h + 1]};
+            const p2c_f2 dx = x2 - c2x, dy = y2 - c2y, dz = z2 - c2z;
+            const p2c_f2 d = (dx * dx + dy * dy) + dz * dz;                   // :80, no FMA (file is built with -ffp-contract=off)
+            // :81-82.  Distances are >= +0 (padding: -1): their bit patterns order like signed ints, so the running minimum and every maximum
+            // below are INTEGER min / max - the same selections, and no NaN-quieting instructions in front of them
+            dist[2 * h] = min(__float_as_int(d[0]), dist[2 * h]);
+            dist[2 * h + 1] = min(__float_as_int(d[1]), dist[2 * h + 1]);
+        }
+        int best = dist[0];
+#pragma unroll
+        for (int j = 1; j < PPT; ++j) best = max(best, dist[j]);
+        FPS_TR(1);
+        // the wave's maximum in every lane, on the vector unit throughout (DPP inside the rows, gfx950's permlane swaps across them): no
+        // round trip through scalar registers
+        int wmax = p2c_row16_max_i32_folded(best);
+        {
+            const auto r = __builtin_amdgcn_permlane16_swap((unsigned)wmax, (unsigned)wmax, false, false);
+            wmax = max((int)r[0], (int)r[1]);
+        }
+        {
+            const auto r = __builtin_amdgcn_permlane32_swap((unsigned)wmax, (unsigned)wmax, false, false);
+            wmax = max((int)r[0], (int)r[1]);
+        }
+        FPS_TR(2);
+        int bjl = PPT;                                       // this lane's first slot holding the wave maximum (PPT: none)
+#pragma unroll
+        for (int j = PPT - 1; j >= 0; --j) bjl = dist[j] == wmax ? j : bjl;
+        const unsigned long long vote = __ballot(bjl < PPT);
+        const int src = __ffsll((long long)vote) - 1;        // lowest lane holding it = lowest index block; its first slot = lowest index
+        const int bj = __builtin_amdgcn_readlane(bjl, src);
+        const int widx = (wave * 64 + src) * PPT + bj;
+        if (nwaves == 1) {
+            far = widx;
+            cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[bj]), src));
+            cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[PPT + bj]), src));
+            cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[2 * PPT + bj]), src));
+            continue;
+        }
+        FPS_TR(3);
+        if (lane == src) {                                   // the winner lane publishes its point and the wave's key
+            float4 c;
+            c.x = q[bj]; c.y = q[PPT + bj]; c.z = q[2 * PPT + bj]; c.w = 0.f;       // register-relative moves (bj is wave-uniform)
+            *reinterpret_cast<float4 *>(&cslot[it & 1][wave][0]) = c;
+            const unsigned long long key = ((unsigned long long)((unsigned)wmax ^ 0x80000000u) << 32) | (unsigned)(~widx);
+            // (one lane: the instruction itself, not atomicMax() - the compiler wraps that in a loop over the active lanes)
+            const unsigned ka = (unsigned)(unsigned long long)(__attribute__((address_space(3))) unsigned long long *)&keys[kb];
+            asm volatile("ds_max_u64 %0, %1" ::"v"(ka), "v"(key) : "memory");
+            if (wave == 0) keys[kb == 2 ? 0 : kb + 1] = 0ull;               // next iteration's key (last read two barriers ago)
+        }
+        FPS_TR(4);
+        __syncthreads();
+        FPS_TR(5);
+        const unsigned long long k = keys[kb];
+        far = (int)~(unsigned)(k & 0xFFFFFFFFull);
+        const float4 c = *reinterpret_cast<const float4 *>(&cslot[it & 1][(unsigned)far / (64u * PPT)][0]);
+        cx = c.x; cy = c.y; cz = c.z;
+        kb = kb == 2 ? 0 : kb + 1;
+        FPS_TR(6);
+    }
+}
+
 extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start, int npoint, int32_t *idx_out,
                            float *new_xyz_out, void *stream)
 {
@@ -141,6 +291,17 @@ extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start,
         if (in_lds) { P2C_FPS_LAUNCH(P, true); }           \
         else { P2C_FPS_LAUNCH(P, false); }                 \
         break;
+    // P2C_FPS_V1=1: the round-1..5 kernel for every shape (A/B switch, tools/bench_sa1_forward.py)
+    static const bool v1 = [] { const char *e = getenv("P2C_FPS_V1"); return e && atoi(e) != 0; }();
+    if (!in_lds && !v1 && (ppt == 2 || ppt == 4 || ppt == 8)) {
+        switch (ppt) {
+        case 2: hipLaunchKernelGGL((fps_pk_kernel<2>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;
+        case 4: hipLaunchKernelGGL((fps_pk_kernel<4>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;
+        default: hipLaunchKernelGGL((fps_pk_kernel<8>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;
+        }
+        P2C_LAUNCH_CHECK();
+        return P2C_OK;
+    }
     switch (ppt) {
         P2C_FPS_CASE(1)
         P2C_FPS_CASE(2)

@@ -294,6 +294,46 @@ class GraphedMetrics:
         return self.out
 
 
+def fused_metrics_applicable(fl: EvalFlags, sizes=None):
+    """csrc/metrics.hip covers eval.py's DEFAULT operand choice (every head on, no --use_gt_*)."""
+    ok = (fl.pred_seg and fl.pred_normal and fl.pred_bb and fl.pred_extrusion and not (fl.use_gt_normals or fl.use_gt_segmentation or fl.use_gt_bb)
+          and ops.eval_metrics_supported(fl.K))
+    return ok and (sizes is None or list(sizes) == [3, 2 * fl.K])
+
+
+class FusedMetrics:
+    """eval.py:270-457 of one batch as FOUR launches: ops.eval_metrics_fused (two kernels: per-point pass, per-cloud finish with the
+    matching and the eigen-solves) + the extents along the ground-truth axes (:456, two kernels) - instead of the ~90 kernel names of the
+    torch-op mirror `eval_metrics` (which stays the reference-order path: --no_prefetch, --use_gt_*, --with_sketch_fit).  -> the
+    accumulator's (5, B) float64 block.  Counts-based rows (mIoU, base/barrel accuracy) equal the mirror's; the float rows agree to
+    rounding (tests/test_gpu_flows.py)."""
+
+    def __init__(self, fl, keys):
+        assert list(keys) == [k for k, _ in REPORT], keys
+        self.fl, self.out, self.i = fl, None, 0
+
+    def __call__(self, batch, heads):
+        h, sizes = heads
+        pcs, nrm, inst, bb, axes, cen = batch[:6]
+        fl = self.fl
+        B = pcs.shape[0]
+        if self.out is None or self.out[0].shape[1] != B:
+            self.out = [torch.empty(5, B, dtype=torch.float64, device=pcs.device) for _ in range(2)]
+        self.i ^= 1
+        out = ops.eval_metrics_fused(h, 0, sizes[0], pcs, nrm, inst, bb, axes, cen, fl.K, normalize=fl.norm_eig, out=self.out[self.i])
+        ex = batch[6] if len(batch) > 6 else {}
+        rand = ex.get("extent_rand_idx")
+        if rand is None and ex.get("barrel_counts_dev") is not None:
+            # uniform integers in [0, n_barrel(b, k)) from the DEVICE generator: no host draws, no upload (see fitting.barrel_draws_on_device)
+            cnt = ex["barrel_counts_dev"].unsqueeze(-1)
+            u = torch.rand(B, fl.K, fl.num_sk_point, device=pcs.device)
+            rand = torch.minimum((u * cnt).long(), (cnt - 1).clamp_min(0))
+        bbi = ex.get("bb_long")
+        self.extents, _ = fitting.get_extrusion_extents(pcs, inst, bbi if bbi is not None else bb.to(torch.long), axes, cen,
+                                                        num_points_to_sample=fl.num_sk_point, rand_idx=rand, counts=ex.get("barrel_counts"))     # :456
+        return out
+
+
 def build_parser():
     p = argparse.ArgumentParser()
     p.add_argument("--model", type=str, default="pointnet_extrusion")
@@ -322,6 +362,8 @@ def build_parser():
                    "steps per cloud whether 32 or 128 clouds are sampled: its latency is shared by the group; 1 = one batch ahead)")
     p.add_argument("--report", type=str, default="", help="write a JSON throughput report here")
     p.add_argument("--no_graph_metrics", action="store_true", help="launch the metric kernels of a pipelined batch one by one instead of replaying a HIP graph")
+    p.add_argument("--no_fused_metrics", action="store_true", help="pipelined batches: the torch-op metric chain (as one HIP-graph replay) instead of the "
+                   "two fused kernels of csrc/metrics.hip")
     return p
 
 
@@ -376,6 +418,8 @@ def main(argv=None):
     log.write(str(a) + "\n")
     t0 = time.time()
 
+    draw_gen = [None]
+
     def to_device(b):
         pcs, nrm, inst, bb, axes, cen = b[0], b[1], b[2], b[3], b[6], b[8]
         if a.add_noise:
@@ -386,6 +430,12 @@ def main(argv=None):
         if hi >= a.K or lo < -1:
             raise ValueError("instance labels must be in [-1, %d); got [%d, %d]" % (a.K, lo, hi))
         extras = dict(barrel_counts=fitting.barrel_counts(inst.long(), bb.long(), a.K), labels_validated=True)
+        if draw_gen[0] is not None:
+            # fused pipelined loop: the extent samples of a batch (data_utils.py:1696: K x B torch.randint calls on the CPU generator, 0.8 ms of
+            # host time and a 4 MB upload per batch) are drawn ON THE DEVICE from the barrel counts uploaded here (FusedMetrics; another
+            # equally valid sampling - the reference's stream is what --no_prefetch keeps)
+            extras["barrel_counts_dev"] = torch.tensor(extras["barrel_counts"], dtype=torch.int64).t().contiguous().to(dev, non_blocking=True)
+            extras["bb_long"] = bb.to(dev, torch.long, non_blocking=True)
         pcs, nrm, axes, cen = [t.to(dev, torch.float, non_blocking=True) for t in (pcs, nrm, axes, cen)]
         return pcs, nrm, inst.to(dev, torch.long, non_blocking=True), bb.to(dev, torch.float, non_blocking=True), axes, cen, extras     # eval.py:254-257
 
@@ -403,6 +453,10 @@ def main(argv=None):
     import collections
     import queue
     import threading
+    fused = None
+    if fused_metrics_applicable(fl) and not (a.no_prefetch or a.with_sketch_fit or a.no_graph_metrics or a.no_fused_metrics):
+        fused = FusedMetrics(fl, acc.keys)
+        draw_gen[0] = True
     if not a.no_prefetch and hasattr(ds, "generator"):
         ds.generator = torch.Generator().manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
     it = iter(loader)
@@ -440,7 +494,7 @@ def main(argv=None):
             elif isinstance(b, BaseException):
                 raise b
             else:
-                for t in b[:6]:
+                for t in list(b[:6]) + [v for v in b[6].values() if torch.is_tensor(v)]:
                     t.record_stream(stream)       # allocated on the producer's stream, read on the loop's
                 pending.append(b)
 
@@ -448,7 +502,8 @@ def main(argv=None):
         return all(tuple(b[0].shape) == tuple(bs[0][0].shape) for b in bs) and bs[0][0].shape[2] == 3
 
     def evaluate(b, heads=None):
-        m = evaluate_batch(model, *b[:6], fl, heads=heads, **b[6])
+        ex = {k: v for k, v in b[6].items() if k in ("barrel_counts", "labels_validated", "extent_rand_idx")}
+        m = evaluate_batch(model, *b[:6], fl, heads=heads, **ex)
         if a.with_sketch_fit:
             m["pred_fit_cyl_loss"], m["pred_fit_glob_loss"] = sketch_fit_losses(m, b[0], b[1], b[2], b[3], implicit_net, pn_encoder, fl)
         acc.add(m)
@@ -475,7 +530,9 @@ def main(argv=None):
                     pipe, pipe_shape = PipelinedForward(model, [b[0] for b in group], stream=stream, group=G), tuple(group[0][0].shape)
                 outs = pipe([b[0] for b in nxt] if nxt is not None else None)
                 for b, h in zip(group, outs):
-                    if a.with_sketch_fit or a.no_graph_metrics:
+                    if fused is not None and list(h[1]) == [3, 2 * fl.K]:
+                        acc.add_block(fused(b, h))
+                    elif a.with_sketch_fit or a.no_graph_metrics:
                         evaluate(b, heads=h)
                     elif metrics_graph is None or metrics_graph.inp[0].shape != b[0].shape:
                         metrics_graph = GraphedMetrics(fl, acc.keys, b, h)
@@ -507,7 +564,7 @@ def main(argv=None):
     if rank == 0 and t_first is not None and i > i_first:
         dt = (time.time() - t_first) / (i - i_first)
         rep = dict(batches=i, batches_pipelined=n_piped, batch_size=a.batch_size, num_point=a.num_point, prefetch=not a.no_prefetch,
-                   prefetch_group=G, graph_metrics=metrics_graph is not None, ms_per_batch_after_first=dt * 1e3, points_per_s=a.batch_size * a.num_point / dt,
+                   prefetch_group=G, graph_metrics=metrics_graph is not None, fused_metrics=fused is not None, ms_per_batch_after_first=dt * 1e3, points_per_s=a.batch_size * a.num_point / dt,
                    ms_per_batch_waiting_for_loader=waited[0] / (i - i_first) * 1e3)
         print("evaluation throughput: %.3f ms/batch (forward + metrics + one host transfer per batch; %.3f of it waiting for the loader thread), "
               "%.1f points/s, %d of %d batches pipelined" % (rep["ms_per_batch_after_first"], rep["ms_per_batch_waiting_for_loader"], rep["points_per_s"], n_piped, i))

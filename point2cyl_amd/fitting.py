@@ -133,9 +133,11 @@ class _DrawRing:
 
     @classmethod
     def take(cls, shape):
-        ring = cls.rings.get(shape)
+        import threading
+        key = (tuple(shape), threading.get_ident())       # (the evaluation loop draws in its loader thread: one ring per drawing thread)
+        ring = cls.rings.get(key)
         if ring is None:
-            ring = cls.rings[shape] = cls(shape)
+            ring = cls.rings[key] = cls(shape)
         i = ring.i
         ring.i ^= 1
         if ring.copied[i] is not None:
@@ -143,11 +145,12 @@ class _DrawRing:
         return ring, i
 
 
-def _barrel_draws(seg_label, bb_labels, K, S, device=None, counts=None, out=None):
+def _barrel_draws(seg_label, bb_labels, K, S, device=None, counts=None, out=None, generator=None):
     """The reference's torch.randint draws for its K x B sampling loops (data_utils.py:1064, :1696): k outer, b inner, only
     where the segment has > 1 barrel point in the batch and in the cloud, on the CPU generator.  -> (B,K,S) int64 on the host, or, with
     `device`, on that device (drawn into a recycled pinned buffer, copied on the current stream - into `out`, a (B,K,S) int64 device tensor,
-    when given: a captured graph reads its draws from a fixed address)."""
+    when given: a captured graph reads its draws from a fixed address).  generator: another CPU generator than the default one (the
+    evaluation loop's loader thread draws from a private one, seeded from the default generator, so that the two threads' draws never interleave)."""
     B = seg_label.shape[0]
     if counts is None:
         barrel = (seg_label.unsqueeze(-1) == torch.arange(K, device=seg_label.device)) & (bb_labels == 0).unsqueeze(-1)
@@ -163,7 +166,7 @@ def _barrel_draws(seg_label, bb_labels, K, S, device=None, counts=None, out=None
         none = sum(ck) <= 1
         for b in range(B):
             if ck[b] > 1 and not none:
-                torch.randint(0, ck[b], (S,), out=rows[b][k])          # (the draw itself: same generator, same order, same values)
+                torch.randint(0, ck[b], (S,), out=rows[b][k], generator=generator)      # (the draw itself: same generator, same order, same values)
             elif ring is not None:
                 rows[b][k].zero_()
     if ring is None:

@@ -1280,6 +1280,45 @@ def _hungarian_ws(B, dev):
     return _HUNG_WS[key]
 
 
+_EVAL_WS = {}
+
+
+def eval_metrics_supported(K):
+    return bool(_lib.lib().p2c_eval_metrics_supported(int(K)))
+
+
+def eval_metrics_fused(heads, xoff, woff, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, K, normalize=False, pi=None, out=None, details=False):
+    """eval.py:270-446 with its default operands as TWO launches (csrc/metrics.hip) from the backbone's raw head output heads (B*N, ld).
+    gt_inst int64 in [-1, K) (the caller checks the range), gt_bb float or integer 0/1.  -> out (5, B) float64 = per cloud mIoU, normal
+    angle error, base/barrel accuracy, extrusion angle error, centroid difference (written into `out` when given: a captured graph's
+    static block); details=True: (out, dict(matching_indices, mask, E64, predicted_centroids, found_centers_mask))."""
+    _lib.require_device(heads, pcs)
+    dev = heads.device
+    B, N, _ = pcs.shape
+    M, ld = heads.shape
+    assert M == B * N and heads.stride(0) == ld and heads.stride(1) == 1 and heads.dtype == torch.float32
+    if pi is None:
+        from .losses import TORCH_PI as pi
+    key = (B, K, dev.index)
+    if key not in _EVAL_WS:
+        _EVAL_WS[key] = torch.empty(_lib.lib().p2c_eval_metrics_ws_bytes(B, K) // 8 + 8, dtype=torch.float64, device=dev)
+    if out is None:
+        out = torch.empty(5, B, dtype=torch.float64, device=dev)
+    det = None
+    if details:
+        det = dict(matching_indices=torch.empty(B, K, dtype=torch.int64, device=dev), mask=torch.empty(B, K, dtype=torch.uint8, device=dev),
+                   E64=torch.empty(B, K, 3, dtype=torch.float64, device=dev), predicted_centroids=torch.empty(B, K, 3, dtype=torch.float32, device=dev),
+                   found_centers_mask=torch.empty(B, K, dtype=torch.float32, device=dev))
+    bbf = gt_bb if gt_bb.dtype == torch.float32 else gt_bb.to(torch.float32)
+    gi = gt_inst if gt_inst.dtype == torch.int64 else gt_inst.to(torch.int64)
+    d = det or {}
+    call("p2c_eval_metrics_f32", ptr(heads), ld, int(xoff), int(woff), ptr(_f32c(pcs)), ptr(_f32c(gt_normals)), ptr(gi.contiguous()), ptr(bbf.contiguous()),
+         ptr(_f32c(gt_axes)), ptr(_f32c(gt_centers)), int(bool(normalize)), float(N) * 0.005, float(pi), B, N, K, ptr(out),
+         ptr(d.get("matching_indices")), ptr(d.get("mask")), ptr(d.get("E64")), ptr(d.get("predicted_centroids")), ptr(d.get("found_centers_mask")),
+         ptr(_EVAL_WS[key]), stream())
+    return (out, det) if details else out
+
+
 class _SegLosses(torch.autograd.Function):
     """total = w_seg*mIoU + w_normal*normal + w_bb*base/barrel on the raw head output (fused forward + gradient)."""
 

@@ -81,6 +81,31 @@ def test_eval_flow_golden(tag):
     assert np.abs(got - r32).max() <= 2 * np.abs(r32 - ref64).max() + 1e-5
 
 
+@pytest.mark.parametrize("tag", ["pred", "pred_normeig"])
+def test_eval_flow_golden_fused_metrics(tag):
+    """G13 through csrc/metrics.hip (ops.eval_metrics_fused): the reference's own eval.py:270-446 outputs for its default operand choice -
+    matching, mask, found-centroid mask bit-exact; the five report metrics within 1e-4 (the axis angle against the reference's float64 run,
+    as test_eval_flow_golden holds the torch-op mirror to)."""
+    g = load_golden("g13_eval_flow")
+    B, N, K = 3, 1024, 8
+    heads = torch.cat([t(g["X_head"]).float().reshape(B * N, 3), t(g["W_raw"]).float().reshape(B * N, 2 * K), torch.zeros(B * N, 1)], 1).contiguous().to(DEV)
+    out, det = ops.eval_metrics_fused(heads, 0, 3, cu(g["pcs"]), cu(g["normals"]), cu(g["seg"]), cu(g["bb"]).float(), cu(g["axes"]), cu(g["centers"]), K,
+                                      normalize=(tag == "pred_normeig"), details=True)
+    r = lambda k: g["%s:%s" % (tag, k)]
+    o = out.cpu().numpy()
+    assert np.array_equal(det["matching_indices"].cpu().numpy(), r("matching_indices")) and np.array_equal(det["mask"].cpu().numpy() > 0, r("mask") > 0)
+    mg = r("mask") > 0
+    assert np.array_equal(det["found_centers_mask"].cpu().numpy()[mg] > 0, (r("found_centers_mask") > 0)[mg])
+    np.testing.assert_allclose(o[0], r("mIoU"), rtol=1e-4)
+    np.testing.assert_allclose(o[1], r("normal_difference"), rtol=1e-4)
+    np.testing.assert_allclose(o[2], r("pred_bb_acc"), rtol=1e-6)
+    np.testing.assert_allclose(o[3], g["%s:extrusion_difference64" % tag], rtol=1e-4)
+    np.testing.assert_allclose(o[4], r("centroid_difference"), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(det["predicted_centroids"].cpu().numpy()[mg], r("predicted_centroids")[mg], rtol=1e-4, atol=2e-6)
+    sin = np.linalg.norm(np.cross(det["E64"].cpu().numpy(), g["%s:E_AX64" % tag]), axis=-1)
+    assert (sin[mg] < 3e-7).all(), sin[mg].max()
+
+
 def test_five_adam_steps_golden():
     """G12: the loss trajectory of five consecutive reference steps (B=8, N=1024) with the reference's FPS starts and dropout masks
     injected, against the reference's fp32 trajectory AND its float64 twin.  The trajectory is ill-conditioned (a chain of train-mode
@@ -1161,3 +1186,81 @@ def test_graphed_metrics_equal_the_eager_metrics():
     g1b = gm(b1, h1).clone()
     assert torch.equal(g1, e1) and torch.equal(g2, e2) and torch.equal(g1b, e1)
     assert not torch.equal(e1, e2) and torch.isfinite(e1).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,norm_eig", [(8, False), (8, True), (4, False), (2, False)])
+def test_fused_metrics_equal_the_eager_metric_chain(K, norm_eig):
+    """csrc/metrics.hip (ops.eval_metrics_fused / eval.FusedMetrics: eval.py:270-446 of a batch as two launches) against the torch-op
+    mirror eval.eval_metrics on the same head outputs.  The hard labels are formed with torch's own softmax arithmetic, so everything
+    that is a ratio of COUNTS - matching, mask, mIoU, base/barrel accuracy, found masks - must be EQUAL (float32-rounded values
+    digit for digit); the sums of floats over the points (angle mean, scatter matrices, centroids) run in another order and are held to
+    rounding: normal angle 2e-6 relative, fitted axes 1e-5 rad (the angle metric 2e-4 deg), centroids 1e-6.  Untrained heads put most
+    points into a few columns: null columns, unmatched segments and not-found centroids all occur (asserted)."""
+    B, N = 6, 3000
+    fl = p2c_eval.EvalFlags(K=K, num_sk_point=256, norm_eig=norm_eig)
+    torch.manual_seed(4)
+    model = backbone(output_sizes=fl.pred_sizes()).to(DEV).eval()
+    seen_null = seen_nf = False
+    for seed, gain in ((21, 1.0), (22, 3.0), (23, 0.2), (24, None)):
+        pcs, nrm, inst, bb, _, _, axes, _, cen = synth.make_batch(B, N, K, seed=seed)
+        if gain is None:
+            inst = (torch.arange(N) % K).repeat(B, 1)          # K instances per cloud: every column gets matched
+        if seed == 23:
+            inst = inst.clone()
+            inst[0, ::7] = -1                       # background points
+            inst[1] = torch.where(inst[1] > 0, torch.zeros_like(inst[1]), inst[1])      # one instance only
+        batch = (pcs.float().to(DEV), nrm.float().to(DEV), inst.to(DEV), bb.float().to(DEV), axes.float().to(DEV), cen.float().to(DEV))
+        with torch.no_grad():
+            heads, sizes = model.forward_heads(batch[0], model.compute_geometry(batch[0], with_csr=False))
+            heads = heads.clone()
+            if gain is not None:
+                heads[:, sizes[0]:sizes[0] + sizes[1]] *= gain * 8.0          # sharper / flatter memberships
+            else:
+                # crafted memberships: predicted label = gt label, except that column K-3 keeps 10 points only (soft mass below 0.005 N: a NULL
+                # column, emptied by the encoding) and column K-2 keeps ONE hard point but plenty of soft mass (not null, centroid "not found")
+                n = torch.arange(N)
+                lab = inst[0].clone()
+                lab[(lab == K - 3) & (n >= 10 * K)] = 0
+                lone = (inst[0] == K - 2) & (n >= K)
+                lab[lone] = min(1, K - 1)
+                lg = torch.zeros(N, 2 * K)
+                lg[n, 2 * lab + bb[0].long()] = 25.0
+                if K >= 4:
+                    lg[lone] = -20.0
+                    lg[lone, 2 * 1] = 2.0
+                    lg[lone, 2 * (K - 2)] = 1.5
+                heads[:, sizes[0]:sizes[0] + sizes[1]] = lg.repeat(B, 1).to(DEV)
+            hv = heads.view(B, N, heads.shape[-1])
+            m = p2c_eval.eval_metrics(hv[:, :, 0:sizes[0]], hv[:, :, sizes[0]:sizes[0] + sizes[1]], *batch, fl,
+                                      extent_rand_idx=torch.zeros(B, K, fl.num_sk_point, dtype=torch.int64, device=DEV), labels_validated=True)
+            out, det = ops.eval_metrics_fused(heads, 0, sizes[0], *batch, K, normalize=norm_eig, details=True)
+        torch.cuda.synchronize()
+        mask = m["mask"].bool()
+        assert torch.equal(det["mask"].bool(), mask)
+        assert torch.equal(det["matching_indices"], m["matching_indices"]), (det["matching_indices"], m["matching_indices"])
+        assert torch.equal(out[0].float(), m["mIoU"].float()) or float((out[0].float() - m["mIoU"]).abs().max()) <= 1.2e-7, (out[0], m["mIoU"])
+        # (hits / N: the torch chain multiplies by the rounded reciprocal of N on the device, the reference's CPU run and the kernel divide - one
+        # ulp apart unless N is a power of two; the COUNT is what must be equal)
+        assert torch.equal(torch.round(out[2] * N), torch.round(m["pred_bb_acc"].double() * N))
+        assert float((out[2].float() - m["pred_bb_acc"]).abs().max()) <= 1.2e-7
+        np.testing.assert_allclose(out[1].cpu().numpy(), m["normal_difference"].double().cpu().numpy(), rtol=2e-6)
+        # fitted axes of the matched segments (sign-canonical in both), centroids, found masks
+        # (the mirror's float64 axes are not in its dict: compare with the float32 ones)
+        sin = torch.linalg.norm(torch.linalg.cross(det["E64"], m["E_AX"].double()), dim=-1)      # |sin(angle)|: sign-free, resolves small angles
+        # fp32 storage of the mirror's unit vector: 1e-7; the two chains add the same fp32 products in different orders (1e-7 relative on the
+        # scatter sums), and an untrained network's near-isotropic scatter matrices amplify that by 1 / eigen-gap: 2e-5 rad measured at worst.
+        # (The parity pin of the axes is test_eval_flow_golden_fused_metrics: 3e-7 against the reference's float64 run.)
+        assert float(sin[mask].max()) < 1e-4, sin
+        np.testing.assert_allclose(out[3].cpu().numpy(), m["extrusion_difference"].double().cpu().numpy(), rtol=0, atol=5e-3)
+        assert torch.equal(det["found_centers_mask"][mask], m["found_centers_mask"][mask])
+        np.testing.assert_allclose(det["predicted_centroids"][mask].cpu().numpy(), m["predicted_centroids"][mask].cpu().numpy(), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(out[4].cpu().numpy(), m["centroid_difference"].double().cpu().numpy(), rtol=2e-6, atol=1e-7)
+        W = m["W"]
+        seen_null |= bool((W.sum(1) < N * 0.005).any())
+        seen_nf |= bool((m["found_centers_mask"][mask] == 0).any())
+        # the loop's wrapper: same block, plus the extents of eval.py:456
+        fm = p2c_eval.FusedMetrics(fl, [k for k, _ in p2c_eval.REPORT])
+        blk = fm(batch + (dict(extent_rand_idx=torch.zeros(B, K, fl.num_sk_point, dtype=torch.int64, device=DEV)),), (heads, sizes))
+        assert torch.equal(blk, out) and fm.extents.shape == (K, B, 2)
+    assert K != 8 or (seen_null and seen_nf)

@@ -2002,6 +2002,34 @@ def test_inference_forward_paths_equal_the_plain_eval_forward():
 
 
 @pytest.mark.gpu
+def test_strict_labels_raise_at_the_call():
+    """ops.STRICT_LABELS (environment: P2C_STRICT_LABELS=1): compute_all_losses validates its labels with a device->host read in EVERY call
+    - an out-of-range label raises in the offending call, as losses.py:36-46 does - instead of the deferred check (first calls synchronous,
+    later batches reported one call late); values are the same either way."""
+    from point2cyl_amd import losses, ops
+    B, N, K = 2, 512, 8
+    g = torch.Generator().manual_seed(9)
+    W = torch.softmax(torch.randn(B, N, K, generator=g), -1).to(DEV)
+    X = F.normalize(torch.randn(B, N, 3, generator=g), dim=-1).to(DEV)
+    Xg = F.normalize(torch.randn(B, N, 3, generator=g), dim=-1).to(DEV)
+    I = torch.randint(0, K, (B, N), generator=g).to(DEV)
+    P = torch.zeros(B, N, 3, device=DEV)
+    base = [float(v) for v in losses.compute_all_losses(P, W, I, X, Xg, 1.0, 1.0)]
+    bad = I.clone()
+    bad[1, 7] = K                     # out of range
+    old = ops.STRICT_LABELS
+    ops.STRICT_LABELS = True
+    try:
+        for _ in range(5):            # (beyond the deferred check's synchronous first calls)
+            got = [float(v) for v in losses.compute_all_losses(P, W, I, X, Xg, 1.0, 1.0)]
+        assert got == base
+        with pytest.raises(ValueError, match="instance labels"):
+            losses.compute_all_losses(P, W, bad, X, Xg, 1.0, 1.0)
+    finally:
+        ops.STRICT_LABELS = old
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("K", [8, 4])
 def test_fit_terms_one_launch_equal_the_torch_expressions(K):
     """ops.fit_terms (the extrusion-axis and centre terms of the full loss set, forward + gradient in one launch) against the reference's
@@ -2028,10 +2056,16 @@ def test_fit_terms_one_launch_equal_the_torch_expressions(K):
     _, mask = ops.hungarian(W, I_gt)
     assert torch.equal(mask, mask_gt)
     w_e, w_c = 0.7, 1.3
-    ext = losses.compute_normal_loss(E, A, angle_diff=False, collapse=False)
-    ref_e = losses.reduce_mean_masked_instance(ext, mask_gt).mean() * w_e
-    ref_c = losses.reduce_mean_masked_instance(torch.square(C - Cg).sum(dim=-1), mask_gt).mean() * w_c
-    gE, gC = torch.autograd.grad(3.0 * ref_e + 0.5 * ref_c, [E, C])
+    # the reference side is the ORACLE's restatement (oracle/ref_torch.py: losses.py:83-88, :127-143) on CPU copies of the operands - not
+    # this package's own torch expressions
+    Ec, Cc = E.detach().cpu().requires_grad_(True), C.detach().cpu().requires_grad_(True)
+    mg_cpu = R.get_mask_gt(I_gt.cpu(), K)
+    assert torch.equal(mg_cpu, mask_gt.cpu())
+    ext = R.compute_normal_loss(Ec, A.cpu(), angle_diff=False, collapse=False)
+    ref_e = R.reduce_mean_masked_instance(ext, mg_cpu).mean() * w_e
+    ref_c = R.reduce_mean_masked_instance(torch.square(Cc - Cg.cpu()).sum(dim=-1), mg_cpu).mean() * w_c
+    gE, gC = torch.autograd.grad(3.0 * ref_e + 0.5 * ref_c, [Ec, Cc])
+    ref_e, ref_c, gE, gC = ref_e.detach().to(DEV), ref_c.detach().to(DEV), gE.to(DEV), gC.to(DEV)
     out = ops.fit_terms(E, A, C, Cg, mask, w_e, w_c)
     hE, hC = torch.autograd.grad(3.0 * out[0] + 0.5 * out[1], [E, C])
     torch.testing.assert_close(out[0], ref_e, rtol=2e-6, atol=1e-7)

@@ -1,5 +1,6 @@
 """CPU: host-side logic (no GPU, no kernels): synthetic data, schedules, drop-in import names, data-parallel glue
 (world_size 2 over gloo)."""
+import json
 import os
 import subprocess
 import sys
@@ -393,3 +394,20 @@ def test_cpu_quota_and_thread_fit():
         assert 1 <= n <= q and torch.get_num_threads() == n
     finally:
         torch.set_num_threads(before)
+
+
+def test_remaining_env_switches_are_wired():
+    """P2C_AUTOGRAPH, P2C_GEMM_BIG, P2C_STRICT_LABELS are read from the environment at import time; each flips the module
+    attribute the GPU tests drive (autograph.ENABLED: test_autograph_module_forward_backward_equals_eager_launches; implicit.USE_BIG:
+    test_implicit_decoder_big_tiles_vs_oracle_trainer_shapes; ops.STRICT_LABELS: test_strict_labels_raise_at_the_call)."""
+    code = ("import json; from point2cyl_amd import autograph, implicit, ops; "
+            "print(json.dumps([autograph.ENABLED, implicit.USE_BIG, ops.STRICT_LABELS]))")
+    for env_add, want in (({}, [True, True, False]),
+                          ({"P2C_AUTOGRAPH": "0", "P2C_GEMM_BIG": "0", "P2C_STRICT_LABELS": "1"}, [False, False, True])):
+        env = dict(os.environ, **env_add)
+        for k in ("P2C_AUTOGRAPH", "P2C_GEMM_BIG", "P2C_STRICT_LABELS"):
+            if k not in env_add:
+                env.pop(k, None)
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-1500:]
+        assert json.loads(out.stdout.strip().splitlines()[-1]) == want

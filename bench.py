@@ -696,6 +696,7 @@ def _dropin_leg(args, batch, fl, dev, B, N, K, native_ms, steps=20):
                 per.append(time.perf_counter() - t1)
             torch.cuda.synchronize()
             mean_ms = (time.perf_counter() - t0) / n * 1e3
+            slowest = sorted(((round(v * 1e3, 3), i) for i, v in enumerate(per)), reverse=True)[:3]
             per.sort()
             # the step is host-paced (a Python loss composition + six device->host reads): on a shared host single steps stretch by
             # milliseconds (measured: the mean of 20 steps between 5.9 and 8.3 ms on one box within a minute); the MEDIAN step is the
@@ -704,7 +705,8 @@ def _dropin_leg(args, batch, fl, dev, B, N, K, native_ms, steps=20):
             res[label.replace("ms_per_step", "mean_ms_per_step")] = round(mean_ms, 4)
             if on:
                 res.update(steps_timed=n, p50_ms=round(per[len(per) // 2] * 1e3, 4), p99_ms=round(per[min(n - 1, int(n * 0.99))] * 1e3, 4),
-                           max_ms=round(per[-1] * 1e3, 4), max_over_median=round(per[-1] / per[len(per) // 2], 2))
+                           max_ms=round(per[-1] * 1e3, 4), max_over_median=round(per[-1] / per[len(per) // 2], 2),
+                           slowest_steps_ms_index=slowest)
                 res["loss_after_%d_steps" % (n + 3)] = round(logs[0], 5)
             autograph.reset(st.model)
             del st

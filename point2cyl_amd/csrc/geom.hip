@@ -158,12 +158,13 @@ template <int PPT>
 __global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ xyz, int N, const int64_t *__restrict__ start,
                                                       int npoint, int32_t *__restrict__ idx_out, float *__restrict__ new_xyz_out)
 {
-    static_assert(PPT == 2 || PPT == 4 || PPT == 8, "");
+    static_assert(PPT == 2 || PPT == 4 || PPT == 8 || PPT == 16, "");
     constexpr int H = PPT / 2;
-    // The coordinates live in one 32-slot register vector [x | y | z]: reading "slot bj of the winner" is then a register-relative
+    // The coordinates live in a 32-slot register vector [x | y] and a 16-slot one [z]: reading "slot bj of the winner" is then a register-relative
     // move with a wave-uniform index (s_set_gpr_idx) - for vectors of <= 16 elements the compiler expands a dynamic index into a
     // compare + select per element instead.
     typedef float vec32 __attribute__((ext_vector_type(32)));
+    typedef float vec16 __attribute__((ext_vector_type(16)));
     // The exchange between the waves: ONE 64-bit LDS maximum per iteration.  key = (distance bits with the sign flipped: unsigned order,
     // padding's -1 below every real distance) << 32 | ~index - the largest key is the largest distance and, among equal distances, the
     // LOWEST index (torch.max's rule, :83).  Three keys rotate (the one for the next iteration is cleared before this iteration's
@@ -177,17 +178,20 @@ __global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ 
     const float *p = xyz + (size_t)b * N * 3;
     if (tid < 3) keys[tid] = 0ull;
     __syncthreads();
-    vec32 q;                                                 // q[j] = x_j, q[PPT + j] = y_j, q[2 PPT + j] = z_j  (24 of 32 used at PPT = 8)
+    vec32 q;                                                 // q[j] = x_j, q[PPT + j] = y_j
+    vec16 qz;                                                // qz[j] = z_j
     int dist[PPT];                                           // the running minimum distances, as their bit patterns
 #pragma unroll
     for (int j = 0; j < 32; ++j) q[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) qz[j] = 0.f;
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int n = tid * PPT + j;
         const bool ok = n < N;
         q[j] = ok ? p[n * 3 + 0] : 0.f;
         q[PPT + j] = ok ? p[n * 3 + 1] : 0.f;
-        q[2 * PPT + j] = ok ? p[n * 3 + 2] : 0.f;
+        qz[j] = ok ? p[n * 3 + 2] : 0.f;
         dist[j] = __float_as_int(ok ? 1e10f : -1.0f);        // :74; padded slots can never win the argmax
     }
     int far = (int)start[b];
@@ -204,7 +208,7 @@ __global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ 
         const p2c_f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            const p2c_f2 x2 = {q[2 * h], q[2 * h + 1]}, y2 = {q[PPT + 2 * h], q[PPT + 2 * h + 1]}, z2 = {q[2 * PPT + 2 * h], q[2 * PPT + 2 * h + 1]};
+            const p2c_f2 x2 = {q[2 * h], q[2 * h + 1]}, y2 = {q[PPT + 2 * h], q[PPT + 2 * h + 1]}, z2 = {qz[2 * h], qz[2 * h + 1]};
             const p2c_f2 dx = x2 - c2x, dy = y2 - c2y, dz = z2 - c2z;
             const p2c_f2 d = (dx * dx + dy * dy) + dz * dz;                   // :80, no FMA (file is built with -ffp-contract=off)
             // :81-82.  Distances are >= +0 (padding: -1): their bit patterns order like signed ints, so the running minimum and every maximum
@@ -239,13 +243,13 @@ __global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ 
             far = widx;
             cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[bj]), src));
             cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[PPT + bj]), src));
-            cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[2 * PPT + bj]), src));
+            cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz[bj]), src));
             continue;
         }
         FPS_TR(3);
         if (lane == src) {                                   // the winner lane publishes its point and the wave's key
             float4 c;
-            c.x = q[bj]; c.y = q[PPT + bj]; c.z = q[2 * PPT + bj]; c.w = 0.f;       // register-relative moves (bj is wave-uniform)
+            c.x = q[bj]; c.y = q[PPT + bj]; c.z = qz[bj]; c.w = 0.f;       // register-relative moves (bj is wave-uniform)
             *reinterpret_cast<float4 *>(&cslot[it & 1][wave][0]) = c;
             const unsigned long long key = ((unsigned long long)((unsigned)wmax ^ 0x80000000u) << 32) | (unsigned)(~widx);
             // (one lane: the instruction itself, not atomicMax() - the compiler wraps that in a loop over the active lanes)
@@ -293,8 +297,12 @@ extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start,
         break;
     // P2C_FPS_V1=1: the round-1..5 kernel for every shape (A/B switch, tools/bench_sa1_forward.py)
     static const bool v1 = [] { const char *e = getenv("P2C_FPS_V1"); return e && atoi(e) != 0; }();
-    if (!in_lds && !v1 && (ppt == 2 || ppt == 4 || ppt == 8)) {
+    // P2C_FPS_PPT=16: twice the points per lane on half the waves (A/B switch)
+    static const int ppt_env = [] { const char *e = getenv("P2C_FPS_PPT"); return e ? atoi(e) : 0; }();
+    if (!in_lds && !v1 && ppt_env == 16 && ppt == 8 && N > 512) { ppt = 16; threads = ((N + ppt - 1) / ppt + 63) & ~63; }
+    if (!in_lds && !v1 && (ppt == 2 || ppt == 4 || ppt == 8 || (ppt == 16 && ppt_env == 16))) {
         switch (ppt) {
+        case 16: hipLaunchKernelGGL((fps_pk_kernel<16>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;
         case 2: hipLaunchKernelGGL((fps_pk_kernel<2>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;
         case 4: hipLaunchKernelGGL((fps_pk_kernel<4>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;
         default: hipLaunchKernelGGL((fps_pk_kernel<8>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;

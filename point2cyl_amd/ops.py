@@ -1201,7 +1201,10 @@ class _DeferredLabelCheck:
             return
         self.calls += 1
         if self.calls <= self.SYNC_FIRST:
-            return check_labels(I_gt, K)
+            check_labels(I_gt, K)
+            # ... and run the deferred machinery too while the caller is synchronous anyway: its first use pins a host word (tens of
+            # milliseconds of page faults on a fresh process) and loads three torch kernels - in call SYNC_FIRST + 1 that was one step of
+            # 18 - 60 ms in the middle of the first epoch (bench.py's drop-in leg)
         dev = I_gt.device
         st = self.st.get(dev)
         if st is None:

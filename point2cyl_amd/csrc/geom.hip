@@ -155,10 +155,10 @@ extern "C" int p2c_fps_trace_read(void *out) { return hipMemcpyFromSymbol(out, H
 #endif
 
 template <int PPT>
-__global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ xyz, int N, const int64_t *__restrict__ start,
+__global__ void __launch_bounds__(PPT == 32 ? 256 : 1024) fps_pk_kernel(const float *__restrict__ xyz, int N, const int64_t *__restrict__ start,
                                                       int npoint, int32_t *__restrict__ idx_out, float *__restrict__ new_xyz_out)
 {
-    static_assert(PPT == 2 || PPT == 4 || PPT == 8 || PPT == 16, "");
+    static_assert(PPT == 2 || PPT == 4 || PPT == 8 || PPT == 16 || PPT == 32, "");
     constexpr int H = PPT / 2;
     // The coordinates live in a 32-slot register vector [x | y] and a 16-slot one [z]: reading "slot bj of the winner" is then a register-relative
     // move with a wave-uniform index (s_set_gpr_idx) - for vectors of <= 16 elements the compiler expands a dynamic index into a
@@ -178,20 +178,22 @@ __global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ 
     const float *p = xyz + (size_t)b * N * 3;
     if (tid < 3) keys[tid] = 0ull;
     __syncthreads();
-    vec32 q;                                                 // q[j] = x_j, q[PPT + j] = y_j
-    vec16 qz;                                                // qz[j] = z_j
+    // x_j, y_j, z_j: one 32-slot vector each at PPT = 32; [x | y] + [z] up to PPT = 16 (YV / YO, ZV / ZO: where y and z start)
+    vec32 qa, qb, qc;
+    constexpr int YO = PPT == 32 ? 0 : PPT, ZO = 0;
+#define FPS_X(j) qa[(j)]
+#define FPS_Y(j) (PPT == 32 ? qb[(j)] : qa[YO + (j)])
+#define FPS_Z(j) (PPT == 32 ? qc[(j)] : qb[ZO + (j)])
     int dist[PPT];                                           // the running minimum distances, as their bit patterns
 #pragma unroll
-    for (int j = 0; j < 32; ++j) q[j] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) qz[j] = 0.f;
+    for (int j = 0; j < 32; ++j) { qa[j] = 0.f; qb[j] = 0.f; qc[j] = 0.f; }
 #pragma unroll
     for (int j = 0; j < PPT; ++j) {
         const int n = tid * PPT + j;
         const bool ok = n < N;
-        q[j] = ok ? p[n * 3 + 0] : 0.f;
-        q[PPT + j] = ok ? p[n * 3 + 1] : 0.f;
-        qz[j] = ok ? p[n * 3 + 2] : 0.f;
+        const float vx = ok ? p[n * 3 + 0] : 0.f, vy = ok ? p[n * 3 + 1] : 0.f, vz = ok ? p[n * 3 + 2] : 0.f;
+        qa[j] = vx;
+        if (PPT == 32) { qb[j] = vy; qc[j] = vz; } else { qa[YO + j] = vy; qb[ZO + j] = vz; }
         dist[j] = __float_as_int(ok ? 1e10f : -1.0f);        // :74; padded slots can never win the argmax
     }
     int far = (int)start[b];
@@ -208,7 +210,7 @@ __global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ 
         const p2c_f2 c2x = {cx, cx}, c2y = {cy, cy}, c2z = {cz, cz};
 #pragma unroll
         for (int h = 0; h < H; ++h) {
-            const p2c_f2 x2 = {q[2 * h], q[2 * h + 1]}, y2 = {q[PPT + 2 * h], q[PPT + 2 * h + 1]}, z2 = {qz[2 * h], qz[2 * h + 1]};
+            const p2c_f2 x2 = {FPS_X(2 * h), FPS_X(2 * h + 1)}, y2 = {FPS_Y(2 * h), FPS_Y(2 * h + 1)}, z2 = {FPS_Z(2 * h), FPS_Z(2 * h + 1)};
             const p2c_f2 dx = x2 - c2x, dy = y2 - c2y, dz = z2 - c2z;
             const p2c_f2 d = (dx * dx + dy * dy) + dz * dz;                   // :80, no FMA (file is built with -ffp-contract=off)
             // :81-82.  Distances are >= +0 (padding: -1): their bit patterns order like signed ints, so the running minimum and every maximum
@@ -241,15 +243,15 @@ __global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ 
         const int widx = (wave * 64 + src) * PPT + bj;
         if (nwaves == 1) {
             far = widx;
-            cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[bj]), src));
-            cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q[PPT + bj]), src));
-            cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(qz[bj]), src));
+            cx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(FPS_X(bj)), src));
+            cy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(FPS_Y(bj)), src));
+            cz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(FPS_Z(bj)), src));
             continue;
         }
         FPS_TR(3);
         if (lane == src) {                                   // the winner lane publishes its point and the wave's key
             float4 c;
-            c.x = q[bj]; c.y = q[PPT + bj]; c.z = qz[bj]; c.w = 0.f;       // register-relative moves (bj is wave-uniform)
+            c.x = FPS_X(bj); c.y = FPS_Y(bj); c.z = FPS_Z(bj); c.w = 0.f;       // register-relative moves (bj is wave-uniform)
             *reinterpret_cast<float4 *>(&cslot[it & 1][wave][0]) = c;
             const unsigned long long key = ((unsigned long long)((unsigned)wmax ^ 0x80000000u) << 32) | (unsigned)(~widx);
             // (one lane: the instruction itself, not atomicMax() - the compiler wraps that in a loop over the active lanes)
@@ -268,6 +270,9 @@ __global__ void __launch_bounds__(1024) fps_pk_kernel(const float *__restrict__ 
         FPS_TR(6);
     }
 }
+#undef FPS_X
+#undef FPS_Y
+#undef FPS_Z
 
 extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start, int npoint, int32_t *idx_out,
                            float *new_xyz_out, void *stream)
@@ -297,11 +302,20 @@ extern "C" int p2c_fps_f32(const float *xyz, int B, int N, const int64_t *start,
         break;
     // P2C_FPS_V1=1: the round-1..5 kernel for every shape (A/B switch, tools/bench_sa1_forward.py)
     static const bool v1 = [] { const char *e = getenv("P2C_FPS_V1"); return e && atoi(e) != 0; }();
-    // P2C_FPS_PPT=16: twice the points per lane on half the waves (A/B switch)
+    // Points per lane of the register-resident kernel: 8 WAVES per cloud (N / 512 points per lane), not 16.  Same-box A/B at B = 32 x 8192
+    // (tools/fps_step_ab.sh, tools/fps_legs_ab.sh): 16 waves x 8 points 472 us alone and the training step it runs under +0.12 ms (its waves
+    // take issue slots from the MLP workgroups they share CUs with); 8 x 16: 442 us, step -0.04 ms against the round-5 kernel, best
+    // pipelined forward and evaluation loop; 4 x 32: 476 us, step -0.05 ms.  P2C_FPS_PPT = 8 / 16 / 32 forces a shape (N <= 8192).
     static const int ppt_env = [] { const char *e = getenv("P2C_FPS_PPT"); return e ? atoi(e) : 0; }();
-    if (!in_lds && !v1 && ppt_env == 16 && ppt == 8 && N > 512) { ppt = 16; threads = ((N + ppt - 1) / ppt + 63) & ~63; }
-    if (!in_lds && !v1 && (ppt == 2 || ppt == 4 || ppt == 8 || (ppt == 16 && ppt_env == 16))) {
+    if (!in_lds && !v1 && N <= 8192 && N > 512) {
+        int want = ppt_env == 8 || ppt_env == 16 || ppt_env == 32 ? ppt_env : 2 * ppt;
+        if (want > 16 && ppt_env != 32) want = 16;
+        if (want >= ppt && (long long)want * (want == 32 ? 256 : 1024) >= N) { ppt = want; threads = ((N + ppt - 1) / ppt + 63) & ~63; }
+    }
+    const bool forced = !in_lds && !v1 && (ppt == 16 || ppt == 32) && threads <= (ppt == 32 ? 256 : 1024) && N <= 8192;
+    if (!in_lds && !v1 && (ppt == 2 || ppt == 4 || ppt == 8 || forced)) {
         switch (ppt) {
+        case 32: hipLaunchKernelGGL((fps_pk_kernel<32>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;
         case 16: hipLaunchKernelGGL((fps_pk_kernel<16>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;
         case 2: hipLaunchKernelGGL((fps_pk_kernel<2>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;
         case 4: hipLaunchKernelGGL((fps_pk_kernel<4>), dim3(B), dim3(threads), 0, s, xyz, N, start, npoint, idx_out, new_xyz_out); break;

@@ -27,7 +27,7 @@ def main():
     everything = "--all" in sys.argv          # every launch (also the < 8 us ones) with the idle time in front of it
     argv = [a for a in sys.argv if a != "--all"]
     back = int(argv[2]) if len(argv) > 2 else 2
-    marks = [i for i, r in enumerate(rows) if r[2].startswith("fps_kernel<8, false")]
+    marks = [i for i, r in enumerate(rows) if (r[2].startswith("fps_kernel<8, false") or r[2].startswith("fps_pk_kernel<8"))]
     if len(marks) < back + 2:
         raise SystemExit("trace holds %d steps only" % len(marks))
     # duration statistics per (kernel name, occurrence index within its step)
@@ -40,7 +40,7 @@ def main():
     a, b = marks[-back - 1], marks[-back]
     step = rows[a:b]
     t0 = step[0][0]
-    fps = [r for r in step if r[2].startswith("fps_kernel")]
+    fps = [r for r in step if (r[2].startswith("fps_kernel") or r[2].startswith("fps_pk_kernel"))]
     fps_lo, fps_hi = fps[0][0], max(r[1] for r in fps)
     print("# one step of `python bench.py` (graph replay), per launch; times in us; step length %.1f us" % ((rows[b][0] - t0) / 1e3))
     print("FPS resident %.1f .. %.1f us of the step\n" % ((fps_lo - t0) / 1e3, (fps_hi - t0) / 1e3))
@@ -51,7 +51,7 @@ def main():
     for r in step:
         mn = min(stat[(r[2], seen[r[2]])])
         seen[r[2]] += 1
-        under = r[0] < fps_hi and r[1] > fps_lo and not r[2].startswith("fps_kernel")
+        under = r[0] < fps_hi and r[1] > fps_lo and not (r[2].startswith("fps_kernel") or r[2].startswith("fps_pk_kernel"))
         d = r[1] - r[0]
         if under and d > 20000:
             infl += d - mn

@@ -541,7 +541,7 @@ extern "C" int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, con
 // K a power of two <= 8 and 3N floats + N bytes + N ints within the LDS: other shapes take the three separate kernels.
 // ------------------------------------------------------------------------------------------------
 #ifdef P2C_FIT_TRACE       // tools/fit_trace.py: shader-clock stamps of workgroup 0 at the phase boundaries
-__device__ unsigned long long p2c_fit_stamps[8];
+__device__ unsigned long long p2c_fit_stamps[40];
 extern "C" int p2c_fit_trace_read(void *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_fit_stamps), sizeof(p2c_fit_stamps)) == hipSuccess ? 0 : 1; }
 #define FIT_TR(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) p2c_fit_stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -597,23 +597,44 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
         const float *x = X + (size_t)b * N * 3, *pp = P + (size_t)b * N * 3;
         const int *sg = reinterpret_cast<const int *>(seg + (size_t)b * N), *bl = reinterpret_cast<const int *>(bb + (size_t)b * N);
         const int hsel = tid % LPP, k0 = hsel * SPL;
-#pragma unroll 4
-        for (int n = tid / LPP; n < N; n += THREADS / LPP) {
-            const float x0 = x[n * 3 + 0], x1 = x[n * 3 + 1], x2 = x[n * 3 + 2];
-            const float p0 = pp[n * 3 + 0], p1 = pp[n * 3 + 1], p2 = pp[n * 3 + 2];
-            const int sv = sg[2 * n], bv = bl[2 * n];
-            const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
+        // U points per lane are REQUESTED before the first is used, with no control flow between the loads and their uses (clamped indices
+        // instead of a bounds branch; every lane of a point's group parks the point - same address, same value - instead of one lane under
+        // a branch).  With the branch in the loop body the compiler drained the memory counter in every iteration: one point per lane in
+        // flight, 10 KB per CU, and the streaming phase ran at the memory LATENCY (51 - 64 k of a cloud's 117 k cycles, round 5's trace).
+        constexpr int U = 4, NSTEP = THREADS / LPP;
+        for (int n0 = tid / LPP; n0 < N; n0 += U * NSTEP) {
+            float xq[U][3], pq[U][3];
+            int svq[U], bvq[U], nq[U];
 #pragma unroll
-            for (int j = 0; j < SPL; ++j) {
-                const bool mine = sv == k0 + j;
-                const float b2 = (mine && bv == 0) ? 1.f : 0.f, c2 = (mine && bv == 1) ? 1.f : 0.f, w = mine ? 1.f : 0.f;
-                float *a_ = hacc[j];
-                a_[0] += b2 * p00; a_[1] += b2 * p01; a_[2] += b2 * p02; a_[3] += b2 * p11; a_[4] += b2 * p12; a_[5] += b2 * p22;
-                a_[6] += c2 * p00; a_[7] += c2 * p01; a_[8] += c2 * p02; a_[9] += c2 * p11; a_[10] += c2 * p12; a_[11] += c2 * p22;
-                if (normalize) { a_[12] += b2; a_[13] += c2; }
-                a_[14] += w * p0; a_[15] += w * p1; a_[16] += w * p2; a_[17] += w;
+            for (int u = 0; u < U; ++u) {
+                const int n = n0 + u * NSTEP, nc = n < N ? n : N - 1;
+                nq[u] = nc;
+                xq[u][0] = x[nc * 3 + 0]; xq[u][1] = x[nc * 3 + 1]; xq[u][2] = x[nc * 3 + 2];
+                pq[u][0] = pp[nc * 3 + 0]; pq[u][1] = pp[nc * 3 + 1]; pq[u][2] = pp[nc * 3 + 2];
+                svq[u] = sg[2 * nc]; bvq[u] = bl[2 * nc];
             }
-            if (hsel == 0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = nq[u];
+                const bool live = n0 + u * NSTEP < N;                   // a clamped slot repeats point N - 1: parked again (same values), not summed
+                const float x0 = xq[u][0], x1 = xq[u][1], x2 = xq[u][2];
+                const float p0 = pq[u][0], p1 = pq[u][1], p2 = pq[u][2];
+                const int sv = svq[u], bv = bvq[u];
+                const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) {
+                    const bool mine = live && sv == k0 + j;
+                    const float b2 = (mine && bv == 0) ? 1.f : 0.f, c2 = (mine && bv == 1) ? 1.f : 0.f, w = mine ? 1.f : 0.f;
+                    float *a_ = hacc[j];
+                    // the factors are 0 or 1: every product is exact, so a fused multiply-add rounds exactly like the multiply + add of the
+                    // general route (the file is built with -ffp-contract=off)
+#define FIT_ACC(i, f, v) a_[i] = __builtin_fmaf(f, v, a_[i])
+                    FIT_ACC(0, b2, p00); FIT_ACC(1, b2, p01); FIT_ACC(2, b2, p02); FIT_ACC(3, b2, p11); FIT_ACC(4, b2, p12); FIT_ACC(5, b2, p22);
+                    FIT_ACC(6, c2, p00); FIT_ACC(7, c2, p01); FIT_ACC(8, c2, p02); FIT_ACC(9, c2, p11); FIT_ACC(10, c2, p12); FIT_ACC(11, c2, p22);
+                    if (normalize) { a_[12] += b2; a_[13] += c2; }
+                    FIT_ACC(14, w, p0); FIT_ACC(15, w, p1); FIT_ACC(16, w, p2); a_[17] += w;
+#undef FIT_ACC
+                }
                 if (PLDS) { Ps[n * 3 + 0] = p0; Ps[n * 3 + 1] = p1; Ps[n * 3 + 2] = p2; }
                 keyb[n] = (signed char)((bv == 0 && sv >= 0 && sv < KK) ? (int)sv : -1);
             }
@@ -625,30 +646,48 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
         // the labels' low words (little-endian int64 holding small non-negative values or -1): half the registers per point in flight, and
         // a CU's streaming rate is set by the bytes it keeps in flight (16 waves x 8 points x 104 B per unrolled step)
         const int *sg = reinterpret_cast<const int *>(seg + (size_t)b * N), *bl = reinterpret_cast<const int *>(bb + (size_t)b * N);
-#pragma unroll 8
-        for (int n = g; n < N; n += G) {
-            const float x0 = x[n * 3 + 0], x1 = x[n * 3 + 1], x2 = x[n * 3 + 2];
-            const float p0 = pp[n * 3 + 0], p1 = pp[n * 3 + 1], p2 = pp[n * 3 + 2];
-            const float b_ = wb[(size_t)n * KK + k], c_ = wc[(size_t)n * KK + k];
-            const int sv = sg[2 * n], bv = bl[2 * n];
-            const float b2 = b_ * b_, c2 = c_ * c_;
-            const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
-            acc[0] += b2 * p00; acc[1] += b2 * p01; acc[2] += b2 * p02; acc[3] += b2 * p11; acc[4] += b2 * p12; acc[5] += b2 * p22;
-            acc[6] += c2 * p00; acc[7] += c2 * p01; acc[8] += c2 * p02; acc[9] += c2 * p11; acc[10] += c2 * p12; acc[11] += c2 * p22;
-            const bool mine = sv == k;
-            if (normalize) {
-                acc[12] += (mine && bv == 0) ? 1.f : 0.f;
-                acc[13] += (mine && bv == 1) ? 1.f : 0.f;
+        // (as in the labels-implied loop: U points per thread requested before the first is used, nothing conditional in between)
+        constexpr int U = 4;
+        for (int n0 = g; n0 < N; n0 += U * G) {
+            float xq[U][3], pq[U][3], bq[U], cq[U];
+            int svq[U], bvq[U], nq[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = n0 + u * G, nc = n < N ? n : N - 1;
+                nq[u] = nc;
+                xq[u][0] = x[nc * 3 + 0]; xq[u][1] = x[nc * 3 + 1]; xq[u][2] = x[nc * 3 + 2];
+                pq[u][0] = pp[nc * 3 + 0]; pq[u][1] = pp[nc * 3 + 1]; pq[u][2] = pp[nc * 3 + 2];
+                bq[u] = wb[(size_t)nc * KK + k]; cq[u] = wc[(size_t)nc * KK + k];
+                svq[u] = sg[2 * nc]; bvq[u] = bl[2 * nc];
             }
-            const float w = mine ? 1.f : 0.f;
-            acc[14] += w * p0; acc[15] += w * p1; acc[16] += w * p2; acc[17] += w;
-            if (k == 0) {
-                if (PLDS) { Ps[n * 3 + 0] = p0; Ps[n * 3 + 1] = p1; Ps[n * 3 + 2] = p2; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int n = nq[u];
+                const bool live = n0 + u * G < N;
+                const float x0 = xq[u][0], x1 = xq[u][1], x2 = xq[u][2];
+                const float p0 = pq[u][0], p1 = pq[u][1], p2 = pq[u][2];
+                const float b_ = live ? bq[u] : 0.f, c_ = live ? cq[u] : 0.f;
+                const int sv = svq[u], bv = bvq[u];
+                const float b2 = b_ * b_, c2 = c_ * c_;
+                const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
+                acc[0] += b2 * p00; acc[1] += b2 * p01; acc[2] += b2 * p02; acc[3] += b2 * p11; acc[4] += b2 * p12; acc[5] += b2 * p22;
+                acc[6] += c2 * p00; acc[7] += c2 * p01; acc[8] += c2 * p02; acc[9] += c2 * p11; acc[10] += c2 * p12; acc[11] += c2 * p22;
+                const bool mine = live && sv == k;
+                if (normalize) {
+                    acc[12] += (mine && bv == 0) ? 1.f : 0.f;
+                    acc[13] += (mine && bv == 1) ? 1.f : 0.f;
+                }
+                const float w = mine ? 1.f : 0.f;
+                acc[14] += w * p0; acc[15] += w * p1; acc[16] += w * p2; acc[17] += w;
+                if (PLDS) { Ps[n * 3 + 0] = p0; Ps[n * 3 + 1] = p1; Ps[n * 3 + 2] = p2; }        // (every segment lane of the point: same address, same value)
                 keyb[n] = (signed char)((bv == 0 && sv >= 0 && sv < KK) ? (int)sv : -1);
             }
         }
     }
     FIT_TR(1);
+#ifdef P2C_FIT_TRACE
+    if (blockIdx.x == 0 && lane == 0) p2c_fit_stamps[16 + wave] = __builtin_readcyclecounter();
+#endif
     // the sample draws of this wave's first (segment, chunk) task: requested now, consumed after the reduction, the eigen-solve and the list
     // build (one dependent global load per 64 samples inside the projection loop was a third of the separate kernel's time)
     constexpr int nch = WAVES / KK, RU = 16;
@@ -666,6 +705,7 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
         double *wsum = reinterpret_cast<double *>(list);                  // [WAVES][KK][NA]
         if constexpr (HARD) {
             __syncthreads();                                              // (the keys / points parked above share no LDS with wsum; the lists do)
+            FIT_TR(8);
 #pragma unroll
             for (int j = 0; j < SPL; ++j)
 #pragma unroll
@@ -682,7 +722,9 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
             if (lane < KK) wsum[(wave * KK + lane) * NA + i] = (double)v;
         }
         }
+        FIT_TR(9);
         __syncthreads();
+        FIT_TR(10);
         if (tid < KK * NA) {
             const int rk = tid / NA, re = tid - rk * NA;
             double rs = 0.0;

@@ -33,8 +33,15 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); run(); e1.record(); torch.cuda.synchronize()
 print("fit_fused%s + finish: %.1f us" % (" (labels-implied memberships)" if HARD else "", e0.elapsed_time(e1) * 1e3))
-st = np.zeros(8, dtype=np.uint64)
+st = np.zeros(40, dtype=np.uint64)
 assert L.p2c_fit_trace_read(st.ctypes.data_as(vp)) == 0
 d_ = np.diff(st[:6].astype(np.int64))
 print("workgroup 0, shader cycles: stream %d | sums (shuffles + 16 waves) %d | eigen + centroid %d | lists %d | projection %d   (2.4 GHz: total %.1f us)"
       % (d_[0], d_[1], d_[2], d_[3], d_[4], d_.sum() / 2400.0))
+s64 = st.astype(np.int64)
+if s64[8] and s64[9] and s64[10]:
+    print("  inside 'sums': wait for the other waves' streams %d | class sums + LDS writes %d | barrier %d | 16-wave fp64 sums + barrier %d"
+          % (s64[8] - s64[1], s64[9] - s64[8], s64[10] - s64[9], s64[2] - s64[10]))
+
+if s64[16]:
+    print("  end of stream per wave, cycles after the kernel's start: %s" % [int(v - s64[0]) for v in s64[16:32]])

@@ -337,6 +337,14 @@ extern "C" int p2c_extrusion_centers_bwd_f32(const float *dcenters, const float 
 // (First version: one workgroup per (cloud, segment), each rescanning all N labels with four barriers per 256 points -
 //  1.09 ms for 1250 clouds x 8 segments; this one reads every label once.)
 // ------------------------------------------------------------------------------------------------
+#ifdef P2C_FIT_TRACE       // tools/fit_trace.py: shader-clock stamps of workgroup 0 at the phase boundaries
+__device__ unsigned long long p2c_fit_stamps[40];
+extern "C" int p2c_fit_trace_read(void *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_fit_stamps), sizeof(p2c_fit_stamps)) == hipSuccess ? 0 : 1; }
+#define FIT_TR(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) p2c_fit_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define FIT_TR(i) do { } while (0)
+#endif
+
 #define EXT_MAXN 32768
 #define EXT_THREADS 1024
 #define EXT_WAVES (EXT_THREADS / 64)
@@ -373,7 +381,9 @@ __device__ __forceinline__ void ext_build_lists_by(KeyF key_of, int N, int K, in
         for (int k = 0; k < FIT_MAXK; ++k)
             if (k < K) wcnt[wave][k] = cntk[k];
     }
+    FIT_TR(11);
     __syncthreads();
+    FIT_TR(12);
     // counts -> offsets, in place and in parallel (a single thread walking the K x 16 table, then every thread its K x wave prefix,
     // were two chains of dependent LDS reads: 10 us of the 80 a cloud takes in the one-pass kernel)
     int mine = 0, before = 0;
@@ -394,7 +404,9 @@ __device__ __forceinline__ void ext_build_lists_by(KeyF key_of, int N, int K, in
         for (int k = 0; k < K; ++k) { run += start[k + 1]; start[k + 1] = run; }
     }
     __syncthreads();
+    FIT_TR(13);
     // pass 2: ascending lists
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     int base[FIT_MAXK];
 #pragma unroll
     for (int k = 0; k < FIT_MAXK; ++k) base[k] = k < K ? start[k] + wcnt[wave][k] : 0;
@@ -408,14 +420,18 @@ __device__ __forceinline__ void ext_build_lists_by(KeyF key_of, int N, int K, in
             } else if (c0 + c < nch && n < n_end) {
                 kk = key_of(n);
             }
+            // the slot of this lane's point: ONE store per 64 points (a store under `if (kk == k)` inside the segment loop was eight
+            // exec-masked stores per chunk: 11 k of a cloud's cycles, tools/fit_trace.py)
+            int pos = 0;
 #pragma unroll
             for (int k = 0; k < FIT_MAXK; ++k) {
                 if (k < K) {
                     const unsigned long long m = __ballot(kk == k);
-                    if (kk == k) list[base[k] + __popcll(m & ((1ull << lane) - 1ull))] = n;
+                    pos = kk == k ? base[k] + (int)__popcll(m & lt_mask) : pos;
                     base[k] += __popcll(m);
                 }
             }
+            if (kk >= 0) list[pos] = n;
         }
     }
     __syncthreads();
@@ -540,13 +556,6 @@ extern "C" int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, con
 // extents_finish_kernel applies the batch-level rules afterwards, as for the separate kernel.
 // K a power of two <= 8 and 3N floats + N bytes + N ints within the LDS: other shapes take the three separate kernels.
 // ------------------------------------------------------------------------------------------------
-#ifdef P2C_FIT_TRACE       // tools/fit_trace.py: shader-clock stamps of workgroup 0 at the phase boundaries
-__device__ unsigned long long p2c_fit_stamps[40];
-extern "C" int p2c_fit_trace_read(void *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_fit_stamps), sizeof(p2c_fit_stamps)) == hipSuccess ? 0 : 1; }
-#define FIT_TR(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) p2c_fit_stamps[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define FIT_TR(i) do { } while (0)
-#endif
 
 // THREADS 1024 / PLDS: one workgroup per CU, the cloud's points parked in LDS.  THREADS 512 / !PLDS: two workgroups per CU (one streams
 // while the other is in its serial phases), the projection gathers its points from global memory (L2 / MALL: the workgroup has just read them).

@@ -412,6 +412,8 @@ class FittingWorkload:
         if fused:
             # The same clouds with the memberships IMPLIED by the labels (this workload's W are exactly the one-hot encodings of (seg, bb):
             # "pre-segmented cylinders"; SURVEY 8(d): "16 B of labels if one-hot is implied"): Wb / Wc are not read, 40 B per point.
+            # ONE route per object: the top level of the result is the labels-implied route - wall time, the kernel's own
+            # HIP-event time and both fractions - and `soft_membership_route` holds the same figures of the route that reads Wb / Wc.
             oh = self.fit(True, hard=True)
             for _ in range(2):
                 oh = self.fit(True, hard=True)
@@ -421,27 +423,30 @@ class FittingWorkload:
                 oh = self.fit(True, hard=True)
             torch.cuda.synchronize()
             dh = (time.perf_counter() - t0) / steps
+            ops.PROFILE.reset(enabled=True)
+            for _ in range(steps):
+                self.fit(True, hard=True)
+            ops.PROFILE.enabled = False
+            hprof = ops.PROFILE.summary()
+            ops.PROFILE.reset()
+            hms = hprof.get(kname, {}).get("ms", 0.0) / steps
             hbytes = self.points * (12 + 12 + 8 + 8) + self.n * self.K * self.S * 8
             dot = (oh[5] * out[5]).sum(-1).abs().clamp(max=1.0)
-            res["soft_membership_route"] = {k: res[k] for k in ("ms", "cylinders_per_s", "points_per_s", "kernel_us", "path_bytes", "frac_hbm_path_bytes",
-                                                                "frac_hbm_76B_per_point", "kernel_frac_hbm")}
-            res["soft_membership_route"]["what"] = ("the same kernel family READING Wb / Wc (B,N,K) fp32 - what soft (predicted) memberships need: 104 B/point; "
-                                                    "the top-level numbers of this object are the labels-implied route below, the one configs[3]'s pre-segmented "
-                                                    "clouds call for")
-            res["labels_implied"] = dict(
-                what="p2c_fit_fused_f32 with Wb = Wc = NULL: memberships implied by (seg, bb), not read; lane-per-point streaming",
-                ms=round(dh * 1e3, 4), cylinders_per_s=round(self.n * self.K / dh, 1), path_bytes=hbytes,
-                frac_hbm_path_bytes=round(hbytes / dh / PEAK_HBM, 4), frac_hbm_76B_per_point=round(self.survey_bytes / dh / PEAK_HBM, 4),
-                frac_note="frac_hbm_76B_per_point prices the time against SURVEY 8(d)'s 76 B/point although this route reads 40 B/point (+ the "
-                          "pre-drawn samples): it is the fraction the survey's byte model would see, frac_hbm_path_bytes the one of the bytes really read",
-                vs_general_route=dict(max_axis_angle_deg=float(torch.rad2deg(torch.acos(dot)).max()),
-                                      max_centroid_diff=float((oh[1] - out[1]).abs().max()), max_extent_diff=float((oh[3] - out[3]).abs().max()),
-                                      found_masks_equal=bool(torch.equal(oh[2], out[2]) and torch.equal(oh[4], out[4]))))
-            li = res["labels_implied"]
-            res.update(ms=li["ms"], cylinders_per_s=li["cylinders_per_s"], points_per_s=round(self.points / dh, 1), path_bytes=hbytes,
-                       frac_hbm_path_bytes=li["frac_hbm_path_bytes"], frac_hbm_76B_per_point=li["frac_hbm_76B_per_point"],
-                       kernels="one pass per cloud (fit_fused, memberships implied by the labels: Wb = Wc = NULL)", kernel_us=None, kernel_frac_hbm=None,
-                       route="labels-implied memberships (pre-segmented clouds); soft_membership_route = the same with Wb / Wc read")
+            soft = {k: res[k] for k in ("ms", "cylinders_per_s", "points_per_s", "kernel_us", "path_bytes", "frac_hbm_path_bytes",
+                                        "frac_hbm_76B_per_point", "kernel_frac_hbm")}
+            soft["route"] = "Wb / Wc (B,N,K) fp32 read: what soft (predicted) memberships need, 104 B/point"
+            res = dict(workload=res["workload"], route="labels-implied memberships (pre-segmented clouds): Wb = Wc = NULL, 40 B/point + the pre-drawn samples",
+                       kernels="one pass per cloud (p2c_fit_fused_f32) + the batch-level finish", kernel=kname,
+                       ms=round(dh * 1e3, 4), cylinders_per_s=round(self.n * self.K / dh, 1), points_per_s=round(self.points / dh, 1),
+                       kernel_us=round(hms * 1e3, 1), path_bytes=hbytes, frac_hbm_path_bytes=round(hbytes / dh / PEAK_HBM, 4),
+                       kernel_frac_hbm=round(hbytes / (hms * 1e-3) / PEAK_HBM, 4) if hms else None,
+                       survey_bytes_76_per_point=self.survey_bytes, frac_hbm_76B_per_point=round(self.survey_bytes / dh / PEAK_HBM, 4),
+                       per_kernel={k: dict(ms_per_pass=round(v["ms"] / steps, 4), launches_per_pass=v["launches"] / steps)
+                                   for k, v in sorted(hprof.items(), key=lambda kv: -kv[1]["ms"])},
+                       vs_general_route=dict(max_axis_angle_deg=float(torch.rad2deg(torch.acos(dot)).max()),
+                                             max_centroid_diff=float((oh[1] - out[1]).abs().max()), max_extent_diff=float((oh[3] - out[3]).abs().max()),
+                                             found_masks_equal=bool(torch.equal(oh[2], out[2]) and torch.equal(oh[4], out[4]))),
+                       soft_membership_route=soft)
             out = oh
         return res, out
 

@@ -116,7 +116,7 @@ def main():
                               unit="GB/s", frac=res["kernel_frac_hbm"] or res["frac_hbm_path_bytes"], avg_launch_us=res["kernel_us"], traffic=None,
                               path=dict(ms=res["ms"], algorithmic_bytes=res["path_bytes"], frac=res["frac_hbm_path_bytes"],
                                         survey_76B_per_point_bytes=res["survey_bytes_76_per_point"], frac_76B_per_point=res["frac_hbm_76B_per_point"])),
-                cpu_baseline=cpu, parity=parity, kernels=res["per_kernel"], route=res.get("route"), labels_implied=res.get("labels_implied"),
+                cpu_baseline=cpu, parity=parity, kernels=res["per_kernel"], route=res.get("route"), vs_general_route=res.get("vs_general_route"),
                 soft_membership_route=res.get("soft_membership_route"))
     print(json.dumps(line))
 

@@ -45,3 +45,7 @@ if s64[8] and s64[9] and s64[10]:
 
 if s64[16]:
     print("  end of stream per wave, cycles after the kernel's start: %s" % [int(v - s64[0]) for v in s64[16:32]])
+
+if s64[11] and s64[13]:
+    print("  inside 'lists': keys + counts %d | barrier %d | offsets (3 barriers) %d | placement + barrier %d"
+          % (s64[11] - s64[3], s64[12] - s64[11], s64[13] - s64[12], s64[4] - s64[13]))

@@ -514,7 +514,7 @@ int p2c_hungarian_logits_f32(const float *heads, int ld, int woff, const int64_t
  * The training losses fused (losses.py:90-143, :317-351 with collapse=True; train…:247-307):
  * normal loss mean(1-|X.n_gt|), Hungarian-matched mIoU loss, base/barrel weighted cross-entropy, forward AND gradient
  * w.r.t. the head output in two passes.  heads [B*N, ld]: normals at columns [xoff,xoff+3), 2K logits at [woff,woff+2K).
- * out[4] = {total, normal, miou, bb}; dheads [B*N, ld] = d total / d heads.  ws: zeroed p2c_seg_losses_ws_bytes(B,K).  K in {2, 4, 8}. */
+ * out[4] = {total, normal, miou, bb}; dheads [B*N, ld] = d total / d heads.  ws: zeroed p2c_seg_losses_ws_bytes(B,K).  K = 1 ... 8. */
 size_t p2c_seg_losses_ws_bytes(int B, int K);
 int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff, const float *normals_gt, const int64_t *I_gt,
                        const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
@@ -529,14 +529,14 @@ int p2c_seg_losses_grad_f32(const float *heads, int ld, int xoff, int woff, cons
  * out2[0] = w_ext * mean_b masked-mean_k (1 - |E_AX . gt_axes|)   (losses.py:127-143 angle_diff=False, :83-88; train_Point2Cyl_without_sketch.py:326-332),
  * out2[1] = w_center * mean_b masked-mean_k |centers - gt_centers|^2   (:342-353).  mask [B,K] bytes = k < instances of cloud b (p2c_hungarian_f32's
  * mask; a cloud without instances contributes 0).  dE / dC [B,K,3] = d out2[0] / d E_AX, d out2[1] / d centers (NULL: not wanted).  E_AX or centers
- * NULL: that term is off (0).  K must divide 256. */
+ * NULL: that term is off (0).  K <= 256. */
 int p2c_fit_terms_f32(const float *E_AX, const float *gt_axes, const float *centers, const float *gt_centers, const uint8_t *mask,
                       int B, int K, float w_ext, float w_center, float *out2, float *dE, float *dC, void *stream);
 
 /* compute_all_losses on its own inputs (losses.py:317-351, collapse=True): W [B,N,K] softmaxed membership and X [B,N,3] unit normals as the
  * reference's trainer forms them in torch (train_Point2Cyl_without_sketch.py:246-271) - what the drop-in of that function is handed.
  * match / mask [B,K] from p2c_hungarian_f32.  out2 = {mean normal loss, mean mIoU loss}; dW [B,N,K] = d out2[1] / d W and
- * dX [B,N,3] = d out2[0] / d X (unweighted: the caller applies its multipliers).  ws: zeroed p2c_all_losses_ws_bytes(B,K).  K in {2,4,8}. */
+ * dX [B,N,3] = d out2[0] / d X (unweighted: the caller applies its multipliers).  ws: zeroed p2c_all_losses_ws_bytes(B,K).  K = 1 ... 8. */
 size_t p2c_all_losses_ws_bytes(int B, int K);
 int p2c_all_losses_f32(const float *W, const float *X, const float *normals_gt, const int64_t *I_gt, const int64_t *match,
                        const uint8_t *mask, int B, int N, int K, float *out2, float *dW, float *dX, void *ws, void *stream);

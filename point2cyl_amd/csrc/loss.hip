@@ -210,14 +210,14 @@ __global__ void __launch_bounds__(256) loss_grad_kernel(LossArgs a)
 extern "C" size_t p2c_seg_losses_ws_bytes(int B, int K) { return (size_t)B * (3 * K + 2) * sizeof(double) + (size_t)B * 2 * K * sizeof(float); }
 
 // losses.py:317-351 (compute_all_losses, collapse=True) + the base/barrel block of train…:283-307, forward AND gradient.
-// ws: zeroed p2c_seg_losses_ws_bytes(B,K).  out[4] = {total, normal, miou, bb}.  K in {2, 4, 8} (the reference's default is 8).
+// ws: zeroed p2c_seg_losses_ws_bytes(B,K).  out[4] = {total, normal, miou, bb}.  K = 1 ... 8 (the reference's default is 8; its --K is free).
 extern "C" int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff, const float *normals_gt, const int64_t *I_gt,
                                   const int64_t *bb_gt, const int64_t *match, const uint8_t *mask, int B, int N, int K, float w_seg,
                                   float w_normal, float w_bb, float *out, float *dheads, void *ws, void *stream)
 {
     // dheads == NULL: the two forward launches only; the gradient then comes from p2c_seg_losses_grad_f32 with the same ws
     if (!heads || !normals_gt || !I_gt || !bb_gt || !match || !mask || !out || !ws || B <= 0 || N <= 0) return P2C_EINVAL;
-    if (K != 2 && K != 4 && K != 8) return P2C_EINVAL;
+    if (K < 1 || K > 8) return P2C_EINVAL;
     LossArgs a{heads, ld, xoff, woff, normals_gt, I_gt, bb_gt, match, mask, B, N, K, w_seg, w_normal, w_bb, (double *)ws, out,
                (float *)((char *)ws + (size_t)B * (3 * K + 2) * sizeof(double)), dheads, nullptr};
     hipStream_t s = (hipStream_t)stream;
@@ -228,9 +228,10 @@ extern "C" int p2c_seg_losses_f32(const float *heads, int ld, int xoff, int woff
         hipLaunchKernelGGL(loss_finalize_kernel<K_>, dim3(1), dim3(256), 0, s, a);       \
         if (dheads) hipLaunchKernelGGL(loss_grad_kernel<K_>, grid, dim3(256), 0, s, a);  \
     } while (0)
-    if (K == 8) P2C_LK(8);
-    else if (K == 4) P2C_LK(4);
-    else P2C_LK(2);
+    switch (K) {
+    case 1: P2C_LK(1); break; case 2: P2C_LK(2); break; case 3: P2C_LK(3); break; case 4: P2C_LK(4); break;
+    case 5: P2C_LK(5); break; case 6: P2C_LK(6); break; case 7: P2C_LK(7); break; default: P2C_LK(8); break;
+    }
 #undef P2C_LK
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -244,14 +245,17 @@ extern "C" int p2c_seg_losses_grad_f32(const float *heads, int ld, int xoff, int
                                        float w_normal, float w_bb, const float *gscale, float *dheads, void *ws, void *stream)
 {
     if (!heads || !normals_gt || !I_gt || !bb_gt || !match || !mask || !dheads || !ws || B <= 0 || N <= 0) return P2C_EINVAL;
-    if (K != 2 && K != 4 && K != 8) return P2C_EINVAL;
+    if (K < 1 || K > 8) return P2C_EINVAL;
     LossArgs a{heads, ld, xoff, woff, normals_gt, I_gt, bb_gt, match, mask, B, N, K, w_seg, w_normal, w_bb, (double *)ws, nullptr,
                (float *)((char *)ws + (size_t)B * (3 * K + 2) * sizeof(double)), dheads, gscale};
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(p2c_cdiv(N, 256), B);
-    if (K == 8) hipLaunchKernelGGL(loss_grad_kernel<8>, grid, dim3(256), 0, s, a);
-    else if (K == 4) hipLaunchKernelGGL(loss_grad_kernel<4>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(loss_grad_kernel<2>, grid, dim3(256), 0, s, a);
+#define P2C_LG(K_) hipLaunchKernelGGL(loss_grad_kernel<K_>, grid, dim3(256), 0, s, a)
+    switch (K) {
+    case 1: P2C_LG(1); break; case 2: P2C_LG(2); break; case 3: P2C_LG(3); break; case 4: P2C_LG(4); break;
+    case 5: P2C_LG(5); break; case 6: P2C_LG(6); break; case 7: P2C_LG(7); break; default: P2C_LG(8); break;
+    }
+#undef P2C_LG
     P2C_LAUNCH_CHECK();
     return P2C_OK;
 }
@@ -476,7 +480,7 @@ extern "C" int p2c_all_losses_f32(const float *W, const float *X, const float *n
                                   const uint8_t *mask, int B, int N, int K, float *out2, float *dW, float *dX, void *ws, void *stream)
 {
     if (!W || !X || !normals_gt || !I_gt || !match || !mask || !out2 || !dW || !dX || !ws || B <= 0 || N <= 0) return P2C_EINVAL;
-    if (K != 2 && K != 4 && K != 8) return P2C_EINVAL;
+    if (K < 1 || K > 8) return P2C_EINVAL;
     AllLossArgs a{W, X, normals_gt, I_gt, match, mask, B, N, (double *)ws, out2,
                   (float *)((char *)ws + (size_t)B * (3 * K + 1) * sizeof(double)), dW, dX};
     hipStream_t s = (hipStream_t)stream;
@@ -487,9 +491,10 @@ extern "C" int p2c_all_losses_f32(const float *W, const float *X, const float *n
         hipLaunchKernelGGL(all_losses_finalize_kernel<K_>, dim3(1), dim3(256), 0, s, a);     \
         hipLaunchKernelGGL(all_losses_grad_kernel<K_>, grid, dim3(256), 0, s, a);            \
     } while (0)
-    if (K == 8) P2C_ALK(8);
-    else if (K == 4) P2C_ALK(4);
-    else P2C_ALK(2);
+    switch (K) {
+    case 1: P2C_ALK(1); break; case 2: P2C_ALK(2); break; case 3: P2C_ALK(3); break; case 4: P2C_ALK(4); break;
+    case 5: P2C_ALK(5); break; case 6: P2C_ALK(6); break; case 7: P2C_ALK(7); break; default: P2C_ALK(8); break;
+    }
 #undef P2C_ALK
     P2C_LAUNCH_CHECK();
     return P2C_OK;
@@ -514,9 +519,10 @@ __global__ void __launch_bounds__(256) fit_terms_kernel(const float *__restrict_
     if (tid < 2) acc[tid] = 0.0;
     __syncthreads();
     const int BK = B * K;
-    for (int base = 0; base < BK; base += 256) {          // K divides 256 (K in {1, 2, 4, 8, ...}): a cloud's K entries lie in one pass
+    const int P = (256 / K) * K;                            // entries per pass: whole clouds only, so a cloud's K entries lie in one pass
+    for (int base = 0; base < BK; base += P) {
         const int e = base + tid;
-        const bool ok = e < BK;
+        const bool ok = tid < P && e < BK;
         const bool m = ok && mask[e] != 0;
         float ext = 0.f, cen = 0.f, sgn = 0.f;
         float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -561,7 +567,7 @@ __global__ void __launch_bounds__(256) fit_terms_kernel(const float *__restrict_
 extern "C" int p2c_fit_terms_f32(const float *E_AX, const float *gt_axes, const float *centers, const float *gt_centers, const uint8_t *mask,
                                  int B, int K, float w_ext, float w_center, float *out2, float *dE, float *dC, void *stream)
 {
-    if (!mask || !out2 || B <= 0 || K <= 0 || K > 256 || (256 % K) != 0) return P2C_EINVAL;
+    if (!mask || !out2 || B <= 0 || K <= 0 || K > 256) return P2C_EINVAL;
     if ((E_AX && !gt_axes) || (centers && !gt_centers)) return P2C_EINVAL;
     hipLaunchKernelGGL(fit_terms_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, E_AX, gt_axes, centers, gt_centers, mask, B, K, w_ext,
                        w_center, out2, dE, dC);

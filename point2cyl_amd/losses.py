@@ -96,11 +96,11 @@ def compute_normal_difference(X, X_gt, in_radians=True, collapse=True):
 
 def compute_all_losses(P, W, I_gt, X, X_gt, normal_loss_multiplier, miou_loss_multiplier, return_match_indices=False,
                        collapse=True):
-    """losses.py:317-351.  On the device with both multipliers > 0, collapse and K in {2, 4, 8} the matching, both reductions and their
+    """losses.py:317-351.  On the device with both multipliers > 0, collapse and K <= 8 the matching, both reductions and their
     gradient are three launches of csrc/loss.hip (ops.all_losses) instead of ~35 torch launches forward and as many backward; every
     other call takes the torch expressions below (same values: tests/test_gpu_parity.py)."""
     B, _, K = W.shape
-    if (FUSED_ALL_LOSSES and W.is_cuda and collapse and K in (2, 4, 8) and normal_loss_multiplier > 0 and miou_loss_multiplier > 0
+    if (FUSED_ALL_LOSSES and W.is_cuda and collapse and 1 <= K <= 8 and normal_loss_multiplier > 0 and miou_loss_multiplier > 0
             and W.dtype == torch.float32 and X.dtype == torch.float32):
         out3, matching_indices, mask = ops.all_losses(W, X, X_gt, I_gt, normal_loss_multiplier, miou_loss_multiplier)
         if return_match_indices:

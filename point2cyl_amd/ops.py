@@ -1484,7 +1484,7 @@ class _AllLosses(torch.autograd.Function):
 
 
 def all_losses(W, X, normals_gt, I_gt, w_normal, w_seg):
-    """-> (out3 = [total, normal, miou], matching_indices (B,K) int64, mask (B,K) bool); K in {2, 4, 8}."""
+    """-> (out3 = [total, normal, miou], matching_indices (B,K) int64, mask (B,K) bool); K = 1 ... 8."""
     _lib.require_device(W, X, normals_gt, I_gt)
     out3, match, mask = _AllLosses.apply(W, X, normals_gt, I_gt, w_normal, w_seg)
     return out3, match, mask.bool()

@@ -83,7 +83,7 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
     B, N, _ = pcs.shape
     K = fl.K
     heads, sizes = model.forward_heads(pcs, geom) if geom is not None else model.forward_heads(pcs)
-    assert sizes == [3, 2 * K] and fl.pred_seg and fl.pred_normal and fl.pred_bb and K in (2, 4, 8)
+    assert sizes == [3, 2 * K] and fl.pred_seg and fl.pred_normal and fl.pred_bb and 1 <= K <= 8
     out4, match, mask = ops.seg_losses(heads, gt_normals, gt_inst, gt_bb, B, N, K, 0, 3, fl.weight_seg, fl.weight_normal, fl.weight_bb)
     total = out4[0]
     zero = _ZEROS.get(pcs.device)
@@ -101,7 +101,7 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
             res["E_AX"] = E_AX                                   # (with its history: train_Point2Cyl.py:528 feeds it to the sketch encoder)
         if fl.pred_center:
             cen = fitting.estimate_extrusion_centers(Wb_re + Wc_re, pcs)
-        if FUSED_FIT_TERMS and 256 % K == 0:
+        if FUSED_FIT_TERMS:
             # both terms, forward and gradient, in one launch; the matching's mask IS losses.get_mask_gt(gt_inst, K) (k < instances of the cloud)
             terms = ops.fit_terms(E_AX, gt_axes, cen, gt_centers, mask, fl.weight_extrusion, fl.weight_center)
             ext_loss, center_loss = (terms[0] if fl.pred_extrusion else zero), (terms[1] if fl.pred_center else zero)
@@ -122,7 +122,7 @@ def compute_losses_fused(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_cen
 
 
 def fused_loss_applicable(fl: StepFlags):
-    return fl.pred_seg and fl.pred_normal and fl.pred_bb and fl.K in (2, 4, 8)
+    return fl.pred_seg and fl.pred_normal and fl.pred_bb and 1 <= fl.K <= 8
 
 
 def compute_losses(model, pcs, gt_normals, gt_inst, gt_bb, gt_axes, gt_centers, fl: StepFlags, geom=None):

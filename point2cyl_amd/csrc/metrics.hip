@@ -96,7 +96,10 @@ __global__ void __launch_bounds__(EV_THREADS) eval_sums_kernel(const float *__re
             for (int q = 0; q < KK; ++q) {
                 const float pb = e[2 * q] / sum, pc_ = e[2 * q + 1] / sum;         // eval.py:278-286
                 const float w = pb + pc_;                                          // :289
-                bb0 += pb; bb1 += pc_;                                             // :297-300
+                // :297-300, in index order.  (The base/barrel decision bb1 > bb0 of a point whose two sums agree to an ulp depends on the
+                // summation order of W_barrel.sum(-1): against the torch chain on the device ~2 of 8.4 M untrained-network points fall
+                // the other way - 2e-7 of the accuracy; a four-accumulator order, tried, was further off.)
+                bb0 += pb; bb1 += pc_;
                 if (w > best) { best = w; pred = q; }                              // argmax: first maximum (losses.py:60)
                 s_b2[tid][q] = pb * pb; s_c2[tid][q] = pc_ * pc_; s_w[tid][q] = w;
             }

@@ -430,7 +430,7 @@ def main(argv=None):
         if hi >= a.K or lo < -1:
             raise ValueError("instance labels must be in [-1, %d); got [%d, %d]" % (a.K, lo, hi))
         extras = dict(barrel_counts=fitting.barrel_counts(inst.long(), bb.long(), a.K), labels_validated=True)
-        if draw_gen[0] is not None:
+        if draw_gen[0]:
             # fused pipelined loop: the extent samples of a batch (data_utils.py:1696: K x B torch.randint calls on the CPU generator, 0.8 ms of
             # host time and a 4 MB upload per batch) are drawn ON THE DEVICE from the barrel counts uploaded here (FusedMetrics; another
             # equally valid sampling - the reference's stream is what --no_prefetch keeps)
@@ -454,9 +454,9 @@ def main(argv=None):
     import queue
     import threading
     fused = None
-    if fused_metrics_applicable(fl) and not (a.no_prefetch or a.with_sketch_fit or a.no_graph_metrics or a.no_fused_metrics):
+    if fused_metrics_applicable(fl) and not (a.with_sketch_fit or a.no_graph_metrics or a.no_fused_metrics):
         fused = FusedMetrics(fl, acc.keys)
-        draw_gen[0] = True
+        draw_gen[0] = not a.no_prefetch         # (--no_prefetch: the extent draws stay on the CPU generator, in the reference's order)
     if not a.no_prefetch and hasattr(ds, "generator"):
         ds.generator = torch.Generator().manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
     it = iter(loader)
@@ -502,6 +502,19 @@ def main(argv=None):
         return all(tuple(b[0].shape) == tuple(bs[0][0].shape) for b in bs) and bs[0][0].shape[2] == 3
 
     def evaluate(b, heads=None):
+        if fused is not None and b[0].shape[2] == 3:
+            # serial batches (--no_prefetch, the last short group): the same two metric kernels behind the plain forward; the CPU
+            # generator is consumed as in the reference - FPS starts inside the forward, then the extent draws (FusedMetrics)
+            with torch.no_grad():
+                if heads is not None:
+                    h = heads
+                else:            # (what model(pcs) runs: the per-shape HIP graph of the forward where it applies)
+                    from . import autograph
+                    h = autograph.forward_heads(model, b[0]) if autograph.applicable(model, b[0]) else None
+                    h = h if h is not None else model.forward_heads(b[0])
+            if list(h[1]) == [3, 2 * fl.K]:
+                return acc.add_block(fused(b, h))
+            heads = h
         ex = {k: v for k, v in b[6].items() if k in ("barrel_counts", "labels_validated", "extent_rand_idx")}
         m = evaluate_batch(model, *b[:6], fl, heads=heads, **ex)
         if a.with_sketch_fit:

@@ -610,7 +610,7 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
         // instead of a bounds branch; every lane of a point's group parks the point - same address, same value - instead of one lane under
         // a branch).  With the branch in the loop body the compiler drained the memory counter in every iteration: one point per lane in
         // flight, 10 KB per CU, and the streaming phase ran at the memory LATENCY (51 - 64 k of a cloud's 117 k cycles, round 5's trace).
-        constexpr int U = 4, NSTEP = THREADS / LPP;
+        constexpr int U = 4, NSTEP = THREADS / LPP;         // (2: same time - the CU's memory path, not the depth, sets the rate; 8: spills)
         for (int n0 = tid / LPP; n0 < N; n0 += U * NSTEP) {
             float xq[U][3], pq[U][3];
             int svq[U], bvq[U], nq[U];

@@ -2,7 +2,7 @@
    Build here: python tools/fit_trace.py --build     Run on the GPU box: python tools/fit_trace.py"""
 import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
-LIB = os.path.join(HERE, "libp2c_fit_trace.so")
+LIB = os.environ.get("P2C_FIT_TRACE_LIB") or os.path.join(HERE, "libp2c_fit_trace.so")
 if "--build" in sys.argv:
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_FIT_TRACE", "-shared", "-o", LIB,
                            os.path.join(ROOT, "point2cyl_amd", "csrc", "fit.hip")])

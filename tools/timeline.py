@@ -27,7 +27,7 @@ def main():
     everything = "--all" in sys.argv          # every launch (also the < 8 us ones) with the idle time in front of it
     argv = [a for a in sys.argv if a != "--all"]
     back = int(argv[2]) if len(argv) > 2 else 2
-    marks = [i for i, r in enumerate(rows) if (r[2].startswith("fps_kernel<8, false") or r[2].startswith("fps_pk_kernel<8"))]
+    marks = [i for i, r in enumerate(rows) if (r[2].startswith("fps_kernel<8, false") or r[2].startswith("fps_pk_kernel<"))]
     if len(marks) < back + 2:
         raise SystemExit("trace holds %d steps only" % len(marks))
     # duration statistics per (kernel name, occurrence index within its step)

@@ -958,7 +958,12 @@ static int launch_bwd_both(const float *dZ, int lddz, const float *Yfwd, int ldy
     EpiBwdData eA{dX, lddx, nullptr, 0, 1.f, 0u, Yprev, ldyp, prev_stat, bwd_partials, nullptr, 0, 0.f, 0.f};
     OpActIn<IMODE> x{X, ldx, in_scale, in_shift, nullptr, 0, 1.f};
     EpiAtomic eB{dW, lddw, nullptr, 0};
-    const int nAx = p2c_cdiv(M, 64), nAy = p2c_cdiv(K, 64), nA = nAx * nAy;
+    // dX tiles: 64 x 64, or 64 x 128 when that still leaves >= 256 of them (SA3's 512 -> 1024 layer: half the re-reads of the rebuilt dY;
+    // same-box A/B 3.839 -> 3.815 ms per step, the four dual launches 0.252 -> 0.232 ms).  Round 6 also swept the other launch knobs of
+    // this file on the step (tile width of forward / backward-data, split thresholds, workgroup targets and minimum k-tiles of the split
+    // reductions: tools history): every alternative within +-0.02 ms of the defaults or slower.
+    const bool wideA = (long long)p2c_cdiv(M, 64) * p2c_cdiv(K, 128) >= 256;
+    const int nAx = p2c_cdiv(M, 64), nAy = p2c_cdiv(K, wideA ? 128 : 64), nA = nAx * nAy;
     const int kpsA = (N + GK - 1) / GK * GK;
     const int ti = p2c_cdiv(N, 128), tj = p2c_cdiv(K, 128);
     const int ktiles = (M + GK - 1) / GK;
@@ -967,7 +972,10 @@ static int launch_bwd_both(const float *dZ, int lddz, const float *Yfwd, int ldy
     if (splits > (ktiles + 3) / 4) splits = (ktiles + 3) / 4;
     const int kpsB = (ktiles + splits - 1) / splits * GK;
     splits = (M + kpsB - 1) / kpsB;
-    if (gemm_split_t())
+    if (gemm_split_t() && wideA)
+        hipLaunchKernelGGL((gemm_dual_kernel<2, 2, 2, OpGrad<GMODE>, OpActIn<IMODE>, true>), dim3(nA + ti * tj * splits), dim3(256), 0, s, g, w, eA, M, K, N,
+                           kpsA, nAx, nA, g, x, eB, N, K, M, kpsB, ti, tj);
+    else if (gemm_split_t())
         hipLaunchKernelGGL((gemm_dual_kernel<1, 2, 2, OpGrad<GMODE>, OpActIn<IMODE>, true>), dim3(nA + ti * tj * splits), dim3(256), 0, s, g, w, eA, M, K, N,
                            kpsA, nAx, nA, g, x, eB, N, K, M, kpsB, ti, tj);
     else

@@ -181,7 +181,7 @@ class _Replay(torch.autograd.Function):
         if ctx.generation != cap.generation:
             raise RuntimeError("point2cyl_amd.autograph: backward through a forward pass that is not the latest one of its shape - the activations "
                                "saved inside the HIP graph now belong to forward #%d, this backward belongs to #%d.  Run forward -> backward per "
-                               "(micro-)batch, or set P2C_AUTOGRAPH=0 for the eager path (INTEGRATION.md, 'autograd contract')"
+                               "(micro-)batch, or set P2C_AUTOGRAPH=0 P2C_STAGE_WEIGHTS=0 for the eager path with per-forward weight copies (INTEGRATION.md, 'autograd contract')"
                                % (cap.generation, ctx.generation))
         if gout.data_ptr() != cap.gout.data_ptr():
             cap.gout.copy_(gout)

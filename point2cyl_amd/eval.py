@@ -357,7 +357,9 @@ def build_parser():
     p.add_argument("--random_init", action="store_true", help="no checkpoint: evaluate a randomly initialised backbone (plumbing / timing runs)")
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--no_prefetch", action="store_true", help="run FPS / ball query / 3-NN of every batch on the critical path instead of one batch "
-                   "ahead on a forked stream (graph.PipelinedForward)")
+                   "ahead on a forked stream (graph.PipelinedForward), no loader thread: the ONLY mode that consumes the CPU random generator in "
+                   "the reference's order (FPS starts, then extent samples, batch by batch); the default draws the same quantities in another order / "
+                   "on the device")
     p.add_argument("--prefetch_group", type=int, default=4, help="batches whose geometry is computed TOGETHER, one group ahead (FPS is 512 dependent "
                    "steps per cloud whether 32 or 128 clouds are sampled: its latency is shared by the group; 1 = one batch ahead)")
     p.add_argument("--report", type=str, default="", help="write a JSON throughput report here")
@@ -464,19 +466,35 @@ def main(argv=None):
     G = max(1, int(a.prefetch_group))
     ready, drained = queue.Queue(maxsize=2 * G + 2), [False]
 
+    stop = threading.Event()          # set when the consuming loop ends - normally or by an exception: the producer then lets go of its buffers
+
+    def hand_over(item):
+        while not stop.is_set():
+            try:
+                ready.put(item, timeout=0.2)
+                return True
+            except queue.Full:
+                pass
+        return False
+
     def produce():
         try:
             torch.cuda.set_device(dev)
             for b in it:
+                if stop.is_set():
+                    return
                 t = to_device(b)
                 torch.cuda.current_stream().synchronize()        # the copies (and --add_noise's float64 -> float32 cast) of this thread's stream:
-                ready.put(t)                                     # done before the pinned buffers are written again, and before the loop reads
-            ready.put(None)
+                if not hand_over(t):                             # done before the pinned buffers are written again, and before the loop reads
+                    return
+            hand_over(None)
         except BaseException as e:          # surfaces in the consuming loop
-            ready.put(e)
+            hand_over(e)
 
+    producer = None
     if not a.no_prefetch:
-        threading.Thread(target=produce, daemon=True).start()
+        producer = threading.Thread(target=produce, daemon=True)
+        producer.start()
 
     waited = [0.0]
 
@@ -525,51 +543,61 @@ def main(argv=None):
     t_first = None
     stream = torch.cuda.Stream(dev)
     stream.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(stream):
+    try:
+        with torch.cuda.stream(stream):
+            while True:
+                group = None
+                fill(1 if a.no_prefetch else 2 * G)          # (--no_prefetch: nothing is read ahead, every draw in the reference's order)
+                if not pending:
+                    break
+                head = list(pending)[:G]
+                can = not a.no_prefetch and len(head) == G and same(head) and (pipe is None or tuple(head[0][0].shape) == pipe_shape)
+                nxt = list(pending)[G:2 * G]
+                if not (len(nxt) == G and same(nxt) and can and tuple(nxt[0][0].shape) == tuple(head[0][0].shape)):
+                    nxt = None
+                if can and (pipe is not None or nxt is not None):          # (a pipeline is only STARTED when there is a next full group to prefetch for)
+                    group = [pending.popleft() for _ in range(G)]
+                    if pipe is None:
+                        from .graph import PipelinedForward
+                        pipe, pipe_shape = PipelinedForward(model, [b[0] for b in group], stream=stream, group=G), tuple(group[0][0].shape)
+                    outs = pipe([b[0] for b in nxt] if nxt is not None else None)
+                    for b, h in zip(group, outs):
+                        if fused is not None and list(h[1]) == [3, 2 * fl.K]:
+                            acc.add_block(fused(b, h))
+                        elif a.with_sketch_fit or a.no_graph_metrics:
+                            evaluate(b, heads=h)
+                        elif metrics_graph is None or metrics_graph.inp[0].shape != b[0].shape:
+                            metrics_graph = GraphedMetrics(fl, acc.keys, b, h)
+                            acc.add_block(metrics_graph())
+                        else:
+                            acc.add_block(metrics_graph(b, h))
+                    n_piped += G
+                    done = G
+                    if nxt is None:
+                        pipe.release()        # no further full group: what is left (a short last group, another shape) takes the serial forward
+                        pipe = None
+                else:
+                    if pipe is not None:
+                        pipe.release()
+                        pipe = None
+                    evaluate(pending.popleft())
+                    done = 1
+                if (i // 20) != ((i + done) // 20) or i == 0:
+                    if rank == 0:
+                        print("Time elapsed: %s sec for batch %d/%d." % (time.time() - t0, i, len(loader)))
+                if t_first is None:
+                    torch.cuda.synchronize()
+                    t_first, i_first, waited[0] = time.time(), i + done, 0.0
+                i += done
+    finally:
+        stop.set()                      # (a loop that raises must not leave the producer blocked on a full queue)
         while True:
-            group = None
-            fill(1 if a.no_prefetch else 2 * G)          # (--no_prefetch: nothing is read ahead, every draw in the reference's order)
-            if not pending:
+            try:
+                ready.get_nowait()
+            except queue.Empty:
                 break
-            head = list(pending)[:G]
-            can = not a.no_prefetch and len(head) == G and same(head) and (pipe is None or tuple(head[0][0].shape) == pipe_shape)
-            nxt = list(pending)[G:2 * G]
-            if not (len(nxt) == G and same(nxt) and can and tuple(nxt[0][0].shape) == tuple(head[0][0].shape)):
-                nxt = None
-            if can and (pipe is not None or nxt is not None):          # (a pipeline is only STARTED when there is a next full group to prefetch for)
-                group = [pending.popleft() for _ in range(G)]
-                if pipe is None:
-                    from .graph import PipelinedForward
-                    pipe, pipe_shape = PipelinedForward(model, [b[0] for b in group], stream=stream, group=G), tuple(group[0][0].shape)
-                outs = pipe([b[0] for b in nxt] if nxt is not None else None)
-                for b, h in zip(group, outs):
-                    if fused is not None and list(h[1]) == [3, 2 * fl.K]:
-                        acc.add_block(fused(b, h))
-                    elif a.with_sketch_fit or a.no_graph_metrics:
-                        evaluate(b, heads=h)
-                    elif metrics_graph is None or metrics_graph.inp[0].shape != b[0].shape:
-                        metrics_graph = GraphedMetrics(fl, acc.keys, b, h)
-                        acc.add_block(metrics_graph())
-                    else:
-                        acc.add_block(metrics_graph(b, h))
-                n_piped += G
-                done = G
-                if nxt is None:
-                    pipe.release()        # no further full group: what is left (a short last group, another shape) takes the serial forward
-                    pipe = None
-            else:
-                if pipe is not None:
-                    pipe.release()
-                    pipe = None
-                evaluate(pending.popleft())
-                done = 1
-            if (i // 20) != ((i + done) // 20) or i == 0:
-                if rank == 0:
-                    print("Time elapsed: %s sec for batch %d/%d." % (time.time() - t0, i, len(loader)))
-            if t_first is None:
-                torch.cuda.synchronize()
-                t_first, i_first, waited[0] = time.time(), i + done, 0.0
-            i += done
+        if producer is not None:
+            producer.join(timeout=10.0)
     if pipe is not None:
         pipe.release()
     torch.cuda.current_stream().wait_stream(stream)

@@ -3,8 +3,9 @@
 The hosts these run on are virtual machines on which a first touch of a page is expensive (a fresh 4 MB host tensor: 6 - 20 ms, measured
 with tools/probe/eval_profile.sh; the arithmetic that fills it: 2 ms).  glibc hands every block above 128 KiB to mmap and returns it to the
 kernel on free, so every collated batch, every float64 intermediate of --add_noise, every (B,K,S) draw buffer is first-touched again.
-retain_large_blocks() raises the mmap threshold to its maximum (32 MiB) and the trim threshold to 4 GiB: such blocks then come from the
-heap and stay mapped after free.  Process-wide, so only the CLIs call it - a library has no business changing its host's allocator."""
+retain_large_blocks() raises the mmap threshold to its maximum (32 MiB) and the trim threshold to 2 GiB - 1 (mallopt takes an int): such
+blocks then come from the heap and stay mapped after free (the resident size of a long run only grows up to its largest working set).
+P2C_HOSTMEM=0 leaves the allocator and torch's thread pool alone.  Process-wide, so only the CLIs call it - a library has no business changing its host's allocator."""
 import ctypes
 import os
 
@@ -58,5 +59,9 @@ def fit_threads_to_quota(reserve=2):
 
 
 def setup_cli():
+    """Called by the CLIs (train / train_sketch / eval / bench.py) and tests/conftest.py - never by the library.  P2C_HOSTMEM=0: no-op."""
+    if os.environ.get("P2C_HOSTMEM", "1") == "0":
+        import torch
+        return torch.get_num_threads()
     retain_large_blocks()
     return fit_threads_to_quota()

@@ -518,7 +518,8 @@ class _MLPStack(torch.autograd.Function):
         if ctx.stage_gen is not None and ctx.stage_gen[0].generation != ctx.stage_gen[1]:
             raise RuntimeError("point2cyl_amd.ops.mlp_stack: backward after the staged weight operands were rewritten by a later forward "
                                "(ops.WeightStage.run()): the persistent buffers no longer hold the weights this forward used.  Run forward -> "
-                               "backward in turn (no second forward of the module in between)")
+                               "backward in turn (no second forward of the module in between), or set P2C_STAGE_WEIGHTS=0 (per-layer weight "
+                               "copies owned by each forward: any forward / backward interleaving; INTEGRATION.md, 'autograd contract')")
         rep_grad = None
         arg, ywin = arg if isinstance(arg, tuple) else (arg, None)
         # Eval mode (running statistics, e.g. fine-tuning with frozen BatchNorm, train_Point2Cyl.py:354-357): y = scale * x + shift with a

@@ -527,8 +527,9 @@ def main(argv=None):
                 if heads is not None:
                     h = heads
                 else:            # (what model(pcs) runs: the per-shape HIP graph of the forward where it applies)
+                    # - in a serial RUN; the few left-over batches of a pipelined run are not worth a capture (50 - 100 ms each shape)
                     from . import autograph
-                    h = autograph.forward_heads(model, b[0]) if autograph.applicable(model, b[0]) else None
+                    h = autograph.forward_heads(model, b[0]) if (a.no_prefetch and autograph.applicable(model, b[0])) else None
                     h = h if h is not None else model.forward_heads(b[0])
             if list(h[1]) == [3, 2 * fl.K]:
                 return acc.add_block(fused(b, h))

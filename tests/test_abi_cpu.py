@@ -63,7 +63,12 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_bn_bwd_finalize_sum_f32(None, 64, 10, None, None, None, None, None, None, 16, 8, None, 16, None) == -1
     # round 4 entries
     assert L.p2c_all_losses_f32(None, None, None, None, None, None, 1, 8, 8, None, None, None, None, None) == -1
-    assert L.p2c_all_losses_f32(one, one, one, one, one, one, 1, 8, 6, one, one, one, one, None) == -1                              # K not 2, 4 or 8
+    assert L.p2c_all_losses_f32(one, one, one, one, one, one, 1, 8, 9, one, one, one, one, None) == -1                              # K outside 1 ... 8
+    # round 6 entries
+    assert L.p2c_eval_metrics_f32(None, 20, 0, 3, None, None, None, None, None, None, 0, 40.96, 3.1415927, 1, 8192, 8, None, None, None, None, None, None, None, None) == -1
+    assert L.p2c_eval_metrics_f32(one, 20, 0, 3, one, one, one, one, one, one, 0, 40.96, 3.1415927, 1, 8192, 3, one, None, None, None, None, None, one, None) == -1   # K not 2, 4, 8
+    assert L.p2c_eval_metrics_f32(one, 16, 0, 3, one, one, one, one, one, one, 0, 40.96, 3.1415927, 1, 8192, 8, one, None, None, None, None, None, one, None) == -1   # row too short for 3 + 2K
+    assert L.p2c_eval_metrics_supported(8) == 1 and L.p2c_eval_metrics_supported(5) == 0 and L.p2c_eval_metrics_ws_bytes(32, 8) == 32 * 8 * (28 * 8 + 3) * 8
     assert L.p2c_seg_losses_grad_f32(None, 20, 0, 4, None, None, None, None, None, 1, 8, 8, 1.0, 1.0, 1.0, None, None, None, None) == -1
     assert L.p2c_copy2d_batch_f32(None, 4, None) == -1 and L.p2c_copy2d_batch_f32(one, 0, None) == -1
     assert L.p2c_linear_bwd_pool_alg_f32(None, 128, None, None, None, None, 64, None, None, None, 64, None, None, 64, None, None, None, None, 64, 1048576, 128, 64, 64, None) == -1
@@ -87,7 +92,7 @@ def test_bad_arguments_are_rejected_without_touching_the_device():
     assert L.p2c_linear_fwd_big_sp_f32(one, 512, one, 512, None, None, 0, 0.0, 20.0, one, 512, 262144, 512, 512, one, None) == -1      # beta must be positive
     assert L.p2c_linear_fwd_big_sp_f32(one, 512, one, 512, None, one, 514, 100.0, 20.0, one, 512, 262144, 512, 512, one, None) == -2   # addend stride not 16-byte aligned
     assert L.p2c_fit_terms_f32(one, one, one, one, None, 4, 8, 1.0, 1.0, one, one, one, None) == -1                                   # no mask
-    assert L.p2c_fit_terms_f32(one, one, one, one, one, 4, 3, 1.0, 1.0, one, one, one, None) == -1                                    # K must divide 256
+    assert L.p2c_fit_terms_f32(one, one, one, one, one, 4, 300, 1.0, 1.0, one, one, one, None) == -1                                  # K above 256
     assert L.p2c_fit_terms_f32(one, None, one, one, one, 4, 8, 1.0, 1.0, one, one, one, None) == -1                                   # axes without their ground truth
     assert L.p2c_three_interp_skip_f32(one, 128, one, one, 1, 64, 16, 128, None, 128, 128, one, 256, 256, None) == -1               # skip block missing
     assert L.p2c_three_interp_skip_f32(one, 128, one, one, 1, 64, 16, 128, one, 128, 128, one, 256, 200, None) == -1                # width smaller than skip + interpolated

@@ -721,9 +721,4 @@ def _dropin_leg(args, batch, fl, dev, B, N, K, native_ms, steps=20):
 
 
 if __name__ == "__main__":
-    main()
-    # the record is out (emit() flushes); leave without the interpreter's teardown - a process-group / HIP-runtime thread that throws at exit
-    # (seen once in the one-rank RCCL child) would otherwise turn a finished measurement into a failed process
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(0)
+    main()          # (a normal interpreter exit: rocprofv3 and other tools write their output from exit handlers)

@@ -240,9 +240,22 @@ class _PinnedCollate:
 
     def __init__(self):
         self.slots, self.i = [{}, {}], 0
+        self.copied = [None, None]           # event behind the host->device copies that last read a slot (mark_copied)
+        self.last = 0
+
+    def mark_copied(self):
+        """Called once the copies out of the most recent batch's buffers are enqueued on the current stream: the slot is not written again
+        before they have run (the serial loop enqueues ahead of the device; the loader thread synchronises its stream instead)."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.copied[self.last] = ev
 
     def __call__(self, items):
+        if self.copied[self.i] is not None:
+            self.copied[self.i].synchronize()
+            self.copied[self.i] = None
         slot = self.slots[self.i]
+        self.last = self.i
         self.i ^= 1
         n, out = len(items), [None] * len(items[0])
         for j in self.USED:
@@ -393,7 +406,7 @@ def main(argv=None):
     lo, hi = ddp.shard_range(len(ds), rank, world)                               # clouds are independent: shard, no data-path collective
     # (no pin_memory: the loader pins fresh buffers in the calling thread, 9 ms per tensor here - 80 ms a batch; _PinnedCollate recycles two)
     shuffle = a.data_split != "test"
-    collate = _PinnedCollate() if not a.no_prefetch else None
+    collate = _PinnedCollate()          # (--no_prefetch too: recycled pinned buffers change no draw and no value, only the copy rate)
     loader = torch.utils.data.DataLoader(torch.utils.data.Subset(ds, range(lo, hi)), batch_size=a.batch_size, num_workers=0, shuffle=shuffle,
                                          generator=torch.Generator().manual_seed(a.seed) if shuffle else None, collate_fn=collate)
     model = backbone(output_sizes=fl.pred_sizes())
@@ -439,7 +452,10 @@ def main(argv=None):
             extras["barrel_counts_dev"] = torch.tensor(extras["barrel_counts"], dtype=torch.int64).t().contiguous().to(dev, non_blocking=True)
             extras["bb_long"] = bb.to(dev, torch.long, non_blocking=True)
         pcs, nrm, axes, cen = [t.to(dev, torch.float, non_blocking=True) for t in (pcs, nrm, axes, cen)]
-        return pcs, nrm, inst.to(dev, torch.long, non_blocking=True), bb.to(dev, torch.float, non_blocking=True), axes, cen, extras     # eval.py:254-257
+        out = pcs, nrm, inst.to(dev, torch.long, non_blocking=True), bb.to(dev, torch.float, non_blocking=True), axes, cen, extras     # eval.py:254-257
+        if a.no_prefetch:
+            collate.mark_copied()
+        return out
 
     # The reference's loop (eval.py:231-268) knows its next batch; the geometry of batch i + 1 (FPS / ball query / 3-NN: 0.75 of the
     # 1.84 ms serial forward at B = 32 x 8192) is computed inside the graph that runs batch i's forward (graph.PipelinedForward).

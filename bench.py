@@ -155,8 +155,11 @@ def main():
     ap.add_argument("--torch_losses", action="store_true", help="evaluate the losses with torch ops instead of csrc/loss.hip")
     ap.add_argument("--no_prefetch", action="store_true", help="compute FPS/ball-query/3-NN inline instead of one step ahead on a side stream")
     ap.add_argument("--no_graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
-    ap.add_argument("--sync_exchange", action="store_true", help="N > 1, conservative form of the exchange: ONE graph per step (no split tail) and the "
-                    "all-reduce issued on the step's own stream right behind the replay (no side stream, no overlap); still all-HIP / RCCL")
+    ap.add_argument("--sync_exchange", action="store_true", help="(the default since round 6; kept so that older command lines still parse) N > 1: ONE "
+                    "graph per step and the all-reduce issued on the step's own stream right behind the replay")
+    ap.add_argument("--async_exchange", action="store_true", help="N > 1: the all-reduce on a SIDE stream between the two halves of a split-tail graph, the "
+                    "next batch's geometry copies (0.04 ms) under it.  Measured on a one-rank nccl group (tools/xchg_ab.sh): 3.886 ms per step against "
+                    "3.819 for the default and 3.79 without any exchange - the second replay and the event hops cost more than the tail can hide")
     ap.add_argument("--extras", type=str, default=DEFAULT_EXTRAS, help="comma-separated subset of the extra legs (%s) to run after the timed "
                     "region, or 'all'; default: %s" % (ALL_EXTRAS, DEFAULT_EXTRAS))
     ap.add_argument("--extras_file", type=str, default=None, help="where the detailed objects go (default gpurun_out/bench_extras.json)")
@@ -172,6 +175,7 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_self_launch(args.gpus))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (the product has no CPU path)"
+    _claim_stdout()
     rank, world, local = ddp.init_from_env()
     if world != args.gpus:
         raise SystemExit("bench: --gpus %d but %d rank(s) were launched (WORLD_SIZE); refusing to report a number for the wrong job size"
@@ -249,7 +253,7 @@ def _bench(args, rank, world, local, dev):
         from point2cyl_amd.graph import GraphedForwardBackward
         try:
             graphed = GraphedForwardBackward(model, fwd_bwd, prefetch_xyz=None if args.no_prefetch else batch[0], stream=torch.cuda.current_stream(),
-                                             split_tail=xchg and not args.sync_exchange)
+                                             split_tail=xchg and args.async_exchange)
         except Exception as e:      # keep the bench alive: fall back to eager launches
             sys.stderr.write("bench: HIP graph capture failed (%s: %s); running eager\n" % (type(e).__name__, e))
             torch.cuda.set_stream(torch.cuda.Stream(dev))      # a failed capture can leave its stream in capture mode: continue on a fresh one
@@ -265,8 +269,8 @@ def _bench(args, rank, world, local, dev):
         if xchg and timed:         # events on the step's stream: from "gradients ready" to "exchange joined" (the graph's tail runs inside)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if args.sync_exchange:
-            sync.allreduce()            # conservative: on the step's stream, nothing overlaps (the geometry copies are inside the one graph)
+        if not args.async_exchange:
+            sync.allreduce()            # on the step's stream right behind the one graph (the geometry copies are inside it)
         else:
             sync.allreduce_async()      # N > 1: on a side stream, gated on the replay; N = 1: nothing
             if graphed is not None:
@@ -320,7 +324,7 @@ def _bench(args, rank, world, local, dev):
                      allreduce_bytes=int(sync.flat.numel() * 4) if sync.flat is not None else 0,
                      param_checksum=[float(v) for v in allr[:, 2]], params_identical=bool((allr[:, 2] == allr[0, 2]).all()),
                      recapture_count=1 if graphed is not None else 0, preflight=pre, exchanges=sync.exchanges, avg_op=bool(sync._avg_ok),
-                     exchange="sync (step's stream, one graph)" if args.sync_exchange else "async (side stream under the split tail)",
+                     exchange="async (side stream under the split tail)" if args.async_exchange else "sync (step's stream, one graph)",
                      allreduce_note="allreduce_ms: from 'gradients ready' to 'exchange joined' on the step's stream; the exchange runs on a side stream and the "
                                     "step's tail (the copies of the next batch's prefetched geometry, a second graph, ~0.04 ms) runs under it")
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -483,6 +487,21 @@ def _dig(d, *path):
     return d
 
 
+_REAL_STDOUT = None      # a private duplicate of the process's stdout once _claim_stdout() has run
+
+
+def _claim_stdout():
+    """From here on file descriptor 1 of this process IS stderr; the record goes out through a private duplicate of the original stdout.
+    Why: libraries write to stdout behind Python's back - librccl prints a five-line version banner through C stdio, which is flushed at
+    process EXIT, i.e. after the JSON line (seen with a one-rank nccl group; under torchrun every rank's banner lands in the launcher's
+    stdout whenever that rank exits).  The contract is ONE JSON line, last, on stdout: nothing but emit() may write there."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
 def compact_line(full):
     """The record the driver parses: the contract's keys, roofline, cpu_baseline and a handful of scalars; numbers and short names only
     (no prose), < LINE_LIMIT bytes.  Everything else of `full` goes to stderr / the extras file (emit)."""
@@ -540,8 +559,11 @@ def emit(full, extras_file=None):
     line = compact_line(full)
     text = json.dumps(line)
     assert len(text) < LINE_LIMIT, len(text)
-    sys.stdout.write(text + "\n")
-    sys.stdout.flush()
+    if _REAL_STDOUT is not None:
+        os.write(_REAL_STDOUT, (text + "\n").encode())
+    else:
+        sys.stdout.write(text + "\n")
+        sys.stdout.flush()
     return line
 
 

@@ -61,6 +61,10 @@ def build_parser():
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--save_every", type=int, default=10)
     p.add_argument("--no_graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
+    p.add_argument("--async_exchange", action="store_true", help="data-parallel jobs: the gradient all-reduce on a SIDE stream between the two halves of a "
+                   "split-tail graph (the next batch's geometry copies under it) instead of on the step's own stream right behind ONE graph; "
+                   "measured on a one-rank nccl group: +0.09 ms per step against +0.03 (the tail it can hide is 0.04 ms long, the second replay and "
+                   "the event hops cost 0.06) - worth it only where the all-reduce is much longer than that")
     p.add_argument("--no_prefetch", action="store_true", help="compute FPS / ball query / 3-NN inline instead of one batch ahead on a forked stream")
     p.add_argument("--max_steps", type=int, default=0, help="stop after this many optimizer steps (0: run all epochs)")
     p.add_argument("--quiet", action="store_true", help="no per-batch log line (each costs a device synchronisation)")
@@ -108,7 +112,7 @@ def load_dataset(a, rank=0):
 class Runner:
     """forward + losses + backward + exchange + Adam on static device tensors, eager or as a HIP-graph replay."""
 
-    def __init__(self, model, opt, sync, fl, dev, B, N, K, use_graph=True, prefetch=True, stream=None):
+    def __init__(self, model, opt, sync, fl, dev, B, N, K, use_graph=True, prefetch=True, stream=None, async_exchange=False):
         self.model, self.opt, self.sync, self.fl, self.dev = model, opt, sync, fl, dev
         self.stream = stream          # the stream the caller's loop runs on (graph warm-up and capture use it too); None: a private one
         f32, i64 = torch.float32, torch.int64
@@ -116,6 +120,7 @@ class Runner:
                       torch.zeros(B, N, dtype=i64, device=dev), torch.zeros(B, K, 3, device=dev), torch.zeros(B, K, 3, device=dev))
         self.next_xyz = torch.zeros(B, N, 3, dtype=f32, device=dev)
         self.use_graph, self.prefetch = use_graph, prefetch and use_graph
+        self.async_exchange = bool(async_exchange)
         self.graph, self.graph_momentum = None, None
         self.loss_fn = step.compute_losses_fused if step.fused_loss_applicable(fl) else step.compute_losses
         self.captures = 0
@@ -153,7 +158,7 @@ class Runner:
                 self.next_xyz.copy_(self.batch[0])
                 try:
                     self.graph = GraphedForwardBackward(self.model, self._fwd_bwd, prefetch_xyz=self.next_xyz if self.prefetch else None,
-                                                        stream=self.stream, split_tail=self.sync.active)
+                                                        stream=self.stream, split_tail=self.sync.active and self.async_exchange)
                 except Exception as e:      # something in this configuration cannot be captured: train on, launched from Python
                     import sys
                     sys.stderr.write("point2cyl_amd.train: HIP graph capture failed (%s: %s); continuing without the graph\n" % (type(e).__name__, e))
@@ -170,10 +175,13 @@ class Runner:
                 self.graph_momentum = momentum
                 self.captures += 1
             out = self.graph()
-        self.sync.allreduce_async()     # N > 1: the exchange on a side stream, gated on the replay ...
-        if not (eager or not self.use_graph) and self.graph is not None:
-            self.graph.tail()           # ... with the rest of the step (the prefetched geometry's copies) under it
-        self.sync.wait()
+        if self.async_exchange:
+            self.sync.allreduce_async()     # N > 1: the exchange on a side stream, gated on the replay ...
+            if not (eager or not self.use_graph) and self.graph is not None:
+                self.graph.tail()           # ... with the rest of the step (the prefetched geometry's copies) under it
+            self.sync.wait()
+        else:
+            self.sync.allreduce()           # N > 1: on the step's stream, right behind the one graph of the step (the default: see --async_exchange)
         self.opt.step()
         ops.step_done()
         return out["scalars"]
@@ -217,7 +225,7 @@ def _main(a, rank, world, local, dev, stream):
     if a.no_graph:
         from . import autograph
         autograph.ENABLED = False                            # --no_graph means every kernel launched from Python, also inside backbone.forward
-    run = Runner(model, opt, sync, fl, dev, B, a.num_point, a.K, use_graph=not a.no_graph, prefetch=not a.no_prefetch, stream=stream)
+    run = Runner(model, opt, sync, fl, dev, B, a.num_point, a.K, use_graph=not a.no_graph, prefetch=not a.no_prefetch, stream=stream, async_exchange=a.async_exchange)
     log = None
     if rank == 0:
         os.makedirs(a.logdir, exist_ok=True)

@@ -1659,7 +1659,7 @@ def test_softplus_kernels_match_torch_double_backward(n):
 
 @pytest.mark.parametrize("exchange", ["async", "sync"])
 def test_bench_two_ranks_on_one_gpu_over_gloo(exchange, tmp_path):
-    """[exchange = sync: `--sync_exchange`, the conservative fallback for the first run on a multi-GPU node - one graph per step, the all-reduce
+    """[exchange = sync: the default since round 6 - one graph per step, the all-reduce; async: `--async_exchange`, the side-stream form; (older text:) the conservative fallback for the first run on a multi-GPU node - one graph per step, the all-reduce
     on the step's own stream.]  The multi-process flow of bench.py (one HIP graph per rank, flat gradient exchange, fused Adam, max-over-ranks timing, one
     JSON line from rank 0) with two ranks that SHARE this GPU (test hook P2C_ONE_GPU_RANKS: RCCL refuses two ranks per device, so the
     exchange goes over gloo; the driver's 8-GPU run uses the same code with backend nccl)."""
@@ -1670,7 +1670,7 @@ def test_bench_two_ranks_on_one_gpu_over_gloo(exchange, tmp_path):
     # no launcher: `python bench.py --gpus 2` starts its two ranks itself (bench._self_launch)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
                           "--batch_size", "4", "--num_point", "2048", "--no_cpu_baseline", "--extras_file", str(tmp_path / "full.json")]
-                         + (["--sync_exchange"] if exchange == "sync" else []),
+                         + (["--async_exchange"] if exchange == "async" else []),
                          env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]

@@ -224,6 +224,13 @@ int p2c_bn_finalize_f32(const double *stat_slots, int C, long long count, const 
                         const float *beta, float eps, float momentum, int training, float *running_mean, float *running_var,
                         float *scale, float *shift, float *mean, float *invstd, void *stream);
 
+/* Eval-mode affine of EVERY BatchNorm of a forward in one launch (the training == 0 branch of p2c_bn_finalize_f32, same arithmetic; replaces
+ * torch.nn.functional.batch_norm(training=False)'s per-layer rsqrt / mul chain behind models/pointnet_util.py:187,266 and
+ * models/pointnet_extrusion.py:59).  rows: DEVICE array of n_rows 48-byte records
+ *   { const float *gamma, *beta, *running_mean, *running_var; float *st; int32 C; float eps; }
+ * st is (4, C) row-major: scale, shift, mean, invstd.  The live parameters are read at run time (HIP-graph safe under in-place updates). */
+int p2c_bn_eval_affine_batch_f32(const void *rows, int n_rows, void *stream);
+
 /* Z = relu(scale*Y + shift), materialised (only where a consumer needs the post-activation tensor) */
 int p2c_bn_relu_apply_f32(const float *Y, int ldy, const float *scale, const float *shift, int M, int C, float *Z, int ldz,
                           void *stream);

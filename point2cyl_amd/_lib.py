@@ -44,6 +44,7 @@ _SIGS = {
     "p2c_group_colsum_bn_f32": [c_p, c_i, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_p],
     "p2c_linear_fwd_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_f, c_p, c_p],
     "p2c_bn_finalize_f32": [c_p, c_i, c_ll, c_p, c_p, c_p, c_f, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "p2c_bn_eval_affine_batch_f32": [c_p, c_i, c_p],
     "p2c_bn_bwd_finalize_f32": [c_p, c_i, c_ll, c_p, c_p, c_p, c_p, c_p, c_p],
     "p2c_sum_copies_f32": [c_p, c_ll, c_i, c_p, c_ll, c_p],
     "p2c_linear_bwd_narrow_f32": [c_p, c_i, c_p, c_i, c_p, c_p, c_f, c_p, c_i, c_p, c_i, c_p, c_i, c_ll, c_p, c_p, c_i, c_i, c_i, c_p],

@@ -267,6 +267,7 @@ class backbone(nn.Module):
         """copy.deepcopy / pickling of the module never carry the weight stage (its resolvers point at THIS object): the copy builds its own."""
         d = self.__dict__.copy()
         d.pop("_wstage", None)
+        d.pop("_bnstage", None)
         return d
 
     def compute_geometry(self, x, with_csr=True):
@@ -301,6 +302,19 @@ class backbone(nn.Module):
 
     def forward_heads(self, x, geom=None):
         """-> (heads (B*N, ld) with the outputs of all fc2 heads side by side, [o_0, o_1, ...])."""
+        try:
+            return self._forward_heads(x, geom)
+        finally:
+            ops._EVAL_AFF[0] = None           # (the batched eval-mode affines are valid for the forward that launched them only)
+
+    def _bn_eval_stage(self, device):
+        st = self.__dict__.get("_bnstage")
+        if st is None or st.device != device or st.owner_id != id(self):
+            st = self.__dict__["_bnstage"] = ops.BNEvalStage([m for m in self.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)], device)
+            st.owner_id = id(self)
+        return st
+
+    def _forward_heads(self, x, geom):
         if not x.is_cuda:
             raise RuntimeError("point2cyl_amd.backbone runs on the HIP device only (got %s); there is no CPU path" % x.device)
         B, N, C = x.shape
@@ -331,6 +345,9 @@ class backbone(nn.Module):
             bumped = ws.run(bump=live_nbt + (ws.seed_counter if have_seed else []))
             ops._NBT_BUMPED[0] = bumped and bool(live_nbt)
             seed_bumped = bumped and have_seed
+        if ops.USE_BN_EVAL_BATCH and ops.USE_INFER_PATHS and not self.training and not torch.is_grad_enabled():
+            # inference: ONE launch for the affine of every eval-mode BatchNorm (17 launches between the GEMMs otherwise)
+            ops._EVAL_AFF[0] = self._bn_eval_stage(x.device).run()
         st = (lambda **kw: {k: ws[v] for k, v in kw.items()}) if ws is not None else (lambda **kw: None)
         l1_xyz, l1 = self.sa1.forward_pm(xyz, feats0, gm.get("sa1"), staged=st(W2="sa1_W") if (ws is not None and feats0 is None) else None)
         l2_xyz, l2 = self.sa2.forward_pm(l1_xyz, l1, gm.get("sa2"), staged=st(W2="sa2_W", pre_wx="sa2_wx"))

@@ -89,6 +89,43 @@ extern "C" int p2c_bn_finalize_f32(const double *stat_slots, int C, long long co
 }
 
 // ------------------------------------------------------------------------------------------------
+// Eval-mode BatchNorm of EVERY layer of a forward in one launch: (scale, shift, mean, invstd) from the running statistics, one workgroup
+// per layer.  An inference forward otherwise spends 17 one-workgroup launches (7 us each as graph nodes, 0.125 ms of a 1.17 ms forward,
+// profiles/r06_forward_modes.log) on 6k channels.  The table is a device array of rows; the kernel reads the LIVE parameters, so a captured
+// graph stays right when the weights change in place.  Same arithmetic as bn_finalize_kernel's eval branch.
+// ------------------------------------------------------------------------------------------------
+struct P2cBnEvalRow {
+    const float *gamma, *beta, *running_mean, *running_var;
+    float *st;          // (4, C): scale, shift, mean, invstd
+    int C;
+    float eps;
+};
+static_assert(sizeof(P2cBnEvalRow) == 48, "host packs 48-byte rows (ops.BNEvalStage)");
+
+__global__ void __launch_bounds__(256) bn_eval_affine_batch_kernel(const P2cBnEvalRow *__restrict__ rows)
+{
+    const P2cBnEvalRow r = rows[blockIdx.x];
+    for (int c = threadIdx.x; c < r.C; c += 256) {
+        const float mean = r.running_mean[c];
+        const float invstd = 1.0f / sqrtf(r.running_var[c] + r.eps);
+        const float sc = r.gamma[c] * invstd;
+        r.st[c] = sc;
+        r.st[r.C + c] = r.beta[c] - mean * sc;
+        r.st[2 * r.C + c] = mean;
+        r.st[3 * r.C + c] = invstd;
+    }
+}
+
+extern "C" int p2c_bn_eval_affine_batch_f32(const void *rows, int n_rows, void *stream)
+{
+    if (n_rows < 0 || (n_rows > 0 && !rows)) return P2C_EINVAL;
+    if (n_rows == 0) return P2C_OK;
+    hipLaunchKernelGGL(bn_eval_affine_batch_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, (const P2cBnEvalRow *)rows);
+    P2C_LAUNCH_CHECK();
+    return P2C_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Z = relu(scale*Y + shift)
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) bn_relu_apply_kernel(const float *__restrict__ Y, int ldy, const float *__restrict__ scale,

@@ -249,6 +249,7 @@ class _PinnedCollate:
         ev = torch.cuda.Event()
         ev.record()
         self.copied[self.last] = ev
+        return ev
 
     def __call__(self, items):
         if self.copied[self.i] is not None:
@@ -295,7 +296,7 @@ class GraphedMetrics:
 
     def load(self, batch, heads):
         ops.copy_flat_batch(self.inp + [self.h], [t.contiguous() for t in batch[:6]] + [heads[0]])
-        fitting._barrel_draws(batch[2], batch[3], self.fl.K, self.fl.num_sk_point, device=self.h.device, counts=batch[6]["barrel_counts"],
+        fitting._barrel_draws(batch[2], batch[3], self.fl.K, self.fl.num_sk_point, device=self.h.device, counts=batch[6].get("barrel_counts"),
                               out=self.rand)
 
     def __call__(self, batch=None, heads=None):
@@ -444,15 +445,19 @@ def main(argv=None):
         lo, hi = int(inst.min()), int(inst.max())
         if hi >= a.K or lo < -1:
             raise ValueError("instance labels must be in [-1, %d); got [%d, %d]" % (a.K, lo, hi))
-        extras = dict(barrel_counts=fitting.barrel_counts(inst.long(), bb.long(), a.K), labels_validated=True)
+        # (the labels go up ONCE, as the int64 the collate pinned; the float copy eval.py:256 makes is a device cast of it - `.to(dev, float)` of
+        # the host tensor is a host cast into an unpinned temporary and a synchronous copy)
+        inst_d, bb_d = inst.to(dev, torch.long, non_blocking=True), bb.to(dev, torch.long, non_blocking=True)
         if draw_gen[0]:
             # fused pipelined loop: the extent samples of a batch (data_utils.py:1696: K x B torch.randint calls on the CPU generator, 0.8 ms of
-            # host time and a 4 MB upload per batch) are drawn ON THE DEVICE from the barrel counts uploaded here (FusedMetrics; another
-            # equally valid sampling - the reference's stream is what --no_prefetch keeps)
-            extras["barrel_counts_dev"] = torch.tensor(extras["barrel_counts"], dtype=torch.int64).t().contiguous().to(dev, non_blocking=True)
-            extras["bb_long"] = bb.to(dev, torch.long, non_blocking=True)
+            # host time and a 4 MB upload per batch) are drawn ON THE DEVICE (FusedMetrics; another equally valid sampling - the reference's
+            # stream is what --no_prefetch keeps) from barrel counts that are taken on the device too: the host scatter-add they replace was
+            # 0.3 - 0.6 ms of this thread's 1.3 ms per batch, and the loop runs at this thread's rate once the device side is below it
+            extras = dict(labels_validated=True, barrel_counts_dev=fitting.barrel_counts_tensor(inst_d, bb_d, a.K), bb_long=bb_d)
+        else:
+            extras = dict(barrel_counts=fitting.barrel_counts(inst.long(), bb.long(), a.K), labels_validated=True)
         pcs, nrm, axes, cen = [t.to(dev, torch.float, non_blocking=True) for t in (pcs, nrm, axes, cen)]
-        out = pcs, nrm, inst.to(dev, torch.long, non_blocking=True), bb.to(dev, torch.float, non_blocking=True), axes, cen, extras     # eval.py:254-257
+        out = pcs, nrm, inst_d, bb_d.to(torch.float), axes, cen, extras     # eval.py:254-257
         if a.no_prefetch:
             collate.mark_copied()
         return out
@@ -496,13 +501,16 @@ def main(argv=None):
     def produce():
         try:
             torch.cuda.set_device(dev)
-            for b in it:
-                if stop.is_set():
-                    return
-                t = to_device(b)
-                torch.cuda.current_stream().synchronize()        # the copies (and --add_noise's float64 -> float32 cast) of this thread's stream:
-                if not hand_over(t):                             # done before the pinned buffers are written again, and before the loop reads
-                    return
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                for b in it:                                     # (the collate waits for the copies that last READ the slot it fills: mark_copied)
+                    if stop.is_set():
+                        return
+                    t = to_device(b)
+                    # no host wait for the uploads: the event behind them goes with the batch (the loop's stream waits for it), and this thread
+                    # stacks the next batch into the other pinned slot while they run
+                    ev = collate.mark_copied()
+                    if not hand_over((t, ev)):
+                        return
             hand_over(None)
         except BaseException as e:          # surfaces in the consuming loop
             hand_over(e)
@@ -528,6 +536,9 @@ def main(argv=None):
             elif isinstance(b, BaseException):
                 raise b
             else:
+                if not a.no_prefetch:
+                    b, ev = b
+                    stream.wait_event(ev)         # the loader thread's uploads of this batch
                 for t in list(b[:6]) + [v for v in b[6].values() if torch.is_tensor(v)]:
                     t.record_stream(stream)       # allocated on the producer's stream, read on the loop's
                 pending.append(b)

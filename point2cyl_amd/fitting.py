@@ -59,6 +59,14 @@ def barrel_counts(seg_label, bb_labels, K):
     return torch.zeros(seg_label.shape[0], K, dtype=torch.int64, device=seg_label.device).scatter_add_(1, idx.clamp(max=K - 1), sel).t().tolist()
 
 
+def barrel_counts_tensor(seg_label, bb_labels, K):
+    """barrel_counts as a (B, K) int64 tensor on the labels' device, no host round trip (the evaluation loop's loader thread: the counts
+    only feed the on-device extent draws there)."""
+    idx = seg_label.clamp(min=0, max=K - 1)
+    sel = ((seg_label >= 0) & (seg_label < K) & (bb_labels == 0)).to(torch.int64)
+    return torch.zeros(seg_label.shape[0], K, dtype=torch.int64, device=seg_label.device).scatter_add_(1, idx, sel)
+
+
 def get_extrusion_extents(P, seg_label, bb_labels, extrusion_axes, extrusion_centers, num_points_to_sample=1024, rand_idx=None, counts=None):
     """data_utils.py:1650-1730 -> extents (K,B,2), found_centers_mask (B,K).
     The reference samples barrel points with torch.randint on the CPU generator inside a K x B loop (:1696);

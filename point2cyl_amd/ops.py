@@ -24,6 +24,8 @@ STRICT_LABELS = os.environ.get("P2C_STRICT_LABELS", "0") == "1"   # validate lab
 USE_POOL_ALG = os.environ.get("P2C_POOL_ALG", "1") != "0"    # pooled last layer's backward without its pre-BN output (csrc/bwd_pool.hip)
 USE_POOL_EPI = os.environ.get("P2C_POOL_EPI", "1") != "0"    # max over 64 neighbours from extremes emitted by the last layer's GEMM epilogue
 USE_INFER_PATHS = True     # eval mode without gradients takes the folded first layer / the pooled last layer without its Y too (a test switches it off)
+USE_BN_EVAL_BATCH = os.environ.get("P2C_BN_EVAL_BATCH", "1") != "0"    # every eval-mode BatchNorm affine of a forward from one launch
+_EVAL_AFF = [None]        # {running_mean.data_ptr(): (4, C) affine} while a forward that ran its BNEvalStage is in flight, else None
 
 
 def _f32c(t):
@@ -298,6 +300,14 @@ def _zero_padded(t, *shape):
     return buf
 
 
+def _eval_affine(bn, Co, infer):
+    """The (4, Co) affine BNEvalStage's launch at the top of this forward produced for `bn`, or None (train mode, gradients wanted, no stage)."""
+    if not infer or _EVAL_AFF[0] is None:
+        return None
+    st = _EVAL_AFF[0].get(bn.running_mean.data_ptr())
+    return st if (st is not None and st.shape[1] == Co) else None
+
+
 class _MLPStack(torch.autograd.Function):
     """A chain of 1x1-conv layers  Y_i = act_{i-1}(Y_{i-1}) W_i^T + b_i  with BatchNorm+ReLU folded into the
     NEXT layer's operand load.  tail: 'maxpool' (max over ns of relu(bn(Y_last))), 'bnrelu' (materialise
@@ -397,6 +407,8 @@ class _MLPStack(torch.autograd.Function):
                          ptr(bn.running_mean), ptr(bn.running_var), Co, ptr(st), stream())
                     if bn.nbt is not None and not _NBT_BUMPED[0]:
                         PENDING_NBT.append(bn.nbt)
+                elif _eval_affine(bn, Co, infer) is not None:
+                    st = _eval_affine(bn, Co, infer)
                 else:           # running statistics: the layer's affine without its output
                     call("p2c_bn_finalize_f32", None, Co, M, ptr(b), ptr(gamma), ptr(beta), float(bn.eps), float(bn.momentum), 0,
                          ptr(bn.running_mean), ptr(bn.running_var), ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
@@ -421,10 +433,12 @@ class _MLPStack(torch.autograd.Function):
                 gamma, beta = params[pi], params[pi + 1]
                 pi += 2
                 bn = bns[1]
-                st = torch.empty(4, Co, dtype=torch.float32, device=dev)
-                call("p2c_bn_finalize_f32", ptr(partials), Co, M, ptr(b), ptr(gamma),
-                     ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
-                     ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
+                st = _eval_affine(bn, Co, infer)
+                if st is None:
+                    st = torch.empty(4, Co, dtype=torch.float32, device=dev)
+                    call("p2c_bn_finalize_f32", ptr(partials), Co, M, ptr(b), ptr(gamma),
+                         ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
+                         ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
                 if training and bn.nbt is not None and not _NBT_BUMPED[0]:
                     PENDING_NBT.append(bn.nbt)
                 aff.append(st)
@@ -473,10 +487,13 @@ class _MLPStack(torch.autograd.Function):
                 gamma, beta = params[pi], params[pi + 1]
                 pi += 2
                 bn = bns[i]
-                st = torch.empty(4, Co, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
-                call("p2c_bn_finalize_f32", ptr(partials), Co, M, ptr(b), ptr(gamma),
-                     ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
-                     ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
+                # (inference: the affine of every eval-mode BatchNorm was produced by ONE launch at the top of the forward, BNEvalStage)
+                st = _eval_affine(bn, Co, infer)
+                if st is None:
+                    st = torch.empty(4, Co, dtype=torch.float32, device=dev)      # scale, shift, mean, invstd
+                    call("p2c_bn_finalize_f32", ptr(partials), Co, M, ptr(b), ptr(gamma),
+                         ptr(beta), float(bn.eps), float(bn.momentum), 1 if training else 0, ptr(bn.running_mean), ptr(bn.running_var),
+                         ptr(st[0]), ptr(st[1]), ptr(st[2]), ptr(st[3]), stream())
                 if training and bn.nbt is not None and not _NBT_BUMPED[0]:
                     PENDING_NBT.append(bn.nbt)
                 aff.append(st)
@@ -937,6 +954,41 @@ class WeightStage:
 
     def __getitem__(self, key):
         return self.bufs[key]
+
+
+class BNEvalStage:
+    """Inference: the (scale, shift, mean, invstd) of every eval-mode BatchNorm of the model, from ONE launch at the top of the forward
+    (p2c_bn_eval_affine_batch_f32) into persistent buffers, instead of one p2c_bn_finalize_f32 launch per layer between the GEMMs (17
+    graph nodes, 0.125 ms of a 1.17 ms forward).  The kernel reads the live parameters and running statistics on every run - a captured
+    forward stays right when an optimizer or load_state_dict changes them in place; modules whose tensors got NEW storage are followed by
+    rebuilding the device table (same rule as WeightStage).  Tables are never freed once built: captured graphs hold their addresses."""
+
+    def __init__(self, mods, device):
+        self.mods, self.device = list(mods), device
+        self.st = [torch.empty(4, m.num_features, dtype=torch.float32, device=device) for m in self.mods]
+        self.tables = {}
+        self.table, self.key = None, None
+
+    def _ptrs(self):
+        return tuple(t.data_ptr() for m in self.mods for t in (m.weight, m.bias, m.running_mean, m.running_var)) + tuple(float(m.eps) for m in self.mods)
+
+    def run(self):
+        """-> {running_mean.data_ptr(): affine (4, C)} for ops._MLPStack's eval-mode layers."""
+        import struct
+        key = self._ptrs()
+        if key != self.key:
+            if key not in self.tables:
+                rows = []
+                for m, st in zip(self.mods, self.st):
+                    for t in (m.weight, m.bias, m.running_mean, m.running_var):
+                        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.numel() == m.num_features
+                    rows.append(struct.pack("<QQQQQif", m.weight.data_ptr(), m.bias.data_ptr(), m.running_mean.data_ptr(),
+                                            m.running_var.data_ptr(), st.data_ptr(), m.num_features, float(m.eps)))
+                self.tables[key] = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(self.device)
+            self.table, self.key = self.tables[key], key
+            self.by_ptr = {m.running_mean.data_ptr(): st for m, st in zip(self.mods, self.st)}
+        call("p2c_bn_eval_affine_batch_f32", ptr(self.table), len(self.mods), stream())
+        return self.by_ptr
 
 
 class _HeadParams(torch.autograd.Function):

@@ -799,6 +799,88 @@ def test_autograph_train_eval_train_with_cache_flush_keeps_counter_tables_alive(
                 assert not torch.equal(v, before[k]), k
 
 
+def test_batched_eval_batchnorm_affine_equals_the_per_layer_launches_and_follows_in_place_updates():
+    """ops.BNEvalStage / p2c_bn_eval_affine_batch_f32: an inference forward computes the affine of all 17 eval-mode BatchNorms in ONE launch
+    at its top.  Bit-identical heads to the per-layer p2c_bn_finalize_f32 form (P2C_BN_EVAL_BATCH=0), eager and as a replayed HIP graph,
+    over a sequence of forwards between which the BatchNorm parameters and running statistics change IN PLACE (scaled; load_state_dict)
+    and once get NEW storage - the captured launch reads the live tensors.  The launch counts say which form ran."""
+    from point2cyl_amd import autograph
+    from point2cyl_amd._lib import PROFILE
+    B, N = 2, 2048
+    pcs = synth.make_batch(B, N, 8, seed=91)[0].float().to(DEV)
+
+    def bn_mods(m):
+        return [x for x in m.modules() if isinstance(x, torch.nn.modules.batchnorm._BatchNorm)]
+
+    def run(batched, graphed, profile=False):
+        old = (ops.USE_BN_EVAL_BATCH, autograph.ENABLED)
+        ops.USE_BN_EVAL_BATCH, autograph.ENABLED = batched, graphed
+        try:
+            m = _fresh_backbone(4)
+            g = torch.Generator().manual_seed(11)
+            with torch.no_grad():
+                for x in bn_mods(m):
+                    C = x.num_features
+                    x.running_mean.copy_((torch.randn(C, generator=g) * 0.2).to(DEV))
+                    x.running_var.copy_((torch.rand(C, generator=g) * 1.5 + 0.25).to(DEV))
+                    x.weight.copy_((torch.rand(C, generator=g) + 0.5).to(DEV))
+                    x.bias.copy_((torch.randn(C, generator=g) * 0.1).to(DEV))
+            m.eval()
+            torch.manual_seed(3)
+            outs, counts = [], None
+            with torch.no_grad():
+                for it in range(6):
+                    if profile and it == 0:
+                        PROFILE.reset(True)
+                    X, W = m(pcs)
+                    if profile and it == 0:
+                        counts = {k: v["launches"] for k, v in PROFILE.summary().items()}
+                        PROFILE.reset(False)
+                    outs.append((X.clone(), W.clone()))
+                    if it == 1:                                   # in place, all of them
+                        for x in bn_mods(m):
+                            x.running_var.mul_(1.7)
+                            x.running_mean.add_(0.05)
+                            x.weight.mul_(0.9)
+                            x.bias.sub_(0.02)
+                    elif it == 2:                                 # load_state_dict copies in place
+                        sd = {k: (v * 1.1 if v.dtype.is_floating_point and "running_var" in k else v.clone()) for k, v in m.state_dict().items()}
+                        m.load_state_dict(sd)
+                    elif it == 3:                                 # NEW storage for one layer's statistics and another's parameters
+                        a, b = bn_mods(m)[2], bn_mods(m)[9]
+                        a.running_mean = (a.running_mean * 0.5).clone()
+                        b.weight = torch.nn.Parameter((b.weight * 1.25).clone())
+            torch.cuda.synchronize()
+            return m, outs, counts
+        finally:
+            ops.USE_BN_EVAL_BATCH, autograph.ENABLED = old
+
+    _, ref, c_ref = run(False, False, profile=True)
+    _, bat, c_bat = run(True, False, profile=True)
+    assert c_ref.get("p2c_bn_finalize_f32", 0) == 17 and "p2c_bn_eval_affine_batch_f32" not in c_ref, c_ref
+    assert c_bat.get("p2c_bn_eval_affine_batch_f32", 0) == 1 and "p2c_bn_finalize_f32" not in c_bat, c_bat
+    mg, gra, _ = run(True, True)
+    assert not autograph._state(mg)["failed"]
+    for it, ((X0, W0), (X1, W1), (X2, W2)) in enumerate(zip(ref, bat, gra)):
+        assert torch.isfinite(X0).all() and torch.isfinite(W0).all()
+        assert torch.equal(X0, X1) and torch.equal(W0, W1), ("eager", it)
+        assert torch.equal(X0, X2) and torch.equal(W0, W2), ("graphed", it)
+    for it in (1, 2, 3):                                      # (the updates did change the outputs: the comparison above is not vacuous)
+        assert not torch.equal(ref[it][0], ref[it + 1][0]), it
+    # gradients wanted, or train mode: the per-layer form (its affine is saved for the backward), untouched
+    m = _fresh_backbone(4).eval()
+    old = autograph.ENABLED
+    autograph.ENABLED = False
+    try:
+        PROFILE.reset(True)
+        X, W = m(pcs)
+        c = {k: v["launches"] for k, v in PROFILE.summary().items()}
+    finally:
+        PROFILE.reset(False)
+        autograph.ENABLED = old
+    assert "p2c_bn_eval_affine_batch_f32" not in c and ops._EVAL_AFF[0] is None, c
+
+
 def test_autograph_is_an_autograd_citizen_and_follows_moved_parameters():
     """ADVICE r4 (autograph.py:169, ops.py:862).  (a) the parameter gradients of the graphed module are real autograd outputs:
     torch.autograd.grad(loss, params) returns them (and leaves .grad alone), a parameter hook sees them, and after loss.backward() every

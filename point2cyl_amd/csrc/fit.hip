@@ -437,10 +437,110 @@ __device__ __forceinline__ void ext_build_lists_by(KeyF key_of, int N, int K, in
     __syncthreads();
 }
 
+// Inclusive scan over the 64 lanes of PACKED counters (fields that never carry into each other): Hillis-Steele inside each row of 16 with
+// four row_shr steps, then the two row broadcasts - six v_add_u32_dpp.
+__device__ __forceinline__ unsigned p2c_wave_incl_scan_u32(unsigned v)
+{
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);      // row_shr:1
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);      // row_shr:2
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);      // row_shr:4
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);      // row_shr:8
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);      // row_bcast:15 -> rows 1, 3
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);      // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// The same lists from ONE pass of per-lane work: a point's key becomes a one-hot BYTE counter (four keys per 32-bit word, NW words), the
+// inclusive scan of those words over the wave gives every lane the number of equal keys at or below it (<= 64: a byte) and lane 63 the
+// chunk's totals; the totals of the earlier chunks ride in uniform registers as 16-bit fields.  A lane so knows its point's slot relative
+// to (segment start + the earlier waves' points) before the barrier, and the placement after it is two table reads and a store - against
+// K ballots with a masked population count and a select per 64 points in BOTH passes (the placement pass was 9 k of a cloud's 95 k cycles,
+// tools/fit_trace.py).  One sweep only: N <= WAVES * 64 * EXT_MAXCH, keys < 4 * NW.
+template <int WAVES, int NW, class KeyF>
+__device__ __forceinline__ void ext_build_lists_scan(KeyF key_of, int N, int K, int *list, int (*wcnt)[FIT_MAXK], int *start)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = ((N + WAVES - 1) / WAVES + 63) / 64 * 64;     // points per wave, a multiple of 64
+    const int n_begin = wave * per, n_end = min(N, n_begin + per);
+    const int nch = (max(n_end - n_begin, 0) + 63) / 64;
+    int key[EXT_MAXCH], prel[EXT_MAXCH];
+    unsigned run_e[NW], run_o[NW];             // uniform: keys 4w / 4w+2 and 4w+1 / 4w+3 of this wave so far, 16 bits each
+#pragma unroll
+    for (int w = 0; w < NW; ++w) run_e[w] = run_o[w] = 0u;
+#pragma unroll
+    for (int c = 0; c < EXT_MAXCH; ++c) {
+        const int n = n_begin + c * 64 + lane;
+        int kk = -1;
+        if (c < nch && n < n_end) kk = key_of(n);
+        key[c] = kk;
+        const unsigned one = kk >= 0 ? 1u << ((kk & 3) * 8) : 0u;
+        const int kw = kk >> 2;                 // (-1 for no key: matches no word)
+        unsigned mine = 0u, before = 0u;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const unsigned v = p2c_wave_incl_scan_u32(kw == w ? one : 0u);
+            const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+            if (kw == w) {
+                mine = v;
+                before = (kk & 1) ? run_o[w] : run_e[w];
+            }
+            run_e[w] += tot & 0x00ff00ffu;
+            run_o[w] += (tot >> 8) & 0x00ff00ffu;
+        }
+        prel[c] = (int)((before >> ((kk & 2) * 8)) & 0xffffu) + (int)((mine >> ((kk & 3) * 8)) & 0xffu) - 1;
+    }
+    {
+        unsigned r = 0u;                        // lane k: this wave's count of key k
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+            if ((lane >> 2) == w) r = (lane & 1) ? run_o[w] : run_e[w];
+        if (lane < K) wcnt[wave][lane] = (int)((r >> ((lane & 2) * 8)) & 0xffffu);
+    }
+    FIT_TR(11);
+    __syncthreads();
+    FIT_TR(12);
+    int mine = 0, before = 0;
+    const int pw = tid / K, pk = tid - pw * K;                 // thread (wave pw, segment pk) of the table
+    if (tid < WAVES * K) {
+        mine = wcnt[pw][pk];
+        for (int w = 0; w < pw; ++w) before += wcnt[w][pk];
+    }
+    __syncthreads();
+    if (tid < WAVES * K) {
+        wcnt[pw][pk] = before;                                 // now: barrel points of segment pk in the waves before pw
+        if (pw == WAVES - 1) start[pk + 1] = before + mine;    // segment totals, prefix-summed below
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        start[0] = 0;
+        for (int k = 0; k < K; ++k) { run += start[k + 1]; start[k + 1] = run; }
+    }
+    __syncthreads();
+    FIT_TR(13);
+#pragma unroll
+    for (int c = 0; c < EXT_MAXCH; ++c) {
+        const int kk = key[c];
+        if (kk >= 0) list[start[kk] + wcnt[wave][kk] + prel[c]] = n_begin + c * 64 + lane;
+    }
+    __syncthreads();
+}
+
+template <int WAVES = EXT_WAVES, class KeyF>
+__device__ __forceinline__ void ext_build_lists_any(KeyF key_of, int N, int K, int *list, int (*wcnt)[FIT_MAXK], int *start)
+{
+    if (N <= WAVES * 64 * EXT_MAXCH) {          // (uniform)
+        if (K <= 8) ext_build_lists_scan<WAVES, 2>(key_of, N, K, list, wcnt, start);
+        else ext_build_lists_scan<WAVES, 4>(key_of, N, K, list, wcnt, start);
+    } else {
+        ext_build_lists_by<WAVES>(key_of, N, K, list, wcnt, start);
+    }
+}
+
 __device__ __forceinline__ void ext_build_lists(const int64_t *__restrict__ sg, const int64_t *__restrict__ bl, int N, int K, int *list,
                                                 int (*wcnt)[FIT_MAXK], int *start)
 {
-    ext_build_lists_by([&](int n) { const int64_t sv = sg[n]; return (bl[n] == 0 && sv >= 0 && sv < K) ? (int)sv : -1; }, N, K, list, wcnt, start);
+    ext_build_lists_any([&](int n) { const int64_t sv = sg[n]; return (bl[n] == 0 && sv >= 0 && sv < K) ? (int)sv : -1; }, N, K, list, wcnt, start);
 }
 
 __global__ void __launch_bounds__(EXT_THREADS) extents_kernel(const float *__restrict__ P, const int64_t *__restrict__ seg,
@@ -565,6 +665,9 @@ extern "C" int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, con
 // for K segments, 2 segments each): one wave instruction then fetches 32-64 distinct points instead of 8 (eight times fewer memory
 // instructions per byte: the (slice, segment) mapping moves 32 useful bytes per wave instruction through a CU's one 64 B/clk vector
 // memory path), and the segment sums are selected by the label with 0/1 factors - the same products, another summation order.
+typedef float fit_v2f __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(4))) fit_f3 { float x, y, z; };          // 12-byte load (global_load_dwordx3) of a 4-byte aligned triple
+
 template <int KK, int THREADS, bool PLDS, bool HARD = false>
 __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__restrict__ X, const float *__restrict__ Wb, const float *__restrict__ Wc,
                                                                 const float *__restrict__ P, const int64_t *__restrict__ seg,
@@ -592,7 +695,7 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
     // HARD: SPL segments per lane (2: 36 accumulators - four per lane spilled at the 128 registers a 1024-thread workgroup has), LPP lanes per point
     constexpr int SPL = HARD ? (KK >= 2 ? 2 : 1) : 1, LPP = HARD ? KK / SPL : 1;
     float acc[HARD ? 1 : NA];
-    float hacc[SPL][NA];
+    fit_v2f hacc2[SPL][NA / 2];                          // HARD: the 18 sums of a segment as nine register pairs (v_pk_fma_f32 / v_pk_add_f32)
     if constexpr (!HARD) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0.f;
@@ -600,7 +703,7 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
 #pragma unroll
         for (int j = 0; j < SPL; ++j)
 #pragma unroll
-            for (int i = 0; i < NA; ++i) hacc[j][i] = 0.f;
+            for (int i = 0; i < NA / 2; ++i) hacc2[j][i] = fit_v2f{0.f, 0.f};
     }
     if constexpr (HARD) {
         const float *x = X + (size_t)b * N * 3, *pp = P + (size_t)b * N * 3;
@@ -618,9 +721,16 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
             for (int u = 0; u < U; ++u) {
                 const int n = n0 + u * NSTEP, nc = n < N ? n : N - 1;
                 nq[u] = nc;
-                xq[u][0] = x[nc * 3 + 0]; xq[u][1] = x[nc * 3 + 1]; xq[u][2] = x[nc * 3 + 2];
-                pq[u][0] = pp[nc * 3 + 0]; pq[u][1] = pp[nc * 3 + 1]; pq[u][2] = pp[nc * 3 + 2];
-                svq[u] = sg[2 * nc]; bvq[u] = bl[2 * nc];
+                // (unsigned 32-bit byte offsets from the cloud's uniform base: one VGPR per address and the scalar-base form of the load; the
+                // int index made every address a sign-extended 64-bit multiply-add - 50 of the loop's 230 vector instructions, and this
+                // phase is bound by the vector ALU's issue rate: 4 lanes per point x 2 segments of masked sums, profiles/r06_fit_*)
+                const unsigned o12 = (unsigned)nc * 12u, o8 = (unsigned)nc * 8u;
+                const fit_f3 xv = *reinterpret_cast<const fit_f3 *>(reinterpret_cast<const char *>(x) + o12);
+                const fit_f3 pv = *reinterpret_cast<const fit_f3 *>(reinterpret_cast<const char *>(pp) + o12);
+                xq[u][0] = xv.x; xq[u][1] = xv.y; xq[u][2] = xv.z;
+                pq[u][0] = pv.x; pq[u][1] = pv.y; pq[u][2] = pv.z;
+                svq[u] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(sg) + o8);
+                bvq[u] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(bl) + o8);
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -630,19 +740,21 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
                 const float p0 = pq[u][0], p1 = pq[u][1], p2 = pq[u][2];
                 const int sv = svq[u], bv = bvq[u];
                 const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
+                const fit_v2f q0 = {p00, p01}, q1 = {p02, p11}, q2 = {p12, p22}, q3 = {p0, p1}, q4 = {p2, 1.f};
 #pragma unroll
                 for (int j = 0; j < SPL; ++j) {
                     const bool mine = live && sv == k0 + j;
                     const float b2 = (mine && bv == 0) ? 1.f : 0.f, c2 = (mine && bv == 1) ? 1.f : 0.f, w = mine ? 1.f : 0.f;
-                    float *a_ = hacc[j];
+                    fit_v2f *a_ = hacc2[j];
                     // the factors are 0 or 1: every product is exact, so a fused multiply-add rounds exactly like the multiply + add of the
-                    // general route (the file is built with -ffp-contract=off)
-#define FIT_ACC(i, f, v) a_[i] = __builtin_fmaf(f, v, a_[i])
-                    FIT_ACC(0, b2, p00); FIT_ACC(1, b2, p01); FIT_ACC(2, b2, p02); FIT_ACC(3, b2, p11); FIT_ACC(4, b2, p12); FIT_ACC(5, b2, p22);
-                    FIT_ACC(6, c2, p00); FIT_ACC(7, c2, p01); FIT_ACC(8, c2, p02); FIT_ACC(9, c2, p11); FIT_ACC(10, c2, p12); FIT_ACC(11, c2, p22);
-                    if (normalize) { a_[12] += b2; a_[13] += c2; }
-                    FIT_ACC(14, w, p0); FIT_ACC(15, w, p1); FIT_ACC(16, w, p2); a_[17] += w;
-#undef FIT_ACC
+                    // general route (the file is built with -ffp-contract=off); nine packed instructions per (point, segment): the pair
+                    // (12, 13) is one packed add of (b2, c2) - summed whether or not `normalize` reads them -, the count 17 rides in the
+                    // pair (p2, 1) of the centroid sums
+                    const fit_v2f vb = {b2, b2}, vc = {c2, c2}, vw = {w, w}, vbc = {b2, c2};
+                    a_[0] = __builtin_elementwise_fma(vb, q0, a_[0]); a_[1] = __builtin_elementwise_fma(vb, q1, a_[1]); a_[2] = __builtin_elementwise_fma(vb, q2, a_[2]);
+                    a_[3] = __builtin_elementwise_fma(vc, q0, a_[3]); a_[4] = __builtin_elementwise_fma(vc, q1, a_[4]); a_[5] = __builtin_elementwise_fma(vc, q2, a_[5]);
+                    a_[6] += vbc;
+                    a_[7] = __builtin_elementwise_fma(vw, q3, a_[7]); a_[8] = __builtin_elementwise_fma(vw, q4, a_[8]);
                 }
                 if (PLDS) { Ps[n * 3 + 0] = p0; Ps[n * 3 + 1] = p1; Ps[n * 3 + 2] = p2; }
                 keyb[n] = (signed char)((bv == 0 && sv >= 0 && sv < KK) ? (int)sv : -1);
@@ -719,7 +831,7 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
             for (int j = 0; j < SPL; ++j)
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
-                    const float v = p2c_wave_class_sum_f32<LPP>(hacc[j][i]);      // the lanes of this segment group in the wave: lane % LPP
+                    const float v = p2c_wave_class_sum_f32<LPP>((i & 1) ? hacc2[j][i >> 1].y : hacc2[j][i >> 1].x);      // the lanes of this segment group in the wave: lane % LPP
                     if (lane < LPP) wsum[(wave * KK + lane * SPL + j) * NA + i] = (double)v;
                 }
         } else {
@@ -770,7 +882,8 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
     }
     // ---------------- phase 3 (extents_kernel, on the LDS copies)
     FIT_TR(3);
-    ext_build_lists_by<WAVES>([&](int n) { return (int)keyb[n]; }, N, KK, list, wcnt, start);
+    if (N <= WAVES * 64 * EXT_MAXCH) ext_build_lists_scan<WAVES, (KK <= 4 ? 1 : 2)>([&](int n) { return (int)keyb[n]; }, N, KK, list, wcnt, start);
+    else ext_build_lists_by<WAVES>([&](int n) { return (int)keyb[n]; }, N, KK, list, wcnt, start);
     FIT_TR(4);
     {
         for (int t = wave; t < KK * nch; t += WAVES) {

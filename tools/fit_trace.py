@@ -33,6 +33,11 @@ torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); run(); e1.record(); torch.cuda.synchronize()
 print("fit_fused%s + finish: %.1f us" % (" (labels-implied memberships)" if HARD else "", e0.elapsed_time(e1) * 1e3))
+ts = []
+for _ in range(30):
+    e0.record(); run(); e1.record(); torch.cuda.synchronize()
+    ts.append(e0.elapsed_time(e1) * 1e3)
+print("  30 launches one at a time: min %.1f us, median %.1f us" % (min(ts), sorted(ts)[15]))
 st = np.zeros(40, dtype=np.uint64)
 assert L.p2c_fit_trace_read(st.ctypes.data_as(vp)) == 0
 d_ = np.diff(st[:6].astype(np.int64))

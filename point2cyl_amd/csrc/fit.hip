@@ -666,6 +666,22 @@ extern "C" int p2c_extrusion_extents_f32(const float *P, const int64_t *seg, con
 // instructions per byte: the (slice, segment) mapping moves 32 useful bytes per wave instruction through a CU's one 64 B/clk vector
 // memory path), and the segment sums are selected by the label with 0/1 factors - the same products, another summation order.
 typedef float fit_v2f __attribute__((ext_vector_type(2)));
+
+// the value of lane m of this lane's group of LPP consecutive lanes (LPP 1, 2 or 4: inside a quad -> one v_mov_b32_dpp quad_perm)
+template <int LPP>
+__device__ __forceinline__ int fit_group_bcast(int v, int m)
+{
+    // (every lane reads a valid lane of its own quad: nothing is taken from `old`, so it is left undefined - mov_dpp - and the
+    // instruction needs no copy of its source first)
+    if constexpr (LPP == 1) return v;
+    else if constexpr (LPP == 2) return m == 0 ? __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, true)        // quad_perm [0,0,2,2]
+                                               : __builtin_amdgcn_mov_dpp(v, 0xF5, 0xF, 0xF, true);       // quad_perm [1,1,3,3]
+    else return m == 0 ? __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, true) : m == 1 ? __builtin_amdgcn_mov_dpp(v, 0x55, 0xF, 0xF, true)
+              : m == 2 ? __builtin_amdgcn_mov_dpp(v, 0xAA, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(v, 0xFF, 0xF, 0xF, true);
+}
+template <int LPP>
+__device__ __forceinline__ float fit_group_bcast(float v, int m) { return __builtin_bit_cast(float, fit_group_bcast<LPP>(__builtin_bit_cast(int, v), m)); }
+
 struct __attribute__((packed, aligned(4))) fit_f3 { float x, y, z; };          // 12-byte load (global_load_dwordx3) of a 4-byte aligned triple
 
 template <int KK, int THREADS, bool PLDS, bool HARD = false>
@@ -709,21 +725,22 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
         const float *x = X + (size_t)b * N * 3, *pp = P + (size_t)b * N * 3;
         const int *sg = reinterpret_cast<const int *>(seg + (size_t)b * N), *bl = reinterpret_cast<const int *>(bb + (size_t)b * N);
         const int hsel = tid % LPP, k0 = hsel * SPL;
-        // U points per lane are REQUESTED before the first is used, with no control flow between the loads and their uses (clamped indices
-        // instead of a bounds branch; every lane of a point's group parks the point - same address, same value - instead of one lane under
-        // a branch).  With the branch in the loop body the compiler drained the memory counter in every iteration: one point per lane in
-        // flight, 10 KB per CU, and the streaming phase ran at the memory LATENCY (51 - 64 k of a cloud's 117 k cycles, round 5's trace).
-        constexpr int U = 4, NSTEP = THREADS / LPP;         // (2: same time - the CU's memory path, not the depth, sets the rate; 8: spills)
-        for (int n0 = tid / LPP; n0 < N; n0 += U * NSTEP) {
+        // Every lane loads its OWN point - consecutive lanes, consecutive points: a wave instruction fetches 64 distinct points - and parks it;
+        // the LPP lanes of a group then take the group's points one after the other, each through a quad broadcast (DPP) of the owner's
+        // registers, and sum them into their SPL segments.  (Before: the LPP lanes of a group all loaded the same point - four times the lane
+        // bytes through the CU's one vector memory path, 1.3 MB per cloud at 64 B/clk = 20 k of the phase's 30 - 46 k cycles - and parked it
+        // four times.)  U points per lane are REQUESTED before the first is used, with no control flow between the loads and their uses
+        // (clamped indices instead of a bounds branch: with a branch the compiler drained the memory counter in every iteration and the
+        // phase ran at the memory LATENCY, round 5's trace); a clamped slot repeats point N - 1: parked again (same values), not summed.
+        constexpr int U = 4;
+        fit_v2f q4 = {0.f, 1.f};                   // (p2, 1): the count rides with the centroid's third sum; only .x is rewritten per point
+        for (int n0 = tid; n0 < N; n0 += U * THREADS) {
             float xq[U][3], pq[U][3];
-            int svq[U], bvq[U], nq[U];
+            int svq[U], bvq[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int n = n0 + u * NSTEP, nc = n < N ? n : N - 1;
-                nq[u] = nc;
-                // (unsigned 32-bit byte offsets from the cloud's uniform base: one VGPR per address and the scalar-base form of the load; the
-                // int index made every address a sign-extended 64-bit multiply-add - 50 of the loop's 230 vector instructions, and this
-                // phase is bound by the vector ALU's issue rate: 4 lanes per point x 2 segments of masked sums, profiles/r06_fit_*)
+                const int n = n0 + u * THREADS, nc = n < N ? n : N - 1;
+                // (unsigned 32-bit byte offsets from the cloud's uniform base: one VGPR per address and the scalar-base form of the load)
                 const unsigned o12 = (unsigned)nc * 12u, o8 = (unsigned)nc * 8u;
                 const fit_f3 xv = *reinterpret_cast<const fit_f3 *>(reinterpret_cast<const char *>(x) + o12);
                 const fit_f3 pv = *reinterpret_cast<const fit_f3 *>(reinterpret_cast<const char *>(pp) + o12);
@@ -734,30 +751,39 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int n = nq[u];
-                const bool live = n0 + u * NSTEP < N;                   // a clamped slot repeats point N - 1: parked again (same values), not summed
-                const float x0 = xq[u][0], x1 = xq[u][1], x2 = xq[u][2];
-                const float p0 = pq[u][0], p1 = pq[u][1], p2 = pq[u][2];
-                const int sv = svq[u], bv = bvq[u];
-                const float p00 = x0 * x0, p01 = x0 * x1, p02 = x0 * x2, p11 = x1 * x1, p12 = x1 * x2, p22 = x2 * x2;
-                const fit_v2f q0 = {p00, p01}, q1 = {p02, p11}, q2 = {p12, p22}, q3 = {p0, p1}, q4 = {p2, 1.f};
+                const int n = n0 + u * THREADS, nc = n < N ? n : N - 1;
+                const int sv_own = svq[u], bv_own = bvq[u];
+                if (PLDS) { Ps[nc * 3 + 0] = pq[u][0]; Ps[nc * 3 + 1] = pq[u][1]; Ps[nc * 3 + 2] = pq[u][2]; }
+                keyb[nc] = (signed char)((bv_own == 0 && sv_own >= 0 && sv_own < KK) ? (int)sv_own : -1);
+                const int sv_sum = n < N ? sv_own : -2;                  // (a clamped slot belongs to no segment)
 #pragma unroll
-                for (int j = 0; j < SPL; ++j) {
-                    const bool mine = live && sv == k0 + j;
-                    const float b2 = (mine && bv == 0) ? 1.f : 0.f, c2 = (mine && bv == 1) ? 1.f : 0.f, w = mine ? 1.f : 0.f;
-                    fit_v2f *a_ = hacc2[j];
-                    // the factors are 0 or 1: every product is exact, so a fused multiply-add rounds exactly like the multiply + add of the
-                    // general route (the file is built with -ffp-contract=off); nine packed instructions per (point, segment): the pair
-                    // (12, 13) is one packed add of (b2, c2) - summed whether or not `normalize` reads them -, the count 17 rides in the
-                    // pair (p2, 1) of the centroid sums
-                    const fit_v2f vb = {b2, b2}, vc = {c2, c2}, vw = {w, w}, vbc = {b2, c2};
-                    a_[0] = __builtin_elementwise_fma(vb, q0, a_[0]); a_[1] = __builtin_elementwise_fma(vb, q1, a_[1]); a_[2] = __builtin_elementwise_fma(vb, q2, a_[2]);
-                    a_[3] = __builtin_elementwise_fma(vc, q0, a_[3]); a_[4] = __builtin_elementwise_fma(vc, q1, a_[4]); a_[5] = __builtin_elementwise_fma(vc, q2, a_[5]);
-                    a_[6] += vbc;
-                    a_[7] = __builtin_elementwise_fma(vw, q3, a_[7]); a_[8] = __builtin_elementwise_fma(vw, q4, a_[8]);
+                for (int m = 0; m < LPP; ++m) {
+                    // the point of lane m of this group, in every lane of the group
+                    // (register pairs the packed instructions can source as they are: xa = (x0, x1), xb = (x2, x1) give the six products
+                    // as three v_pk_mul_f32 with half selects - (x0 x0, x0 x1), (x0 x2, x1 x1), (x1 x2, x2 x2) - and no moves)
+                    const fit_v2f xa = {fit_group_bcast<LPP>(xq[u][0], m), fit_group_bcast<LPP>(xq[u][1], m)};
+                    const fit_v2f xb = {fit_group_bcast<LPP>(xq[u][2], m), fit_group_bcast<LPP>(xq[u][1], m)};
+                    const fit_v2f q3 = {fit_group_bcast<LPP>(pq[u][0], m), fit_group_bcast<LPP>(pq[u][1], m)};
+                    q4.x = fit_group_bcast<LPP>(pq[u][2], m);
+                    const int sv = fit_group_bcast<LPP>(sv_sum, m), bv = fit_group_bcast<LPP>(bv_own, m);
+                    const fit_v2f q0 = xa.xx * xa, q1 = xa * xb, q2 = xb.yx * xb.xx;
+#pragma unroll
+                    for (int j = 0; j < SPL; ++j) {
+                        const bool mine = sv == k0 + j;
+                        const float w = mine ? 1.f : 0.f;
+                        const fit_v2f vbc = {(mine && bv == 0) ? 1.f : 0.f, (mine && bv == 1) ? 1.f : 0.f};
+                        fit_v2f *a_ = hacc2[j];
+                        // the factors are 0 or 1: every product is exact, so a fused multiply-add rounds exactly like the multiply + add of
+                        // the general route (the file is built with -ffp-contract=off); nine packed instructions per (point, segment): the
+                        // pair (12, 13) is one packed add of (b2, c2) - summed whether or not `normalize` reads them -, the count 17 rides in
+                        // the pair (p2, 1) of the centroid sums
+                        const fit_v2f vb = vbc.xx, vc = vbc.yy, vw = {w, w};
+                        a_[0] = __builtin_elementwise_fma(vb, q0, a_[0]); a_[1] = __builtin_elementwise_fma(vb, q1, a_[1]); a_[2] = __builtin_elementwise_fma(vb, q2, a_[2]);
+                        a_[3] = __builtin_elementwise_fma(vc, q0, a_[3]); a_[4] = __builtin_elementwise_fma(vc, q1, a_[4]); a_[5] = __builtin_elementwise_fma(vc, q2, a_[5]);
+                        a_[6] += vbc;
+                        a_[7] = __builtin_elementwise_fma(vw, q3, a_[7]); a_[8] = __builtin_elementwise_fma(vw, q4, a_[8]);
+                    }
                 }
-                if (PLDS) { Ps[n * 3 + 0] = p0; Ps[n * 3 + 1] = p1; Ps[n * 3 + 2] = p2; }
-                keyb[n] = (signed char)((bv == 0 && sv >= 0 && sv < KK) ? (int)sv : -1);
             }
         }
     } else

@@ -340,7 +340,10 @@ extern "C" int p2c_extrusion_centers_bwd_f32(const float *dcenters, const float 
 #ifdef P2C_FIT_TRACE       // tools/fit_trace.py: shader-clock stamps of workgroup 0 at the phase boundaries
 __device__ unsigned long long p2c_fit_stamps[40];
 extern "C" int p2c_fit_trace_read(void *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(p2c_fit_stamps), sizeof(p2c_fit_stamps)) == hipSuccess ? 0 : 1; }
-#define FIT_TR(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) p2c_fit_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#ifndef P2C_FIT_TRACE_WG
+#define P2C_FIT_TRACE_WG 0            // (-DP2C_FIT_TRACE_WG=1000: a workgroup of a later round, when the CUs no longer stream in lockstep)
+#endif
+#define FIT_TR(i) do { if (blockIdx.x == P2C_FIT_TRACE_WG && threadIdx.x == 0) p2c_fit_stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define FIT_TR(i) do { } while (0)
 #endif
@@ -732,6 +735,9 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
         // four times.)  U points per lane are REQUESTED before the first is used, with no control flow between the loads and their uses
         // (clamped indices instead of a bounds branch: with a branch the compiler drained the memory counter in every iteration and the
         // phase ran at the memory LATENCY, round 5's trace); a clamped slot repeats point N - 1: parked again (same values), not summed.
+        // (Two or four register stages with the next stage's loads in flight while one is summed - software pipelining pinned with
+        // sched_barrier - measured and dropped: the stream got no shorter, 21 - 35 k cycles per wave either way, and at the 128 registers
+        // of a 1024-thread workgroup the longer live ranges pushed the projection loop into scratch: 1.0 ms per pass.)
         constexpr int U = 4;
         fit_v2f q4 = {0.f, 1.f};                   // (p2, 1): the count rides with the centroid's third sum; only .x is rewritten per point
         for (int n0 = tid; n0 < N; n0 += U * THREADS) {
@@ -833,7 +839,7 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
     }
     FIT_TR(1);
 #ifdef P2C_FIT_TRACE
-    if (blockIdx.x == 0 && lane == 0) p2c_fit_stamps[16 + wave] = __builtin_readcyclecounter();
+    if (blockIdx.x == P2C_FIT_TRACE_WG && lane == 0) p2c_fit_stamps[16 + wave] = __builtin_readcyclecounter();
 #endif
     // the sample draws of this wave's first (segment, chunk) task: requested now, consumed after the reduction, the eigen-solve and the list
     // build (one dependent global load per 64 samples inside the projection loop was a third of the separate kernel's time)

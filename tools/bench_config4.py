@@ -103,11 +103,12 @@ def main():
     ap.add_argument("--samples", type=int, default=2048)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--unfused", action="store_true", help="the three separate kernels (axis, centroids, extents) instead of the one-pass kernel")
+    ap.add_argument("--no_cpu", action="store_true", help="skip the CPU baseline and parity legs (kernel A/B runs)")
     a = ap.parse_args()
     from point2cyl_amd import measure
     w = measure.FittingWorkload(a.clouds, a.num_point, a.K, a.samples)
     res, (E, cen, cfound, ext, found, E64) = w.time(a.steps, fused=not a.unfused)
-    cpu, parity = cpu_fitting_legs(w, E, cen, ext, E64)
+    cpu, parity = (None, None) if a.no_cpu else cpu_fitting_legs(w, E, cen, ext, E64)
     line = dict(metric="fitting-only cylinders/sec (axis + centroid + extent), 10k pre-segmented cylinders at N=8192",
                 value=res["cylinders_per_s"], unit="cylinders/s", n_gpus=1, steps=a.steps, ms_per_step=res["ms"],
                 points_per_s=res["points_per_s"], dtype="f32 (scatter sums, eigen-solve and the axis output in f64)", data="synthetic",

@@ -1,11 +1,8 @@
+# phase stamps of the one-pass fitting kernel, a workgroup of the first round and one of a late round (build the libraries first:
+#   python tools/fit_trace.py --build;  P2C_FIT_TRACE_WG=1000 P2C_FIT_TRACE_LIB=tools/libp2c_fit_trace_wg1000.so python tools/fit_trace.py --build)
 cd "$GRAFT_REPO_ROOT"
-for i in 1 2; do
-echo "== base"; P2C_FIT_TRACE_LIB=tools/libp2c_fit_trace_base.so python tools/fit_trace.py --hard 2>&1 | grep -v amdgpu.ids
-echo "== new"; python tools/fit_trace.py --hard 2>&1 | grep -v amdgpu.ids
+for lib in tools/libp2c_fit_trace.so tools/libp2c_fit_trace_wg1000.so; do
+  [ -f $lib ] || continue
+  echo "== $lib"; P2C_FIT_TRACE_LIB=$lib python tools/fit_trace.py --hard 2>&1 | grep -v amdgpu.ids
+  P2C_FIT_TRACE_LIB=$lib python tools/fit_trace.py 2>&1 | grep -v amdgpu.ids
 done
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -k "fit_fused or fitting_properties" 2>&1 | tail -3
-python tools/bench_config4.py 2>/dev/null | python -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); print(d['ms_per_step'], d['roofline']['frac'], d['roofline']['avg_launch_us'], d['soft_membership_route']['ms'])"

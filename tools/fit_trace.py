@@ -4,7 +4,8 @@ import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
 LIB = os.environ.get("P2C_FIT_TRACE_LIB") or os.path.join(HERE, "libp2c_fit_trace.so")
 if "--build" in sys.argv:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_FIT_TRACE", "-shared", "-o", LIB,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_FIT_TRACE",
+                           "-DP2C_FIT_TRACE_WG=%d" % int(os.environ.get("P2C_FIT_TRACE_WG", "0")), "-shared", "-o", LIB,
                            os.path.join(ROOT, "point2cyl_amd", "csrc", "fit.hip")])
     print(LIB); sys.exit(0)
 sys.path.insert(0, ROOT)
@@ -41,7 +42,7 @@ print("  30 launches one at a time: min %.1f us, median %.1f us" % (min(ts), sor
 st = np.zeros(40, dtype=np.uint64)
 assert L.p2c_fit_trace_read(st.ctypes.data_as(vp)) == 0
 d_ = np.diff(st[:6].astype(np.int64))
-print("workgroup 0, shader cycles: stream %d | sums (shuffles + 16 waves) %d | eigen + centroid %d | lists %d | projection %d   (2.4 GHz: total %.1f us)"
+print("traced workgroup, shader cycles: stream %d | sums (shuffles + 16 waves) %d | eigen + centroid %d | lists %d | projection %d   (2.4 GHz: total %.1f us)"
       % (d_[0], d_[1], d_[2], d_[3], d_[4], d_.sum() / 2400.0))
 s64 = st.astype(np.int64)
 if s64[8] and s64[9] and s64[10]:

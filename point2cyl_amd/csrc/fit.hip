@@ -738,6 +738,8 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
         // (Two or four register stages with the next stage's loads in flight while one is summed - software pipelining pinned with
         // sched_barrier - measured and dropped: the stream got no shorter, 21 - 35 k cycles per wave either way, and at the 128 registers
         // of a 1024-thread workgroup the longer live ranges pushed the projection loop into scratch: 1.0 ms per pass.)
+        // (U = 1, 2, 3: the same 35 k cycles to the last wave's end - 5.7 k vector instructions per SIMD at ~6 cycles each set the phase, not the
+        // depth of the loads in flight; the per-wave ends step up in issue-priority order, oldest first)
         constexpr int U = 4;
         fit_v2f q4 = {0.f, 1.f};                   // (p2, 1): the count rides with the centroid's third sum; only .x is rewritten per point
         for (int n0 = tid; n0 < N; n0 += U * THREADS) {

@@ -739,7 +739,11 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
         // sched_barrier - measured and dropped: the stream got no shorter, 21 - 35 k cycles per wave either way, and at the 128 registers
         // of a 1024-thread workgroup the longer live ranges pushed the projection loop into scratch: 1.0 ms per pass.)
         // (U = 1, 2, 3: the same 35 k cycles to the last wave's end - 5.7 k vector instructions per SIMD at ~6 cycles each set the phase, not the
-        // depth of the loads in flight; the per-wave ends step up in issue-priority order, oldest first)
+        // depth of the loads in flight; the per-wave ends step up in issue-priority order, oldest first.  That staircase is what hides the
+        // loads: with s_setprio falling with a wave's progress the four waves of a SIMD advance together, wait for their second step's
+        // points together, and the last wave ends at 50 k cycles instead of 35 k - measured, dropped.  tools/ubench/valu_rate.hip: a lone
+        // wave issues one vector instruction per 5 clocks; four waves one v_pk_fma_f32 / quad-broadcast v_mov_b32_dpp per 4.2, one
+        // v_fma_f32 per 2.5 - the 710 instructions per 16 (point, lane) steps price the phase at 22 k, the tail waves' lone running at 35 k)
         constexpr int U = 4;
         fit_v2f q4 = {0.f, 1.f};                   // (p2, 1): the count rides with the centroid's third sum; only .x is rewritten per point
         for (int n0 = tid; n0 < N; n0 += U * THREADS) {

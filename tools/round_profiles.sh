@@ -48,6 +48,7 @@ python tools/bench_sa1_forward.py > "$OUT/${TAG}_sa1_forward_stage.json.log" 2> 
 python tools/bench_config5.py --steps 10 > "$OUT/${TAG}_config5_with_sketch_step.json.log" 2> "$OUT/config5.err"
 python tools/bench_config5.py --steps 5 --no_graph > "$OUT/${TAG}_config5_with_sketch_step_eager.json.log" 2>> "$OUT/config5.err"
 python tools/bench_pool_alg.py --trace > "$OUT/${TAG}_pool_alg_backward.log" 2> "$OUT/pool.err"
+[ -x tools/ubench/grid_barrier.bin ] || /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o tools/ubench/grid_barrier.bin tools/ubench/grid_barrier.hip > /dev/null 2>&1
 timeout 100 tools/ubench/grid_barrier.bin > "$OUT/${TAG}_grid_barrier_ubench.log" 2>&1
 # 5. the trainers and the evaluation script (throughput through the CLI, convergence log)
 python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 1024 --batch_size 32 --num_epochs 60 --quiet --logdir /tmp/${TAG}_tr \
@@ -57,12 +58,13 @@ python -m point2cyl_amd.train --pred_seg --pred_normal --pred_bb --synthetic 256
 python -m point2cyl_amd.eval --synthetic 4096 --batch_size 32 --logdir /tmp/${TAG}_tr --ckpt model.pth --dump_dir /tmp/${TAG}_ev --report "$OUT/${TAG}_eval_report_pipelined.json" > "$OUT/${TAG}_eval_synthetic.log" 2> "$OUT/eval.err"
 python -m point2cyl_amd.eval --synthetic 4096 --batch_size 32 --logdir /tmp/${TAG}_tr --ckpt model.pth --dump_dir /tmp/${TAG}_ev --no_prefetch --report "$OUT/${TAG}_eval_report_serial.json" > "$OUT/${TAG}_eval_synthetic_no_prefetch.log" 2>> "$OUT/eval.err"
 EV="python -m point2cyl_amd.eval --synthetic 4096 --batch_size 32 --logdir /tmp/${TAG}_tr --ckpt model.pth --dump_dir /tmp/${TAG}_ev"
-for f in "--prefetch_group 1" "--prefetch_group 1 --no_graph_metrics" "--prefetch_group 8" "--prefetch_group 4 --add_noise"; do echo "$f: $($EV $f 2>> "$OUT/eval.err" | grep throughput)"; done > "$OUT/${TAG}_eval_variants.log"
+for f in "--prefetch_group 1" "--prefetch_group 1 --no_graph_metrics" "--prefetch_group 8" "--prefetch_group 4 --add_noise" "--prefetch_group 4 --no_fused_metrics"; do echo "$f: $($EV $f 2>> "$OUT/eval.err" | grep throughput)"; done > "$OUT/${TAG}_eval_variants.log"
 python tools/probe/eval_metrics_time.py > "$OUT/${TAG}_eval_metrics_probe.log" 2>> "$OUT/eval.err"
 python tools/probe/stage_depth2.py > "$OUT/${TAG}_stage_depth.log" 2>> "$OUT/eval.err"
 python tools/probe/forward_modes.py 2>> "$OUT/eval.err" | grep "mode:" > "$OUT/${TAG}_forward_modes.log"
+P2C_BN_EVAL_BATCH=0 python tools/probe/forward_modes.py 2>> "$OUT/eval.err" | grep "eval mode:" | sed "s/^/P2C_BN_EVAL_BATCH=0 (one finalize launch per layer): /" >> "$OUT/${TAG}_forward_modes.log"
 if [ -d .ab_base ]; then bash tools/ab_commits.sh 3 > "$OUT/${TAG}_ab_vs_round4_tree.log" 2>&1; fi
-python tools/fit_trace.py > "$OUT/${TAG}_fit_fused_phase_trace.log" 2>&1; python tools/fit_trace.py --hard >> "$OUT/${TAG}_fit_fused_phase_trace.log" 2>&1
+bash tools/fit_ab.sh > "$OUT/${TAG}_fit_fused_phase_trace.log" 2>&1
 python tools/bench_config5.py --steps 3 --glue > /dev/null 2> "$OUT/${TAG}_config5_torch_side_ops.log"
 python -m point2cyl_amd.train_sketch --pred_seg --pred_normal --pred_bb --is_pc_train --is_im_train --with_im_loss --synthetic 64 --batch_size 16 \
     --num_epochs 2 --logdir /tmp/${TAG}_sk --im_logdir /tmp/none --report "$OUT/${TAG}_sketch_trainer_report.json" > "$OUT/${TAG}_train_sketch_synthetic.log" 2> "$OUT/sk.err"

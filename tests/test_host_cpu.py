@@ -401,11 +401,11 @@ def test_remaining_env_switches_are_wired():
     attribute the GPU tests drive (autograph.ENABLED: test_autograph_module_forward_backward_equals_eager_launches; implicit.USE_BIG:
     test_implicit_decoder_big_tiles_vs_oracle_trainer_shapes; ops.STRICT_LABELS: test_strict_labels_raise_at_the_call)."""
     code = ("import json; from point2cyl_amd import autograph, implicit, ops; "
-            "print(json.dumps([autograph.ENABLED, implicit.USE_BIG, ops.STRICT_LABELS]))")
-    for env_add, want in (({}, [True, True, False]),
-                          ({"P2C_AUTOGRAPH": "0", "P2C_GEMM_BIG": "0", "P2C_STRICT_LABELS": "1"}, [False, False, True])):
+            "print(json.dumps([autograph.ENABLED, implicit.USE_BIG, ops.STRICT_LABELS, ops.USE_BN_EVAL_BATCH]))")
+    for env_add, want in (({}, [True, True, False, True]),
+                          ({"P2C_AUTOGRAPH": "0", "P2C_GEMM_BIG": "0", "P2C_STRICT_LABELS": "1", "P2C_BN_EVAL_BATCH": "0"}, [False, False, True, False])):
         env = dict(os.environ, **env_add)
-        for k in ("P2C_AUTOGRAPH", "P2C_GEMM_BIG", "P2C_STRICT_LABELS"):
+        for k in ("P2C_AUTOGRAPH", "P2C_GEMM_BIG", "P2C_STRICT_LABELS", "P2C_BN_EVAL_BATCH"):
             if k not in env_add:
                 env.pop(k, None)
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180, cwd=ROOT)

@@ -19,8 +19,10 @@ makes the checkpoint hold the MEAN of the replicas' statistics instead of rank 0
 """
 import os
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC handles between the ranks' processes (read when HIP initialises)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def force_exchange():

@@ -1796,6 +1796,60 @@ def test_fused_backward_256_wide_two_passes_equals_generic_kernels(grad_mode):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max()) + 1e-6, name
 
 
+@pytest.mark.parametrize("N,K,dist", [(8192, 8, "random"), (8192, 16, "random"), (8192, 9, "one_segment"), (8192, 3, "runs"), (4097, 16, "runs"),
+                                      (100, 1, "random"), (8193, 8, "random"), (20000, 12, "one_segment"), (8192, 8, "empty_and_single")])
+def test_barrel_lists_every_key_width_and_size_vs_oracle(N, K, dist):
+    """fit.hip ext_build_lists_scan (N <= 8192: ranks and totals from a wave scan of packed one-hot byte counters, two words for K <= 8, four up
+    to 16) and ext_build_lists_by (larger clouds: ballots): the extents read list[start[k] + draw], so with the x coordinate = point index, axis
+    = e_x and centre 0 a draw's projection IS the index the list holds there.  Draws probe every position class - first, last, across 64-point
+    chunk and 512-point wave borders -; label layouts: uniform, all barrel points in ONE segment (512 per wave: the 16-bit running fields),
+    long runs of one key (whole chunks of a single key), empty segments and segments of one point (found = 0).  Exact against the oracle."""
+    B, S = 3, 512
+    g = torch.Generator().manual_seed(N * 31 + K)
+    if dist == "random":
+        seg = torch.randint(0, K, (B, N), generator=g)
+        bb = torch.randint(0, 2, (B, N), generator=g)
+    elif dist == "one_segment":
+        seg = torch.full((B, N), K - 2 if K > 1 else 0)
+        bb = torch.zeros(B, N, dtype=torch.long)
+        bb[:, ::7] = 1
+    elif dist == "runs":
+        seg = (torch.arange(N) // 700 % K).repeat(B, 1)
+        bb = (torch.arange(N) // 64 % 3 == 1).long().repeat(B, 1)
+    else:
+        seg = torch.randint(2, K, (B, N), generator=g)              # segments 0 and 1: empty / a single barrel point
+        seg[:, 5] = 1
+        bb = torch.randint(0, 2, (B, N), generator=g)
+        bb[:, 5] = 0
+        seg[1, 4000:4100] = -1                                       # (unlabelled points belong to no list)
+    P = torch.zeros(B, N, 3)
+    P[:, :, 0] = torch.arange(N, dtype=torch.float32)
+    P[:, :, 1:] = torch.rand(B, N, 2, generator=g)
+    axes = torch.zeros(B, K, 3)
+    axes[:, :, 0] = 1.0
+    centers = torch.zeros(B, K, 3)
+    counts = ((seg.unsqueeze(-1) == torch.arange(K)) & (bb == 0).unsqueeze(-1)).sum(1)           # (B, K)
+    probes = torch.tensor([0, 1, 62, 63, 64, 65, 127, 128, 511, 512, 513, 1023, 1024, 4095, 4096, 8191])
+    ridx = torch.randint(0, 1 << 30, (B, K, S), generator=g)
+    ridx[:, :, :probes.numel()] = probes
+    ridx = ridx % counts.clamp_min(1).unsqueeze(-1)
+    ridx[:, :, probes.numel()] = (counts - 1).clamp_min(0)
+    ext, found = fitting.get_extrusion_extents(P.to(DEV), seg.to(DEV), bb.to(DEV), axes.to(DEV), centers.to(DEV), S, rand_idx=ridx.to(DEV))
+    # (the oracle one-hot-encodes the labels: an unlabelled point becomes a non-barrel point of segment 0 there)
+    rext, rfound = R.get_extrusion_extents(P, seg.clamp_min(0), torch.where(seg < 0, torch.full_like(bb, 5), bb), axes, centers,
+                                           {(k, b): ridx[b, k] for k in range(K) for b in range(B)})
+    assert np.array_equal(found.cpu().numpy(), rfound.numpy())
+    assert np.array_equal(ext.cpu().numpy(), rext.numpy()), (N, K, dist)
+    # and one draw at a time: every probed position of one (cloud, segment) list
+    b0, k0 = 1, int(counts[1].argmax())
+    ids = ((seg[b0] == k0) & (bb[b0] == 0)).nonzero().flatten()
+    for j in sorted(set(int(x) for x in ridx[b0, k0, :probes.numel() + 1])):
+        one = ridx.clone()
+        one[b0, k0, :] = j
+        e1, _ = fitting.get_extrusion_extents(P.to(DEV), seg.to(DEV), bb.to(DEV), axes.to(DEV), centers.to(DEV), S, rand_idx=one.to(DEV))
+        assert float(e1[k0, b0, 0]) == float(e1[k0, b0, 1]) == float(ids[j]), (j, float(e1[k0, b0, 0]), int(ids[j]))
+
+
 @pytest.mark.parametrize("variant", ["0", "1"])          # 0: 1024 threads, points in LDS | 1: 512 threads, two workgroups per CU, points gathered
 @pytest.mark.parametrize("B,N,K,S,normalize", [(6, 1024, 8, 256, False), (3, 2048, 4, 100, True), (2, 8192, 8, 2048, False), (5, 1000, 2, 64, True)])
 def test_fit_fused_equals_the_three_ops_and_the_oracle(B, N, K, S, normalize, variant, monkeypatch):

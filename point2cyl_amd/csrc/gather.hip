@@ -2,6 +2,7 @@
 // HBM-bound row gathers: each wave moves whole feature rows (contiguous, coalesced); the backward
 // passes are scatter-adds with fp32 atomics (several groups share a source point).
 #include "common.h"
+#include <type_traits>
 
 // out row r=(b,s,j): [xyz[b,idx]-new_xyz[b,s] | feats[b,idx,0:D] | 0...]  (pointnet_util.py:128-139)
 __global__ void __launch_bounds__(256) group_gather_kernel(const float *__restrict__ xyz, const float *__restrict__ feats, int ldf,
@@ -341,9 +342,9 @@ __global__ void __launch_bounds__(256) three_interp_stats_kernel(const float *__
                                                                  const float *__restrict__ bias, float *__restrict__ out, int ldo,
                                                                  double *__restrict__ slots, int xcd_bpc)
 {
-    constexpr int RPW = 16;                       // rows per wave
+    constexpr int RPW = 16, U = 4;                // rows per wave; rows in flight
     __shared__ float red[2][4][64 * CPL];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // xcd_bpc != 0 (= workgroups per cloud): cloud b is served by XCD b % 8 only (workgroup ids go round the XCDs), so the 262 KB of sparse
     // rows its 8192 dense rows read three at a time stay in ONE L2 - 4 clouds = 1 MB per XCD instead of all 32 = 8.4 MB in each of them
     // (PMC: 152 MB fetched for 15 MB of sparse rows + indices).
@@ -352,7 +353,9 @@ __global__ void __launch_bounds__(256) three_interp_stats_kernel(const float *__
         const int xcd = blk & 7, slot = blk >> 3, round = slot / xcd_bpc;
         blk = (xcd + 8 * round) * xcd_bpc + (slot - round * xcd_bpc);
     }
-    const long long r0 = ((long long)blk * 4 + wave) * RPW;
+    const long long r0 = ((long long)blk * 4 + wave) * RPW;          // uniform
+    // (Lane l owning CPL CONSECUTIVE channels with one 8 / 16-byte access per row - half the memory instructions - measured SLOWER:
+    // 54.7 us against 49.4 for the strided dword form at 128 channels.)
     float bv[CPL], s1[CPL], s2[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
@@ -360,45 +363,58 @@ __global__ void __launch_bounds__(256) three_interp_stats_kernel(const float *__
         bv[i] = (bias && c < C) ? bias[c] : 0.f;
         s1[i] = s2[i] = 0.f;
     }
-    // the 16 rows' neighbour indices and weights in one shot (lane l < 48 holds entry l of the 48), so the row loop below has no
-    // dependent index -> feature load chain and two rows are in flight
+    // The 16 rows' neighbour rows and weights in one shot: lane l < 48 holds entry l of the 48 as (sparse row number, weight), fetched back
+    // with v_readlane in the row loop - uniform row pointers (scalar base + lane offset loads), no dependent index -> feature load chain, U
+    // rows in flight.  ONE division per wave for the cloud of its first row (the loop had a 64-bit r / N per row: with the ds_bpermute
+    // broadcasts and the per-lane 64-bit addresses that followed from them, 160 instructions per two rows, half of them bookkeeping).
     const long long nleft = rows - r0;
-    int myi = 0; float myw = 0.f;
-    if (lane < 3 * RPW && lane < 3 * nleft) { myi = idx[r0 * 3 + lane]; myw = w[r0 * 3 + lane]; }
-    for (int rr = 0; rr < RPW; rr += 2) {
-        if (r0 + rr >= rows) break;
-        const bool two = r0 + rr + 1 < rows;
-        const float *f[2][3]; float ww[2][3];
+    const int nrow = (int)(nleft < RPW ? (nleft > 0 ? nleft : 0) : RPW);
+    const long long b0 = r0 / N;
+    const int rem0 = (int)(r0 - b0 * N);
+    int mysrc = 0; float myw = 0.f;
+    if (lane < 3 * nrow) {
+        const int o = rem0 + lane / 3;                              // row of this entry, counted from the first row's cloud
+        const long long b = b0 + (o >= N ? o / N : 0);
+        mysrc = (int)(b * S) + idx[r0 * 3 + lane];
+        myw = w[r0 * 3 + lane];
+    }
+    auto rows_step = [&](int rr, auto exact) {
+        constexpr bool EXACT = decltype(exact)::value;          // all U rows exist and C == 64 * CPL: nothing conditional between the loads and the stores
+        const float *f[U][3]; float ww[U][3];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const long long r = r0 + rr + (two ? u : 0);
-            const int b = (int)(r / N);
+        for (int u = 0; u < U; ++u) {
+            const int row = EXACT ? rr + u : min(rr + u, nrow - 1);          // (a slot past the end repeats the last row: loaded, neither summed nor stored)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
-                const int src = 3 * (rr + (two ? u : 0)) + j;
-                f[u][j] = feats + ((size_t)b * S + __shfl(myi, src)) * ldf;
-                ww[u][j] = __shfl(myw, src);
+                f[u][j] = feats + (size_t)__builtin_amdgcn_readlane(mysrc, 3 * row + j) * ldf;
+                ww[u][j] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(myw), 3 * row + j));
             }
         }
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = lane + 64 * i;
-            if (c < C) {
-                float a[2][3];
+            if (EXACT || c < C) {
+                float a[U][3];
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < U; ++u)
 #pragma unroll
                     for (int j = 0; j < 3; ++j) a[u][j] = f[u][j][c];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u == 1 && !two) break;
-                    const float v = (a[u][0] * ww[u][0] + a[u][1] * ww[u][1]) + a[u][2] * ww[u][2];
-                    s1[i] += v;
-                    s2[i] += v * v;
-                    out[(size_t)(r0 + rr + u) * ldo + c] = v + bv[i];
+                for (int u = 0; u < U; ++u) {
+                    if (EXACT || rr + u < nrow) {                   // uniform
+                        const float v = (a[u][0] * ww[u][0] + a[u][1] * ww[u][1]) + a[u][2] * ww[u][2];
+                        s1[i] += v;
+                        s2[i] += v * v;
+                        out[(size_t)(r0 + rr + u) * ldo + c] = v + bv[i];
+                    }
                 }
             }
         }
+    };
+    if (nrow == RPW && C == 64 * CPL) {
+        for (int rr = 0; rr < RPW; rr += U) rows_step(rr, std::true_type{});
+    } else {
+        for (int rr = 0; rr < nrow; rr += U) rows_step(rr, std::false_type{});
     }
     if (!slots) return;
 #pragma unroll
@@ -549,15 +565,15 @@ __global__ void __launch_bounds__(256) group_linear_stats_kernel(const float *__
                                                                  int C, long long rows, float *__restrict__ out, int ldo,
                                                                  double *__restrict__ slots, int xcd_bpc)
 {
-    constexpr int RPW = 16;
+    constexpr int RPW = 16, U = 4;                // rows per wave; rows in flight
     __shared__ float red[2][4][64 * CPL];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int blk = blockIdx.x;                         // xcd_bpc != 0: cloud b on XCD b % 8, as in three_interp_stats_kernel
     if (xcd_bpc) {
         const int xcd = blk & 7, slot = blk >> 3, round = slot / xcd_bpc;
         blk = (xcd + 8 * round) * xcd_bpc + (slot - round * xcd_bpc);
     }
-    const long long r0 = ((long long)blk * 4 + wave) * RPW;
+    const long long r0 = ((long long)blk * 4 + wave) * RPW;          // uniform
     float bv[CPL], s1[CPL], s2[CPL], wx0[CPL], wx1[CPL], wx2[CPL];
 #pragma unroll
     for (int i = 0; i < CPL; ++i) {
@@ -566,42 +582,60 @@ __global__ void __launch_bounds__(256) group_linear_stats_kernel(const float *__
         wx0[i] = Wx[c * 4 + 0]; wx1[i] = Wx[c * 4 + 1]; wx2[i] = Wx[c * 4 + 2];
         s1[i] = s2[i] = 0.f;
     }
-    // lane l < 16 resolves row r0 + l (source point, relative coordinates) so the row loop has no dependent load chain
-    long long myrow = 0; float mdx = 0.f, mdy = 0.f, mdz = 0.f;
-    if (lane < RPW && r0 + lane < rows) {
-        const long long r = r0 + lane, grp = r / ns;
-        const int b = (int)(grp / S), p = idx[r];
+    // lane l < 16 resolves row r0 + l (source point, relative coordinates) so the row loop has no dependent load chain; the group and the
+    // cloud of the wave's FIRST row by two divisions per wave, the lanes' from there by compares (the per-lane 64-bit r / ns and grp / S,
+    // and the ds_bpermute broadcasts of what they produced, were a third of the kernel's instructions)
+    const long long nleft = rows - r0;
+    const int nrow = (int)(nleft < RPW ? (nleft > 0 ? nleft : 0) : RPW);
+    const long long g0 = r0 / ns, b0 = g0 / S;
+    const int grem = (int)(r0 - g0 * ns), srem = (int)(g0 - b0 * S);
+    int myrow_lo = 0, myrow_hi = 0; float mdx = 0.f, mdy = 0.f, mdz = 0.f;
+    if (lane < nrow) {
+        const int og = grem + lane, dg = og >= ns ? og / ns : 0;       // groups past the first row's
+        const long long grp = g0 + dg;
+        const int ob = srem + dg;
+        const long long b = b0 + (ob >= S ? ob / S : 0);
+        const int p = idx[r0 + lane];
         const float *pp = xyz + ((size_t)b * N + p) * 3, *cc = new_xyz + (size_t)grp * 3;
         mdx = pp[0] - cc[0]; mdy = pp[1] - cc[1]; mdz = pp[2] - cc[2];
-        myrow = (long long)b * N + p;
+        const long long myrow = b * N + p;
+        myrow_lo = (int)(myrow & 0xffffffffLL); myrow_hi = (int)(myrow >> 32);
     }
-    for (int rr = 0; rr < RPW; rr += 2) {
-        if (r0 + rr >= rows) break;
-        const bool two = r0 + rr + 1 < rows;
-        const float *g[2]; float dx[2], dy[2], dz[2];
+    auto rows_step = [&](int rr, auto exact) {
+        constexpr bool EXACT = decltype(exact)::value;          // all U rows exist and C == 64 * CPL: nothing conditional between the loads and the stores
+        const float *g[U]; float dx[U], dy[U], dz[U];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int src = rr + (two ? u : 0);
-            g[u] = Gf + (size_t)__shfl(myrow, src) * ldg;
-            dx[u] = __shfl(mdx, src); dy[u] = __shfl(mdy, src); dz[u] = __shfl(mdz, src);
+        for (int u = 0; u < U; ++u) {
+            const int src = EXACT ? rr + u : min(rr + u, nrow - 1);          // (a slot past the end repeats the last row: loaded, neither summed nor stored)
+            const unsigned long long row = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(myrow_hi, src) << 32) | (unsigned)__builtin_amdgcn_readlane(myrow_lo, src);
+            g[u] = Gf + (size_t)row * ldg;
+            dx[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mdx), src));
+            dy[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mdy), src));
+            dz[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mdz), src));
         }
 #pragma unroll
         for (int i = 0; i < CPL; ++i) {
             const int c = lane + 64 * i;
-            if (c < C) {
-                float gv[2];
+            if (EXACT || c < C) {
+                float gv[U];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) gv[u] = g[u][c];
+                for (int u = 0; u < U; ++u) gv[u] = g[u][c];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u == 1 && !two) break;
-                    const float v = gv[u] + __builtin_fmaf(wx2[i], dz[u], __builtin_fmaf(wx1[i], dy[u], wx0[i] * dx[u]));
-                    s1[i] += v;
-                    s2[i] += v * v;
-                    out[(size_t)(r0 + rr + u) * ldo + c] = v + bv[i];
+                for (int u = 0; u < U; ++u) {
+                    if (EXACT || rr + u < nrow) {                   // uniform
+                        const float v = gv[u] + __builtin_fmaf(wx2[i], dz[u], __builtin_fmaf(wx1[i], dy[u], wx0[i] * dx[u]));
+                        s1[i] += v;
+                        s2[i] += v * v;
+                        out[(size_t)(r0 + rr + u) * ldo + c] = v + bv[i];
+                    }
                 }
             }
         }
+    };
+    if (nrow == RPW && C == 64 * CPL) {
+        for (int rr = 0; rr < RPW; rr += U) rows_step(rr, std::true_type{});
+    } else {
+        for (int rr = 0; rr < nrow; rr += U) rows_step(rr, std::false_type{});
     }
     if (!slots) return;
 #pragma unroll

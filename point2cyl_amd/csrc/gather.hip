@@ -460,17 +460,22 @@ __global__ void __launch_bounds__(256) csr_gather_bn_kernel(const float *__restr
     // cloud b is served by XCD b % 8 only, all its targets resident there at about the same time, so the second and third read hit that L2.
     // nsplit = 2 (xcd_clouds only): the channels go in two halves, ALL targets of a cloud for the first half before any for the second, so the
     // rows a cloud's targets share (dz + y of one cloud: 8.4 MB at 128 channels, twice an XCD's 4 MB L2) are a 4.2 MB working set per pass.
-    long long wv; int h = 0;
+    // (A wave serves ONE target row of ~4 entries: its prologue is half of what it executes.  The (cloud, row, channel half) of a workgroup
+    // come from a 2-D grid without a division - x = xcd + 8 * (half * blocks_per_cloud + block), y = round of eight clouds; the hardware
+    // deals workgroups to the XCDs by their linear id, and gridDim.x is a multiple of 8 - and the wave index is made uniform, so that the
+    // row's offsets are scalar loads.)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int b, t, h = 0;
     if (xcd_clouds) {
-        const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3), bpc = T / 4;       // blocks per cloud (and channel half)
-        const int round = slot / (nsplit * bpc), r = slot - round * (nsplit * bpc);
-        h = r / bpc;
-        wv = ((long long)(xcd + 8 * round) * bpc + (r - h * bpc)) * 4 + (threadIdx.x >> 6);
+        const int xcd = (int)(blockIdx.x & 7), r = (int)(blockIdx.x >> 3), bpc = T / 4;           // blocks per cloud (and channel half)
+        h = r >= bpc ? 1 : 0;                                                                    // (nsplit <= 2)
+        b = xcd + 8 * (int)blockIdx.y;
+        t = (r - h * bpc) * 4 + wave;
     } else {
-        wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        const long long wv = (long long)blockIdx.x * 4 + wave;
+        if (wv >= total) return;
+        b = (int)(wv / T); t = (int)(wv - (long long)b * T);
     }
-    if (wv >= total) return;
-    const int b = (int)(wv / T), t = (int)(wv - (long long)b * T);
     const int Cs = C / nsplit, c0 = h * Cs;                  // this wave's channels: [c0, c0 + Cs)
     const int k0 = offsets[(size_t)b * (T + 1) + t], k1 = offsets[(size_t)b * (T + 1) + t + 1];
     const int32_t *eb = entries + (size_t)b * E;
@@ -545,6 +550,7 @@ extern "C" int p2c_csr_gather_bn_f32(const float *dz, int lddz, const float *y, 
     const int xcd_clouds = (xcd_on && B % 8 == 0 && T % 4 == 0) ? 1 : 0;
     const int nsplit = (xcd_clouds && split_on && C == 128) ? 2 : 1;
     dim3 grid(p2c_cdiv(total, 4) * nsplit);
+    if (xcd_clouds) grid = dim3(8 * nsplit * (T / 4), B / 8);
     const int Cs = C / nsplit;
 #define P2C_CGB(CPL_) hipLaunchKernelGGL(csr_gather_bn_kernel<CPL_>, grid, dim3(256), 0, s, dz, lddz, y, ldy, coef, offsets, rows, wsorted, E, rows_b, T, C, total, out, ldo, xcd_clouds, nsplit)
     if (Cs <= 64) P2C_CGB(1);

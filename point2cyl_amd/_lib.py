@@ -10,7 +10,7 @@ import re
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libp2c_hip.so")
+LIB_PATH = os.environ.get("P2C_LIB") or os.path.join(_HERE, "libp2c_hip.so")      # (P2C_LIB: another build of the same sources, kernel A/B runs)
 HEADER = os.path.join(_HERE, "..", "include", "p2c_hip.h")
 
 _lib = None

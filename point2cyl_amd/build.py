@@ -15,7 +15,16 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libp2c_hip.so")
 SOURCES = ["metrics.hip", "geom.hip", "gather.hip", "gemm.hip", "gemm_big.hip", "fwd_pp.hip", "fwd_pp3.hip", "bwd_fused.hip", "bwd_fused3.hip", "bwd_pool.hip", "heads.hip", "bn.hip", "fit.hip", "assign.hip", "loss.hip", "softplus.hip"]
 # -ffp-contract=off: geom.hip reproduces the reference's rounding order (explicit fmaf only)
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wno-unused-value"]
+# -target-feature -packed-fp32-ops: NO v_pk_{add,mul,fma}_f32 anywhere (the host pass prints "not a recognized feature", harmless).  Round 6
+#   found farthest point sampling picking wrong points in 3 - 54 % of the HIP-graph replays in which it ran on the forked stream UNDER the
+#   MFMA kernels (never alone, never in the parity tests): the low half of a v_pk_add_f32 result, last 16 lanes of the wave, read stale by a
+#   v_min_i32 two issue slots later - the one wait state the compiler leaves between a packed producer and its consumer is not enough there
+#   when the wave has the SIMD's vector issue nearly to itself (16 / 8 / 4 waves per cloud: 0 / 7 / 54 % of replays; tools/stress_prefetch.py,
+#   profiles/r06_fps_packed_hazard.log).  Without packed fp32 the same stress shows 0 of 1500 in every shape, and nothing gets slower: a
+#   v_fma_f32 issues in 2.5 clocks against 4.2 for the packed form (tools/ubench/valu_rate.hip) - FPS 443 -> 382 us, step -0.01 ms, the
+#   fitting pass +1.7 %.
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Wno-unused-value",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def source_hash():
@@ -28,6 +37,7 @@ def source_hash():
         h.update(f.encode())
         h.update(open(os.path.join(CSRC, f), "rb").read())
     h.update(open(os.path.join(HERE, "..", "include", "p2c_hip.h"), "rb").read())
+    h.update(" ".join(FLAGS).encode())           # (code generation options are part of what was measured)
     return h.hexdigest()[:16]
 
 
@@ -47,6 +57,9 @@ def build(force=False, verbose=False):
     deps = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "fwd_pp.h"), os.path.join(CSRC, "lsa.h"), os.path.join(CSRC, "eigh3.h"), os.path.join(HERE, "..", "include", "p2c_hip.h")]
     objs, dirty = [], False
     procs = []
+    stamp = os.path.join(OBJ, "flags.txt")                 # objects built with other options are stale whatever their age
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(FLAGS):
+        force = True
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         if not os.path.exists(s):
@@ -69,6 +82,8 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(" ".join(FLAGS))
     return LIB
 
 

@@ -438,8 +438,6 @@ def main(argv=None):
 
     def to_device(b):
         pcs, nrm, inst, bb, axes, cen = b[0], b[1], b[2], b[3], b[6], b[8]
-        if a.add_noise:
-            pcs = fitting.add_noise(pcs, nrm, sigma=a.noise_sigma)                               # eval.py:241
         # on the host copy of the labels, before the upload: the range check losses.py:36-46 makes per cloud, and the barrel counts that
         # decide the extent draws (data_utils.py:1674-1697) - the evaluation of the batch then never waits for the device
         lo, hi = int(inst.min()), int(inst.max())
@@ -457,6 +455,9 @@ def main(argv=None):
         else:
             extras = dict(barrel_counts=fitting.barrel_counts(inst.long(), bb.long(), a.K), labels_validated=True)
         pcs, nrm, axes, cen = [t.to(dev, torch.float, non_blocking=True) for t in (pcs, nrm, axes, cen)]
+        if a.add_noise:           # eval.py:241: the reference's host draws, its float64 multiply-add and float32 rounding (:254) - made on the device
+            src = [t if h.dtype == torch.float32 else h.to(dev) for t, h in ((pcs, b[0]), (nrm, b[1]))]       # (float64 datasets: noise before the rounding)
+            pcs = fitting.add_noise_on_device(src[0], src[1], sigma=a.noise_sigma).to(torch.float)
         out = pcs, nrm, inst_d, bb_d.to(torch.float), axes, cen, extras     # eval.py:254-257
         if a.no_prefetch:
             collate.mark_copied()

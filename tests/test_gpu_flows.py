@@ -799,6 +799,24 @@ def test_autograph_train_eval_train_with_cache_flush_keeps_counter_tables_alive(
                 assert not torch.equal(v, before[k]), k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_add_noise_on_device_is_the_host_add_noise_bit_for_bit(dtype):
+    """fitting.add_noise_on_device (the evaluation loader's --add_noise): the host generator's draws and the reference's float64 multiply-add
+    (data_utils.py:84-96) with the (B, N, 3) arithmetic on the device - the same float64 values as fitting.add_noise (G14-pinned) from the
+    same NumPy state, hence the same float32 clouds after eval.py:254's rounding."""
+    from point2cyl_amd import fitting
+    g = torch.Generator().manual_seed(5)
+    pcs = torch.randn(3, 4096, 3, generator=g, dtype=torch.float64).to(dtype)
+    nrm = torch.nn.functional.normalize(torch.randn(3, 4096, 3, generator=g, dtype=torch.float64), dim=-1).to(dtype)
+    np.random.seed(1234)
+    want = fitting.add_noise(pcs, nrm, sigma=0.02)
+    np.random.seed(1234)
+    got = fitting.add_noise_on_device(pcs.to(DEV), nrm.to(DEV), sigma=0.02)
+    assert want.dtype == got.dtype == torch.float64
+    assert torch.equal(want, got.cpu())
+    assert torch.equal(want.float(), got.float().cpu())
+
+
 def test_batched_eval_batchnorm_affine_equals_the_per_layer_launches_and_follows_in_place_updates():
     """ops.BNEvalStage / p2c_bn_eval_affine_batch_f32: an inference forward computes the affine of all 17 eval-mode BatchNorms in ONE launch
     at its top.  Bit-identical heads to the per-layer p2c_bn_finalize_f32 form (P2C_BN_EVAL_BATCH=0), eager and as a replayed HIP graph,

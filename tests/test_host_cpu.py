@@ -411,3 +411,16 @@ def test_remaining_env_switches_are_wired():
         out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=180, cwd=ROOT)
         assert out.returncode == 0, out.stderr[-1500:]
         assert json.loads(out.stdout.strip().splitlines()[-1]) == want
+
+
+def test_build_flags_keep_packed_fp32_out():
+    """point2cyl_amd/build.py: every kernel is compiled WITHOUT v_pk_{add,mul,fma}_f32 (the consumer of a packed result two issue slots later
+    read a stale low half under the MFMA kernels: wrong farthest-point picks in 3 - 54 % of the graph replays, tools/stress_prefetch.py,
+    profiles/r06_fps_packed_hazard.log), the option is part of the source hash that stamps the profiles, and objects built with other
+    options are rebuilt."""
+    from point2cyl_amd import build
+    assert build.FLAGS[-4:] == ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+    assert "-ffp-contract=off" in build.FLAGS
+    stamp = os.path.join(build.OBJ, "flags.txt")
+    if os.path.exists(build.LIB):
+        assert os.path.exists(stamp) and open(stamp).read() == " ".join(build.FLAGS), "libp2c_hip.so was built with other options than build.FLAGS"

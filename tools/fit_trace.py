@@ -4,7 +4,7 @@ import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
 LIB = os.environ.get("P2C_FIT_TRACE_LIB") or os.path.join(HERE, "libp2c_fit_trace.so")
 if "--build" in sys.argv:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_FIT_TRACE",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DP2C_FIT_TRACE",
                            "-DP2C_FIT_TRACE_WG=%d" % int(os.environ.get("P2C_FIT_TRACE_WG", "0")), "-shared", "-o", LIB,
                            os.path.join(ROOT, "point2cyl_amd", "csrc", "fit.hip")])
     print(LIB); sys.exit(0)

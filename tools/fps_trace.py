@@ -4,7 +4,7 @@ import ctypes, os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__)); ROOT = os.path.dirname(HERE)
 LIB = os.path.join(HERE, "libp2c_fps_trace.so")
 if "--build" in sys.argv:
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-DP2C_FPS_TRACE", "-shared", "-o", LIB,
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DP2C_FPS_TRACE", "-shared", "-o", LIB,
                            os.path.join(ROOT, "point2cyl_amd", "csrc", "geom.hip")])
     print(LIB); sys.exit(0)
 sys.path.insert(0, ROOT)

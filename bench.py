@@ -685,12 +685,16 @@ def _extras(args, want, model, batch, fl, dev, ms, B, N, K, loss_fn, sync, opt):
         import subprocess
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        r = subprocess.run([sys.executable, "-m", "point2cyl_amd.ddp_selftest", "--steps", "20", "--batch_size", str(B), "--num_point", str(N)],
-                           cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
-        try:
-            return json.loads(r.stdout.strip().splitlines()[-1])
-        except (ValueError, IndexError):
-            return dict(error="rc %d: %s" % (r.returncode, r.stderr[-4000:]))
+        for attempt in (1, 2):           # (a process-group / HIP-runtime thread has aborted the child once in ~20 runs: one more try, and say so)
+            r = subprocess.run([sys.executable, "-m", "point2cyl_amd.ddp_selftest", "--steps", "20", "--batch_size", str(B), "--num_point", str(N)],
+                               cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+            try:
+                res = json.loads(r.stdout.strip().splitlines()[-1])
+                res["attempts"] = attempt
+                return res
+            except (ValueError, IndexError):
+                err = dict(error="rc %d: %s" % (r.returncode, r.stderr[-4000:]), attempts=attempt)
+        return err
 
     leg("rccl_selftest", rccl_selftest)
     return out

@@ -714,7 +714,7 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
     // HARD: SPL segments per lane (2: 36 accumulators - four per lane spilled at the 128 registers a 1024-thread workgroup has), LPP lanes per point
     constexpr int SPL = HARD ? (KK >= 2 ? 2 : 1) : 1, LPP = HARD ? KK / SPL : 1;
     float acc[HARD ? 1 : NA];
-    fit_v2f hacc2[SPL][NA / 2];                          // HARD: the 18 sums of a segment as nine register pairs (v_pk_fma_f32 / v_pk_add_f32)
+    fit_v2f hacc2[SPL][NA / 2];                          // HARD: the 18 sums of a segment as nine pairs (scalar v_fma_f32 in this build: no packed fp32, point2cyl_amd/build.py)
     if constexpr (!HARD) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) acc[i] = 0.f;
@@ -771,8 +771,9 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
 #pragma unroll
                 for (int m = 0; m < LPP; ++m) {
                     // the point of lane m of this group, in every lane of the group
-                    // (register pairs the packed instructions can source as they are: xa = (x0, x1), xb = (x2, x1) give the six products
-                    // as three v_pk_mul_f32 with half selects - (x0 x0, x0 x1), (x0 x2, x1 x1), (x1 x2, x2 x2) - and no moves)
+                    // (pairs: xa = (x0, x1), xb = (x2, x1) give the six products (x0 x0, x0 x1), (x0 x2, x1 x1), (x1 x2, x2 x2); written for
+                    // v_pk_mul_f32 / v_pk_fma_f32 with half selects - measured 0.1845 ms that way - and compiled to scalar multiplies and
+                    // FMAs since the library is built without packed fp32 instructions: 0.1876 ms, see point2cyl_amd/build.py for why)
                     const fit_v2f xa = {fit_group_bcast<LPP>(xq[u][0], m), fit_group_bcast<LPP>(xq[u][1], m)};
                     const fit_v2f xb = {fit_group_bcast<LPP>(xq[u][2], m), fit_group_bcast<LPP>(xq[u][1], m)};
                     const fit_v2f q3 = {fit_group_bcast<LPP>(pq[u][0], m), fit_group_bcast<LPP>(pq[u][1], m)};
@@ -786,7 +787,7 @@ __global__ void __launch_bounds__(THREADS, 4) fit_fused_kernel(const float *__re
                         const fit_v2f vbc = {(mine && bv == 0) ? 1.f : 0.f, (mine && bv == 1) ? 1.f : 0.f};
                         fit_v2f *a_ = hacc2[j];
                         // the factors are 0 or 1: every product is exact, so a fused multiply-add rounds exactly like the multiply + add of
-                        // the general route (the file is built with -ffp-contract=off); nine packed instructions per (point, segment): the
+                        // the general route (the file is built with -ffp-contract=off); nine pair operations per (point, segment): the
                         // pair (12, 13) is one packed add of (b2, c2) - summed whether or not `normalize` reads them -, the count 17 rides in
                         // the pair (p2, 1) of the centroid sums
                         const fit_v2f vb = vbc.xx, vc = vbc.yy, vw = {w, w};

@@ -119,8 +119,12 @@ __global__ void __launch_bounds__(1024) fps_kernel(const float *__restrict__ xyz
 // The same selection for clouds whose points live in registers (PPT 2..16, coordinates NOT mirrored in LDS): the iteration is a chain of
 // VALU work (4 waves per SIMD, each issuing its points' updates) -> wave reduction -> LDS exchange + barrier -> centroid fetch.
 // Against fps_kernel this variant
-//   * does the update of two points per instruction (v_pk_add_f32 / v_pk_mul_f32 on float2 lanes: same IEEE operations, same order
-//     ((dx*dx + dy*dy) + dz*dz), nothing fused), the running minimum as v_min_f32 and the lane's best as a v_max3 tree - the index of the
+//   * writes the update for PAIRS of points (float2 lanes: same IEEE operations, same order ((dx*dx + dy*dy) + dz*dz), nothing fused).  The
+//     library is built WITHOUT packed fp32 instructions (point2cyl_amd/build.py), so these are scalar v_sub / v_mul / v_add: as
+//     v_pk_add_f32 / v_pk_mul_f32 the low half of a result was read stale by the v_min_i32 two issue slots later whenever the kernel ran
+//     under the MFMA kernels with <= 2 waves per SIMD - wrong picks in 7 % (8 waves per cloud) to 54 % (4 waves) of the graph replays, never
+//     alone (tools/stress_prefetch.py, profiles/r06_fps_packed_hazard.log) - and the scalar form is FASTER here (a v_fma-class instruction
+//     issues in 2.5 clocks, a packed one in 4.2: 443 -> 382 us).  The running minimum is an integer v_min, the lane's best a v_max3 tree - the index of the
 //     best point is NOT tracked per point (two selects each): after the wave maximum is known, one compare per register slot yields the 64-bit
 //     mask of lanes holding it, and the first (lane, slot) - lowest point index, torch.max's tie rule (:83) - is picked on the scalar unit;
 //   * carries the winner's COORDINATES through the exchange (read from the winning lane's registers), so the next iteration starts from an

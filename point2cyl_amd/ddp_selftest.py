@@ -138,7 +138,8 @@ def run(steps=20, B=32, N=8192, K=8, device=0):
     res["ok"] = bool(a["grads_identical_every_step"] and s["grads_identical_every_step"] and a["exchanges"] == steps and s["exchanges"] == steps
                      and res["async_split_tail"]["max_loss_diff_vs_plain"] <= tol and res["sync_one_graph"]["max_loss_diff_vs_plain"] <= tol)
     res["loss_tolerance"] = tol
-    dist.destroy_process_group()
+    # (no destroy_process_group(): tearing the communicator down is where a process-group watchdog / HIP-runtime thread has aborted the
+    # process - once in ~20 runs at interpreter exit, once before the result was printed; main() prints and leaves with os._exit)
     return res
 
 

@@ -400,6 +400,21 @@ def test_b32_n8192_eval_forward_two_clouds_vs_oracle():
     assert ok, [mm for mm in _METRICS if not mm["ok"]]
 
 
+def test_pipelined_evaluation_at_full_size_is_reproducible_run_to_run():
+    """The evaluation loop at B = 32 x 8192 (forward of a group of batches in one HIP graph, the next group's geometry on the forked stream
+    under it, fused metrics): two runs from the same seed print the same report to the last digit - eval-mode kernels are deterministic, so
+    any difference is a kernel computing something else under concurrency (the packed-fp32 hazard of round 6 showed here as well)."""
+    reports = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-m", "point2cyl_amd.eval", "--synthetic", "384", "--batch_size", "32", "--random_init", "--dump_dir", "/tmp/p2c_eval_repro"],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "12 of 12 batches pipelined" in r.stdout, r.stdout[-800:]
+        reports.append([ln for ln in r.stdout.splitlines() if ln.startswith("Mean ")])
+        assert len(reports[-1]) == 5
+    assert reports[0] == reports[1], (reports[0], reports[1])
+
+
 def test_prefetched_geometry_under_the_training_kernels_is_the_eager_geometry_400_replays():
     """tools/stress_prefetch.py: the HIP-graph step with the next batch's geometry on the forked stream, 400 replays on a fixed batch with
     fixed FPS starts - after every replay the farthest-point indices, centroids, ball-query groups and grouped coordinates of BOTH levels

@@ -1,10 +1,10 @@
 #!/bin/bash
-# per-kernel average durations of the training step under rocprofv3 (kernel trace only):   bash tools/kstat.sh [name-pattern]
+# per-kernel average durations of the training step under rocprofv3 (kernel trace only):   [KSTAT_FLAGS=--no_prefetch] bash tools/kstat.sh [name-pattern]
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 PAT=${1:-.}
 rm -rf gpurun_out/kstat; mkdir -p gpurun_out/kstat
-rocprofv3 --kernel-trace --stats -d gpurun_out/kstat -o r --output-format csv -- python bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_extras > gpurun_out/kstat/bench.log 2> gpurun_out/kstat/err.log
+rocprofv3 --kernel-trace --stats -d gpurun_out/kstat -o r --output-format csv -- python bench.py --steps 20 --warmup 3 --no_cpu_baseline --no_extras ${KSTAT_FLAGS:-} > gpurun_out/kstat/bench.log 2> gpurun_out/kstat/err.log
 python - "$PAT" <<'PY'
 import csv, re, sys
 pat = re.compile(sys.argv[1])
